@@ -1,0 +1,257 @@
+/* include/airband_hip.h -- C ABI of libairband_hip.so
+ *
+ * MI355X (gfx950) backend for the one data-parallel hot path of RTLSDR-Airband: the demodulate()
+ * loop (reference: src/rtl_airband.cpp:286-672) -- sliding windowed-FFT channelizer, per-bin AM/NFM
+ * demodulation, squelch (+CTCSS), IIR notch / Bessel lowpass -- for many independent "dongles"
+ * (device_t) at once.  Plain C, plain pointers and sizes; no C++/torch types cross this boundary.
+ *
+ * Shape of the API follows the only GPU-offload precedent in the reference, the VideoCore FFT
+ * backend (reference: src/hello_fft/gpu_fft.h:66-74 gpu_fft_prepare/execute/release, used at
+ * src/rtl_airband.cpp:296,458,363): prepare -> {submit, process, collect}* -> release, negative int
+ * error codes with the same meaning (-1 no device, -2 unsupported size, -3 out of memory).
+ *
+ * What each entry point replaces in the reference is cited next to it.
+ */
+#ifndef AIRBAND_HIP_H
+#define AIRBAND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIRBAND_HIP_ABI_VERSION 1u
+
+/* error codes (negative ints; 0 = success).  -1/-2/-3 keep gpu_fft_prepare()'s meaning
+ * (reference: src/rtl_airband.cpp:297-310). */
+#define AIRBAND_HIP_OK 0
+#define AIRBAND_HIP_ENODEV (-1)   /* no usable HIP device / HIP runtime error at prepare            */
+#define AIRBAND_HIP_EBADSIZE (-2) /* fft_size_log outside [8,13], bad wave_rate, bad counts         */
+#define AIRBAND_HIP_ENOMEM (-3)   /* device or host allocation failed                                */
+#define AIRBAND_HIP_EINVAL (-4)   /* NULL / inconsistent argument                                    */
+#define AIRBAND_HIP_EAGAIN (-5)   /* not enough input queued for a batch / no batch to collect       */
+#define AIRBAND_HIP_ERUNTIME (-6) /* HIP launch / copy failure after prepare                         */
+
+/* sample formats: numeric values equal sample_format_t (reference: src/input-common.h:31) */
+#define AIRBAND_SFMT_U8 1
+#define AIRBAND_SFMT_S8 2
+#define AIRBAND_SFMT_S16 3
+#define AIRBAND_SFMT_F32 4
+
+/* modulations: numeric values equal enum modulations (reference: src/rtl_airband.h:195-200) */
+#define AIRBAND_MOD_AM 0
+#define AIRBAND_MOD_NFM 1
+
+/* FM discriminator choice: enum fm_demod_algo (reference: src/rtl_airband.cpp:88-89, -Q option) */
+#define AIRBAND_FM_FAST_ATAN2 0
+#define AIRBAND_FM_QUADRI_DEMOD 1
+
+/* constants of the reference build (reference: src/rtl_airband.h:67-75) */
+#define AIRBAND_AGC_EXTRA 100
+
+/* prepare() flags */
+#define AIRBAND_HIP_FLAG_TRACE_SQUELCH 0x1u /* record per-sample squelch state (parity debugging;       \
+                                               mirrors the reference's DEBUG_SQUELCH dump,               \
+                                               src/squelch.cpp:593-633)                                 */
+#define AIRBAND_HIP_FLAG_KEEP_BINS 0x2u     /* keep stage-1 output (wavein/iq_in) readable after a batch */
+#define AIRBAND_HIP_FLAG_FORCE_FFT 0x4u     /* always use the full wavefront-FFT channelizer             */
+
+/* Per-channel configuration: the values a multichannel-mode `channels` entry carries after
+ * parse_channels() (reference: src/config.cpp:306-726).  The library derives bin index, derotation
+ * step, filter coefficients, squelch constants and CTCSS tone banks from these exactly the way the
+ * reference does (bins :666-667, dm_dphi :679-712, notch :516-564, ctcss :565-591,
+ * bandwidth :592-619, ampfactor :620-645, tau :646-650, squelch thresholds :436-515). */
+typedef struct airband_hip_channel_cfg {
+    int32_t frequency;                /* Hz; freq_t.frequency                                          */
+    int32_t modulation;               /* AIRBAND_MOD_*                                                 */
+    int32_t afc;                      /* channel_t.afc, 0 = off                                        */
+    int32_t squelch_threshold_dbfs;   /* `squelch_threshold`: 0 = auto squelch, <0 = manual level      */
+    float squelch_snr_threshold_db;   /* `squelch_snr_threshold`: -1 = keep default 9.54 dB            */
+    float notch_freq;                 /* `notch` in Hz, 0 = off                                        */
+    float notch_q;                    /* `notch_q`, 0 = default 10                                     */
+    float ctcss_freq;                 /* `ctcss` in Hz, 0 = off                                        */
+    int32_t bandwidth_hz;             /* `bandwidth`, 0 = off; lowpass at bandwidth/2, needs raw I/Q   */
+    float ampfactor;                  /* `ampfactor` (default 1.0)                                     */
+    int32_t tau_us;                   /* `tau` in microseconds, -1 = inherit device/global             */
+    int32_t has_iq_outputs;           /* channel has a raw-I/Q output (channel_t.has_iq_outputs)       */
+} airband_hip_channel_cfg;
+
+/* Per-device ("dongle") configuration: the input_t fields demodulate() reads
+ * (reference: src/input-common.h:39-57) plus the channel list. */
+typedef struct airband_hip_device_cfg {
+    int32_t sample_rate; /* Hz, input_t.sample_rate                                                   */
+    int32_t centerfreq;  /* Hz, input_t.centerfreq                                                    */
+    int32_t sfmt;        /* AIRBAND_SFMT_*                                                            */
+    float fullscale;     /* input_t.fullscale; 0 = the driver default for sfmt                        */
+    int32_t tau_us;      /* device-level `tau`, -1 = global default (200 us)                          */
+    int32_t channel_count;
+    const airband_hip_channel_cfg* channels;
+} airband_hip_device_cfg;
+
+typedef struct airband_hip_config {
+    uint32_t abi_version; /* AIRBAND_HIP_ABI_VERSION                                                   */
+    uint32_t flags;       /* AIRBAND_HIP_FLAG_*                                                        */
+    int32_t fft_size_log; /* global fft_size_log, 8..13 (reference: src/rtl_airband.cpp:786-800)       */
+    int32_t wave_rate;    /* 8000 = AM-only build, 16000 = NFM build (reference: src/rtl_airband.h:67) */
+    int32_t fm_demod;     /* AIRBAND_FM_*                                                              */
+    int32_t hip_device;   /* HIP device ordinal this handle lives on                                   */
+    int32_t device_count;
+    const airband_hip_device_cfg* devices;
+} airband_hip_config;
+
+/* Mixer wiring (reference: src/mixer.cpp:57-94 mixer_connect_input, :133-140 mix_waveforms).
+ * One entry per (channel -> mixer) connection. */
+typedef struct airband_hip_mixer_input {
+    int32_t device;   /* dongle index                                                                 */
+    int32_t channel;  /* channel index within the dongle                                              */
+    int32_t mixer;    /* destination mixer index                                                      */
+    float ampfactor;  /* mixinput_t.ampfactor                                                         */
+    float balance;    /* -1..1; ampl=min(1,1-bal), ampr=min(1,1+bal)                                  */
+} airband_hip_mixer_input;
+
+/* Geometry the library derived; lets the caller size its buffers. */
+typedef struct airband_hip_geometry {
+    int32_t fft_size;          /* 1 << fft_size_log                                                   */
+    int32_t wave_rate;         /* WAVE_RATE                                                           */
+    int32_t wave_batch;        /* WAVE_BATCH = WAVE_RATE/8 output samples per batch per channel        */
+    int32_t device_count;
+    int32_t total_channels;    /* sum of channel_count                                                */
+    int32_t max_channels;      /* max channel_count                                                   */
+    int32_t mixer_count;
+    int32_t reserved;
+    int64_t first_batch_bytes; /* per device: IQ bytes the first batch consumes (incl. AGC_EXTRA hops) */
+    int64_t batch_bytes;       /* per device: IQ bytes every later batch consumes                     */
+    int64_t lookahead_bytes;   /* per device: bytes past the batch the last FFT window still reads    */
+} airband_hip_geometry;
+
+/* Per-channel squelch/AGC statistics mirrored back to the host after every batch: the getters the
+ * stats file and TUI read (reference: src/output.cpp:617-761, src/rtl_airband.cpp:633-640). */
+typedef struct airband_hip_channel_stats {
+    float noise_level;    /* Squelch::noise_level()                                                   */
+    float signal_level;   /* Squelch::signal_level()                                                  */
+    float squelch_level;  /* Squelch::squelch_level()                                                 */
+    float agcavgfast;     /* freq_t.agcavgfast                                                        */
+    uint64_t open_count;  /* Squelch::open_count()                                                    */
+    uint64_t flappy_count;
+    uint64_t ctcss_count;
+    uint64_t no_ctcss_count;
+    uint64_t active_counter; /* freq_t.active_counter                                                 */
+    int32_t bin;             /* dev->bins[i] (moves only with AFC)                                    */
+    int32_t squelch_state;   /* Squelch::State after the batch                                        */
+} airband_hip_channel_stats;
+
+typedef struct airband_hip_handle airband_hip_handle;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+
+/* Replaces: fftwf plan creation in init_demod() (reference: src/rtl_airband.cpp:253-266), the
+ * LUT/window set-up at the top of demodulate() (:316-351), sincosf_lut_init() (src/util.cpp:105)
+ * and the per-channel derivations of parse_channels() listed above.
+ * Returns 0 or a negative AIRBAND_HIP_E* code; *out is NULL on failure. */
+int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out);
+
+/* Optional: wire channels into mixers before the first batch (reference: src/config.cpp mixer outputs,
+ * src/mixer.cpp:57-94).  mixer_count mixers, n_inputs connections. */
+int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const airband_hip_mixer_input* inputs, int32_t n_inputs);
+
+/* Replaces: gpu_fft_release() on do_exit (reference: src/rtl_airband.cpp:360-365). */
+void airband_hip_release(airband_hip_handle* h);
+
+int airband_hip_get_geometry(const airband_hip_handle* h, airband_hip_geometry* out);
+
+/* Human-readable text of the last error on this handle (or of the last failed prepare when h is NULL). */
+const char* airband_hip_last_error(const airband_hip_handle* h);
+
+/* ---- data path ------------------------------------------------------------------------------ */
+
+/* Host-ring path.  Appends `nbytes` of raw interleaved I/Q of device `dev` to the library's
+ * staging ring (pinned host -> HBM, asynchronous on the handle's stream).
+ * Replaces: the consumer side of input->buffer (reference: src/rtl_airband.cpp:370-375,:669); the
+ * reference-side shim calls it with the span [bufs, bufe) the rx thread produced
+ * (circbuffer_append, src/input-helpers.cpp:37-63) and then advances bufs.
+ * Returns number of bytes accepted (may be < nbytes when the staging ring is full) or <0. */
+int64_t airband_hip_submit(airband_hip_handle* h, int32_t dev, const void* iq, size_t nbytes);
+
+/* Runs ONE batch (WAVE_BATCH output samples for every channel of every device) if every device has
+ * enough queued input (the availability rule of src/rtl_airband.cpp:394-400 applied per batch);
+ * AIRBAND_HIP_EAGAIN otherwise.  Asynchronous: returns after enqueueing the kernels.
+ * Replaces: one WAVE_BATCH worth of demodulate() iterations for all devices
+ * (reference: src/rtl_airband.cpp:402-492 stage 1 and :494-655 stage 2). */
+int airband_hip_process(airband_hip_handle* h);
+
+/* Zero-copy path for HBM-resident I/Q.  `d_iq` is a DEVICE pointer; device `d`'s span for this batch
+ * starts at d_iq + d*stride_bytes and holds at least (first_)batch_bytes + lookahead_bytes bytes:
+ * the stream bytes of this batch followed by the bytes the last window overlaps into the next batch
+ * (exactly what a tail-replicated ring, src/input-helpers.cpp:43-51, holds at that offset).
+ * `stream` is a hipStream_t (NULL = the handle's own stream). */
+int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t stride_bytes, void* stream);
+
+/* Waits for the oldest un-collected batch and copies its results to HOST memory.  Any pointer may be
+ * NULL to skip that output.
+ *   waveout  [total_channels][wave_batch]   = channel->waveout[0..WAVE_BATCH) as process_outputs()
+ *            sees it (reference: src/output.cpp:460,535) -- the library performs the output thread's
+ *            tail copy (src/output.cpp:920) itself;
+ *   iq_out   [total_channels][2*wave_batch] = channel->iq_out (zeros for channels without I/Q outputs);
+ *   axcindicate [total_channels]            = channel->axcindicate (' ', '*', '<', '>');
+ *   stats    [total_channels].
+ * Channels are numbered device-major: index = (sum of channel_count of earlier devices) + channel.
+ * Replaces: the hand-off at src/rtl_airband.cpp:649-662 (waveavail / Signal::send). */
+int airband_hip_collect(airband_hip_handle* h, float* waveout, float* iq_out, char* axcindicate, airband_hip_channel_stats* stats);
+
+/* Mixer outputs of the batch last collected: left [mixer_count][wave_batch], right likewise (zeros for
+ * mono mixers), has_signal [mixer_count] (reference: src/mixer.cpp:201-214). HOST pointers.
+ * Multi-GPU callers all-reduce (sum / max) these across ranks. */
+int airband_hip_collect_mixers(airband_hip_handle* h, float* left, float* right, uint8_t* has_signal);
+
+/* Device-side views of the current result buffers (valid until the next process call), for consumers
+ * that stay on the GPU (e.g. an RCCL all-reduce of the mixer sums).  Any out-pointer may be NULL. */
+int airband_hip_device_results(airband_hip_handle* h, float** d_waveout, float** d_iq_out, uint8_t** d_axc, float** d_mix_left, float** d_mix_right,
+                               uint8_t** d_mix_signal);
+
+/* Blocks until everything enqueued on the handle has finished. */
+int airband_hip_synchronize(airband_hip_handle* h);
+
+/* ---- introspection used by parity tests and the bench ---------------------------------------- */
+
+/* Stage-2 only: run the per-channel demod/squelch/filter batch on caller-provided stage-1 output
+ * (HOST pointers): wavein [total_channels][wave_batch] magnitudes and iq_in [total_channels][2*wave_batch]
+ * raw bin I/Q for the batch's WAVE_BATCH new hops.  Lets tests feed the oracle's exact stage-1 values
+ * and demand bit-identical stage-2 results. */
+int airband_hip_process_bins(airband_hip_handle* h, const float* wavein, const float* iq_in);
+
+/* Stage-1 output of the last batch (needs AIRBAND_HIP_FLAG_KEEP_BINS): wavein [total_channels][wave_batch],
+ * iq_in [total_channels][2*wave_batch].  HOST pointers. */
+int airband_hip_read_bins(airband_hip_handle* h, float* wavein, float* iq_in);
+
+/* Per-sample squelch trace of the last batch (needs AIRBAND_HIP_FLAG_TRACE_SQUELCH):
+ * state [total_channels][wave_batch] bytes: bits 0-2 Squelch::State after process_raw_sample,
+ * bit 3 is_open(), bit 4 should_process_audio(), bit 5 CTCSS has_tone (slow if enough samples else fast). */
+int airband_hip_read_trace(airband_hip_handle* h, uint8_t* state);
+
+/* Derived per-channel constants (bin, dm_dphi, filter taps ...) as the library computed them; lets
+ * tests compare against the reference's own derivation.  out_vals must hold 16 doubles:
+ *  [0] bin  [1] dm_dphi  [2] alpha  [3] notch d0 [4] d1 [5] d2  [6] lowpass gain [7] ycoeff0 [8] ycoeff1
+ *  [9] normal_signal_ratio [10] manual_level(-1 if auto) [11] n_tones_fast [12] n_tones_slow
+ *  [13] needs_raw_iq [14] window_fast [15] window_slow */
+int airband_hip_channel_constants(const airband_hip_handle* h, int32_t channel_index, double* out_vals);
+
+/* Milliseconds the GPU spent in each stage during the last process call (HIP events on the handle's
+ * stream): [0] channelizer kernel, [1] demod kernel(s), [2] emit/transposes, [3] whole batch. */
+int airband_hip_last_timings(airband_hip_handle* h, float* ms4);
+
+/* Name of the channelizer variant the handle selected ("fft_wave64" / "dft_mfma_i8"). */
+const char* airband_hip_channelizer_name(const airband_hip_handle* h);
+
+/* Deterministic synthetic dongles, generated on the GPU straight into HBM (integer-only arithmetic so
+ * the numpy generator in the tests produces identical bytes).  Fills, for every device d in
+ * [0, device_count), nbytes of u8 I/Q starting at stream byte offset `start_byte` into
+ * d_iq + d*stride_bytes.  See DESIGN.md "synthetic dongles".  d_iq is a DEVICE pointer. */
+int airband_hip_generate_iq(airband_hip_handle* h, void* d_iq, size_t stride_bytes, uint64_t start_byte, size_t nbytes, uint64_t seed,
+                            int32_t device_index_offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIRBAND_HIP_H */

@@ -1,0 +1,463 @@
+/* oracle/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product library).
+ *
+ * Builds the REAL reference hot path into oracle/_ref/: this translation unit #includes the
+ * reference's src/rtl_airband.cpp where it lies (so `static int devices_running`, demodulate(), AFC,
+ * the FM helpers etc. are the reference's own object code) and adds a small C API around it.
+ * No reference source is copied into this repository.
+ *
+ * What this file restates (because the reference only does it inside the libconfig++ parser,
+ * which cannot run here) is the hand-construction of device_t / channel_t / freq_t / input_t:
+ *   mk_freqlist()            src/config.cpp:265-281
+ *   channel defaults         src/config.cpp:313-331
+ *   squelch thresholds       src/config.cpp:436-515
+ *   notch / ctcss / bandwidth / ampfactor / tau   src/config.cpp:516-650
+ *   bins                     src/config.cpp:666-667
+ *   dm_dphi                  src/config.cpp:679-712
+ *   ring sizing              src/config.cpp:796-806
+ *   file-input defaults      src/input-file.cpp:162-181
+ * and the roles of the two neighbouring threads:
+ *   rx thread  -> circbuffer_append()          src/input-helpers.cpp:37-63 (the reference's own function)
+ *   output thread -> read waveout[0..WAVE_BATCH), tail copy, clear waveavail   src/output.cpp:917-922
+ */
+#define main reference_main
+#include "rtl_airband.cpp" /* found through -I/root/reference/src */
+#undef main
+
+#include <limits.h>
+#include <sched.h>
+
+#include "../include/airband_hip.h"
+#include "input-helpers.h"
+
+/* ---- symbols main()/demodulate() reference but the oracle never reaches ---------------------- */
+char const* RTL_AIRBAND_VERSION = "oracle-harness";
+static void refh_unreachable(const char* what) {
+    fprintf(stderr, "oracle/ref_harness: %s must never be reached\n", what);
+    abort();
+}
+int parse_devices(libconfig::Setting&) { refh_unreachable("parse_devices"); return 0; }
+int parse_mixers(libconfig::Setting&) { refh_unreachable("parse_mixers"); return 0; }
+lame_t airlame_init(mix_modes, int, int) { refh_unreachable("airlame_init"); return NULL; }
+void shout_setup(icecast_data*, mix_modes) { refh_unreachable("shout_setup"); }
+void disable_device_outputs(device_t*) {}
+void disable_channel_outputs(channel_t*) {}
+void* output_check_thread(void*) { refh_unreachable("output_check_thread"); return NULL; }
+void* output_thread(void*) { refh_unreachable("output_thread"); return NULL; }
+void* mixer_thread(void*) { refh_unreachable("mixer_thread"); return NULL; }
+mixer_t* getmixerbyname(const char*) { return NULL; }
+const char* mixer_get_error() { return ""; }
+
+/* ---- harness state --------------------------------------------------------------------------- */
+#define REFH_MAX_THREADS 256
+static pthread_t g_demod_thread[REFH_MAX_THREADS];
+static int g_threads_running = 0;
+static demod_params_t g_demod_params[REFH_MAX_THREADS];
+static Signal g_signal;
+static size_t* g_hops_fed_bytes = NULL;  /* total bytes fed per device */
+static char g_trace_dir[512] = "";
+
+extern "C" {
+
+int refh_wave_rate(void) { return WAVE_RATE; }
+int refh_wave_batch(void) { return WAVE_BATCH; }
+int refh_agc_extra(void) { return AGC_EXTRA; }
+int refh_has_nfm(void) {
+#ifdef NFM
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+void refh_set_trace_dir(const char* dir) { snprintf(g_trace_dir, sizeof(g_trace_dir), "%s", dir ? dir : ""); }
+
+int refh_init(int n_devices, int fft_log, int fm_demod_algo, int global_tau_us) {
+    if (fft_log < MIN_FFT_SIZE_LOG || fft_log > MAX_FFT_SIZE_LOG) return -2;
+    log_destination = NONE;
+    fft_size_log = (size_t)fft_log;
+    fft_size = (size_t)1 << fft_size_log;
+    device_count = n_devices;
+    devices = (device_t*)XCALLOC(n_devices, sizeof(device_t));
+    g_hops_fed_bytes = (size_t*)XCALLOC(n_devices, sizeof(size_t));
+    mixer_count = 0;
+    do_exit = 0;
+#ifdef NFM
+    fm_demod = fm_demod_algo ? FM_QUADRI_DEMOD : FM_FAST_ATAN2;
+    /* global tau: src/rtl_airband.cpp:87 default, :825-826 override */
+    alpha = exp(-1.0f / (WAVE_RATE * 2e-4));
+    if (global_tau_us >= 0) alpha = (global_tau_us == 0 ? 0.0f : exp(-1.0f / (WAVE_RATE * 1e-6 * global_tau_us)));
+#else
+    (void)fm_demod_algo;
+    (void)global_tau_us;
+#endif
+    sincosf_lut_init(); /* src/rtl_airband.cpp:1107 */
+    return 0;
+}
+
+int refh_add_device(int d, const airband_hip_device_cfg* cfg) {
+    device_t* dev = devices + d;
+    input_t* input = (input_t*)XCALLOC(1, sizeof(input_t));
+    input->state = INPUT_RUNNING;
+    input->sfmt = (sample_format_t)cfg->sfmt;
+    switch (cfg->sfmt) { /* driver defaults: src/input-file.cpp:171-173, src/input-soapysdr.cpp:45-64 */
+        case SFMT_U8:
+        case SFMT_S8:
+            input->bytes_per_sample = 1;
+            input->fullscale = (float)SCHAR_MAX - 0.5f;
+            break;
+        case SFMT_S16:
+            input->bytes_per_sample = 2;
+            input->fullscale = (float)SHRT_MAX - 0.5f;
+            break;
+        case SFMT_F32:
+            input->bytes_per_sample = 4;
+            input->fullscale = 1.0f;
+            break;
+        default:
+            return -4;
+    }
+    if (cfg->fullscale > 0) input->fullscale = cfg->fullscale;
+    input->sample_rate = cfg->sample_rate;
+    input->centerfreq = cfg->centerfreq;
+    pthread_mutex_init(&input->buffer_lock, NULL);
+    dev->input = input;
+    dev->mode = R_MULTICHANNEL;
+#ifdef NFM
+    dev->alpha = alpha; /* src/config.cpp:774-778 */
+    if (cfg->tau_us >= 0) dev->alpha = (cfg->tau_us == 0 ? 0.0f : exp(-1.0f / (WAVE_RATE * 1e-6 * cfg->tau_us)));
+#endif
+    /* ring sizing: src/config.cpp:796-806 */
+    size_t fft_batch_len = FFT_BATCH * (2 * input->bytes_per_sample * (size_t)ceil((double)input->sample_rate / (double)WAVE_RATE));
+    input->buf_size = MIN_BUF_SIZE;
+    if (input->buf_size % fft_batch_len != 0) input->buf_size += fft_batch_len - input->buf_size % fft_batch_len;
+    input->buffer = (unsigned char*)XCALLOC(sizeof(unsigned char), input->buf_size + 2 * input->bytes_per_sample * fft_size);
+    input->bufs = input->bufe = 0;
+    input->overflow_count = 0;
+    dev->output_overrun_count = 0;
+    dev->waveend = dev->waveavail = dev->row = dev->tq_head = dev->tq_tail = 0;
+    dev->last_frequency = -1;
+
+    dev->channel_count = cfg->channel_count;
+    dev->channels = (channel_t*)XCALLOC(cfg->channel_count, sizeof(channel_t));
+    dev->bins = (size_t*)XCALLOC(cfg->channel_count, sizeof(size_t));
+    dev->base_bins = (size_t*)XCALLOC(cfg->channel_count, sizeof(size_t));
+
+    for (int j = 0; j < cfg->channel_count; j++) {
+        const airband_hip_channel_cfg* cc = cfg->channels + j;
+        channel_t* channel = dev->channels + j;
+        for (int k = 0; k < AGC_EXTRA; k++) { /* src/config.cpp:313-316 */
+            channel->wavein[k] = 20;
+            channel->waveout[k] = 0.5;
+        }
+        channel->axcindicate = NO_SIGNAL;
+        channel->mode = MM_MONO;
+        channel->freq_count = 1;
+        channel->freq_idx = 0;
+        channel->highpass = 100;
+        channel->lowpass = 2500;
+#ifdef NFM
+        channel->pr = 0;
+        channel->pj = 0;
+        channel->prev_waveout = 0.5;
+        channel->alpha = dev->alpha;
+#endif
+        channel->afc = (unsigned char)cc->afc;
+        /* mk_freqlist(1): src/config.cpp:265-281 */
+        freq_t* fl = (freq_t*)XCALLOC(1, sizeof(freq_t));
+        fl[0].frequency = cc->frequency;
+        fl[0].label = NULL;
+        fl[0].agcavgfast = 0.5f;
+        fl[0].ampfactor = 1.0f;
+        fl[0].squelch = Squelch();
+        fl[0].active_counter = 0;
+        fl[0].modulation = MOD_AM;
+#ifdef NFM
+        if (cc->modulation == AIRBAND_MOD_NFM) fl[0].modulation = MOD_NFM;
+#else
+        if (cc->modulation != AIRBAND_MOD_AM) return -4;
+#endif
+        channel->freqlist = fl;
+        /* squelch thresholds: src/config.cpp:436-515 */
+        if (cc->squelch_threshold_dbfs < 0) {
+            fl[0].squelch.set_squelch_level_threshold(dBFS_to_level((float)cc->squelch_threshold_dbfs));
+        } else {
+            fl[0].squelch.set_squelch_level_threshold(0);
+        }
+        if (cc->squelch_snr_threshold_db >= 0.0f) fl[0].squelch.set_squelch_snr_threshold(cc->squelch_snr_threshold_db);
+        /* notch: src/config.cpp:516-564 */
+        if (cc->notch_freq > 0) {
+            float q = cc->notch_q > 0 ? cc->notch_q : 10.0f;
+            fl[0].notch_filter = NotchFilter(cc->notch_freq, WAVE_RATE, q);
+        }
+        /* ctcss: src/config.cpp:565-591 */
+        if (cc->ctcss_freq > 0) fl[0].squelch.set_ctcss_freq(cc->ctcss_freq, WAVE_RATE);
+        /* bandwidth: src/config.cpp:592-619 */
+        if (cc->bandwidth_hz != 0) {
+            channel->needs_raw_iq = 1;
+            if (cc->bandwidth_hz > 0) fl[0].lowpass_filter = LowpassFilter((float)cc->bandwidth_hz / 2, WAVE_RATE);
+        }
+        fl[0].ampfactor = cc->ampfactor; /* src/config.cpp:620-645 */
+#ifdef NFM
+        if (cc->tau_us >= 0) channel->alpha = (cc->tau_us == 0 ? 0.0f : exp(-1.0f / (WAVE_RATE * 1e-6 * cc->tau_us)));
+#endif
+        /* raw-I/Q output: parse_outputs() sets both flags for a rawfile output (src/config.cpp:34-263) */
+        if (cc->has_iq_outputs) {
+            channel->has_iq_outputs = 1;
+            channel->needs_raw_iq = 1;
+        }
+        /* bins: src/config.cpp:666-667 */
+        dev->base_bins[j] = dev->bins[j] =
+            (size_t)ceil((fl[0].frequency + input->sample_rate - input->centerfreq) / (double)(input->sample_rate / fft_size) - 1.0) % fft_size;
+#ifdef NFM
+        if (fl[0].modulation == MOD_NFM) channel->needs_raw_iq = 1; /* src/config.cpp:670-677 */
+#endif
+        if (channel->needs_raw_iq) { /* src/config.cpp:679-712 */
+            double dm_dphi = (double)(fl[0].frequency - input->centerfreq);
+            double decimation_factor = ((double)input->sample_rate / (double)WAVE_RATE);
+            double dm_dphi_correction = (double)WAVE_RATE / 2.0;
+            dm_dphi_correction *= (decimation_factor - round(decimation_factor));
+            dm_dphi_correction *= (double)(fl[0].frequency - input->centerfreq) / ((double)input->sample_rate / 2.0);
+            dm_dphi -= dm_dphi_correction;
+            dm_dphi /= (double)WAVE_RATE;
+            dm_dphi -= trunc(dm_dphi);
+            dm_dphi *= 256.0 * 65536.0;
+            channel->dm_dphi = (uint32_t)((int)dm_dphi);
+            channel->dm_phi = 0.f;
+        }
+#ifdef DEBUG_SQUELCH
+        if (g_trace_dir[0]) {
+            char path[1024];
+            snprintf(path, sizeof(path), "%s/squelch_debug-%d-%d.dat", g_trace_dir, d, j);
+            fl[0].squelch.set_debug_file(path);
+        }
+#endif
+    }
+    return 0;
+}
+
+/* n_threads demodulate() instances over contiguous device shards: the reference's own
+ * multiple_demod_threads model (src/rtl_airband.cpp:1052-1086,1110-1112), 1 = its default. */
+int refh_start(int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > device_count) n_threads = device_count;
+    if (n_threads > REFH_MAX_THREADS) n_threads = REFH_MAX_THREADS;
+    devices_running = device_count;
+    for (int t = 0; t < n_threads; t++) {
+        int start = (int)((long)device_count * t / n_threads), end = (int)((long)device_count * (t + 1) / n_threads);
+        init_demod(&g_demod_params[t], &g_signal, start, end); /* src/rtl_airband.cpp:253-266 */
+        if (pthread_create(&g_demod_thread[t], NULL, &demodulate, &g_demod_params[t]) != 0) return -1;
+        g_threads_running = t + 1;
+    }
+    return 0;
+}
+
+void refh_stop(void) {
+    if (!g_threads_running) return;
+    do_exit = 1;
+    for (int t = 0; t < g_threads_running; t++) pthread_join(g_demod_thread[t], NULL);
+    g_threads_running = 0;
+#ifdef DEBUG_SQUELCH
+    for (int d = 0; d < device_count; d++)
+        for (int j = 0; j < devices[d].channel_count; j++) devices[d].channels[j].freqlist[0].squelch.~Squelch(); /* flush traces */
+#endif
+}
+
+static size_t refh_available(input_t* in) {
+    pthread_mutex_lock(&in->buffer_lock);
+    size_t a = in->bufe >= in->bufs ? in->bufe - in->bufs : in->buf_size - in->bufs + in->bufe;
+    pthread_mutex_unlock(&in->buffer_lock);
+    return a;
+}
+
+static size_t refh_bps(input_t* in) { return 2 * in->bytes_per_sample * (size_t)round((double)in->sample_rate / (double)WAVE_RATE); }
+
+/* Role of output_thread (src/output.cpp:903-923) for one device: copy results out, tail copy, clear flag. */
+static void refh_drain(int d, float* waveout, float* iq_out, char* axc) {
+    device_t* dev = devices + d;
+    for (int j = 0; j < dev->channel_count; j++) {
+        channel_t* channel = dev->channels + j;
+        if (waveout) memcpy(waveout + (size_t)j * WAVE_BATCH, channel->waveout, sizeof(float) * WAVE_BATCH);
+        if (iq_out) memcpy(iq_out + (size_t)j * 2 * WAVE_BATCH, channel->iq_out, sizeof(float) * 2 * WAVE_BATCH);
+        if (axc) axc[j] = (char)channel->axcindicate;
+        memcpy(channel->waveout, channel->waveout + WAVE_BATCH, AGC_EXTRA * 4); /* src/output.cpp:920 */
+    }
+    dev->waveavail = 0;
+}
+
+/* Streams `nbytes` of I/Q into device d and collects every batch that completes.
+ * waveout [max_batches][channel_count][WAVE_BATCH], iq_out [max_batches][channel_count][2*WAVE_BATCH],
+ * axc [max_batches][channel_count].  Returns the number of batches produced. */
+int refh_run_device(int d, const unsigned char* iq, size_t nbytes, int max_batches, float* waveout, float* iq_out, char* axc) {
+    device_t* dev = devices + d;
+    input_t* in = dev->input;
+    const size_t bps = refh_bps(in);
+    const size_t need = bps * FFT_BATCH + fft_size * in->bytes_per_sample * 2;
+    const int C = dev->channel_count;
+    int nb = 0;
+    size_t off = 0;
+    while (off < nbytes || refh_available(in) >= need || dev->waveavail) {
+        if (dev->waveavail) {
+            if (nb >= max_batches) break;
+            refh_drain(d, waveout ? waveout + (size_t)nb * C * WAVE_BATCH : NULL, iq_out ? iq_out + (size_t)nb * C * 2 * WAVE_BATCH : NULL,
+                       axc ? axc + (size_t)nb * C : NULL);
+            nb++;
+            continue;
+        }
+        if (refh_available(in) >= need) {
+            sched_yield();
+            continue;
+        }
+        /* feed at most one hop-batch at a time so that at most one output batch can complete */
+        size_t room = in->buf_size - 1 - refh_available(in);
+        size_t n = std::min(nbytes - off, std::min(room, bps * (size_t)WAVE_BATCH / 4));
+        if (n == 0) break;
+        circbuffer_append(in, const_cast<unsigned char*>(iq) + off, n);
+        off += n;
+    }
+    g_hops_fed_bytes[d] += off;
+    return nb;
+}
+
+/* stats mirror: what src/output.cpp:617-761 and the TUI read */
+int refh_channel_stats(int d, int j, airband_hip_channel_stats* out) {
+    device_t* dev = devices + d;
+    channel_t* channel = dev->channels + j;
+    freq_t* f = channel->freqlist;
+    out->noise_level = f->squelch.noise_level();
+    out->signal_level = f->squelch.signal_level();
+    out->squelch_level = f->squelch.squelch_level();
+    out->agcavgfast = f->agcavgfast;
+    out->open_count = f->squelch.open_count();
+    out->flappy_count = f->squelch.flappy_count();
+    out->ctcss_count = f->squelch.ctcss_count();
+    out->no_ctcss_count = f->squelch.no_ctcss_count();
+    out->active_counter = f->active_counter;
+    out->bin = (int32_t)dev->bins[j];
+    out->squelch_state = -1; /* private in the reference */
+    return 0;
+}
+
+/* derived constants, same slot meaning as airband_hip_channel_constants() where the reference exposes them */
+int refh_channel_constants(int d, int j, double* v) {
+    device_t* dev = devices + d;
+    channel_t* channel = dev->channels + j;
+    for (int i = 0; i < 16; i++) v[i] = NAN;
+    v[0] = (double)dev->bins[j];
+    v[1] = (double)channel->dm_dphi;
+#ifdef NFM
+    v[2] = (double)channel->alpha;
+#endif
+    v[13] = (double)channel->needs_raw_iq;
+    return 0;
+}
+
+/* ---- stand-alone pieces of the reference, exported for unit-level pinning of the restatement ---- */
+
+/* Squelch driven exactly like src/test_squelch.cpp drives it: raw samples only. */
+void* refh_squelch_new(float snr_db, int manual_dbfs, float ctcss_freq) {
+    Squelch* s = new Squelch();
+    if (manual_dbfs < 0) s->set_squelch_level_threshold(dBFS_to_level((float)manual_dbfs));
+    if (snr_db >= 0) s->set_squelch_snr_threshold(snr_db);
+    if (ctcss_freq > 0) s->set_ctcss_freq(ctcss_freq, WAVE_RATE);
+    return s;
+}
+void refh_squelch_raw(void* p, const float* x, int n, unsigned char* is_open, float* noise, float* level) {
+    Squelch* s = (Squelch*)p;
+    for (int i = 0; i < n; i++) {
+        s->process_raw_sample(x[i]);
+        if (is_open) is_open[i] = (unsigned char)((s->is_open() ? 1 : 0) | (s->should_process_audio() ? 2 : 0) | (s->should_filter_sample() ? 4 : 0) |
+                                                  (s->first_open_sample() ? 8 : 0) | (s->last_open_sample() ? 16 : 0));
+        if (noise) noise[i] = s->noise_level();
+        if (level) level[i] = s->squelch_level();
+    }
+}
+/* raw + audio path as the ctcss squelch tests do (src/test_squelch.cpp:167-281) */
+void refh_squelch_raw_audio(void* p, const float* raw, const float* audio, int n, unsigned char* is_open) {
+    Squelch* s = (Squelch*)p;
+    for (int i = 0; i < n; i++) {
+        s->process_raw_sample(raw[i]);
+        if (s->should_process_audio()) s->process_audio_sample(audio[i]);
+        if (is_open) is_open[i] = (unsigned char)((s->is_open() ? 1 : 0) | (s->should_process_audio() ? 2 : 0));
+    }
+}
+void refh_squelch_counts(void* p, uint64_t* out4) {
+    Squelch* s = (Squelch*)p;
+    out4[0] = s->open_count();
+    out4[1] = s->flappy_count();
+    out4[2] = s->ctcss_count();
+    out4[3] = s->no_ctcss_count();
+}
+void refh_squelch_free(void* p) { delete (Squelch*)p; }
+
+/* CTCSS detector alone (src/test_ctcss.cpp) */
+void refh_ctcss_run(float ctcss_freq, float sample_rate, int window, const float* x, int n, unsigned char* has_tone, uint64_t* counts2) {
+    CTCSS c(ctcss_freq, sample_rate, window);
+    for (int i = 0; i < n; i++) {
+        c.process_audio_sample(x[i]);
+        if (has_tone) has_tone[i] = (unsigned char)((c.has_tone() ? 1 : 0) | (c.enough_samples() ? 2 : 0));
+    }
+    counts2[0] = c.found_count();
+    counts2[1] = c.not_found_count();
+}
+
+float refh_tone_coeff(float f, float rate, int window) {
+    ToneDetector t(f, rate, window);
+    return t.coefficient();
+}
+
+/* filters alone */
+void refh_notch_run(float freq, float rate, float q, float* x, int n) {
+    NotchFilter f(freq, rate, q);
+    for (int i = 0; i < n; i++) f.apply(x[i]);
+}
+void refh_lowpass_run(float freq, float rate, float* re, float* im, int n) {
+    LowpassFilter f(freq, rate);
+    for (int i = 0; i < n; i++) f.apply(re[i], im[i]);
+}
+void refh_sincos_lut(uint32_t phi, float* s, float* c) { sincosf_lut(phi, s, c); }
+float refh_dbfs_to_level(float dbfs) { return dBFS_to_level(dbfs); }
+#ifdef NFM
+float refh_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+float refh_polar_disc_fast(float ar, float aj, float br, float bj) { return polar_disc_fast(ar, aj, br, bj); }
+float refh_fm_quadri_demod(float ar, float aj, float br, float bj) { return fm_quadri_demod(ar, aj, br, bj); }
+#endif
+
+/* ---- throughput mode (CPU baseline) ------------------------------------------------
+ * Ring of device d is pre-filled once with `iq` (buf_size bytes + tail) and kept "full" by moving the
+ * write cursor, so the timed region contains no memcpy: only demodulate() and the drain. Returns the
+ * number of batches completed over all devices in `seconds` of wall time. */
+long refh_throughput(const unsigned char* const* iq_per_device, double seconds, double* elapsed_out) {
+    for (int d = 0; d < device_count; d++) {
+        input_t* in = devices[d].input;
+        memcpy(in->buffer, iq_per_device[d], in->buf_size + 2 * in->bytes_per_sample * fft_size);
+        pthread_mutex_lock(&in->buffer_lock);
+        in->bufs = 0;
+        in->bufe = in->buf_size - refh_bps(in);
+        pthread_mutex_unlock(&in->buffer_lock);
+    }
+    struct timeval t0, t1;
+    gettimeofday(&t0, NULL);
+    long batches = 0;
+    double el = 0;
+    for (;;) {
+        for (int d = 0; d < device_count; d++) {
+            input_t* in = devices[d].input;
+            if (devices[d].waveavail) {
+                refh_drain(d, NULL, NULL, NULL);
+                batches++;
+            }
+            /* keep the ring full: write cursor trails the read cursor by one hop */
+            pthread_mutex_lock(&in->buffer_lock);
+            in->bufe = (in->bufs + in->buf_size - refh_bps(in)) % in->buf_size;
+            pthread_mutex_unlock(&in->buffer_lock);
+        }
+        gettimeofday(&t1, NULL);
+        el = (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);
+        if (el >= seconds) break;
+        sched_yield();
+    }
+    if (elapsed_out) *elapsed_out = el;
+    return batches;
+}
+
+} /* extern "C" */
