@@ -237,12 +237,19 @@ int airband_hip_read_trace(airband_hip_handle* h, uint8_t* state);
  *  [13] needs_raw_iq [14] window_fast [15] window_slow */
 int airband_hip_channel_constants(const airband_hip_handle* h, int32_t channel_index, double* out_vals);
 
+/* Same slots, computed without any GPU (pure host arithmetic): lets CPU-only tests pin the derivations. */
+int airband_hip_derive_constants(const airband_hip_config* cfg, int32_t channel_index, double* out_vals);
+
 /* Milliseconds the GPU spent in each stage during the last process call (HIP events on the handle's
  * stream): [0] channelizer kernel, [1] demod kernel(s), [2] emit/transposes, [3] whole batch. */
 int airband_hip_last_timings(airband_hip_handle* h, float* ms4);
 
 /* Name of the channelizer variant the handle selected ("fft_wave64" / "dft_mfma_i8"). */
 const char* airband_hip_channelizer_name(const airband_hip_handle* h);
+
+/* Uploads the transmitter table of the synthetic dongles: carriers [n_carriers][12] int64 rows
+ * (rtlsdr-airband_amd/siggen.py::Carrier.as_row), the Q8 noise multiplier and the 4096-entry int16 sine table. */
+int airband_hip_set_signal_plan(airband_hip_handle* h, const int64_t* carriers, int32_t n_carriers, int32_t noise_q8, const int16_t* sin_table4096);
 
 /* Deterministic synthetic dongles, generated on the GPU straight into HBM (integer-only arithmetic so
  * the numpy generator in the tests produces identical bytes).  Fills, for every device d in

@@ -1,0 +1,81 @@
+"""Builds libairband_hip.so in-tree (csrc/ -> rtlsdr-airband_amd/libairband_hip.so) with hipcc for gfx950.
+
+Host-only parameter derivation (params.cpp) is compiled with g++ so its libm / complex arithmetic is the
+platform's; kernels and the C-ABI driver are compiled with hipcc.  demod.hip gets -ffp-contract=off and IEEE
+divide/sqrt: its arithmetic has to match the reference's scalar float code bit for bit.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libairband_hip.so")
+ARCH = "gfx950"
+
+HIP_SOURCES = {
+    "channelizer_fft.hip": ["-O3"],
+    "channelizer_dft.hip": ["-O3"],
+    "misc_kernels.hip": ["-O3"],
+    "demod.hip": ["-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
+    "airband_hip.cpp": ["-O2", "-x", "hip"],
+}
+HOST_SOURCES = {"params.cpp": ["-O2", "-ffp-contract=off", "-fno-fast-math"]}
+
+
+def _newer(src: str, dst: str) -> bool:
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "airband_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd[:3]))
+    return r.stdout
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    changed = False
+    for name, flags in HIP_SOURCES.items():
+        src = os.path.join(CSRC, name)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(OBJ, name + ".o")
+        objs.append(obj)
+        if force or _newer(src, obj):
+            cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            _run(cmd)
+            changed = True
+    for name, flags in HOST_SOURCES.items():
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(OBJ, name + ".o")
+        objs.append(obj)
+        if force or _newer(src, obj):
+            cmd = ["g++", "-std=c++17", "-fPIC", "-Wall"] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            _run(cmd)
+            changed = True
+    if changed or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,--no-undefined"]
+        if verbose:
+            print(" ".join(cmd))
+        _run(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,625 @@
+/* csrc/airband_hip.cpp -- the C ABI of libairband_hip.so (see include/airband_hip.h) and the host-side batch
+ * driver: what demodulate() does around its two inner loops (reference: src/rtl_airband.cpp:359-400 input
+ * accounting, :494/:649-669 batch hand-off), restated for "all dongles, one batch at a time" on one HIP stream.
+ *
+ * There is NO CPU fallback in this library: every data-path entry point needs the HIP device the handle was
+ * prepared on and fails with AIRBAND_HIP_ENODEV / AIRBAND_HIP_ERUNTIME otherwise.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/airband_hip.h"
+#include "common.h"
+#include "kernels.h"
+#include "params.h"
+
+using namespace airband;
+
+namespace {
+
+thread_local std::string g_prepare_error;
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace
+
+struct airband_hip_handle {
+    Plan plan;
+    uint32_t flags = 0;
+    int hip_device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timings_valid = false;
+    std::string error;
+
+    /* geometry */
+    int B = 0, R = 0, N = 0;
+    long stride = 0;      /* floats per ring row */
+    int n_slots = 0;
+    int64_t hop_bytes = 0, first_batch_bytes = 0, batch_bytes = 0, lookahead_bytes = 0;
+    int row0 = 0;
+    uint64_t batches_done = 0;
+    bool results_ready = false;
+    uint64_t overruns = 0;
+
+    /* device memory */
+    DevBuf<DevConst> d_dev;
+    DevBuf<ChanConst> d_cc;
+    DevBuf<ChanState> d_cs;
+    DevBuf<int> d_slot_to_ext;
+    DevBuf<float> d_window, d_sin, d_cos;
+    DevBuf<float> d_mag, d_wave, d_sqbuf, d_ct_coeff, d_ct_q;
+    DevBuf<float2> d_iq, d_iq_out;
+    DevBuf<uint8_t> d_trace;
+    DevBuf<float> d_out_wave, d_out_iq;
+    DevBuf<uint8_t> d_out_axc;
+    DevBuf<airband_hip_channel_stats> d_stats;
+    DevBuf<float> d_tmp_wavein, d_tmp_iqin;
+    DevBuf<uint8_t> d_tmp_trace;
+    int ct_stride = 0;
+
+    /* host-ring path */
+    std::vector<std::vector<uint8_t>> pending; /* per dongle: stream bytes not yet consumed */
+    DevBuf<uint8_t> d_stage;
+    uint8_t* h_stage = nullptr;                /* pinned */
+    int64_t stage_stride = 0;
+
+    /* mixers */
+    int n_mixers = 0;
+    DevBuf<int> d_mix_chan, d_mix_first;
+    DevBuf<float> d_mix_ml, d_mix_mr, d_mix_left, d_mix_right;
+    DevBuf<uint8_t> d_mix_stereo, d_mix_signal;
+
+    /* synthetic dongles */
+    DevBuf<int16_t> d_sin_tab;
+    DevBuf<long long> d_carriers;
+    int n_carriers = 0, noise_q8 = 0;
+};
+
+namespace {
+
+int fail(airband_hip_handle* h, int code, const std::string& msg) {
+    if (h) h->error = msg;
+    else g_prepare_error = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr, code)                                                                                   \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) return fail(h, code, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+template <class T>
+hipError_t upload(DevBuf<T>& b, const std::vector<T>& v) {
+    hipError_t e = b.alloc(v.size());
+    if (e != hipSuccess) return e;
+    if (v.empty()) return hipSuccess;
+    return hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+void destroy(airband_hip_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->hip_device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->d_dev.release(); h->d_cc.release(); h->d_cs.release(); h->d_slot_to_ext.release();
+    h->d_window.release(); h->d_sin.release(); h->d_cos.release();
+    h->d_mag.release(); h->d_wave.release(); h->d_sqbuf.release(); h->d_ct_coeff.release(); h->d_ct_q.release();
+    h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release();
+    h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
+    h->d_tmp_wavein.release(); h->d_tmp_iqin.release(); h->d_tmp_trace.release();
+    h->d_stage.release();
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    h->d_mix_chan.release(); h->d_mix_first.release(); h->d_mix_ml.release(); h->d_mix_mr.release();
+    h->d_mix_left.release(); h->d_mix_right.release(); h->d_mix_stereo.release(); h->d_mix_signal.release();
+    h->d_sin_tab.release(); h->d_carriers.release();
+    for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+template <class T>
+hipError_t fill(T* p, size_t n, T value, hipStream_t s) {
+    std::vector<T> v(n, value);
+    return hipMemcpyAsync(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice, s);
+}
+
+/* stage 2 + emit (+ mixers) of the batch whose stage-1 rows are already in the rings */
+int run_back_half(airband_hip_handle* h, hipStream_t s) {
+    DemodArgs da;
+    da.cc = h->d_cc.p;
+    da.cs = h->d_cs.p;
+    da.mag = h->d_mag.p;
+    da.iq = h->d_iq.p;
+    da.wave = h->d_wave.p;
+    da.iq_out = h->d_iq_out.p;
+    da.sqbuf = h->d_sqbuf.p;
+    da.ct_coeff = h->d_ct_coeff.p;
+    da.ct_q = h->d_ct_q.p;
+    da.trace = (h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH) ? h->d_trace.p : nullptr;
+    da.sin_lut = h->d_sin.p;
+    da.cos_lut = h->d_cos.p;
+    da.stride = h->stride;
+    da.ct_stride = h->ct_stride;
+    da.n_slots = h->n_slots;
+    da.wave_batch = h->B;
+    da.row0 = h->row0;
+    da.ring_rows = h->R;
+    launch_demod(da, s);
+    (void)hipEventRecord(h->ev[2], s);
+
+    EmitArgs ea;
+    ea.wave = h->d_wave.p;
+    ea.iq_out = h->d_iq_out.p;
+    ea.cs = h->d_cs.p;
+    ea.slot_to_ext = h->d_slot_to_ext.p;
+    ea.out_wave = h->d_out_wave.p;
+    ea.out_iq = h->d_out_iq.p;
+    ea.out_axc = h->d_out_axc.p;
+    ea.stride = h->stride;
+    ea.n_slots = h->n_slots;
+    ea.wave_batch = h->B;
+    ea.row0 = h->row0;
+    ea.ring_rows = h->R;
+    launch_emit(ea, s);
+    if (h->n_mixers > 0) {
+        MixArgs ma;
+        ma.out_wave = h->d_out_wave.p;
+        ma.out_axc = h->d_out_axc.p;
+        ma.in_chan = h->d_mix_chan.p;
+        ma.in_ml = h->d_mix_ml.p;
+        ma.in_mr = h->d_mix_mr.p;
+        ma.mixer_first = h->d_mix_first.p;
+        ma.mixer_stereo = h->d_mix_stereo.p;
+        ma.left = h->d_mix_left.p;
+        ma.right = h->d_mix_right.p;
+        ma.has_signal = h->d_mix_signal.p;
+        ma.n_mixers = h->n_mixers;
+        ma.wave_batch = h->B;
+        launch_mix(ma, s);
+    }
+    (void)hipEventRecord(h->ev[3], s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, AIRBAND_HIP_ERUNTIME, std::string("kernel launch: ") + hipGetErrorString(e));
+    /* rotate the rings: this batch's last AGC_EXTRA rows become the next batch's carry */
+    h->row0 = (h->row0 + h->B) % h->R;
+    h->batches_done++;
+    if (h->results_ready) h->overruns++; /* like dev->output_overrun_count (src/rtl_airband.cpp:649-654) */
+    h->results_ready = true;
+    h->timings_valid = true;
+    return AIRBAND_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* airband_hip_last_error(const airband_hip_handle* h) { return h ? h->error.c_str() : g_prepare_error.c_str(); }
+
+int airband_hip_derive_constants(const airband_hip_config* cfg, int32_t channel_index, double* out_vals) {
+    Plan plan;
+    int rc = build_plan(cfg, plan);
+    if (rc != AIRBAND_HIP_OK) return fail(nullptr, rc, plan.error);
+    if (channel_index < 0 || channel_index >= plan.total_ch || !out_vals) return fail(nullptr, AIRBAND_HIP_EINVAL, "bad channel index");
+    channel_constants(plan, channel_index, out_vals);
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out) {
+    if (!out) return fail(nullptr, AIRBAND_HIP_EINVAL, "out is NULL");
+    *out = nullptr;
+    airband_hip_handle* h = new (std::nothrow) airband_hip_handle();
+    if (!h) return fail(nullptr, AIRBAND_HIP_ENOMEM, "host allocation failed");
+    int rc = build_plan(cfg, h->plan);
+    if (rc != AIRBAND_HIP_OK) {
+        g_prepare_error = h->plan.error;
+        delete h;
+        return rc;
+    }
+    const Plan& p = h->plan;
+    if (!p.uniform_hop) {
+        delete h;
+        return fail(nullptr, AIRBAND_HIP_EINVAL, "all dongles of one handle must share sample format and sample_rate/WAVE_RATE hop; use one handle per class");
+    }
+    for (const ChanConst& c : p.cc)
+        if (c.afc != 0) {
+            delete h;
+            return fail(nullptr, AIRBAND_HIP_EINVAL, "afc is not implemented by this backend yet (reference default is afc=0, src/config.cpp:352)");
+        }
+    h->flags = cfg->flags;
+    h->hip_device = cfg->hip_device;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->hip_device < 0 || cfg->hip_device >= ndev) {
+        delete h;
+        return fail(nullptr, AIRBAND_HIP_ENODEV, "no usable HIP device (libairband_hip has no CPU fallback)");
+    }
+#define PREP_TRY(expr, code)                                                                 \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            g_prepare_error = std::string(#expr) + ": " + hipGetErrorString(e_);             \
+            destroy(h);                                                                      \
+            return code;                                                                     \
+        }                                                                                    \
+    } while (0)
+    PREP_TRY(hipSetDevice(cfg->hip_device), AIRBAND_HIP_ENODEV);
+    PREP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), AIRBAND_HIP_ENODEV);
+    for (auto& e : h->ev) PREP_TRY(hipEventCreate(&e), AIRBAND_HIP_ENODEV);
+
+    h->B = p.wave_batch;
+    h->R = p.wave_batch + AB_AGC_EXTRA;
+    h->N = p.fft_size;
+    h->n_slots = p.total_ch;
+    h->stride = ((long)p.total_ch + 63) / 64 * 64;
+    h->hop_bytes = 2LL * p.dev[0].bytes_per_sample * p.dev[0].hop_samples;
+    h->first_batch_bytes = h->hop_bytes * (h->B + AB_AGC_EXTRA);
+    h->batch_bytes = h->hop_bytes * h->B;
+    h->lookahead_bytes = 2LL * p.dev[0].bytes_per_sample * p.fft_size - h->hop_bytes;
+    if (h->lookahead_bytes < 0) h->lookahead_bytes = 0;
+
+    /* constants */
+    PREP_TRY(upload(h->d_dev, p.dev), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(upload(h->d_cc, p.cc), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(upload(h->d_cs, p.cs0), AIRBAND_HIP_ENOMEM);
+    {
+        std::vector<int> ident(p.total_ch);
+        for (int i = 0; i < p.total_ch; i++) ident[i] = i;
+        PREP_TRY(upload(h->d_slot_to_ext, ident), AIRBAND_HIP_ENOMEM);
+    }
+    PREP_TRY(upload(h->d_window, p.window), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(upload(h->d_sin, p.sin_lut), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(upload(h->d_cos, p.cos_lut), AIRBAND_HIP_ENOMEM);
+    /* CTCSS tables, tone-major so a wave of CTCSS lanes reads contiguous words */
+    {
+        const int n_ct = (int)p.tones.size();
+        h->ct_stride = n_ct > 0 ? (n_ct + 63) / 64 * 64 : 64;
+        std::vector<float> coeff((size_t)2 * AB_MAX_TONES * h->ct_stride, 0.0f);
+        for (int s = 0; s < n_ct; s++)
+            for (int k = 0; k < 2; k++)
+                for (int t = 0; t < p.tones[s].n[k]; t++) coeff[((size_t)k * AB_MAX_TONES + t) * h->ct_stride + s] = p.tones[s].coeff[k][t];
+        PREP_TRY(upload(h->d_ct_coeff, coeff), AIRBAND_HIP_ENOMEM);
+        PREP_TRY(h->d_ct_q.alloc((size_t)2 * AB_MAX_TONES * 2 * h->ct_stride), AIRBAND_HIP_ENOMEM);
+        PREP_TRY(hipMemset(h->d_ct_q.p, 0, h->d_ct_q.n * sizeof(float)), AIRBAND_HIP_ENOMEM);
+    }
+    /* rings, with the reference's config-time prefill of the lead-in (src/config.cpp:313-316) */
+    const size_t ring = (size_t)h->R * h->stride;
+    PREP_TRY(h->d_mag.alloc(ring), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(h->d_wave.alloc(ring), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(h->d_iq.alloc(ring), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(h->d_iq_out.alloc((size_t)h->B * h->stride), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(h->d_sqbuf.alloc((size_t)AB_SQ_BUF * h->stride), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(fill(h->d_mag.p, ring, 20.0f, h->stream), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(fill(h->d_wave.p, ring, 0.5f, h->stream), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(hipStreamSynchronize(h->stream), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(hipMemset(h->d_iq.p, 0, ring * sizeof(float2)), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(hipMemset(h->d_iq_out.p, 0, (size_t)h->B * h->stride * sizeof(float2)), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(hipMemset(h->d_sqbuf.p, 0, (size_t)AB_SQ_BUF * h->stride * sizeof(float)), AIRBAND_HIP_ENOMEM);
+    if (h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH) {
+        PREP_TRY(h->d_trace.alloc((size_t)h->B * h->stride), AIRBAND_HIP_ENOMEM);
+        PREP_TRY(hipMemset(h->d_trace.p, 0, (size_t)h->B * h->stride), AIRBAND_HIP_ENOMEM);
+    }
+    /* results */
+    PREP_TRY(h->d_out_wave.alloc((size_t)p.total_ch * h->B), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(h->d_out_axc.alloc((size_t)p.total_ch), AIRBAND_HIP_ENOMEM);
+    bool any_iq_out = false;
+    for (const ChanConst& c : p.cc) any_iq_out |= (c.flags & AB_F_IQ_OUT) != 0;
+    if (any_iq_out) {
+        PREP_TRY(h->d_out_iq.alloc((size_t)p.total_ch * h->B * 2), AIRBAND_HIP_ENOMEM);
+        PREP_TRY(hipMemset(h->d_out_iq.p, 0, h->d_out_iq.n * sizeof(float)), AIRBAND_HIP_ENOMEM);
+    }
+    h->pending.resize(p.n_dev);
+#undef PREP_TRY
+    *out = h;
+    return AIRBAND_HIP_OK;
+}
+
+void airband_hip_release(airband_hip_handle* h) { destroy(h); }
+
+int airband_hip_get_geometry(const airband_hip_handle* h, airband_hip_geometry* g) {
+    if (!h || !g) return AIRBAND_HIP_EINVAL;
+    g->fft_size = h->N;
+    g->wave_rate = h->plan.wave_rate;
+    g->wave_batch = h->B;
+    g->device_count = h->plan.n_dev;
+    g->total_channels = h->plan.total_ch;
+    g->max_channels = h->plan.max_ch;
+    g->mixer_count = h->n_mixers;
+    g->reserved = 0;
+    g->first_batch_bytes = h->first_batch_bytes;
+    g->batch_bytes = h->batch_bytes;
+    g->lookahead_bytes = h->lookahead_bytes;
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const airband_hip_mixer_input* in, int32_t n_in) {
+    if (!h || mixer_count < 1 || !in || n_in < 1) return fail(h, AIRBAND_HIP_EINVAL, "bad mixer arguments");
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    const Plan& p = h->plan;
+    std::vector<int> first(mixer_count + 1, 0), chan(n_in);
+    std::vector<float> ml(n_in), mr(n_in);
+    std::vector<uint8_t> stereo(mixer_count, 0);
+    for (int i = 0; i < n_in; i++) {
+        if (in[i].mixer < 0 || in[i].mixer >= mixer_count || in[i].device < 0 || in[i].device >= p.n_dev || in[i].channel < 0 ||
+            in[i].channel >= p.dev[in[i].device].n_ch)
+            return fail(h, AIRBAND_HIP_EINVAL, "mixer input out of range");
+        first[in[i].mixer + 1]++;
+        if (in[i].balance != 0.0f) stereo[in[i].mixer] = 1; /* src/mixer.cpp:84-85 */
+    }
+    for (int m = 0; m < mixer_count; m++) first[m + 1] += first[m];
+    std::vector<int> cur(first.begin(), first.end() - 1);
+    for (int i = 0; i < n_in; i++) { /* stable: connection order inside a mixer is kept (summation order) */
+        const int k = cur[in[i].mixer]++;
+        chan[k] = p.chan_base[in[i].device] + in[i].channel;
+        ml[k] = in[i].ampfactor * fminf(1.0f, 1.0f - in[i].balance); /* src/mixer.cpp:82-83,203-208 */
+        mr[k] = in[i].ampfactor * fminf(1.0f, 1.0f + in[i].balance);
+    }
+    h->d_mix_chan.release(); h->d_mix_first.release(); h->d_mix_ml.release(); h->d_mix_mr.release();
+    h->d_mix_left.release(); h->d_mix_right.release(); h->d_mix_stereo.release(); h->d_mix_signal.release();
+    HIP_TRY(h, upload(h->d_mix_chan, chan), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, upload(h->d_mix_first, first), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, upload(h->d_mix_ml, ml), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, upload(h->d_mix_mr, mr), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, upload(h->d_mix_stereo, stereo), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, h->d_mix_left.alloc((size_t)mixer_count * h->B), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, h->d_mix_right.alloc((size_t)mixer_count * h->B), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, h->d_mix_signal.alloc((size_t)mixer_count), AIRBAND_HIP_ENOMEM);
+    h->n_mixers = mixer_count;
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t stride_bytes, void* stream) {
+    if (!h || !d_iq) return fail(h, AIRBAND_HIP_EINVAL, "NULL argument");
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    const Plan& p = h->plan;
+    const bool first = h->batches_done == 0;
+    ChannelizerArgs ca;
+    ca.iq = (const uint8_t*)d_iq;
+    ca.iq_stride = (long)stride_bytes;
+    ca.dev = h->d_dev.p;
+    ca.cs = h->d_cs.p;
+    ca.cc = h->d_cc.p;
+    ca.window = h->d_window.p;
+    ca.mag = h->d_mag.p;
+    ca.iq_bins = h->d_iq.p;
+    ca.last_spectrum = nullptr;
+    ca.stride = h->stride;
+    ca.n_dev = p.n_dev;
+    ca.fft_log = p.fft_log;
+    ca.hop_samples = p.dev[0].hop_samples;
+    ca.bytes_per_sample = p.dev[0].bytes_per_sample;
+    ca.sfmt = p.dev[0].sfmt;
+    ca.scale = p.dev[0].scale;
+    ca.row0 = h->row0;
+    ca.ring_rows = h->R;
+    ca.first_row = first ? 0 : AB_AGC_EXTRA; /* the first batch also produces the AGC_EXTRA lead-in hops (waveend starts at 0, src/config.cpp:805) */
+    ca.n_hops = first ? h->B + AB_AGC_EXTRA : h->B;
+    ca.max_ch = p.max_ch;
+    (void)hipEventRecord(h->ev[0], s);
+    launch_channelizer_fft(ca, s);
+    (void)hipEventRecord(h->ev[1], s);
+    return run_back_half(h, s);
+}
+
+int64_t airband_hip_submit(airband_hip_handle* h, int32_t dev, const void* iq, size_t nbytes) {
+    if (!h || !iq) return fail(h, AIRBAND_HIP_EINVAL, "NULL argument");
+    if (dev < 0 || dev >= h->plan.n_dev) return fail(h, AIRBAND_HIP_EINVAL, "device index out of range");
+    /* bounded like the reference's ring (MIN_BUF_SIZE = 2 560 000 bytes ~ 4 batches, src/rtl_airband.h:64): at most
+     * first batch + 4 batches may be queued */
+    const size_t cap = (size_t)(h->first_batch_bytes + 4 * h->batch_bytes + h->lookahead_bytes);
+    std::vector<uint8_t>& q = h->pending[dev];
+    size_t take = nbytes;
+    if (q.size() + take > cap) take = cap > q.size() ? cap - q.size() : 0;
+    q.insert(q.end(), (const uint8_t*)iq, (const uint8_t*)iq + take);
+    return (int64_t)take;
+}
+
+int airband_hip_process(airband_hip_handle* h) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    const bool first = h->batches_done == 0;
+    const int64_t consume = first ? h->first_batch_bytes : h->batch_bytes;
+    const int64_t need = consume + h->lookahead_bytes; /* availability rule (src/rtl_airband.cpp:394-400) applied to a whole batch */
+    for (auto& q : h->pending)
+        if ((int64_t)q.size() < need) return AIRBAND_HIP_EAGAIN;
+    if (!h->d_stage.p) {
+        h->stage_stride = (h->first_batch_bytes + h->lookahead_bytes + 255) / 256 * 256;
+        HIP_TRY(h, h->d_stage.alloc((size_t)h->stage_stride * h->plan.n_dev), AIRBAND_HIP_ENOMEM);
+        HIP_TRY(h, hipHostMalloc((void**)&h->h_stage, (size_t)h->stage_stride * h->plan.n_dev, hipHostMallocDefault), AIRBAND_HIP_ENOMEM);
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream), AIRBAND_HIP_ERUNTIME); /* previous batch may still read the staging buffer */
+    for (int d = 0; d < h->plan.n_dev; d++) {
+        std::vector<uint8_t>& q = h->pending[d];
+        std::memcpy(h->h_stage + (size_t)d * h->stage_stride, q.data(), (size_t)need);
+        q.erase(q.begin(), q.begin() + consume);
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_stage.p, h->h_stage, (size_t)h->stage_stride * h->plan.n_dev, hipMemcpyHostToDevice, h->stream), AIRBAND_HIP_ERUNTIME);
+    return airband_hip_process_device(h, h->d_stage.p, (size_t)h->stage_stride, nullptr);
+}
+
+int airband_hip_process_bins(airband_hip_handle* h, const float* wavein, const float* iq_in) {
+    if (!h || !wavein || !iq_in) return fail(h, AIRBAND_HIP_EINVAL, "NULL argument");
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    const size_t n = (size_t)h->plan.total_ch * h->B;
+    if (!h->d_tmp_wavein.p) {
+        HIP_TRY(h, h->d_tmp_wavein.alloc(n), AIRBAND_HIP_ENOMEM);
+        HIP_TRY(h, h->d_tmp_iqin.alloc(2 * n), AIRBAND_HIP_ENOMEM);
+    }
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_tmp_wavein.p, wavein, n * sizeof(float), hipMemcpyHostToDevice, s), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipMemcpyAsync(h->d_tmp_iqin.p, iq_in, 2 * n * sizeof(float), hipMemcpyHostToDevice, s), AIRBAND_HIP_ERUNTIME);
+    (void)hipEventRecord(h->ev[0], s);
+    launch_scatter_bins(h->d_tmp_wavein.p, h->d_tmp_iqin.p, h->d_slot_to_ext.p, h->d_cc.p, h->d_mag.p, h->d_iq.p, h->stride, h->n_slots, h->B, h->row0, h->R, s);
+    (void)hipEventRecord(h->ev[1], s);
+    return run_back_half(h, s);
+}
+
+int airband_hip_synchronize(airband_hip_handle* h) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    HIP_TRY(h, hipStreamSynchronize(h->stream), AIRBAND_HIP_ERUNTIME);
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_collect(airband_hip_handle* h, float* waveout, float* iq_out, char* axc, airband_hip_channel_stats* stats) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    if (!h->results_ready) return AIRBAND_HIP_EAGAIN;
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    hipStream_t s = h->stream;
+    const size_t nch = (size_t)h->plan.total_ch;
+    if (stats) {
+        if (!h->d_stats.p) HIP_TRY(h, h->d_stats.alloc(nch), AIRBAND_HIP_ENOMEM);
+        launch_stats(h->d_cc.p, h->d_cs.p, h->d_slot_to_ext.p, h->n_slots, h->d_stats.p, s);
+        HIP_TRY(h, hipMemcpyAsync(stats, h->d_stats.p, nch * sizeof(airband_hip_channel_stats), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
+    }
+    if (waveout) HIP_TRY(h, hipMemcpyAsync(waveout, h->d_out_wave.p, nch * h->B * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
+    if (iq_out) {
+        if (h->d_out_iq.p)
+            HIP_TRY(h, hipMemcpyAsync(iq_out, h->d_out_iq.p, nch * h->B * 2 * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
+        else
+            std::memset(iq_out, 0, nch * h->B * 2 * sizeof(float));
+    }
+    if (axc) HIP_TRY(h, hipMemcpyAsync(axc, h->d_out_axc.p, nch, hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipStreamSynchronize(s), AIRBAND_HIP_ERUNTIME);
+    h->results_ready = false;
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_collect_mixers(airband_hip_handle* h, float* left, float* right, uint8_t* has_signal) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    if (h->n_mixers <= 0) return fail(h, AIRBAND_HIP_EINVAL, "no mixers configured");
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    hipStream_t s = h->stream;
+    const size_t n = (size_t)h->n_mixers * h->B;
+    if (left) HIP_TRY(h, hipMemcpyAsync(left, h->d_mix_left.p, n * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
+    if (right) HIP_TRY(h, hipMemcpyAsync(right, h->d_mix_right.p, n * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
+    if (has_signal) HIP_TRY(h, hipMemcpyAsync(has_signal, h->d_mix_signal.p, (size_t)h->n_mixers, hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipStreamSynchronize(s), AIRBAND_HIP_ERUNTIME);
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_device_results(airband_hip_handle* h, float** d_waveout, float** d_iq_out, uint8_t** d_axc, float** d_mix_left, float** d_mix_right,
+                               uint8_t** d_mix_signal) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    if (d_waveout) *d_waveout = h->d_out_wave.p;
+    if (d_iq_out) *d_iq_out = h->d_out_iq.p;
+    if (d_axc) *d_axc = h->d_out_axc.p;
+    if (d_mix_left) *d_mix_left = h->d_mix_left.p;
+    if (d_mix_right) *d_mix_right = h->d_mix_right.p;
+    if (d_mix_signal) *d_mix_signal = h->d_mix_signal.p;
+    return AIRBAND_HIP_OK;
+}
+
+static int gather_last(airband_hip_handle* h, float* wavein, float* iq_in, uint8_t* trace) {
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    if (h->batches_done == 0) return fail(h, AIRBAND_HIP_EAGAIN, "no batch processed yet");
+    const size_t n = (size_t)h->plan.total_ch * h->B;
+    if (!h->d_tmp_wavein.p) {
+        HIP_TRY(h, h->d_tmp_wavein.alloc(n), AIRBAND_HIP_ENOMEM);
+        HIP_TRY(h, h->d_tmp_iqin.alloc(2 * n), AIRBAND_HIP_ENOMEM);
+    }
+    if (trace && !h->d_tmp_trace.p) HIP_TRY(h, h->d_tmp_trace.alloc(n), AIRBAND_HIP_ENOMEM);
+    hipStream_t s = h->stream;
+    const int prev_row0 = (h->row0 + h->R - h->B) % h->R; /* row0 of the batch just finished */
+    launch_gather_bins(h->d_mag.p, h->d_iq.p, h->d_trace.p, h->d_slot_to_ext.p, wavein ? h->d_tmp_wavein.p : nullptr, iq_in ? h->d_tmp_iqin.p : nullptr,
+                       trace ? h->d_tmp_trace.p : nullptr, h->stride, h->n_slots, h->B, prev_row0, h->R, s);
+    if (wavein) HIP_TRY(h, hipMemcpyAsync(wavein, h->d_tmp_wavein.p, n * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
+    if (iq_in) HIP_TRY(h, hipMemcpyAsync(iq_in, h->d_tmp_iqin.p, 2 * n * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
+    if (trace) HIP_TRY(h, hipMemcpyAsync(trace, h->d_tmp_trace.p, n, hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipStreamSynchronize(s), AIRBAND_HIP_ERUNTIME);
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_read_bins(airband_hip_handle* h, float* wavein, float* iq_in) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    return gather_last(h, wavein, iq_in, nullptr);
+}
+
+int airband_hip_read_trace(airband_hip_handle* h, uint8_t* state) {
+    if (!h || !state) return AIRBAND_HIP_EINVAL;
+    if (!(h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH)) return fail(h, AIRBAND_HIP_EINVAL, "handle was prepared without AIRBAND_HIP_FLAG_TRACE_SQUELCH");
+    return gather_last(h, nullptr, nullptr, state);
+}
+
+int airband_hip_channel_constants(const airband_hip_handle* h, int32_t channel_index, double* out_vals) {
+    if (!h || !out_vals || channel_index < 0 || channel_index >= h->plan.total_ch) return AIRBAND_HIP_EINVAL;
+    channel_constants(h->plan, channel_index, out_vals);
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_last_timings(airband_hip_handle* h, float* ms4) {
+    if (!h || !ms4) return AIRBAND_HIP_EINVAL;
+    if (!h->timings_valid) return AIRBAND_HIP_EAGAIN;
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    HIP_TRY(h, hipEventSynchronize(h->ev[3]), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipEventElapsedTime(&ms4[0], h->ev[0], h->ev[1]), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipEventElapsedTime(&ms4[1], h->ev[1], h->ev[2]), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipEventElapsedTime(&ms4[2], h->ev[2], h->ev[3]), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipEventElapsedTime(&ms4[3], h->ev[0], h->ev[3]), AIRBAND_HIP_ERUNTIME);
+    return AIRBAND_HIP_OK;
+}
+
+const char* airband_hip_channelizer_name(const airband_hip_handle* h) {
+    (void)h;
+    return "fft_wave64";
+}
+
+int airband_hip_set_signal_plan(airband_hip_handle* h, const int64_t* carriers, int32_t n_carriers, int32_t noise_q8, const int16_t* sin_table4096) {
+    if (!h || !carriers || !sin_table4096 || n_carriers < 1 || n_carriers > 16) return fail(h, AIRBAND_HIP_EINVAL, "bad signal plan (1..16 carriers)");
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    h->d_carriers.release();
+    h->d_sin_tab.release();
+    std::vector<long long> c(carriers, carriers + (size_t)n_carriers * 12);
+    std::vector<int16_t> t(sin_table4096, sin_table4096 + 4096);
+    HIP_TRY(h, upload(h->d_carriers, c), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, upload(h->d_sin_tab, t), AIRBAND_HIP_ENOMEM);
+    h->n_carriers = n_carriers;
+    h->noise_q8 = noise_q8;
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_generate_iq(airband_hip_handle* h, void* d_iq, size_t stride_bytes, uint64_t start_byte, size_t nbytes, uint64_t seed, int32_t device_index_offset,
+                            void* stream) {
+    if (!h || !d_iq) return fail(h, AIRBAND_HIP_EINVAL, "NULL argument");
+    if (h->n_carriers == 0) return fail(h, AIRBAND_HIP_EINVAL, "call airband_hip_set_signal_plan first");
+    if (h->plan.dev[0].sfmt != AIRBAND_SFMT_U8) return fail(h, AIRBAND_HIP_EINVAL, "the synthetic generator emits u8 I/Q");
+    if ((start_byte & 1) || (nbytes & 1)) return fail(h, AIRBAND_HIP_EINVAL, "byte ranges must cover whole I/Q pairs");
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    SiggenArgs a;
+    a.iq = (uint8_t*)d_iq;
+    a.stride = (long)stride_bytes;
+    a.sin_tab = h->d_sin_tab.p;
+    a.carriers = h->d_carriers.p;
+    a.n_carriers = h->n_carriers;
+    a.n_dev = h->plan.n_dev;
+    a.dev_offset = device_index_offset;
+    a.start_sample = start_byte / 2;
+    a.n_samples = (long)(nbytes / 2);
+    a.seed = seed;
+    a.noise_q8 = h->noise_q8;
+    launch_siggen(a, stream ? (hipStream_t)stream : h->stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, AIRBAND_HIP_ERUNTIME, std::string("siggen launch: ") + hipGetErrorString(e));
+    return AIRBAND_HIP_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,87 @@
+/* csrc/common.h -- data model shared by the host side (params.cpp, airband_hip.cpp) and the HIP kernels.
+ *
+ * Vocabulary follows the reference: a "dongle" is a device_t (reference: src/rtl_airband.h:249-272), a
+ * "channel" is a channel_t with its single freq_t in multichannel mode (:223-247,:201-221), a "hop" is one
+ * slide of the FFT window = one output audio sample (src/rtl_airband.cpp:394,669), a "batch" is WAVE_BATCH
+ * hops (src/rtl_airband.h:73).
+ */
+#ifndef AIRBAND_CSRC_COMMON_H
+#define AIRBAND_CSRC_COMMON_H
+
+#include <stdint.h>
+
+#define AB_AGC_EXTRA 100  /* AGC_EXTRA, src/rtl_airband.h:74 */
+#define AB_SQ_BUF 102     /* Squelch::buffer_size_, src/squelch.cpp:66 */
+#define AB_MAX_TONES 52   /* target + 51 standard CTCSS tones, src/ctcss.cpp:101-122 */
+#define AB_MAX_CH_PER_DEV 64
+
+/* Squelch::State numeric values (src/squelch.h:102-108) */
+enum { AB_ST_CLOSED = 0, AB_ST_OPENING = 1, AB_ST_CLOSING = 2, AB_ST_ABORT = 3, AB_ST_OPEN = 4 };
+
+/* ChanConst.flags */
+#define AB_F_NOTCH 0x1u
+#define AB_F_LOWPASS 0x2u
+#define AB_F_CTCSS 0x4u
+#define AB_F_MANUAL 0x8u
+#define AB_F_RAW_IQ 0x10u
+#define AB_F_IQ_OUT 0x20u
+#define AB_F_NFM 0x40u
+#define AB_F_QUADRI 0x80u
+#define AB_F_VALID 0x100u
+
+/* Per-channel constants (derived once by params.cpp the way src/config.cpp does). */
+struct ChanConst {
+    uint32_t flags;
+    int32_t dev;        /* dongle index */
+    int32_t chan;       /* channel index inside the dongle */
+    int32_t ext_index;  /* device-major external channel number */
+    int32_t base_bin;   /* dev->base_bins[i], src/config.cpp:666-667 */
+    int32_t afc;        /* channel_t.afc */
+    uint32_t dm_dphi;   /* src/config.cpp:679-712 */
+    float alpha;        /* NFM de-emphasis, src/rtl_airband.cpp:87, src/config.cpp:648,775 */
+    float ampfactor;
+    float notch_d0, notch_d1, notch_d2;        /* src/filters.cpp:41-47 */
+    float lp_gain, lp_yc0, lp_yc1;             /* src/filters.cpp:90-96 */
+    float sq_manual_level;                     /* Squelch::manual_signal_level_ */
+    float sq_normal_ratio, sq_flappy_ratio;    /* src/squelch.cpp:93-103 */
+    int32_t ct_slot;                           /* index into the CTCSS tone tables, -1 = none */
+    int32_t ct_ntones[2];                      /* [0] fast detector, [1] slow detector */
+    int32_t ct_window[2];
+    int32_t pad[2];
+};
+
+/* Per-channel mutable state that survives from batch to batch. */
+struct ChanState {
+    /* freq_t / channel_t */
+    float agcavgfast, pr, pj, prev_waveout;
+    uint32_t dm_phi;
+    int32_t bin; /* dev->bins[i]; moves only with AFC */
+    int32_t axc; /* channel->axcindicate of the last batch */
+    uint32_t active_counter;
+    /* Squelch (src/squelch.h:117-158) */
+    float noise_floor, cap, pre_full, pre_capped, post_full, post_capped, level_cache;
+    int32_t using_post, next, cur, delay, low_count, head, tail;
+    uint32_t sample_count; /* only (count % 16) is observable; starts at 0xffffffff like size_t(-1) */
+    uint32_t open_count, flappy_count, recent_open, closed_count;
+    /* NotchFilter / LowpassFilter delay lines */
+    float nx[3], ny[3];
+    float lxr[3], lxi[3], lyr[3], lyi[3];
+    /* CTCSS detectors: [0] fast, [1] slow (src/ctcss.h:84-95) */
+    int32_t ct_enough[2], ct_count[2], ct_has_tone[2];
+    uint32_t ct_found[2], ct_not_found[2];
+    int32_t pad[3];
+};
+
+/* Per-dongle constants for the channelizer. */
+struct DevConst {
+    int32_t sfmt;          /* AIRBAND_SFMT_* */
+    int32_t bytes_per_sample;
+    int32_t hop_samples;   /* round(sample_rate / WAVE_RATE), src/rtl_airband.cpp:394 */
+    int32_t n_ch;
+    int32_t chan_base;     /* first internal slot of this dongle's channels */
+    float scale;           /* 1/fullscale for S16/F32 (src/rtl_airband.cpp:403,421) */
+    int32_t any_raw_iq;
+    int32_t pad;
+};
+
+#endif

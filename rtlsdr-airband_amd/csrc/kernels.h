@@ -1,0 +1,111 @@
+/* csrc/kernels.h -- launch interfaces of the HIP kernels (host side: airband_hip.cpp). */
+#ifndef AIRBAND_CSRC_KERNELS_H
+#define AIRBAND_CSRC_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/airband_hip.h"
+#include "common.h"
+
+namespace airband {
+
+/* Device buffers are time-major rings: logical row r of the current batch lives at physical row
+ * (row0 + r) mod ring_rows, ring_rows = WAVE_BATCH + AGC_EXTRA.  Logical rows [0, AGC_EXTRA) are the carry from
+ * the previous batch (what the reference keeps with its memmove / tail copy, src/rtl_airband.cpp:621-624 and
+ * src/output.cpp:920), rows [AGC_EXTRA, AGC_EXTRA + WAVE_BATCH) are this batch's new hops.  Advancing row0 by
+ * WAVE_BATCH per batch replaces both copies. */
+
+struct ChannelizerArgs {
+    const uint8_t* iq;      /* device: dongle d's span starts at iq + d * iq_stride */
+    long iq_stride;         /* bytes */
+    const DevConst* dev;
+    const ChanState* cs;    /* for the (AFC-movable) bin of every slot */
+    const ChanConst* cc;
+    const float* window;    /* fft_size */
+    float* mag;             /* [ring_rows][stride] */
+    float2* iq_bins;        /* [ring_rows][stride] */
+    float* last_spectrum;   /* [n_dev][2*fft_size] full FFT of the batch's last hop (AFC), or null */
+    long stride;
+    int n_dev, fft_log;
+    int hop_samples, bytes_per_sample, sfmt;
+    float scale;
+    int row0, ring_rows;
+    int first_row;          /* first logical row to produce (0 on the first batch, AGC_EXTRA later) */
+    int n_hops;             /* hops to produce */
+    int max_ch;
+};
+
+struct DemodArgs {
+    const ChanConst* cc;
+    ChanState* cs;
+    float* mag;
+    const float2* iq;
+    float* wave;            /* [ring_rows][stride] */
+    float2* iq_out;         /* [wave_batch][stride] */
+    float* sqbuf;           /* [AB_SQ_BUF][stride] */
+    const float* ct_coeff;  /* [2][AB_MAX_TONES][ct_stride] */
+    float* ct_q;            /* [2][AB_MAX_TONES][2][ct_stride] */
+    uint8_t* trace;         /* [wave_batch][stride] or null */
+    const float* sin_lut;   /* 257 */
+    const float* cos_lut;   /* 257 */
+    long stride;
+    int ct_stride;
+    int n_slots, wave_batch, row0, ring_rows;
+};
+
+struct EmitArgs {
+    const float* wave;
+    const float2* iq_out;
+    const ChanState* cs;
+    const int* slot_to_ext;
+    float* out_wave;        /* [total_channels][wave_batch] */
+    float* out_iq;          /* [total_channels][2*wave_batch] or null */
+    uint8_t* out_axc;       /* [total_channels] */
+    long stride;
+    int n_slots, wave_batch, row0, ring_rows;
+};
+
+struct MixArgs {
+    const float* out_wave;  /* [total_channels][wave_batch] */
+    const uint8_t* out_axc;
+    const int* in_chan;     /* [n_inputs] external channel index, grouped by mixer */
+    const float* in_ml;     /* ampfactor * ampl */
+    const float* in_mr;     /* ampfactor * ampr */
+    const int* mixer_first; /* [n_mixers + 1] offsets into the input arrays */
+    const uint8_t* mixer_stereo;
+    float* left;            /* [n_mixers][wave_batch] */
+    float* right;
+    uint8_t* has_signal;    /* [n_mixers] */
+    int n_mixers, wave_batch;
+};
+
+struct SiggenArgs {
+    uint8_t* iq;
+    long stride;            /* bytes per dongle */
+    const int16_t* sin_tab; /* 4096 */
+    const long long* carriers; /* [n_carriers][12] */
+    int n_carriers;
+    int n_dev;
+    int dev_offset;
+    unsigned long long start_sample;
+    long n_samples;
+    unsigned long long seed;
+    int noise_q8;
+};
+
+void launch_channelizer_fft(const ChannelizerArgs& a, hipStream_t stream);
+void launch_demod(const DemodArgs& a, hipStream_t stream);
+void launch_emit(const EmitArgs& a, hipStream_t stream);
+void launch_mix(const MixArgs& a, hipStream_t stream);
+void launch_stats(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, int n_slots, airband_hip_channel_stats* out, hipStream_t stream);
+void launch_siggen(const SiggenArgs& a, hipStream_t stream);
+/* scatter channel-major host-provided bins into the time-major rings (airband_hip_process_bins) */
+void launch_scatter_bins(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, long stride, int n_slots,
+                         int wave_batch, int row0, int ring_rows, hipStream_t stream);
+/* gather the batch's new rows back into channel-major order (airband_hip_read_bins / read_trace) */
+void launch_gather_bins(const float* mag, const float2* iq, const uint8_t* trace, const int* slot_to_ext, float* wavein, float* iqin, uint8_t* trace_out, long stride,
+                        int n_slots, int wave_batch, int row0, int ring_rows, hipStream_t stream);
+
+}  // namespace airband
+#endif

@@ -1,0 +1,176 @@
+/* csrc/misc_kernels.hip -- small helper kernels around the two hot stages: synthetic-dongle generator, mixer
+ * sum, and the layout shuffles used by the parity/introspection entry points. */
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace airband {
+
+/* ---- synthetic dongles (integer-only twin of rtlsdr-airband_amd/siggen.py::generate_u8) ------------------- */
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    unsigned long long z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void siggen_kernel(SiggenArgs a) {
+    __shared__ short tab[4096];
+    __shared__ long long car[16 * 12];
+    __shared__ unsigned ph0[16];
+    for (int i = threadIdx.x; i < 4096; i += 256) tab[i] = a.sin_tab[i];
+    for (int i = threadIdx.x; i < a.n_carriers * 12; i += 256) car[i] = a.carriers[i];
+    const int d = blockIdx.y;
+    const int dev = a.dev_offset + d;
+    if ((int)threadIdx.x < a.n_carriers)
+        ph0[threadIdx.x] = (unsigned)mix64((a.seed ^ 0xC0FFEEull) + (unsigned long long)((dev << 8) | (int)threadIdx.x));
+    __syncthreads();
+    uint8_t* out = a.iq + (long)d * a.stride;
+    /* each thread produces 8 complex samples = 16 bytes per pass */
+    for (long base = ((long)blockIdx.x * 256 + threadIdx.x) * 8; base < a.n_samples; base += (long)gridDim.x * 256 * 8) {
+        uint8_t bytes[16];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const unsigned long long n = a.start_sample + (unsigned long long)(base + u);
+            const unsigned n32 = (unsigned)n;
+            long long acc_i = 0, acc_q = 0;
+            for (int c = 0; c < a.n_carriers; c++) {
+                const long long* k = car + c * 12;
+                unsigned ph = (unsigned)k[0] * n32 + ph0[c];
+                const unsigned pa = (unsigned)k[3] * n32;
+                const long long s_mod = tab[pa >> 20];
+                long long amp;
+                if (k[2] == 0) {
+                    amp = (k[1] * (32768 + ((k[4] * s_mod) >> 15))) >> 15;
+                } else {
+                    amp = k[1];
+                    long long dphi = k[5] * s_mod;
+                    if (k[6]) {
+                        const unsigned pc = (unsigned)k[6] * n32;
+                        dphi += k[7] * (long long)tab[pc >> 20];
+                    }
+                    ph = (unsigned)((long long)ph + dphi);
+                }
+                if (k[8]) {
+                    const unsigned long long period = (unsigned long long)k[8];
+                    const unsigned long long t0 = (unsigned long long)(k[11] * ((dev + k[10]) % 8));
+                    const bool on = ((n + (period - (t0 % period))) % period) < (unsigned long long)k[9];
+                    if (!on) amp = 0;
+                }
+                const int idx = ph >> 20;
+                acc_i += (amp * (long long)tab[(idx + 1024) & 4095]) >> 15;
+                acc_q += (amp * (long long)tab[idx]) >> 15;
+            }
+            const unsigned long long h = mix64((a.seed ^ ((unsigned long long)dev * 0xD1B54A32D192ED03ull)) + n * 0x9E3779B97F4A7C15ull);
+            const long long n_i = (long long)((h & 0xff) + ((h >> 8) & 0xff) + ((h >> 16) & 0xff) + ((h >> 24) & 0xff)) - 510;
+            const long long n_q = (long long)(((h >> 32) & 0xff) + ((h >> 40) & 0xff) + ((h >> 48) & 0xff) + ((h >> 56) & 0xff)) - 510;
+            acc_i += (n_i * a.noise_q8) >> 8;
+            acc_q += (n_q * a.noise_q8) >> 8;
+            long long vi = 128 + (acc_i >> 8), vq = 128 + (acc_q >> 8);
+            vi = vi < 0 ? 0 : (vi > 255 ? 255 : vi);
+            vq = vq < 0 ? 0 : (vq > 255 ? 255 : vq);
+            bytes[2 * u] = (uint8_t)vi;
+            bytes[2 * u + 1] = (uint8_t)vq;
+        }
+        if (base + 8 <= a.n_samples) {
+            *reinterpret_cast<uint4*>(out + 2 * base) = *reinterpret_cast<const uint4*>(bytes);
+        } else {
+            for (long u = 0; base + u < a.n_samples; u++) {
+                out[2 * (base + u)] = bytes[2 * u];
+                out[2 * (base + u) + 1] = bytes[2 * u + 1];
+            }
+        }
+    }
+}
+
+void launch_siggen(const SiggenArgs& a, hipStream_t stream) {
+    long per_dev_threads = (a.n_samples + 7) / 8;
+    int bx = (int)((per_dev_threads + 255) / 256);
+    if (bx > 1024) bx = 1024;
+    if (bx < 1) bx = 1;
+    /* gridDim.y is limited to 65535: walk the dongles in slabs */
+    for (int d0 = 0; d0 < a.n_dev; d0 += 32768) {
+        SiggenArgs b = a;
+        b.iq = a.iq + (long)d0 * a.stride;
+        b.dev_offset = a.dev_offset + d0;
+        b.n_dev = a.n_dev - d0 < 32768 ? a.n_dev - d0 : 32768;
+        hipLaunchKernelGGL(siggen_kernel, dim3(bx, b.n_dev), dim3(256), 0, stream, b);
+    }
+}
+
+/* ---- mixer sum (reference: src/mixer.cpp:133-140 mix_waveforms, :201-214) ------------------------------- */
+__global__ __launch_bounds__(256) void mix_kernel(MixArgs a) {
+    const int m = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int first = a.mixer_first[m], last = a.mixer_first[m + 1];
+    float l = 0.0f, r = 0.0f;
+    bool any = false;
+    const bool stereo = a.mixer_stereo[m] != 0;
+    for (int i = first; i < last; i++) {
+        const int ch = a.in_chan[i];
+        if (a.out_axc[ch] == ' ') continue; /* has_signal == false: nothing is added (src/mixer.cpp:119-122,203) */
+        any = true;
+        if (t < a.wave_batch) {
+            const float w = a.out_wave[(long)ch * a.wave_batch + t];
+            const float ml = a.in_ml[i], mr = a.in_mr[i];
+            if (ml != 0.0f) l += w * ml;
+            if (stereo && mr != 0.0f) r += w * mr;
+        }
+    }
+    if (t < a.wave_batch) {
+        a.left[(long)m * a.wave_batch + t] = l;
+        a.right[(long)m * a.wave_batch + t] = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.has_signal[m] = any ? 1 : 0;
+}
+
+void launch_mix(const MixArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(mix_kernel, dim3((a.wave_batch + 255) / 256, a.n_mixers), dim3(256), 0, stream, a);
+}
+
+/* ---- layout shuffles for the introspection entry points -------------------------------------------------- */
+__global__ void scatter_bins_kernel(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, long stride, int n_slots,
+                                    int wave_batch, int row0, int ring_rows) {
+    const int slot = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (slot >= n_slots || t >= wave_batch) return;
+    const int ext = slot_to_ext[slot];
+    if (ext < 0) return;
+    int row = row0 + AB_AGC_EXTRA + t;
+    if (row >= ring_rows) row -= ring_rows;
+    mag[(long)row * stride + slot] = wavein[(long)ext * wave_batch + t];
+    if (cc[slot].flags & AB_F_RAW_IQ) iq[(long)row * stride + slot] = make_float2(iqin[((long)ext * wave_batch + t) * 2], iqin[((long)ext * wave_batch + t) * 2 + 1]);
+}
+
+void launch_scatter_bins(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, long stride, int n_slots,
+                         int wave_batch, int row0, int ring_rows, hipStream_t stream) {
+    hipLaunchKernelGGL(scatter_bins_kernel, dim3((n_slots + 63) / 64, (wave_batch + 3) / 4), dim3(256), 0, stream, wavein, iqin, slot_to_ext, cc, mag, iq, stride, n_slots,
+                       wave_batch, row0, ring_rows);
+}
+
+__global__ void gather_bins_kernel(const float* mag, const float2* iq, const uint8_t* trace, const int* slot_to_ext, float* wavein, float* iqin, uint8_t* trace_out,
+                                   long stride, int n_slots, int wave_batch, int row0, int ring_rows) {
+    const int slot = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (slot >= n_slots || t >= wave_batch) return;
+    const int ext = slot_to_ext[slot];
+    if (ext < 0) return;
+    int row = row0 + AB_AGC_EXTRA + t;
+    if (row >= ring_rows) row -= ring_rows;
+    if (wavein) wavein[(long)ext * wave_batch + t] = mag[(long)row * stride + slot];
+    if (iqin) {
+        const float2 q = iq[(long)row * stride + slot];
+        iqin[((long)ext * wave_batch + t) * 2] = q.x;
+        iqin[((long)ext * wave_batch + t) * 2 + 1] = q.y;
+    }
+    if (trace_out && trace) trace_out[(long)ext * wave_batch + t] = trace[(long)t * stride + slot];
+}
+
+void launch_gather_bins(const float* mag, const float2* iq, const uint8_t* trace, const int* slot_to_ext, float* wavein, float* iqin, uint8_t* trace_out, long stride,
+                        int n_slots, int wave_batch, int row0, int ring_rows, hipStream_t stream) {
+    hipLaunchKernelGGL(gather_bins_kernel, dim3((n_slots + 63) / 64, (wave_batch + 3) / 4), dim3(256), 0, stream, mag, iq, trace, slot_to_ext, wavein, iqin, trace_out, stride,
+                       n_slots, wave_batch, row0, ring_rows);
+}
+
+}  // namespace airband

@@ -1,0 +1,309 @@
+/* csrc/params.cpp -- turns the user-level configuration into kernel constants.
+ *
+ * The reference does all of this at config-parse time, in double/float host arithmetic; the results are
+ * plain numbers the hot loop then only reads.  Each block cites the reference lines whose *behaviour*
+ * (formula, operand types, evaluation order) it reproduces, because parity of squelch decisions needs the
+ * very same float constants.
+ */
+#include "params.h"
+
+#include <climits>
+#include <cmath>
+#include <complex>
+#include <cstring>
+
+namespace airband {
+
+namespace {
+
+const float kStandardTones[51] = {67.0f,  69.3f,  71.9f,  74.4f,  77.0f,  79.7f,  82.5f,  85.4f,  88.5f,  91.5f,  94.8f,  97.4f,  100.0f,
+                                  103.5f, 107.2f, 110.9f, 114.8f, 118.8f, 123.0f, 127.3f, 131.8f, 136.5f, 141.3f, 146.2f, 150.0f, 151.4f,
+                                  156.7f, 159.8f, 162.2f, 165.5f, 167.9f, 171.3f, 173.8f, 177.3f, 179.9f, 183.5f, 186.2f, 189.9f, 192.8f,
+                                  196.6f, 199.5f, 203.5f, 206.5f, 210.7f, 218.1f, 225.7f, 229.1f, 233.6f, 241.8f, 250.3f, 254.1f};
+
+/* Goertzel coefficient: nearest DFT bin of the window to the tone (reference: src/ctcss.cpp:31-42). */
+float tone_coeff(float tone, float rate, int window) {
+    const float bin_f = (float)window * tone / rate;
+    const int k = (int)(0.5 + (double)bin_f);
+    const float omega = (float)((2.0 * M_PI * k) / window);
+    return (float)(2.0 * std::cos((double)omega));
+}
+
+/* Bank = target tone first, then the standard tones at least 5 Hz away, without duplicate coefficients
+ * (reference: src/ctcss.cpp:61-73,105-122). */
+void build_bank(float target, float rate, int window, float* coeff, int& n) {
+    n = 0;
+    auto add = [&](float f) {
+        const float c = tone_coeff(f, rate, window);
+        for (int i = 0; i < n; i++)
+            if (coeff[i] == c) return;
+        coeff[n++] = c;
+    };
+    add(target);
+    for (float t : kStandardTones) {
+        if (std::fabs(target - t) < 5) continue;
+        add(t);
+    }
+}
+
+float tau_alpha(int wave_rate, int tau_us) { /* src/config.cpp:648,775; src/rtl_airband.cpp:825-826 */
+    return tau_us == 0 ? 0.0f : (float)std::exp(-1.0f / (wave_rate * 1e-6 * tau_us));
+}
+
+float dbfs_to_level(float dbfs, int fft_size) { /* src/util.cpp:169-176 */
+    const float offset = 7.54f + 10.0f * log10f((float)(fft_size / 2)) - 2.38f;
+    return (float)(std::pow(10.0, (dbfs - offset) / 20.0f) * fft_size);
+}
+
+/* 2nd-order Bessel lowpass via bilinear transform (reference: src/filters.cpp:70-144) */
+void design_lowpass(float cutoff, float rate, float& gain, float& yc0, float& yc1) {
+    typedef std::complex<double> cd;
+    const double raw_alpha = (double)cutoff / rate;
+    const double warped = std::tan(M_PI * raw_alpha) / M_PI;
+    const cd bessel(-1.10160133059e+00, 6.36009824757e-01);
+    auto blt = [](cd p) { return (2.0 + p) / (2.0 - p); };
+    const cd roots_top[2] = {cd(-1.0), cd(-1.0)};
+    const cd roots_bot[2] = {blt(M_PI * 2 * warped * bessel), blt(M_PI * 2 * warped * std::conj(bessel))};
+    auto expand = [](const cd r[2], cd c[3]) {
+        c[0] = 1.0;
+        c[1] = 0.0;
+        c[2] = 0.0;
+        for (int i = 0; i < 2; i++) {
+            const cd nw = -r[i];
+            for (int k = 2; k >= 1; k--) c[k] = (nw * c[k]) + c[k - 1];
+            c[0] = nw * c[0];
+        }
+    };
+    auto eval = [](const cd c[3], cd z) {
+        cd sum(0.0);
+        for (int i = 2; i >= 0; i--) sum = (sum * z) + c[i];
+        return sum;
+    };
+    cd top[3], bot[3];
+    expand(roots_top, top);
+    expand(roots_bot, bot);
+    const cd g = eval(top, cd(1.0)) / eval(bot, cd(1.0));
+    gain = (float)hypot(g.imag(), g.real());
+    yc0 = (float)(-(bot[0].real() / bot[2].real()));
+    yc1 = (float)(-(bot[1].real() / bot[2].real()));
+}
+
+int fail(Plan& p, int code, const std::string& msg) {
+    p.error = msg;
+    return code;
+}
+
+}  // namespace
+
+int build_plan(const airband_hip_config* cfg, Plan& p) {
+    if (!cfg) return fail(p, AIRBAND_HIP_EINVAL, "config is NULL");
+    if (cfg->abi_version != AIRBAND_HIP_ABI_VERSION) return fail(p, AIRBAND_HIP_EINVAL, "abi_version mismatch");
+    if (cfg->fft_size_log < 8 || cfg->fft_size_log > 13) /* MIN/MAX_FFT_SIZE_LOG, src/rtl_airband.h:80-82 */
+        return fail(p, AIRBAND_HIP_EBADSIZE, "fft_size_log must be between 8 and 13");
+    if (cfg->wave_rate != 8000 && cfg->wave_rate != 16000) return fail(p, AIRBAND_HIP_EBADSIZE, "wave_rate must be 8000 (AM build) or 16000 (NFM build)");
+    if (cfg->device_count < 1 || !cfg->devices) return fail(p, AIRBAND_HIP_EBADSIZE, "device_count must be >= 1");
+    if (cfg->fm_demod != AIRBAND_FM_FAST_ATAN2 && cfg->fm_demod != AIRBAND_FM_QUADRI_DEMOD) return fail(p, AIRBAND_HIP_EINVAL, "unknown fm_demod");
+
+    p.fft_log = cfg->fft_size_log;
+    p.fft_size = 1 << cfg->fft_size_log;
+    p.wave_rate = cfg->wave_rate;
+    p.wave_batch = cfg->wave_rate / 8;
+    p.fm_demod = cfg->fm_demod;
+    p.n_dev = cfg->device_count;
+
+    /* sample -> float tables (src/rtl_airband.cpp:316-324); s8 entry 128 is never written by the reference */
+    for (int i = 0; i < 256; i++) p.lev_u8[i] = (i - 127.5f) / 127.5f;
+    std::memset(p.lev_s8, 0, sizeof(p.lev_s8));
+    for (int i = -127; i < 128; i++) p.lev_s8[(uint8_t)i] = i / 128.0f;
+
+    /* window (src/rtl_airband.cpp:335-351): float literals widened to double, evaluated in double */
+    {
+        const double a0 = 0.27105140069342f, a1 = 0.43329793923448f, a2 = 0.21812299954311f, a3 = 0.06592544638803f, a4 = 0.01081174209837f,
+                     a5 = 0.00077658482522f, a6 = 0.00001388721735f;
+        p.window.resize(p.fft_size);
+        const double den = (double)(p.fft_size - 1);
+        for (int i = 0; i < p.fft_size; i++) {
+            const double x = a0 - (a1 * cos((2.0 * M_PI * i) / den)) + (a2 * cos((4.0 * M_PI * i) / den)) - (a3 * cos((6.0 * M_PI * i) / den)) +
+                             (a4 * cos((8.0 * M_PI * i) / den)) - (a5 * cos((10.0 * M_PI * i) / den)) + (a6 * cos((12.0 * M_PI * i) / den));
+            p.window[i] = (float)x;
+        }
+    }
+    /* derotation LUT (src/util.cpp:105-110) */
+    p.sin_lut.resize(257);
+    p.cos_lut.resize(257);
+    for (uint32_t i = 0; i < 256; i++) sincosf((float)(2.0F * M_PI * (float)i / 256.0f), &p.sin_lut[i], &p.cos_lut[i]);
+    p.sin_lut[256] = p.sin_lut[0];
+    p.cos_lut[256] = p.cos_lut[0];
+
+    const float global_alpha = (float)std::exp(-1.0f / (p.wave_rate * 2e-4)); /* src/rtl_airband.cpp:87 */
+    const float rate = (float)p.wave_rate;
+
+    p.dev.resize(p.n_dev);
+    p.chan_base.resize(p.n_dev);
+    p.total_ch = 0;
+    p.max_ch = 0;
+    for (int d = 0; d < p.n_dev; d++) {
+        const airband_hip_device_cfg& dc = cfg->devices[d];
+        DevConst& dev = p.dev[d];
+        std::memset(&dev, 0, sizeof(dev));
+        if (dc.channel_count < 1 || dc.channel_count > AB_MAX_CH_PER_DEV || !dc.channels)
+            return fail(p, AIRBAND_HIP_EBADSIZE, "channel_count must be 1.." + std::to_string(AB_MAX_CH_PER_DEV));
+        if (dc.sample_rate <= p.wave_rate) return fail(p, AIRBAND_HIP_EBADSIZE, "sample_rate must exceed WAVE_RATE"); /* src/config.cpp:790 */
+        float fullscale;
+        switch (dc.sfmt) { /* src/input-file.cpp:171-173, src/input-soapysdr.cpp:45-64 */
+            case AIRBAND_SFMT_U8:
+            case AIRBAND_SFMT_S8: dev.bytes_per_sample = 1; fullscale = (float)SCHAR_MAX - 0.5f; break;
+            case AIRBAND_SFMT_S16: dev.bytes_per_sample = 2; fullscale = (float)SHRT_MAX - 0.5f; break;
+            case AIRBAND_SFMT_F32: dev.bytes_per_sample = 4; fullscale = 1.0f; break;
+            default: return fail(p, AIRBAND_HIP_EINVAL, "unknown sample format");
+        }
+        if (dc.fullscale > 0) fullscale = dc.fullscale;
+        dev.sfmt = dc.sfmt;
+        dev.scale = 1.0f / fullscale;
+        dev.hop_samples = (int)std::round((double)dc.sample_rate / (double)p.wave_rate); /* src/rtl_airband.cpp:394 */
+        dev.n_ch = dc.channel_count;
+        dev.chan_base = p.total_ch;
+        p.chan_base[d] = p.total_ch;
+        const int64_t hop_bytes = 2LL * dev.bytes_per_sample * dev.hop_samples;
+        if (d > 0 && (dev.sfmt != p.dev[0].sfmt || dev.hop_samples != p.dev[0].hop_samples)) p.uniform_hop = false;
+        if (hop_bytes > p.hop_bytes_max) p.hop_bytes_max = hop_bytes;
+        const float dev_alpha = dc.tau_us >= 0 ? tau_alpha(p.wave_rate, dc.tau_us) : global_alpha; /* src/config.cpp:774-778 */
+
+        for (int j = 0; j < dc.channel_count; j++) {
+            const airband_hip_channel_cfg& ch = dc.channels[j];
+            ChanConst c;
+            ChanState s;
+            std::memset(&c, 0, sizeof(c));
+            std::memset(&s, 0, sizeof(s));
+            c.flags = AB_F_VALID;
+            c.dev = d;
+            c.chan = j;
+            c.ext_index = p.total_ch;
+            c.afc = ch.afc & 0xff;
+            c.ct_slot = -1;
+            if (ch.modulation == AIRBAND_MOD_NFM) {
+                if (p.wave_rate != 16000) return fail(p, AIRBAND_HIP_EINVAL, "NFM channels need wave_rate 16000 (the reference's NFM build)");
+                c.flags |= AB_F_NFM | AB_F_RAW_IQ; /* src/config.cpp:670-677 */
+                if (p.fm_demod == AIRBAND_FM_QUADRI_DEMOD) c.flags |= AB_F_QUADRI;
+            } else if (ch.modulation != AIRBAND_MOD_AM) {
+                return fail(p, AIRBAND_HIP_EINVAL, "unknown modulation");
+            }
+            if (ch.ampfactor < 0) return fail(p, AIRBAND_HIP_EINVAL, "ampfactor must not be negative"); /* src/config.cpp:624-627 */
+            c.ampfactor = ch.ampfactor;
+            c.alpha = ch.tau_us >= 0 ? tau_alpha(p.wave_rate, ch.tau_us) : dev_alpha;
+
+            /* Squelch defaults (src/squelch.cpp:36-77) then the two threshold knobs in config order (src/config.cpp:452-515) */
+            s.noise_floor = 5.0f;
+            c.sq_normal_ratio = (float)std::pow(10.0, 9.54f / 20.0);
+            c.sq_manual_level = -1.0f;
+            bool manual = false;
+            if (ch.squelch_threshold_dbfs > 0) return fail(p, AIRBAND_HIP_EINVAL, "squelch_threshold must be <= 0"); /* src/config.cpp:457 */
+            if (ch.squelch_threshold_dbfs < 0) {
+                const float lvl = dbfs_to_level((float)ch.squelch_threshold_dbfs, p.fft_size);
+                if (lvl > 0) { /* Squelch::set_squelch_level_threshold, src/squelch.cpp:79-91 */
+                    manual = true;
+                    c.sq_manual_level = lvl;
+                }
+            }
+            if (ch.squelch_snr_threshold_db >= 0.0f) { /* Squelch::set_squelch_snr_threshold, src/squelch.cpp:93-103 */
+                manual = false;
+                c.sq_normal_ratio = (float)std::pow(10.0, ch.squelch_snr_threshold_db / 20.0);
+            } else if (ch.squelch_snr_threshold_db != -1.0f) {
+                return fail(p, AIRBAND_HIP_EINVAL, "squelch_snr_threshold must be >= 0 (or -1 for the default)"); /* src/config.cpp:494-497 */
+            }
+            c.sq_flappy_ratio = c.sq_normal_ratio * 0.9f;
+            if (manual) c.flags |= AB_F_MANUAL;
+            s.cap = manual ? 1.5f * c.sq_manual_level : 1.5f * c.sq_normal_ratio * s.noise_floor; /* src/squelch.cpp:492-499 */
+            s.pre_full = s.pre_capped = s.post_full = s.post_capped = 0.001f;
+            s.level_cache = 0.0f;
+            s.next = s.cur = AB_ST_CLOSED;
+            s.sample_count = 0xffffffffu;
+            s.head = 0;
+            s.tail = 1;
+
+            if (ch.notch_freq > 0) { /* NotchFilter ctor, src/filters.cpp:30-48; default q src/config.cpp:517 */
+                const float q = ch.notch_q > 0 ? ch.notch_q : 10.0f;
+                const float wo = (float)(2 * M_PI * (double)(ch.notch_freq / rate));
+                const float e = 1 / (1 + std::tan(wo / (q * 2)));
+                const float pc = std::cos(wo);
+                c.notch_d0 = e;
+                c.notch_d1 = 2 * e * pc;
+                c.notch_d2 = (2 * e - 1);
+                c.flags |= AB_F_NOTCH;
+            }
+            if (ch.ctcss_freq > 0) { /* Squelch::set_ctcss_freq, src/squelch.cpp:105-116 */
+                ToneTable t;
+                std::memset(&t, 0, sizeof(t));
+                t.window[0] = (int)(rate * 0.05);
+                t.window[1] = (int)(rate * 0.4);
+                for (int k = 0; k < 2; k++) build_bank(ch.ctcss_freq, rate, t.window[k], t.coeff[k], t.n[k]);
+                c.ct_slot = (int)p.tones.size();
+                for (int k = 0; k < 2; k++) {
+                    c.ct_ntones[k] = t.n[k];
+                    c.ct_window[k] = t.window[k];
+                }
+                p.tones.push_back(t);
+                c.flags |= AB_F_CTCSS;
+            }
+            if (ch.bandwidth_hz != 0) { /* src/config.cpp:592-619 */
+                c.flags |= AB_F_RAW_IQ;
+                if (ch.bandwidth_hz > 0) {
+                    design_lowpass((float)ch.bandwidth_hz / 2, rate, c.lp_gain, c.lp_yc0, c.lp_yc1);
+                    c.flags |= AB_F_LOWPASS;
+                }
+            }
+            if (ch.has_iq_outputs) c.flags |= AB_F_IQ_OUT | AB_F_RAW_IQ;
+
+            /* bin index (src/config.cpp:666-667): the divisor is the INTEGER quotient sample_rate / fft_size */
+            const double pos = (ch.frequency + dc.sample_rate - dc.centerfreq) / (double)(dc.sample_rate / p.fft_size) - 1.0;
+            c.base_bin = (int)((size_t)std::ceil(pos) % (size_t)p.fft_size);
+            s.bin = c.base_bin;
+
+            if (c.flags & AB_F_RAW_IQ) { /* derotation step (src/config.cpp:679-712) */
+                double f = (double)(ch.frequency - dc.centerfreq);
+                const double dec = (double)dc.sample_rate / (double)p.wave_rate;
+                double corr = (double)p.wave_rate / 2.0;
+                corr *= (dec - std::round(dec));
+                corr *= (double)(ch.frequency - dc.centerfreq) / ((double)dc.sample_rate / 2.0);
+                f -= corr;
+                f /= (double)p.wave_rate;
+                f -= std::trunc(f);
+                f *= 256.0 * 65536.0;
+                c.dm_dphi = (uint32_t)((int)f);
+                dev.any_raw_iq = 1;
+            }
+            /* freq_t / channel_t initial values (src/config.cpp:274,313-331) */
+            s.agcavgfast = 0.5f;
+            s.pr = s.pj = 0.0f;
+            s.prev_waveout = 0.5f;
+            s.axc = ' ';
+            p.cc.push_back(c);
+            p.cs0.push_back(s);
+            p.total_ch++;
+        }
+        if (dc.channel_count > p.max_ch) p.max_ch = dc.channel_count;
+    }
+    return AIRBAND_HIP_OK;
+}
+
+void channel_constants(const Plan& p, int i, double* v) {
+    const ChanConst& c = p.cc[i];
+    v[0] = c.base_bin;
+    v[1] = c.dm_dphi;
+    v[2] = c.alpha;
+    v[3] = c.notch_d0;
+    v[4] = c.notch_d1;
+    v[5] = c.notch_d2;
+    v[6] = c.lp_gain;
+    v[7] = c.lp_yc0;
+    v[8] = c.lp_yc1;
+    v[9] = c.sq_normal_ratio;
+    v[10] = (c.flags & AB_F_MANUAL) ? c.sq_manual_level : -1.0;
+    v[11] = c.ct_slot >= 0 ? c.ct_ntones[0] : 0;
+    v[12] = c.ct_slot >= 0 ? c.ct_ntones[1] : 0;
+    v[13] = (c.flags & AB_F_RAW_IQ) ? 1 : 0;
+    v[14] = c.ct_slot >= 0 ? c.ct_window[0] : 0;
+    v[15] = c.ct_slot >= 0 ? c.ct_window[1] : 0;
+}
+
+}  // namespace airband

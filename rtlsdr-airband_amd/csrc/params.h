@@ -1,0 +1,44 @@
+/* csrc/params.h -- host-side derivation of every constant the kernels need from an airband_hip_config.
+ * Compiled with g++ (not hipcc) so that libm / complex-division behaviour is the platform's, the same the
+ * reference's own config-time code would see. */
+#ifndef AIRBAND_CSRC_PARAMS_H
+#define AIRBAND_CSRC_PARAMS_H
+
+#include <string>
+#include <vector>
+
+#include "../../include/airband_hip.h"
+#include "common.h"
+
+namespace airband {
+
+struct ToneTable {               /* one CTCSS-enabled channel: two Goertzel banks */
+    float coeff[2][AB_MAX_TONES]; /* [0] fast (0.05 s window), [1] slow (0.4 s window) */
+    int n[2];
+    int window[2];
+};
+
+struct Plan {
+    int fft_log = 0, fft_size = 0, wave_rate = 0, wave_batch = 0, fm_demod = 0;
+    int n_dev = 0, total_ch = 0, max_ch = 0;
+    std::vector<DevConst> dev;
+    std::vector<int> chan_base;        /* external index of channel 0 of each dongle */
+    std::vector<ChanConst> cc;         /* by external channel index */
+    std::vector<ChanState> cs0;        /* initial state, by external channel index */
+    std::vector<ToneTable> tones;      /* by ct_slot */
+    std::vector<float> window;         /* fft_size coefficients (src/rtl_airband.cpp:335-351) */
+    std::vector<float> sin_lut, cos_lut; /* 257 entries each (src/util.cpp:105-110) */
+    float lev_u8[256], lev_s8[256];    /* src/rtl_airband.cpp:316-324 */
+    int64_t hop_bytes_max = 0;
+    bool uniform_hop = true;           /* every dongle has the same sfmt / hop (needed by the batched launch) */
+    std::string error;
+};
+
+/* Returns 0 or a negative AIRBAND_HIP_E* code (plan.error holds the text). No GPU needed. */
+int build_plan(const airband_hip_config* cfg, Plan& plan);
+
+/* The 16 "derived constants" slots documented at airband_hip_channel_constants(). */
+void channel_constants(const Plan& plan, int ext_index, double* out16);
+
+}  // namespace airband
+#endif

@@ -1,0 +1,42 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+from __future__ import annotations
+
+import importlib
+
+import numpy as np
+
+sg = importlib.import_module("rtlsdr-airband_amd.siggen")
+
+
+def plan_devices(n_dev: int, mixed: bool, tweak=None):
+    """n_dev dongles with the BASELINE channel plan; returns (devices, carriers)."""
+    chans, carriers = sg.baseline_plan(mixed=mixed)
+    devices = []
+    for d in range(n_dev):
+        ch = [dict(c) for c in chans]
+        if tweak:
+            tweak(d, ch)
+        devices.append(dict(channels=ch))
+    return devices, carriers
+
+
+def stream_bytes(n_batches: int, wave_rate: int, fft_size: int = 512, sample_rate: int = 2_560_000) -> int:
+    """Bytes of u8 I/Q one dongle must deliver for n_batches output batches (incl. lead-in and look-ahead)."""
+    hop = round(sample_rate / wave_rate)
+    B = wave_rate // 8
+    return 2 * ((n_batches * B + 100) * hop + fft_size)
+
+
+def rel_rms(a: np.ndarray, b: np.ndarray) -> float:
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    den = np.sqrt(np.mean(b * b))
+    return float(np.sqrt(np.mean((a - b) ** 2)) / (den if den > 0 else 1.0))
+
+
+def rms(a: np.ndarray) -> float:
+    return float(np.sqrt(np.mean(a.astype(np.float64) ** 2)))
+
+
+def axc_str(axc: np.ndarray) -> str:
+    return "\n".join("".join(chr(v) for v in row) for row in np.asarray(axc).T)

@@ -1,0 +1,136 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): squelch open/close decisions bit-exact, float audio within 1e-4 RMS; stage 2 alone
+(same stage-1 input) bit-identical; stage-1 bins within 1e-5 relative RMS of the oracle's float64 FFT.
+"""
+import numpy as np
+import pytest
+
+import helpers
+import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _tweak(d, ch):
+    if d % 2 == 1:
+        ch[3]["has_iq_outputs"] = 1
+        ch[0]["bandwidth_hz"] = 8000
+        ch[2]["squelch_threshold_dbfs"] = -40
+        ch[4]["squelch_snr_threshold_db"] = 6.0
+        ch[6]["ampfactor"] = 2.5
+
+
+@pytest.mark.parametrize("mixed,wave_rate", [(False, 8000), (True, 16000)])
+def test_stage2_bit_exact_on_oracle_bins(pkg, built, mixed, wave_rate):
+    """Feed the ORACLE's stage-1 output into GPU stage 2: everything must be bit-identical."""
+    devices, carriers = helpers.plan_devices(3, mixed, _tweak if mixed else None)
+    n_batches = 10
+    nbytes = helpers.stream_bytes(n_batches, wave_rate)
+    src = pyoracle.Oracle(devices, wave_rate=wave_rate)
+    raw = [src.run_device(d, pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers), n_batches) for d in range(3)]
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate)
+    with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=pkg.capi.FLAG_TRACE_SQUELCH) as hip:
+        for b in range(n_batches):
+            wavein = np.concatenate([r["raw_wavein"][b] for r in raw])
+            iqin = np.concatenate([r["raw_iq"][b] for r in raw])
+            want = [orc.run_bins(d, raw[d]["raw_wavein"][b], raw[d]["raw_iq"][b]) for d in range(3)]
+            hip.process_bins(wavein, iqin)
+            out = hip.collect(iq=True, stats=True)
+            tr = hip.read_trace()
+            assert np.array_equal(tr, np.concatenate([w["trace"] for w in want])), "batch %d: squelch trace" % b
+            assert np.array_equal(out["axc"], np.concatenate([w["axc"] for w in want])), "batch %d: axc" % b
+            ww = np.concatenate([w["waveout"] for w in want])
+            assert np.array_equal(out["waveout"].view(np.uint32), ww.view(np.uint32)), "batch %d: waveout max diff %g" % (b, np.abs(out["waveout"] - ww).max())
+            wi = np.concatenate([w["iq_out"] for w in want])
+            assert np.array_equal(out["iq_out"].view(np.uint32), wi.view(np.uint32)), "batch %d: iq_out" % b
+        k = 0
+        for d in range(3):
+            for j in range(8):
+                o, g = orc.stats(d, j), out["stats"][k]
+                for f in ("noise_level", "signal_level", "squelch_level", "agcavgfast", "open_count", "flappy_count", "ctcss_count", "no_ctcss_count",
+                          "active_counter", "bin", "squelch_state"):
+                    assert o[f] == g[f], (d, j, f, o[f], g[f])
+                k += 1
+
+
+@pytest.mark.parametrize("mixed,wave_rate", [(False, 8000), (True, 16000)])
+def test_end_to_end_stream(pkg, built, mixed, wave_rate):
+    """Raw u8 I/Q through submit/process/collect vs the oracle: decisions exact, audio <= 1e-4 RMS."""
+    n_dev, n_batches = 4, 14
+    devices, carriers = helpers.plan_devices(n_dev, mixed, _tweak if mixed else None)
+    nbytes = helpers.stream_bytes(n_batches, wave_rate)
+    iq = [pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)]
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate)
+    ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
+    assert all(r["n_batches"] == n_batches for r in ref)
+    opened = 0
+    with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=pkg.capi.FLAG_TRACE_SQUELCH) as hip:
+        # ragged submits: the library must cope with arbitrary chunking of the stream
+        pos = [0] * n_dev
+        b = 0
+        chunk = 300_001
+        while b < n_batches:
+            for d in range(n_dev):
+                if pos[d] < nbytes:
+                    pos[d] += hip.submit(d, iq[d][pos[d]:pos[d] + chunk + 2 * d])
+            while hip.process():
+                out = hip.collect(iq=True)
+                tr = hip.read_trace()
+                w, q = hip.read_bins()
+                want_t = np.concatenate([r["trace"][b] for r in ref])
+                assert np.array_equal(out["axc"], np.concatenate([r["axc"][b] for r in ref])), "batch %d axc" % b
+                assert np.array_equal(tr, want_t), "batch %d: %d squelch-state mismatches" % (b, int((tr != want_t).sum()))
+                ww = np.concatenate([r["waveout"][b] for r in ref])
+                assert helpers.rms(out["waveout"] - ww) <= 1e-4, "batch %d audio rms %g" % (b, helpers.rms(out["waveout"] - ww))
+                wi = np.concatenate([r["iq_out"][b] for r in ref])
+                assert helpers.rms(out["iq_out"] - wi) <= 1e-4 * max(1.0, helpers.rms(wi))
+                # stage-1 bins: magnitudes of raw-I/Q channels are rewritten in place by stage 2 (as in the reference,
+                # src/rtl_airband.cpp:524), so compare |bin| on the untouched channels and re/im on all of them
+                plain = np.array([not (c["modulation"] or c["bandwidth_hz"] or c["has_iq_outputs"]) for dev in devices for c in dev["channels"]])
+                assert helpers.rel_rms(w[plain], np.concatenate([r["raw_wavein"][b] for r in ref])[plain]) <= 1e-5
+                assert helpers.rel_rms(q, np.concatenate([r["raw_iq"][b] for r in ref])) <= 1e-5
+                opened += int((out["axc"] == ord("*")).sum())
+                b += 1
+    assert opened > 0, "test signal never opened a squelch: not a meaningful parity run"
+
+
+def test_synthetic_dongles_identical_on_device_and_host(pkg, built):
+    torch = pytest.importorskip("torch")
+    devices, carriers = helpers.plan_devices(3, True)
+    n = 70_000
+    with pkg.AirbandHip(devices, wave_rate=16000) as hip:
+        hip.set_signal_plan(carriers)
+        buf = torch.zeros((3, 2 * n + 64), dtype=torch.uint8, device="cuda")
+        start = 1_234_568
+        hip.generate_iq(buf.data_ptr(), buf.stride(0), start, 2 * n, seed=0x5EED, device_index_offset=5)
+        hip.synchronize()
+        got = buf.cpu().numpy()
+    for d in range(3):
+        want = pkg.siggen.generate_u8(5 + d, start // 2, n, carriers)
+        assert np.array_equal(got[d, :2 * n], want), "dongle %d" % d
+        assert not got[d, 2 * n:].any()
+
+
+def test_zero_copy_device_path_matches_host_ring_path(pkg, built):
+    """airband_hip_process_device on an HBM-resident, tail-replicated span == submit/process on the same bytes."""
+    torch = pytest.importorskip("torch")
+    n_dev, n_batches, wave_rate = 3, 4, 16000
+    devices, carriers = helpers.plan_devices(n_dev, True)
+    nbytes = helpers.stream_bytes(n_batches, wave_rate)
+    iq = np.stack([pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)])
+    with pkg.AirbandHip(devices, wave_rate=wave_rate) as a, pkg.AirbandHip(devices, wave_rate=wave_rate) as b:
+        g = a.geometry
+        dbuf = torch.from_numpy(iq).cuda()
+        off = 0
+        for k in range(n_batches):
+            for d in range(n_dev):
+                a.submit(d, iq[d, off:off + (g.first_batch_bytes if k == 0 else g.batch_bytes) + (g.lookahead_bytes if k == 0 else 0)] if k == 0 else
+                         iq[d, off + g.lookahead_bytes:off + g.lookahead_bytes + g.batch_bytes])
+            assert a.process()
+            ra = a.collect()
+            b.process_device(dbuf.data_ptr() + off, dbuf.stride(0))
+            rb = b.collect()
+            assert np.array_equal(ra["waveout"].view(np.uint32), rb["waveout"].view(np.uint32))
+            assert np.array_equal(ra["axc"], rb["axc"])
+            off += g.first_batch_bytes if k == 0 else g.batch_bytes
