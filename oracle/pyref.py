@@ -96,3 +96,42 @@ def run_reference(devices, iq_list, n_batches, *, nfm: bool, fft_log: int = 9, f
 
 def read_trace(trace_dir: str, d: int, j: int) -> np.ndarray:
     return np.fromfile(os.path.join(trace_dir, "squelch_debug-%d-%d.dat" % (d, j)), dtype=TRACE_DT)
+
+
+def _tp_worker(q, nfm, fast, fft_log, devices, iq_list, seconds, threads):
+    try:
+        lib = _load(nfm, fast)
+        lib.refh_init(len(devices), fft_log, 0, -1)
+        keep = []
+        for d, dev in enumerate(devices):
+            dc, arr = capi.device_cfg(**dev)
+            keep.append(arr)
+            assert lib.refh_add_device(d, C.byref(dc)) == 0
+        lib.refh_start(threads)
+        bufs = [np.ascontiguousarray(x) for x in iq_list]
+        ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+        el = C.c_double(0)
+        nb = lib.refh_throughput(ptrs, float(seconds), C.byref(el))
+        lib.refh_stop()
+        q.put(("ok", (int(nb), float(el.value))))
+    except BaseException as e:  # noqa: BLE001
+        q.put(("err", repr(e)))
+
+
+def ring_bytes(fft_size: int = 512, bytes_per_sample: int = 1) -> int:
+    """Bytes refh_throughput needs per device: the reference's ring (MIN_BUF_SIZE, src/rtl_airband.h:64) + tail."""
+    return 2560000 + 2 * bytes_per_sample * fft_size
+
+
+def reference_throughput(devices, iq_list, seconds: float, threads: int, *, nfm: bool, fast: bool = True, fft_log: int = 9):
+    """CPU baseline: the real reference demodulate() in `threads` pthreads over contiguous device shards, rings
+    pre-filled and kept full by cursor rewind.  Returns (batches completed over all devices, elapsed seconds)."""
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=_tp_worker, args=(q, nfm, fast, fft_log, devices, iq_list, seconds, threads))
+    p.start()
+    status, res = q.get()
+    p.join()
+    if status != "ok":
+        raise RuntimeError(res)
+    return res

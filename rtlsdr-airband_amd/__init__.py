@@ -46,6 +46,13 @@ def load_library() -> C.CDLL:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libairband_hip.so is missing: run __graft_entry__.build() / python rtlsdr-airband_amd/_build.py (no CPU fallback exists)")
+    # PyTorch-ROCm wheels bundle their own HIP runtime (file name libamdhip64.so, SONAME libamdhip64.so.7).  Loading
+    # it FIRST makes the dynamic loader resolve our DT_NEEDED libamdhip64.so.7 to that same copy; the other order
+    # would put two HIP runtimes into one process (and the second one finds no GPU).  C/C++ hosts are unaffected.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # noqa: BLE001
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
     L.airband_hip_prepare.argtypes = [C.POINTER(capi.Config), C.POINTER(vp)]
