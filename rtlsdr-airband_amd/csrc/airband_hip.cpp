@@ -75,6 +75,11 @@ struct airband_hip_handle {
     DevBuf<float> d_tmp_wavein, d_tmp_iqin;
     DevBuf<uint8_t> d_tmp_trace;
     int ct_stride = 0;
+    /* matrix-core channelizer */
+    bool use_dft = false;
+    DevBuf<int> d_dev_bset;
+    DevBuf<int8_t> d_bfrag;
+    DevBuf<double> d_bcorr;
 
     /* host-ring path */
     std::vector<std::vector<uint8_t>> pending; /* per dongle: stream bytes not yet consumed */
@@ -126,6 +131,7 @@ void destroy(airband_hip_handle* h) {
     h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release();
     h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
     h->d_tmp_wavein.release(); h->d_tmp_iqin.release(); h->d_tmp_trace.release();
+    h->d_dev_bset.release(); h->d_bfrag.release(); h->d_bcorr.release();
     h->d_stage.release();
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     h->d_mix_chan.release(); h->d_mix_first.release(); h->d_mix_ml.release(); h->d_mix_mr.release();
@@ -326,6 +332,18 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
         PREP_TRY(h->d_out_iq.alloc((size_t)p.total_ch * h->B * 2), AIRBAND_HIP_ENOMEM);
         PREP_TRY(hipMemset(h->d_out_iq.p, 0, h->d_out_iq.n * sizeof(float)), AIRBAND_HIP_ENOMEM);
     }
+    /* channelizer variant: matrix-core pruned DFT when the configuration qualifies, wavefront FFT otherwise */
+    h->use_dft = !(h->flags & AIRBAND_HIP_FLAG_FORCE_FFT) && dft_supported(p.fft_size, (int)h->hop_bytes, p.dev[0].sfmt, p.max_ch);
+    if (h->use_dft) {
+        build_dft_tables(h->plan);
+        if (p.n_bsets > 4096) {
+            h->use_dft = false; /* table would not stay cache resident; fall back */
+        } else {
+            PREP_TRY(upload(h->d_dev_bset, p.dev_bset), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(upload(h->d_bfrag, p.bfrag), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(upload(h->d_bcorr, p.bcorr), AIRBAND_HIP_ENOMEM);
+        }
+    }
     h->pending.resize(p.n_dev);
 #undef PREP_TRY
     *out = h;
@@ -392,6 +410,38 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const Plan& p = h->plan;
     const bool first = h->batches_done == 0;
+    if (h->use_dft) {
+        DftArgs a;
+        a.iq = (const uint8_t*)d_iq;
+        a.iq_stride = (long)stride_bytes;
+        a.dev = h->d_dev.p;
+        a.cc = h->d_cc.p;
+        a.dev_bset = h->d_dev_bset.p;
+        a.bfrag = h->d_bfrag.p;
+        a.corr = h->d_bcorr.p;
+        a.unscale = p.b_unscale;
+        a.mag = h->d_mag.p;
+        a.iq_bins = h->d_iq.p;
+        a.stride = h->stride;
+        a.n_dev = p.n_dev;
+        a.n_dev_pad = (p.n_dev + 3) / 4 * 4;
+        a.hop_bytes = (int)h->hop_bytes;
+        a.lds_per_buf = dft_lds_per_buf((int)h->hop_bytes);
+        a.row0 = h->row0;
+        a.ring_rows = h->R;
+        a.first_row = first ? 0 : AB_AGC_EXTRA;
+        a.n_hops = first ? h->B + AB_AGC_EXTRA : h->B;
+        /* enough waves to fill 256 CUs x 8 waves even with few dongles: split each dongle's tiles */
+        const int tiles = (a.n_hops + 15) / 16;
+        int splits = (8192 + a.n_dev_pad - 1) / a.n_dev_pad;
+        if (splits > tiles / 4) splits = tiles / 4;
+        if (splits < 1) splits = 1;
+        a.splits = splits;
+        (void)hipEventRecord(h->ev[0], s);
+        launch_channelizer_dft(a, s);
+        (void)hipEventRecord(h->ev[1], s);
+        return run_back_half(h, s);
+    }
     ChannelizerArgs ca;
     ca.iq = (const uint8_t*)d_iq;
     ca.iq_stride = (long)stride_bytes;
@@ -579,8 +629,7 @@ int airband_hip_last_timings(airband_hip_handle* h, float* ms4) {
 }
 
 const char* airband_hip_channelizer_name(const airband_hip_handle* h) {
-    (void)h;
-    return "fft_wave64";
+    return (h && h->use_dft) ? "dft_mfma_i8" : "fft_wave64";
 }
 
 int airband_hip_set_signal_plan(airband_hip_handle* h, const int64_t* carriers, int32_t n_carriers, int32_t noise_q8, const int16_t* sin_table4096) {

@@ -1,0 +1,160 @@
+/* csrc/channelizer_dft.hip -- stage 1 of the hot path on gfx950, fast variant for u8/s8 dongles with <= 8 channels.
+ *
+ * The reference computes a full fft_size-point FFT per hop and then reads ONE bin per channel
+ * (src/rtl_airband.cpp:460 fftwf_execute, :483-489 bin extract).  Per hop and channel that is
+ *      X[bin] = sum_n  lev[b_n] * w[n] * exp(-2 pi i bin n / N)        (lev, w: src/rtl_airband.cpp:316-351)
+ * i.e. a length-2N real dot product of the window's raw bytes with a fixed coefficient row.  With <= 8 channels the
+ * 16 output components (re, im) x 8 form a [hops x 2N] by [2N x 16] product whose left operand is a sliding view
+ * of the raw byte stream -- a dense contraction the matrix cores do at many times the VALU FFT rate, which turns the
+ * channelizer from VALU-bound (36-72 flop/byte) into HBM-bound.
+ *
+ * Exactness: bytes enter as int8 (b - 128, one XOR); the coefficient table is quantised to a 24-bit fixed point
+ * number split into three balanced base-256 digits, so each v_mfma_i32_16x16x64_i8 accumulates EXACT integers
+ * (|acc| <= 2^24); the three partial sums are recombined in float64 and the (b-127.5) offset of the reference's
+ * LUT is restored with a per-column constant.  Result = the exact DFT with coefficients rounded at 2^-24 of full
+ * scale -- the same class of error as a float FFT (~1e-7 relative), no accumulation round-off at all.
+ *
+ * Only u8 takes this path (s8's LUT has an uninitialised entry, s16/f32 are not bytes); everything else -- other
+ * FFT sizes, > 8 channels per dongle, odd hop sizes -- uses channelizer_fft.hip.
+ *
+ * Mapping (wave64, CDNA4): one wavefront owns one dongle and a range of 16-hop tiles.
+ *   A (16 hops x 64 bytes per MFMA): lane l reads the 16 consecutive stream bytes at hop (l&15), k-chunk (l>>4)
+ *     of the current 64-byte step straight from an LDS copy of the raw stream (ds_read_b128); consecutive
+ *     hops overlap, so every HBM byte is fetched once (16 B/lane coalesced) and re-used N/hop times from LDS.
+ *   B (64 x 16 per MFMA, 3 digits x 16 steps): 192 VGPRs, loaded once per wave from a per-bin-set table.
+ *   D: lane l holds column (l&15) = (channel, re|im) of hops (l>>4)*4 + {0..3}; |bin| needs the neighbour lane.
+ */
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace airband {
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int TILE_HOPS = 16;
+
+template <int FFT_N>
+__global__ __launch_bounds__(256, 2) void channelizer_dft_kernel(DftArgs a) {
+    constexpr int WIN_BYTES = 2 * FFT_N;          /* bytes per window (u8/s8 I/Q)      */
+    constexpr int KSTEPS = WIN_BYTES / 64;        /* MFMA k-steps per window           */
+    static_assert(KSTEPS == 16, "B-fragment register budget is sized for fft_size 512");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_global = blockIdx.x * 4 + wave;
+    const int d = wave_global % a.n_dev_pad;              /* 4 consecutive dongles per workgroup */
+    const int split = wave_global / a.n_dev_pad;
+    if (d >= a.n_dev || split >= a.splits) return;
+    const int hop_bytes = a.hop_bytes;
+    const int tile_bytes = TILE_HOPS * hop_bytes;         /* new stream bytes per tile */
+    const int carry = WIN_BYTES - hop_bytes;              /* bytes a tile shares with the next one */
+    const int buf_bytes = tile_bytes + carry;
+    uint8_t* lds = lds_all + wave * 2 * a.lds_per_buf;    /* two buffers per wave */
+
+    const int tiles_total = (a.n_hops + TILE_HOPS - 1) / TILE_HOPS;
+    const int tiles_per_split = (tiles_total + a.splits - 1) / a.splits;
+    const int t_begin = split * tiles_per_split;
+    const int t_end = min(tiles_total, t_begin + tiles_per_split);
+    if (t_begin >= t_end) return;
+
+    const uint8_t* src = a.iq + (long)d * a.iq_stride;    /* first byte of this batch's first hop */
+    const long span_end = (long)(a.n_hops - 1) * hop_bytes + WIN_BYTES; /* bytes of the batch span that may be read */
+
+    /* ---- B fragments: 3 digits x 16 k-steps, resident for the whole wave ---------------------------------- */
+    const int bset = a.dev_bset[d];
+    const v4i* btab = reinterpret_cast<const v4i*>(a.bfrag) + (long)bset * 3 * KSTEPS * 64 + lane;
+    v4i b0[KSTEPS], b1[KSTEPS], b2[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; s++) {
+        b0[s] = btab[(0 * KSTEPS + s) * 64];
+        b1[s] = btab[(1 * KSTEPS + s) * 64];
+        b2[s] = btab[(2 * KSTEPS + s) * 64];
+    }
+    const int col = lane & 15;
+    const double corr = a.corr[bset * 16 + col];
+    const double unscale = a.unscale;
+    const int ch = col >> 1;
+    const DevConst dev = a.dev[d];
+    const bool ch_valid = ch < dev.n_ch;
+    const int slot = dev.chan_base + ch;
+    const bool want_iq = ch_valid && ((a.cc[ch_valid ? slot : dev.chan_base].flags & AB_F_RAW_IQ) != 0);
+
+    /* ---- raw-byte staging: HBM -> LDS without a register round trip (global_load_lds_dwordx4: every lane
+     * supplies its own 16-byte source address, the wave's data lands contiguously at an M0-relative LDS base).
+     * A tile needs stream bytes [t*tile_bytes, t*tile_bytes + buf_bytes); the first `carry` of them were already
+     * fetched for the previous tile, so that part is an L2 hit -- HBM sees every byte once. Lanes past the end of
+     * the batch span re-read its last 16 bytes: they only feed hops >= n_hops, which are never stored. */
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int n_dma = (buf_bytes + 1023) >> 10;
+    auto stage = [&](int tile, uint8_t* buf) {
+        const long base = (long)tile * tile_bytes;
+        for (int i = 0; i < n_dma; i++) {
+            long so = base + i * 1024 + lane * 16;
+            if (so + 16 > span_end) so = span_end - 16;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(uintptr_t)(buf + i * 1024), 16, 0, 0);
+        }
+    };
+    int cur = 0;
+    stage(t_begin, lds);
+
+    const int row_l = lane & 15, grp = lane >> 4;
+    for (int t = t_begin; t < t_end; t++) {
+        uint8_t* buf = lds + cur * a.lds_per_buf;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this tile's bytes have landed in LDS */
+        if (t + 1 < t_end) stage(t + 1, lds + (cur ^ 1) * a.lds_per_buf); /* next tile streams in under this tile's MFMAs */
+
+        v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+        const uint8_t* arow = buf + row_l * hop_bytes + grp * 16;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; s++) {
+            v4i av = *reinterpret_cast<const v4i*>(arow + s * 64);
+            av.x ^= 0x80808080; av.y ^= 0x80808080; av.z ^= 0x80808080; av.w ^= 0x80808080; /* u8 -> b - 128 as int8 */
+            acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b0[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b1[s], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b2[s], acc2, 0, 0, 0);
+        }
+        /* recombine the digits exactly, restore the -127.5 offset of the reference's LUT, undo the fixed-point scale */
+        float val[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double y = ((double)acc2[r] * 65536.0 + (double)acc1[r] * 256.0 + (double)acc0[r] + corr) * unscale;
+            val[r] = (float)y;
+        }
+        /* lane pairs (2ch, 2ch+1) hold (re, im) of the same hop */
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float other = __shfl_xor(val[r], 1);
+            const int hop = t * TILE_HOPS + grp * 4 + r;
+            if (!(col & 1) && ch_valid && hop < a.n_hops) {
+                int row = a.row0 + a.first_row + hop;
+                if (row >= a.ring_rows) row -= a.ring_rows;
+                const float re = val[r], im = other;
+                a.mag[(long)row * a.stride + slot] = sqrtf(re * re + im * im);
+                if (want_iq) a.iq_bins[(long)row * a.stride + slot] = make_float2(re, im);
+            }
+        }
+        cur ^= 1;
+    }
+}
+
+}  // namespace
+
+bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch) {
+    return fft_size == 512 && sfmt == AIRBAND_SFMT_U8 && max_ch <= 8 && (hop_bytes % 16) == 0 && hop_bytes <= 640 && hop_bytes >= 64;
+}
+
+int dft_lds_per_buf(int hop_bytes) { return (TILE_HOPS * hop_bytes + 1024 - hop_bytes + 255) / 256 * 256; }
+
+void launch_channelizer_dft(const DftArgs& a, hipStream_t stream) {
+    const long waves = (long)a.n_dev_pad * a.splits;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    const size_t lds = (size_t)4 * 2 * a.lds_per_buf;
+    hipLaunchKernelGGL(channelizer_dft_kernel<512>, dim3(blocks), dim3(256), lds, stream, a);
+}
+
+}  // namespace airband

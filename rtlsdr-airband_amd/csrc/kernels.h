@@ -36,6 +36,24 @@ struct ChannelizerArgs {
     int max_ch;
 };
 
+/* matrix-core channelizer (channelizer_dft.hip) */
+struct DftArgs {
+    const uint8_t* iq;
+    long iq_stride;
+    const DevConst* dev;
+    const ChanConst* cc;
+    const int* dev_bset;    /* [n_dev] coefficient-table index of every dongle */
+    const int8_t* bfrag;    /* [n_bsets][3 digits][16 k-steps][64 lanes][16 bytes] MFMA B fragments */
+    const double* corr;     /* [n_bsets][16] offset restoring (b - 127.5) from (b - 128), in table units */
+    double unscale;         /* 1 / (table scale * 127.5) */
+    float* mag;
+    float2* iq_bins;
+    long stride;
+    int n_dev, n_dev_pad, splits;
+    int hop_bytes, lds_per_buf;
+    int row0, ring_rows, first_row, n_hops;
+};
+
 struct DemodArgs {
     const ChanConst* cc;
     ChanState* cs;
@@ -95,6 +113,9 @@ struct SiggenArgs {
 };
 
 void launch_channelizer_fft(const ChannelizerArgs& a, hipStream_t stream);
+bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch);
+int dft_lds_per_buf(int hop_bytes);
+void launch_channelizer_dft(const DftArgs& a, hipStream_t stream);
 void launch_demod(const DemodArgs& a, hipStream_t stream);
 void launch_emit(const EmitArgs& a, hipStream_t stream);
 void launch_mix(const MixArgs& a, hipStream_t stream);

@@ -286,6 +286,68 @@ int build_plan(const airband_hip_config* cfg, Plan& p) {
     return AIRBAND_HIP_OK;
 }
 
+/* Coefficient table of the pruned DFT: for window byte k = 2n + {0: I, 1: Q} and column 2c + {0: re, 1: im}
+ *   (I + jQ) * w[n] * exp(-j theta) = (I w cos + Q w sin) + j (Q w cos - I w sin),  theta = 2 pi bin_c n / N
+ * (same transform as src/rtl_airband.cpp:451-460 + :483-489 evaluated for one bin).  Values are scaled to 24-bit
+ * integers and split into balanced base-256 digits d0 + 256 d1 + 65536 d2, each in [-128, 127]. */
+void build_dft_tables(Plan& p) {
+    const int N = p.fft_size, K = 2 * N, KS = K / 64;
+    const double S = 8355000.0; /* max |coefficient| < 1  ->  |value| <= 127*65536 + 127*256 + 127 */
+    p.b_unscale = 1.0 / (S * 127.5);
+    p.dev_bset.assign(p.n_dev, 0);
+    p.bfrag.clear();
+    p.bcorr.clear();
+    std::vector<std::vector<int>> keys;
+    for (int d = 0; d < p.n_dev; d++) {
+        std::vector<int> key;
+        for (int j = 0; j < p.dev[d].n_ch; j++) key.push_back(p.cc[p.chan_base[d] + j].base_bin);
+        int found = -1;
+        for (size_t i = 0; i < keys.size(); i++)
+            if (keys[i] == key) {
+                found = (int)i;
+                break;
+            }
+        if (found < 0) {
+            found = (int)keys.size();
+            keys.push_back(key);
+            std::vector<int> q((size_t)K * 16, 0);
+            for (int c = 0; c < (int)key.size() && c < 8; c++) {
+                for (int n = 0; n < N; n++) {
+                    /* the phase is reduced exactly in integers before it meets a double */
+                    const double th = 2.0 * M_PI * (double)(((long long)key[c] * n) % N) / (double)N;
+                    const double wc = (double)p.window[n] * std::cos(th), ws = (double)p.window[n] * std::sin(th);
+                    q[(size_t)(2 * n) * 16 + 2 * c] = (int)std::llround(wc * S);       /* I -> re */
+                    q[(size_t)(2 * n + 1) * 16 + 2 * c] = (int)std::llround(ws * S);   /* Q -> re */
+                    q[(size_t)(2 * n) * 16 + 2 * c + 1] = (int)std::llround(-ws * S);  /* I -> im */
+                    q[(size_t)(2 * n + 1) * 16 + 2 * c + 1] = (int)std::llround(wc * S); /* Q -> im */
+                }
+            }
+            const size_t base = p.bfrag.size();
+            p.bfrag.resize(base + (size_t)3 * KS * 64 * 16, 0);
+            for (int col = 0; col < 16; col++) {
+                double sum = 0.0;
+                for (int k = 0; k < K; k++) {
+                    const int v = q[(size_t)k * 16 + col];
+                    sum += v;
+                    int dgt[3];
+                    int rest = v;
+                    for (int t = 0; t < 3; t++) {
+                        int lo = ((rest + 128) & 255) - 128; /* balanced digit */
+                        dgt[t] = lo;
+                        rest = (rest - lo) / 256;
+                    }
+                    const int s = k / 64, g = (k % 64) / 16, jj = k % 16;
+                    const int lane = g * 16 + col;
+                    for (int t = 0; t < 3; t++) p.bfrag[base + (((size_t)t * KS + s) * 64 + lane) * 16 + jj] = (int8_t)dgt[t];
+                }
+                p.bcorr.push_back(0.5 * sum); /* (b - 127.5) = (b - 128) + 0.5 */
+            }
+        }
+        p.dev_bset[d] = found;
+    }
+    p.n_bsets = (int)keys.size();
+}
+
 void channel_constants(const Plan& p, int i, double* v) {
     const ChanConst& c = p.cc[i];
     v[0] = c.base_bin;

@@ -29,6 +29,12 @@ struct Plan {
     std::vector<float> window;         /* fft_size coefficients (src/rtl_airband.cpp:335-351) */
     std::vector<float> sin_lut, cos_lut; /* 257 entries each (src/util.cpp:105-110) */
     float lev_u8[256], lev_s8[256];    /* src/rtl_airband.cpp:316-324 */
+    /* matrix-core channelizer tables (channelizer_dft.hip); empty unless the configuration qualifies */
+    std::vector<int> dev_bset;         /* [n_dev] coefficient-table index */
+    std::vector<int8_t> bfrag;         /* [n_bsets][3][16][64][16] */
+    std::vector<double> bcorr;         /* [n_bsets][16] */
+    double b_unscale = 0.0;
+    int n_bsets = 0;
     int64_t hop_bytes_max = 0;
     bool uniform_hop = true;           /* every dongle has the same sfmt / hop (needed by the batched launch) */
     std::string error;
@@ -36,6 +42,9 @@ struct Plan {
 
 /* Returns 0 or a negative AIRBAND_HIP_E* code (plan.error holds the text). No GPU needed. */
 int build_plan(const airband_hip_config* cfg, Plan& plan);
+
+/* Builds the int8 coefficient tables for the matrix-core channelizer (fft_size 512, u8, <= 8 channels/dongle). */
+void build_dft_tables(Plan& plan);
 
 /* The 16 "derived constants" slots documented at airband_hip_channel_constants(). */
 void channel_constants(const Plan& plan, int ext_index, double* out16);

@@ -54,8 +54,9 @@ def test_stage2_bit_exact_on_oracle_bins(pkg, built, mixed, wave_rate):
                 k += 1
 
 
+@pytest.mark.parametrize("force_fft", [False, True], ids=["dft_mfma", "fft_wave64"])
 @pytest.mark.parametrize("mixed,wave_rate", [(False, 8000), (True, 16000)])
-def test_end_to_end_stream(pkg, built, mixed, wave_rate):
+def test_end_to_end_stream(pkg, built, mixed, wave_rate, force_fft):
     """Raw u8 I/Q through submit/process/collect vs the oracle: decisions exact, audio <= 1e-4 RMS."""
     n_dev, n_batches = 4, 14
     devices, carriers = helpers.plan_devices(n_dev, mixed, _tweak if mixed else None)
@@ -65,7 +66,9 @@ def test_end_to_end_stream(pkg, built, mixed, wave_rate):
     ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
     assert all(r["n_batches"] == n_batches for r in ref)
     opened = 0
-    with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=pkg.capi.FLAG_TRACE_SQUELCH) as hip:
+    flags = pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_FORCE_FFT if force_fft else 0)
+    with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=flags) as hip:
+        assert hip.channelizer_name() == ("fft_wave64" if force_fft else "dft_mfma_i8")
         # ragged submits: the library must cope with arbitrary chunking of the stream
         pos = [0] * n_dev
         b = 0
