@@ -294,16 +294,17 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     PREP_TRY(upload(h->d_window, p.window), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_sin, p.sin_lut), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_cos, p.cos_lut), AIRBAND_HIP_ENOMEM);
-    /* CTCSS tables, tone-major so a wave of CTCSS lanes reads contiguous words */
+    /* CTCSS tables: [ct_slot][detector][tone] coefficients and [ct_slot][detector][q1|q2][tone] Goertzel state, so
+     * that the 52 tone lanes of demod phase 2 read one contiguous run */
     {
         const int n_ct = (int)p.tones.size();
-        h->ct_stride = n_ct > 0 ? (n_ct + 63) / 64 * 64 : 64;
-        std::vector<float> coeff((size_t)2 * AB_MAX_TONES * h->ct_stride, 0.0f);
+        h->ct_stride = n_ct;
+        std::vector<float> coeff((size_t)(n_ct > 0 ? n_ct : 1) * 2 * AB_MAX_TONES, 0.0f);
         for (int s = 0; s < n_ct; s++)
             for (int k = 0; k < 2; k++)
-                for (int t = 0; t < p.tones[s].n[k]; t++) coeff[((size_t)k * AB_MAX_TONES + t) * h->ct_stride + s] = p.tones[s].coeff[k][t];
+                for (int t = 0; t < p.tones[s].n[k]; t++) coeff[((size_t)s * 2 + k) * AB_MAX_TONES + t] = p.tones[s].coeff[k][t];
         PREP_TRY(upload(h->d_ct_coeff, coeff), AIRBAND_HIP_ENOMEM);
-        PREP_TRY(h->d_ct_q.alloc((size_t)2 * AB_MAX_TONES * 2 * h->ct_stride), AIRBAND_HIP_ENOMEM);
+        PREP_TRY(h->d_ct_q.alloc((size_t)(n_ct > 0 ? n_ct : 1) * 4 * AB_MAX_TONES), AIRBAND_HIP_ENOMEM);
         PREP_TRY(hipMemset(h->d_ct_q.p, 0, h->d_ct_q.n * sizeof(float)), AIRBAND_HIP_ENOMEM);
     }
     /* rings, with the reference's config-time prefill of the lead-in (src/config.cpp:313-316) */
@@ -424,7 +425,7 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
         a.iq_bins = h->d_iq.p;
         a.stride = h->stride;
         a.n_dev = p.n_dev;
-        a.n_dev_pad = (p.n_dev + 3) / 4 * 4;
+        a.n_dev_pad = p.n_dev;
         a.hop_bytes = (int)h->hop_bytes;
         a.lds_per_buf = dft_lds_per_buf((int)h->hop_bytes);
         a.row0 = h->row0;

@@ -38,22 +38,24 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int TILE_HOPS = 16;
 
 template <int FFT_N>
-__global__ __launch_bounds__(256, 2) void channelizer_dft_kernel(DftArgs a) {
+__global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     constexpr int WIN_BYTES = 2 * FFT_N;          /* bytes per window (u8/s8 I/Q)      */
     constexpr int KSTEPS = WIN_BYTES / 64;        /* MFMA k-steps per window           */
     static_assert(KSTEPS == 16, "B-fragment register budget is sized for fft_size 512");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wave_global = blockIdx.x * 4 + wave;
-    const int d = wave_global % a.n_dev_pad;              /* 4 consecutive dongles per workgroup */
+    /* one wavefront per workgroup: waves share nothing, and a 64-thread block lets the LDS budget (two staging
+     * buffers per wave) rather than the block shape decide how many waves a CU holds */
+    const int lane = threadIdx.x;
+    const int wave_global = blockIdx.x;
+    const int d = wave_global % a.n_dev_pad;
     const int split = wave_global / a.n_dev_pad;
     if (d >= a.n_dev || split >= a.splits) return;
     const int hop_bytes = a.hop_bytes;
     const int tile_bytes = TILE_HOPS * hop_bytes;         /* new stream bytes per tile */
     const int carry = WIN_BYTES - hop_bytes;              /* bytes a tile shares with the next one */
     const int buf_bytes = tile_bytes + carry;
-    uint8_t* lds = lds_all + wave * 2 * a.lds_per_buf;    /* two buffers per wave */
+    uint8_t* lds = lds_all;                               /* two buffers of lds_per_buf bytes */
 
     const int tiles_total = (a.n_hops + TILE_HOPS - 1) / TILE_HOPS;
     const int tiles_per_split = (tiles_total + a.splits - 1) / a.splits;
@@ -148,13 +150,13 @@ bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch) {
     return fft_size == 512 && sfmt == AIRBAND_SFMT_U8 && max_ch <= 8 && (hop_bytes % 16) == 0 && hop_bytes <= 640 && hop_bytes >= 64;
 }
 
-int dft_lds_per_buf(int hop_bytes) { return (TILE_HOPS * hop_bytes + 1024 - hop_bytes + 255) / 256 * 256; }
+/* whole 1 KiB DMA pieces: the last piece of a tile may run past the bytes the tile needs, never past its buffer */
+int dft_lds_per_buf(int hop_bytes) { return (TILE_HOPS * hop_bytes + 1024 - hop_bytes + 1023) / 1024 * 1024; }
 
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream) {
     const long waves = (long)a.n_dev_pad * a.splits;
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
-    const size_t lds = (size_t)4 * 2 * a.lds_per_buf;
-    hipLaunchKernelGGL(channelizer_dft_kernel<512>, dim3(blocks), dim3(256), lds, stream, a);
+    const size_t lds = (size_t)2 * a.lds_per_buf;
+    hipLaunchKernelGGL(channelizer_dft_kernel<512>, dim3((unsigned)waves), dim3(64), lds, stream, a);
 }
 
 }  // namespace airband

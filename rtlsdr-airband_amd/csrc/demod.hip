@@ -3,15 +3,24 @@
  * banks (src/ctcss.cpp), NotchFilter / LowpassFilter (src/filters.cpp), sincosf_lut (src/util.cpp:113-127) and
  * the FM helpers (src/rtl_airband.cpp:141-176).
  *
- * Mapping: one lane per (dongle, channel); 64 consecutive internal channel slots per wavefront; the batch's
- * WAVE_BATCH samples are walked sequentially by every lane (IIR / EMA / FSM state makes time strictly serial),
- * all per-channel state lives in registers for the duration of the batch and in ChanState between batches.
- * Stage-1 results arrive time-major ([hop][slot]) so that the 64 lanes of a wave read one contiguous 256-byte
- * row per step.
+ * Mapping: one wavefront owns 64 consecutive channel slots, one lane per (dongle, channel).  Time is strictly
+ * serial per channel (IIR / EMA / FSM state), so a lane walks the batch's WAVE_BATCH samples in order with all of
+ * its state in registers.  The batch is cut into chunks of CHUNK samples:
+ *   phase 0  the chunk's stage-1 rows (time-major, so one 256-byte row feeds all 64 lanes) are pulled from HBM
+ *            with CHUNK independent loads per lane and parked in LDS -- memory latency is paid once per chunk,
+ *            not once per sample;
+ *   phase 1  squelch FSM + derotation/lowpass + AM AGC / FM discriminator per lane -> pre-notch audio + flags;
+ *   phase 2  (only waves that own CTCSS channels) the wave turns 90 degrees: for each CTCSS channel the 64 lanes
+ *            become the tone bank (lane t = tone t of the fast and the slow detector) and run the Goertzel
+ *            recurrences over the chunk's audio, which is broadcast from LDS -- the reference's 104 multiply-adds
+ *            per sample per channel stay in registers instead of becoming 104 round trips to memory;
+ *   phase 3  output gating (squelch open AND tone present), notch, ampfactor, clamp, fade-out, writes.
+ * Waves without CTCSS channels fuse phase 3 into phase 1.
  *
  * This file MUST be compiled with -ffp-contract=off: squelch decisions have to be bit-identical to the
  * reference's scalar float code given the same stage-1 input, so no FMA contraction, IEEE divide and sqrt
- * (-fhip-fp32-correctly-rounded-divide-sqrt) and the reference's operation order everywhere.
+ * (-fhip-fp32-correctly-rounded-divide-sqrt) and the reference's operation order everywhere (including the
+ * index-order float sum of tone powers in the CTCSS decision).
  */
 #include <hip/hip_runtime.h>
 
@@ -20,26 +29,27 @@
 
 namespace airband {
 
+namespace {
+
+constexpr int CHUNK = 20; /* divides WAVE_BATCH = 1000 and 2000; 64 lanes x 16 B x CHUNK = 20 KiB of LDS per wave */
+
+/* per-sample flag word parked in LDS between the phases */
+constexpr unsigned FL_AUDIO = 1u;   /* Squelch::should_process_audio()                        */
+constexpr unsigned FL_FADE = 2u;    /* AM last_open_sample(): fade out the previous AGC_EXTRA */
+constexpr unsigned FL_RESET = 4u;   /* squelch went CLOSED on this sample: CTCSS::reset()      */
+constexpr unsigned FL_TONE = 64u;   /* CTCSS tone present (written by phase 2)                 */
+constexpr int FL_STATE_SHIFT = 3;   /* bits 3..5: Squelch::State, for the trace                */
+
 struct SqRegs { /* Squelch members that change per sample (src/squelch.h:117-158) */
     float noise_floor, cap, pre_full, pre_capped, post_full, post_capped, level_cache;
     int using_post, next, cur, delay, low_count, head, tail;
     unsigned sample_count, open_count, flappy_count, recent_open, closed_count;
 };
 
-struct CtRegs { /* both CTCSS detectors of one channel (src/ctcss.h:84-95) */
-    int enough[2], count[2], has_tone[2];
-    unsigned found[2], not_found[2];
-};
-
-struct Lane {
+struct Lane { /* per-lane constants */
     unsigned flags;
     float manual_level, normal_ratio, flappy_ratio;
-    /* tables */
-    float* sqbuf;       /* this lane's column of the 102-deep pre-filter delay line, stride S */
-    const float* ctc;   /* this lane's CTCSS coefficient column */
-    float* ctq;         /* this lane's CTCSS q1/q2 column */
-    int ct_stride;
-    int ct_n[2], ct_win[2];
+    float* sqbuf; /* this lane's column of the 102-deep pre-filter delay line, stride S */
     long S;
 };
 
@@ -80,23 +90,10 @@ __device__ __forceinline__ void sq_request(SqRegs& s, int want) {
     s.next = want;
 }
 
-/* CTCSS::reset for both detectors (src/ctcss.cpp:165-172): Goertzel state cleared, magnitude irrelevant */
-__device__ void ct_reset(CtRegs& c, const Lane& L) {
-    if (!(L.flags & AB_F_CTCSS)) return;
-    for (int k = 0; k < 2; k++) {
-        for (int t = 0; t < L.ct_n[k]; t++) {
-            float* q = L.ctq + (long)((k * AB_MAX_TONES + t) * 2) * L.ct_stride;
-            q[0] = 0.0f;
-            q[L.ct_stride] = 0.0f;
-        }
-        c.enough[k] = 0;
-        c.count[k] = 0;
-        c.has_tone[k] = 0;
-    }
-}
-
-/* Squelch::update_current_state (src/squelch.cpp:363-460) */
-__device__ __forceinline__ void sq_advance(SqRegs& s, CtRegs& c, const Lane& L) {
+/* Squelch::update_current_state (src/squelch.cpp:363-460); returns true when the squelch just went CLOSED
+ * (the reference resets both CTCSS detectors at that point, :440-441) */
+__device__ __forceinline__ bool sq_advance(SqRegs& s, const Lane& L) {
+    bool went_closed = false;
     if (s.next == AB_ST_OPENING) {
         if (s.cur != AB_ST_OPENING) {
             s.delay = 0;
@@ -140,7 +137,7 @@ __device__ __forceinline__ void sq_advance(SqRegs& s, CtRegs& c, const Lane& L) 
             s.using_post = 0;
             s.closed_count = 0;
             s.cur = AB_ST_CLOSED;
-            ct_reset(c, L);
+            went_closed = true;
         } else if (s.closed_count < 1000u) {
             s.closed_count++;
         } else if (s.closed_count == 1000u) {
@@ -150,6 +147,7 @@ __device__ __forceinline__ void sq_advance(SqRegs& s, CtRegs& c, const Lane& L) 
     }
     s.tail = s.tail + 1 == AB_SQ_BUF ? 0 : s.tail + 1;
     s.head = s.head + 1 == AB_SQ_BUF ? 0 : s.head + 1;
+    return went_closed;
 }
 
 /* Squelch::update_moving_avg (src/squelch.cpp:501-514) */
@@ -166,8 +164,8 @@ __device__ __forceinline__ void sq_avg(float cap, float& full, float& capped, fl
 }
 
 /* Squelch::process_raw_sample (src/squelch.cpp:195-246) */
-__device__ __forceinline__ void sq_raw(SqRegs& s, CtRegs& c, const Lane& L, float x) {
-    sq_advance(s, c, L);
+__device__ __forceinline__ bool sq_raw(SqRegs& s, const Lane& L, float x) {
+    const bool went_closed = sq_advance(s, L);
     s.sample_count++;
     if ((s.sample_count & 15u) == 0u) { /* calculate_noise_floor, :477-490 */
         const float decay = 0.97f;
@@ -188,6 +186,7 @@ __device__ __forceinline__ void sq_raw(SqRegs& s, CtRegs& c, const Lane& L, floa
             sq_request(s, AB_ST_ABORT);
         }
     }
+    return went_closed;
 }
 
 __device__ __forceinline__ bool sq_should_filter(SqRegs& s, const Lane& L) { return (sq_has_pre(s, L) || s.cur != AB_ST_CLOSED) && s.cur != AB_ST_ABORT; }
@@ -210,61 +209,6 @@ __device__ __forceinline__ void sq_filtered(SqRegs& s, const Lane& L, float x) {
     if (s.post_capped < delayed) sq_request(s, AB_ST_CLOSED);
 }
 
-/* one CTCSS detector, one sample (src/ctcss.cpp:44-54,124-163) */
-__device__ void ct_sample(CtRegs& c, const Lane& L, int k, float x) {
-    const int n = L.ct_n[k];
-    const bool last = (c.count[k] + 1 >= L.ct_win[k]);
-    float total = 0.0f, best = 0.0f, target = 0.0f;
-    for (int t = 0; t < n; t++) {
-        const long off = (long)(k * AB_MAX_TONES + t);
-        const float co = L.ctc[off * L.ct_stride];
-        float* q = L.ctq + off * 2 * L.ct_stride;
-        const float q1 = q[0], q2 = q[L.ct_stride];
-        const float q0 = co * q1 - q2 + x;
-        if (!last) {
-            q[L.ct_stride] = q1;
-            q[0] = q0;
-        } else { /* window complete: power of this tone, then clear for the next window */
-            const float m = q0 * q0 + q1 * q1 - q0 * q1 * co;
-            total += m;
-            if (t == 0) {
-                target = m;
-                best = m;
-            } else if (m > best) {
-                best = m;
-            }
-            q[0] = 0.0f;
-            q[L.ct_stride] = 0.0f;
-        }
-    }
-    c.count[k]++;
-    if (!last) return;
-    c.enough[k] = 1;
-    const float avg = total / (float)n;
-    if (target == best && target > avg) {
-        c.has_tone[k] = 1;
-        c.found[k]++;
-    } else {
-        c.has_tone[k] = 0;
-        c.not_found[k]++;
-    }
-    c.count[k] = 0;
-}
-
-/* Squelch::process_audio_sample (src/squelch.cpp:278-295) */
-__device__ __forceinline__ void sq_audio(const SqRegs& s, CtRegs& c, const Lane& L, float x) {
-    if (!(L.flags & AB_F_CTCSS)) return;
-    if (s.cur != AB_ST_CLOSED) {
-        ct_sample(c, L, 1, x);
-        if (!c.enough[1]) ct_sample(c, L, 0, x);
-    }
-}
-
-__device__ __forceinline__ bool sq_tone(const CtRegs& c, const Lane& L) {
-    if (!(L.flags & AB_F_CTCSS)) return true;
-    return c.enough[1] ? (c.has_tone[1] != 0) : (c.has_tone[0] != 0);
-}
-
 /* fast_atan2 / polar_disc_fast / fm_quadri_demod (src/rtl_airband.cpp:141-176) */
 __device__ __forceinline__ float fast_atan2_dev(float y, float x) {
     const float pi4 = (float)0.78539816339744830962, pi34 = (float)(3 * 0.78539816339744830962);
@@ -278,11 +222,55 @@ __device__ __forceinline__ float fast_atan2_dev(float y, float x) {
     return y < 0.0f ? -a : a;
 }
 
-__global__ __launch_bounds__(64) void demod_kernel(DemodArgs a) {
-    const int slot = blockIdx.x * 64 + threadIdx.x;
-    if (slot >= a.n_slots) return;
-    const ChanConst cc = a.cc[slot];
-    if (!(cc.flags & AB_F_VALID)) return;
+__device__ __forceinline__ int ring_row(int r, int R) { return r >= R ? r - R : r; }
+
+/* Output path of one sample (src/rtl_airband.cpp:532-547 fade-out, :589-620 gating): shared by the fused loop and phase 3 */
+struct OutRegs {
+    float nx0, nx1, nx2, ny0, ny1, ny2; /* NotchFilter delay line */
+    int axc;
+};
+
+__device__ __forceinline__ void emit_sample(const DemodArgs& a, const ChanConst& cc, OutRegs& o, float* wave, float2* iqout, uint8_t* trace, int j, bool audio, bool fade,
+                                            bool tone, int state, float out, float re, float im, bool write_iq_always) {
+    const int R = a.ring_rows;
+    const long S = a.stride;
+    if (fade) { /* AM, squelch just closing: waveout[k] = waveout[k-1] * 0.94 over the previous AGC_EXTRA-1 samples */
+        float prev = wave[(long)ring_row(a.row0 + j, R) * S];
+        for (int k = j + 1; k < j + AB_AGC_EXTRA; k++) {
+            prev = prev * 0.94f;
+            wave[(long)ring_row(a.row0 + k, R) * S] = prev;
+        }
+    }
+    const bool open = audio && tone; /* Squelch::is_open (src/squelch.cpp:118-134) */
+    if (open) {
+        if (cc.flags & AB_F_NOTCH) { /* NotchFilter::apply (src/filters.cpp:50-64) */
+            o.nx0 = o.nx1; o.nx1 = o.nx2; o.nx2 = out;
+            o.ny0 = o.ny1; o.ny1 = o.ny2;
+            o.ny2 = cc.notch_d0 * o.nx2 - cc.notch_d1 * o.nx1 + cc.notch_d0 * o.nx0 + cc.notch_d1 * o.ny1 - cc.notch_d2 * o.ny0;
+            out = o.ny2;
+        }
+        out *= cc.ampfactor;
+        if (out != out) out = 0.0f;
+        else if (out > 1.0f) out = 1.0f;
+        else if (out < -1.0f) out = -1.0f;
+        o.axc = '*';
+    } else {
+        out = 0.0f;
+    }
+    wave[(long)ring_row(a.row0 + AB_AGC_EXTRA + j, R) * S] = out;
+    if (cc.flags & AB_F_IQ_OUT) {
+        if (open) {
+            if (write_iq_always) iqout[(long)j * S] = make_float2(re, im);
+        } else {
+            iqout[(long)j * S] = make_float2(0.0f, 0.0f);
+        }
+    }
+    if (trace) trace[(long)j * S] = (uint8_t)((state & 7) | (open ? 8 : 0) | (audio ? 16 : 0) | (((cc.flags & AB_F_CTCSS) && tone) ? 32 : 0));
+}
+
+template <bool WAVE_HAS_CTCSS>
+__device__ __forceinline__ void demod_wave(const DemodArgs& a, const ChanConst& cc, ChanState* sp, int slot, float4* lds, float* lds_scratch) {
+    const int lane = threadIdx.x & 63;
     const long S = a.stride;
     const int R = a.ring_rows, B = a.wave_batch;
 
@@ -293,192 +281,276 @@ __global__ __launch_bounds__(64) void demod_kernel(DemodArgs a) {
     L.flappy_ratio = cc.sq_flappy_ratio;
     L.sqbuf = a.sqbuf + slot;
     L.S = S;
-    L.ct_stride = a.ct_stride;
-    L.ctc = a.ct_coeff + (cc.ct_slot >= 0 ? cc.ct_slot : 0);
-    L.ctq = a.ct_q + (cc.ct_slot >= 0 ? cc.ct_slot : 0);
-    L.ct_n[0] = cc.ct_ntones[0];
-    L.ct_n[1] = cc.ct_ntones[1];
-    L.ct_win[0] = cc.ct_window[0];
-    L.ct_win[1] = cc.ct_window[1];
 
-    ChanState* sp = a.cs + slot;
     SqRegs s;
-    CtRegs c;
     s.noise_floor = sp->noise_floor; s.cap = sp->cap; s.pre_full = sp->pre_full; s.pre_capped = sp->pre_capped;
     s.post_full = sp->post_full; s.post_capped = sp->post_capped; s.level_cache = sp->level_cache;
     s.using_post = sp->using_post; s.next = sp->next; s.cur = sp->cur; s.delay = sp->delay; s.low_count = sp->low_count;
     s.head = sp->head; s.tail = sp->tail; s.sample_count = sp->sample_count; s.open_count = sp->open_count;
     s.flappy_count = sp->flappy_count; s.recent_open = sp->recent_open; s.closed_count = sp->closed_count;
-    for (int k = 0; k < 2; k++) {
-        c.enough[k] = sp->ct_enough[k]; c.count[k] = sp->ct_count[k]; c.has_tone[k] = sp->ct_has_tone[k];
-        c.found[k] = sp->ct_found[k]; c.not_found[k] = sp->ct_not_found[k];
-    }
     float agc = sp->agcavgfast, pr = sp->pr, pj = sp->pj, prev_out = sp->prev_waveout;
     unsigned dm_phi = sp->dm_phi;
-    float nx0 = sp->nx[0], nx1 = sp->nx[1], nx2 = sp->nx[2], ny0 = sp->ny[0], ny1 = sp->ny[1], ny2 = sp->ny[2];
+    OutRegs o;
+    o.nx0 = sp->nx[0]; o.nx1 = sp->nx[1]; o.nx2 = sp->nx[2]; o.ny0 = sp->ny[0]; o.ny1 = sp->ny[1]; o.ny2 = sp->ny[2];
+    o.axc = ' ';
     float lxr0 = sp->lxr[0], lxr1 = sp->lxr[1], lxr2 = sp->lxr[2], lxi0 = sp->lxi[0], lxi1 = sp->lxi[1], lxi2 = sp->lxi[2];
     float lyr0 = sp->lyr[0], lyr1 = sp->lyr[1], lyr2 = sp->lyr[2], lyi0 = sp->lyi[0], lyi1 = sp->lyi[1], lyi2 = sp->lyi[2];
+    /* CTCSS bookkeeping of this lane's channel: [0] fast, [1] slow (src/ctcss.h:84-95); used only in phase 2 */
+    int ct_enough0 = sp->ct_enough[0], ct_enough1 = sp->ct_enough[1], ct_count0 = sp->ct_count[0], ct_count1 = sp->ct_count[1];
+    int ct_has0 = sp->ct_has_tone[0], ct_has1 = sp->ct_has_tone[1];
+    unsigned ct_found0 = sp->ct_found[0], ct_found1 = sp->ct_found[1], ct_nf0 = sp->ct_not_found[0], ct_nf1 = sp->ct_not_found[1];
 
+    const bool valid = (cc.flags & AB_F_VALID) != 0;
     const bool nfm = cc.flags & AB_F_NFM, raw_iq = cc.flags & AB_F_RAW_IQ, lowpass = cc.flags & AB_F_LOWPASS;
-    const bool notch = cc.flags & AB_F_NOTCH, iq_outputs = cc.flags & AB_F_IQ_OUT;
+    const bool is_ct = valid && (cc.flags & AB_F_CTCSS);
     const float one_minus_alpha = 1.0f - cc.alpha;
-    int axc = ' ';
 
     float* mag = a.mag + slot;
     const float2* iqin = a.iq + slot;
     float* wave = a.wave + slot;
     float2* iqout = a.iq_out + slot;
     uint8_t* trace = a.trace ? a.trace + slot : nullptr;
+    float4* my = lds + lane;
 
-    constexpr int CH = 8; /* samples fetched ahead per round: hides HBM latency behind the serial recurrences */
-    for (int j0 = 0; j0 < B; j0 += CH) {
-        float xs[CH], xd[CH];
-        float2 qd[CH];
+    for (int j0 = 0; j0 < B; j0 += CHUNK) {
+        /* ---- phase 0: CHUNK independent row loads per lane, parked in LDS -------------------------------------- */
+        if (valid) {
 #pragma unroll
-        for (int u = 0; u < CH; u++) {
-            int rc = a.row0 + AB_AGC_EXTRA + j0 + u;   /* current hop (logical row j+AGC_EXTRA) */
-            if (rc >= R) rc -= R;
-            int rd = a.row0 + j0 + u;                  /* hop AGC_EXTRA earlier */
-            if (rd >= R) rd -= R;
-            xs[u] = mag[(long)rc * S];
-            xd[u] = nfm ? 0.0f : mag[(long)rd * S];
-            qd[u] = raw_iq ? iqin[(long)rd * S] : make_float2(0.0f, 0.0f);
+            for (int u = 0; u < CHUNK; u++) {
+                const int rc = ring_row(a.row0 + AB_AGC_EXTRA + j0 + u, R); /* current hop */
+                const int rd = ring_row(a.row0 + j0 + u, R);                /* hop AGC_EXTRA earlier */
+                float4 v;
+                v.x = mag[(long)rc * S];
+                v.y = nfm ? 0.0f : mag[(long)rd * S];
+                const float2 q = raw_iq ? iqin[(long)rd * S] : make_float2(0.0f, 0.0f);
+                v.z = q.x;
+                v.w = q.y;
+                my[u * 64] = v;
+            }
         }
+        /* ---- phase 1 (+3 when fused): the sequential per-sample loop ---------------------------------------------- */
+        if (valid) {
+            for (int u = 0; u < CHUNK; u++) {
+                const int j = j0 + u;
+                const float4 v = my[u * 64];
+                float cur_mag = v.x, re = v.z, im = v.w;
+                /* stage 2 may have rewritten the delayed magnitude (lowpass channels) less than a chunk ago: those
+                 * samples are AGC_EXTRA = 100 > CHUNK steps old, so the value parked in phase 0 is always current */
+                const float delayed_mag = v.y;
+
+                const bool went_closed = sq_raw(s, L, cur_mag);
+
+                if (raw_iq && sq_should_filter(s, L)) { /* src/rtl_airband.cpp:510-530 */
+                    const unsigned idx = dm_phi >> 16; /* sincosf_lut (src/util.cpp:113-127) */
+                    const float fract = (float)(dm_phi & 0xffffu) / 65536.0f;
+                    const float s0 = a.sin_lut[idx], s1 = a.sin_lut[idx + 1], c0 = a.cos_lut[idx], c1 = a.cos_lut[idx + 1];
+                    const float swf = s0 + (s1 - s0) * fract;
+                    const float cwf = c0 + (c1 - c0) * fract;
+                    const float nswf = -swf;
+                    float tr = re * cwf - im * nswf; /* multiply(real, imag, cwf, -swf) */
+                    float ti = im * cwf + re * nswf;
+                    dm_phi = (dm_phi + cc.dm_dphi) & 0xffffffu;
+                    if (lowpass) { /* LowpassFilter::apply (src/filters.cpp:146-163) */
+                        lxr0 = lxr1; lxi0 = lxi1;
+                        lxr1 = lxr2; lxi1 = lxi2;
+                        lxr2 = tr / cc.lp_gain; lxi2 = ti / cc.lp_gain;
+                        lyr0 = lyr1; lyi0 = lyi1;
+                        lyr1 = lyr2; lyi1 = lyi2;
+                        lyr2 = (lxr0 + lxr2) + (2.0f * lxr1) + (cc.lp_yc0 * lyr0) + (cc.lp_yc1 * lyr1);
+                        lyi2 = (lxi0 + lxi2) + (2.0f * lxi1) + (cc.lp_yc0 * lyi0) + (cc.lp_yc1 * lyi1);
+                        tr = lyr2;
+                        ti = lyi2;
+                    }
+                    re = tr;
+                    im = ti;
+                    cur_mag = sqrtf(re * re + im * im); /* double sqrt rounded to float == correctly rounded sqrtf */
+                    mag[(long)ring_row(a.row0 + AB_AGC_EXTRA + j, R) * S] = cur_mag;
+                    if (lowpass) sq_filtered(s, L, cur_mag);
+                }
+
+                bool fade = false;
+                if (!nfm) { /* src/rtl_airband.cpp:532-547 */
+                    if (sq_first_open(s)) {
+                        const float lvl = sq_level(s, L);
+                        for (int k = j; k < j + AB_AGC_EXTRA; k++) { /* the AGC_EXTRA magnitudes before the current one */
+                            const float w = mag[(long)ring_row(a.row0 + k, R) * S];
+                            if (w >= lvl) agc = agc * 0.9f + w * 0.1f;
+                        }
+                    } else if (sq_last_open(s)) {
+                        fade = true;
+                    }
+                }
+
+                float out = 0.0f;
+                const bool audio = sq_should_audio(s);
+                if (audio) {
+                    if (!nfm) { /* AM: src/rtl_airband.cpp:553-563 */
+                        if (cur_mag > sq_level(s, L)) agc = agc * 0.995f + cur_mag * 0.005f;
+                        out = (delayed_mag - agc) / (agc * 1.5f);
+                        if (fabsf(out) > 0.8f) {
+                            out *= 0.85f;
+                            agc *= 1.15f;
+                        }
+                    } else { /* NFM: src/rtl_airband.cpp:565-582 */
+                        if (!(cc.flags & AB_F_QUADRI)) {
+                            const float nbj = -pj;
+                            const float cr = re * pr - im * nbj;
+                            const float cj = im * pr + re * nbj;
+                            out = (float)((double)fast_atan2_dev(cj, cr) * 0.31830988618379067154);
+                        } else {
+                            out = (float)((double)((pr * im - re * pj) / (re * re + im * im + 1.0f)) * 0.31830988618379067154);
+                        }
+                        pr = re;
+                        pj = im;
+                        agc = agc * 0.995f + out * 0.005f;
+                        out -= agc;
+                        out = out * one_minus_alpha + prev_out * cc.alpha;
+                        prev_out = out;
+                    }
+                }
+                if (WAVE_HAS_CTCSS) {
+                    /* park audio + flags; CTCSS channels finish in phases 2/3.  Raw I/Q of an open sample is written now
+                     * (phase 3 zeroes it again if the tone gate turns out closed). */
+                    float4 w;
+                    w.x = out;
+                    w.y = __uint_as_float((audio ? FL_AUDIO : 0u) | (fade ? FL_FADE : 0u) | (went_closed ? FL_RESET : 0u) | ((unsigned)s.cur << FL_STATE_SHIFT));
+                    w.z = re;
+                    w.w = im;
+                    my[u * 64] = w;
+                    if ((cc.flags & AB_F_IQ_OUT) && audio) iqout[(long)j * S] = make_float2(re, im);
+                } else {
+                    emit_sample(a, cc, o, wave, iqout, trace, j, audio, fade, true, s.cur, out, re, im, true);
+                }
+            }
+        }
+        if (WAVE_HAS_CTCSS) {
+            /* ---- phase 2: every CTCSS channel of the wave in turn; lanes = tones ------------------------------------ */
+            unsigned long long todo = __ballot(is_ct);
+            while (todo) {
+                const int owner = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int ct_slot = __builtin_amdgcn_readlane(cc.ct_slot, owner);
+                const int n0 = __builtin_amdgcn_readlane(cc.ct_ntones[0], owner), n1 = __builtin_amdgcn_readlane(cc.ct_ntones[1], owner);
+                const int win0 = __builtin_amdgcn_readlane(cc.ct_window[0], owner), win1 = __builtin_amdgcn_readlane(cc.ct_window[1], owner);
+                int enough0 = __builtin_amdgcn_readlane(ct_enough0, owner), enough1 = __builtin_amdgcn_readlane(ct_enough1, owner);
+                int count0 = __builtin_amdgcn_readlane(ct_count0, owner), count1 = __builtin_amdgcn_readlane(ct_count1, owner);
+                int has0 = __builtin_amdgcn_readlane(ct_has0, owner), has1 = __builtin_amdgcn_readlane(ct_has1, owner);
+                unsigned found0 = __builtin_amdgcn_readlane(ct_found0, owner), found1 = __builtin_amdgcn_readlane(ct_found1, owner);
+                unsigned nf0 = __builtin_amdgcn_readlane(ct_nf0, owner), nf1 = __builtin_amdgcn_readlane(ct_nf1, owner);
+                /* tone tables: [ct_slot][detector][tone] coefficients, [ct_slot][detector][q1|q2][tone] state */
+                const float* ctab = a.ct_coeff + (long)ct_slot * 2 * AB_MAX_TONES;
+                float* qtab = a.ct_q + (long)ct_slot * 4 * AB_MAX_TONES;
+                const bool t0 = lane < n0, t1 = lane < n1;
+                const float c0 = t0 ? ctab[lane] : 0.0f, c1 = t1 ? ctab[AB_MAX_TONES + lane] : 0.0f;
+                float q1f = t0 ? qtab[lane] : 0.0f, q2f = t0 ? qtab[AB_MAX_TONES + lane] : 0.0f;
+                float q1s = t1 ? qtab[2 * AB_MAX_TONES + lane] : 0.0f, q2s = t1 ? qtab[3 * AB_MAX_TONES + lane] : 0.0f;
+                for (int u = 0; u < CHUNK; u++) {
+                    const float4 w = lds[u * 64 + owner]; /* same address in every lane: LDS broadcast */
+                    const float x = w.x;
+                    unsigned f = __builtin_amdgcn_readfirstlane(__float_as_uint(w.y));
+                    if (f & FL_RESET) { /* CTCSS::reset (src/ctcss.cpp:165-172) on both detectors */
+                        q1f = q2f = q1s = q2s = 0.0f;
+                        enough0 = enough1 = count0 = count1 = has0 = has1 = 0;
+                    }
+                    if (f & FL_AUDIO) { /* Squelch::process_audio_sample (src/squelch.cpp:278-295): slow always, fast until slow has a window */
 #pragma unroll
-        for (int u = 0; u < CH; u++) {
-            const int j = j0 + u;
-            int rc = a.row0 + AB_AGC_EXTRA + j;
-            if (rc >= R) rc -= R;
-            float re = qd[u].x, im = qd[u].y;
-            float cur_mag = xs[u];
-
-            sq_raw(s, c, L, cur_mag);
-
-            if (raw_iq && sq_should_filter(s, L)) { /* src/rtl_airband.cpp:510-530 */
-                /* sincosf_lut (src/util.cpp:113-127) */
-                const unsigned idx = dm_phi >> 16;
-                const float fract = (float)(dm_phi & 0xffffu) / 65536.0f;
-                const float s0 = a.sin_lut[idx], s1 = a.sin_lut[idx + 1], c0 = a.cos_lut[idx], c1 = a.cos_lut[idx + 1];
-                const float swf = s0 + (s1 - s0) * fract;
-                const float cwf = c0 + (c1 - c0) * fract;
-                const float nswf = -swf;
-                float tr = re * cwf - im * nswf;  /* multiply(real, imag, cwf, -swf) */
-                float ti = im * cwf + re * nswf;
-                dm_phi = (dm_phi + cc.dm_dphi) & 0xffffffu;
-                if (lowpass) { /* LowpassFilter::apply (src/filters.cpp:146-163) */
-                    lxr0 = lxr1; lxi0 = lxi1;
-                    lxr1 = lxr2; lxi1 = lxi2;
-                    lxr2 = tr / cc.lp_gain; lxi2 = ti / cc.lp_gain;
-                    lyr0 = lyr1; lyi0 = lyi1;
-                    lyr1 = lyr2; lyi1 = lyi2;
-                    lyr2 = (lxr0 + lxr2) + (2.0f * lxr1) + (cc.lp_yc0 * lyr0) + (cc.lp_yc1 * lyr1);
-                    lyi2 = (lxi0 + lxi2) + (2.0f * lxi1) + (cc.lp_yc0 * lyi0) + (cc.lp_yc1 * lyi1);
-                    tr = lyr2;
-                    ti = lyi2;
+                        for (int k = 1; k >= 0; k--) {
+                            if (k == 0 && enough1) break;
+                            float& q1 = k ? q1s : q1f;
+                            float& q2 = k ? q2s : q2f;
+                            const float co = k ? c1 : c0;
+                            int& count = k ? count1 : count0;
+                            const int win = k ? win1 : win0, n = k ? n1 : n0;
+                            const float q0 = co * q1 - q2 + x; /* ToneDetector::process_sample (src/ctcss.cpp:44-54) */
+                            q2 = q1;
+                            q1 = q0;
+                            if (++count >= win) { /* CTCSS::process_audio_sample window end (src/ctcss.cpp:141-162) */
+                                lds_scratch[lane] = q1 * q1 + q2 * q2 - q1 * q2 * co;
+                                float total = 0.0f, best = 0.0f;
+                                for (int i = 0; i < n; i++) { /* index-order float sum, as ToneDetectorSet::sorted_powers does */
+                                    const float m = lds_scratch[i];
+                                    total += m;
+                                    if (i == 0 || m > best) best = m;
+                                }
+                                const float target = lds_scratch[0];
+                                const float avg = total / (float)n;
+                                const bool present = __builtin_amdgcn_readfirstlane((int)(target == best && target > avg)) != 0;
+                                if (k) { enough1 = 1; has1 = present; if (present) found1++; else nf1++; }
+                                else { enough0 = 1; has0 = present; if (present) found0++; else nf0++; }
+                                q1 = 0.0f;
+                                q2 = 0.0f;
+                                count = 0;
+                            }
+                        }
+                    }
+                    const bool tone = enough1 ? (has1 != 0) : (has0 != 0); /* Squelch::is_open's detector choice (src/squelch.cpp:122-130) */
+                    if (tone) f |= FL_TONE;
+                    if (lane == 0) reinterpret_cast<float*>(lds + u * 64 + owner)[1] = __uint_as_float(f);
                 }
-                re = tr;
-                im = ti;
-                cur_mag = sqrtf(re * re + im * im); /* double sqrt rounded to float == correctly rounded sqrtf */
-                mag[(long)rc * S] = cur_mag;
-                if (lowpass) sq_filtered(s, L, cur_mag);
+                if (t0) { qtab[lane] = q1f; qtab[AB_MAX_TONES + lane] = q2f; }
+                if (t1) { qtab[2 * AB_MAX_TONES + lane] = q1s; qtab[3 * AB_MAX_TONES + lane] = q2s; }
+                ct_enough0 = (lane == owner) ? enough0 : ct_enough0; ct_enough1 = (lane == owner) ? enough1 : ct_enough1;
+                ct_count0 = (lane == owner) ? count0 : ct_count0; ct_count1 = (lane == owner) ? count1 : ct_count1;
+                ct_has0 = (lane == owner) ? has0 : ct_has0; ct_has1 = (lane == owner) ? has1 : ct_has1;
+                ct_found0 = (lane == owner) ? found0 : ct_found0; ct_found1 = (lane == owner) ? found1 : ct_found1;
+                ct_nf0 = (lane == owner) ? nf0 : ct_nf0; ct_nf1 = (lane == owner) ? nf1 : ct_nf1;
             }
-
-            if (!nfm) { /* src/rtl_airband.cpp:532-547 */
-                if (sq_first_open(s)) {
-                    const float lvl = sq_level(s, L);
-                    for (int k = j; k < j + AB_AGC_EXTRA; k++) { /* logical rows j .. j+AGC_EXTRA-1 = the AGC_EXTRA hops before the current one */
-                        int rk = a.row0 + k;
-                        if (rk >= R) rk -= R;
-                        const float w = mag[(long)rk * S];
-                        if (w >= lvl) agc = agc * 0.9f + w * 0.1f;
-                    }
-                } else if (sq_last_open(s)) {
-                    int rp = a.row0 + j;           /* logical row (j+AGC_EXTRA) - AGC_EXTRA */
-                    if (rp >= R) rp -= R;
-                    float prev = wave[(long)rp * S];
-                    for (int k = j + 1; k < j + AB_AGC_EXTRA; k++) {
-                        int rk = a.row0 + k;
-                        if (rk >= R) rk -= R;
-                        prev = prev * 0.94f;
-                        wave[(long)rk * S] = prev;
-                    }
+            /* ---- phase 3: gating + output of the chunk ------------------------------------------------------------- */
+            if (valid) {
+                for (int u = 0; u < CHUNK; u++) {
+                    const float4 w = my[u * 64];
+                    const unsigned f = __float_as_uint(w.y);
+                    const bool tone = is_ct ? (f & FL_TONE) != 0 : true;
+                    emit_sample(a, cc, o, wave, iqout, trace, j0 + u, (f & FL_AUDIO) != 0, (f & FL_FADE) != 0, tone, (int)((f >> FL_STATE_SHIFT) & 7u), w.x, w.z, w.w, false);
                 }
             }
-
-            float out = 0.0f;
-            const bool audio = sq_should_audio(s);
-            if (audio) {
-                if (!nfm) { /* AM: src/rtl_airband.cpp:553-563 */
-                    if (cur_mag > sq_level(s, L)) agc = agc * 0.995f + cur_mag * 0.005f;
-                    out = (xd[u] - agc) / (agc * 1.5f);
-                    if (fabsf(out) > 0.8f) {
-                        out *= 0.85f;
-                        agc *= 1.15f;
-                    }
-                } else { /* NFM: src/rtl_airband.cpp:565-582 */
-                    if (!(cc.flags & AB_F_QUADRI)) {
-                        const float nbj = -pj;
-                        const float cr = re * pr - im * nbj;
-                        const float cj = im * pr + re * nbj;
-                        out = (float)((double)fast_atan2_dev(cj, cr) * 0.31830988618379067154);
-                    } else {
-                        out = (float)((double)((pr * im - re * pj) / (re * re + im * im + 1.0f)) * 0.31830988618379067154);
-                    }
-                    pr = re;
-                    pj = im;
-                    agc = agc * 0.995f + out * 0.005f;
-                    out -= agc;
-                    out = out * one_minus_alpha + prev_out * cc.alpha;
-                    prev_out = out;
-                }
-                sq_audio(s, c, L, out);
-            }
-
-            const bool open = audio && sq_tone(c, L); /* Squelch::is_open (src/squelch.cpp:118-134) */
-            float2 qo = make_float2(0.0f, 0.0f);
-            if (open) { /* src/rtl_airband.cpp:590-611 */
-                if (notch) { /* NotchFilter::apply (src/filters.cpp:50-64) */
-                    nx0 = nx1; nx1 = nx2; nx2 = out;
-                    ny0 = ny1; ny1 = ny2;
-                    ny2 = cc.notch_d0 * nx2 - cc.notch_d1 * nx1 + cc.notch_d0 * nx0 + cc.notch_d1 * ny1 - cc.notch_d2 * ny0;
-                    out = ny2;
-                }
-                out *= cc.ampfactor;
-                if (out != out) out = 0.0f;
-                else if (out > 1.0f) out = 1.0f;
-                else if (out < -1.0f) out = -1.0f;
-                axc = '*';
-                qo = make_float2(re, im);
-            } else {
-                out = 0.0f;
-            }
-            /* The AM fade-out above may already have written logical rows up to j+AGC_EXTRA-1; this is row j+AGC_EXTRA */
-            wave[(long)rc * S] = out;
-            if (iq_outputs) iqout[(long)j * S] = qo;
-            if (trace) trace[(long)j * S] = (uint8_t)((s.cur & 7) | (open ? 8 : 0) | (audio ? 16 : 0) | (((cc.flags & AB_F_CTCSS) && sq_tone(c, L)) ? 32 : 0));
         }
     }
 
-    if (axc != ' ') sp->active_counter++;
-    sp->axc = axc;
+    if (!valid) return;
+    if (o.axc != ' ') sp->active_counter++;
+    sp->axc = o.axc;
     sp->agcavgfast = agc; sp->pr = pr; sp->pj = pj; sp->prev_waveout = prev_out; sp->dm_phi = dm_phi;
     sp->noise_floor = s.noise_floor; sp->cap = s.cap; sp->pre_full = s.pre_full; sp->pre_capped = s.pre_capped;
     sp->post_full = s.post_full; sp->post_capped = s.post_capped; sp->level_cache = s.level_cache;
     sp->using_post = s.using_post; sp->next = s.next; sp->cur = s.cur; sp->delay = s.delay; sp->low_count = s.low_count;
     sp->head = s.head; sp->tail = s.tail; sp->sample_count = s.sample_count; sp->open_count = s.open_count;
     sp->flappy_count = s.flappy_count; sp->recent_open = s.recent_open; sp->closed_count = s.closed_count;
-    sp->nx[0] = nx0; sp->nx[1] = nx1; sp->nx[2] = nx2; sp->ny[0] = ny0; sp->ny[1] = ny1; sp->ny[2] = ny2;
+    sp->nx[0] = o.nx0; sp->nx[1] = o.nx1; sp->nx[2] = o.nx2; sp->ny[0] = o.ny0; sp->ny[1] = o.ny1; sp->ny[2] = o.ny2;
     sp->lxr[0] = lxr0; sp->lxr[1] = lxr1; sp->lxr[2] = lxr2; sp->lxi[0] = lxi0; sp->lxi[1] = lxi1; sp->lxi[2] = lxi2;
     sp->lyr[0] = lyr0; sp->lyr[1] = lyr1; sp->lyr[2] = lyr2; sp->lyi[0] = lyi0; sp->lyi[1] = lyi1; sp->lyi[2] = lyi2;
-    for (int k = 0; k < 2; k++) {
-        sp->ct_enough[k] = c.enough[k]; sp->ct_count[k] = c.count[k]; sp->ct_has_tone[k] = c.has_tone[k];
-        sp->ct_found[k] = c.found[k]; sp->ct_not_found[k] = c.not_found[k];
+    sp->ct_enough[0] = ct_enough0; sp->ct_enough[1] = ct_enough1; sp->ct_count[0] = ct_count0; sp->ct_count[1] = ct_count1;
+    sp->ct_has_tone[0] = ct_has0; sp->ct_has_tone[1] = ct_has1;
+    sp->ct_found[0] = ct_found0; sp->ct_found[1] = ct_found1; sp->ct_not_found[0] = ct_nf0; sp->ct_not_found[1] = ct_nf1;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void demod_kernel(DemodArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds_demod[];
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    const int lane = threadIdx.x;
+    ChanConst cc;
+    if (slot < a.n_slots) {
+        cc = a.cc[slot];
+    } else {
+        cc.flags = 0; /* padding lanes stay alive: phase 2 needs all 64 lanes of the wave */
+        cc.ct_slot = -1;
     }
+    (void)lane;
+    float* scratch = reinterpret_cast<float*>(lds_demod + CHUNK * 64);
+    const bool wave_ct = __ballot((cc.flags & AB_F_VALID) && (cc.flags & AB_F_CTCSS)) != 0ull;
+    ChanState* sp = a.cs + (slot < a.n_slots ? slot : 0);
+    if (wave_ct)
+        demod_wave<true>(a, cc, sp, slot, lds_demod, scratch);
+    else
+        demod_wave<false>(a, cc, sp, slot, lds_demod, scratch);
 }
 
 void launch_demod(const DemodArgs& a, hipStream_t stream) {
     const int blocks = (a.n_slots + 63) / 64;
-    hipLaunchKernelGGL(demod_kernel, dim3(blocks), dim3(64), 0, stream, a);
+    const size_t lds = (size_t)CHUNK * 64 * sizeof(float4) + 64 * sizeof(float);
+    hipLaunchKernelGGL(demod_kernel, dim3(blocks), dim3(64), lds, stream, a);
 }
 
 /* ---- emit: time-major device results -> the channel-major layout the output thread consumes -------------

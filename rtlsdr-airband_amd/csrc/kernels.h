@@ -62,8 +62,8 @@ struct DemodArgs {
     float* wave;            /* [ring_rows][stride] */
     float2* iq_out;         /* [wave_batch][stride] */
     float* sqbuf;           /* [AB_SQ_BUF][stride] */
-    const float* ct_coeff;  /* [2][AB_MAX_TONES][ct_stride] */
-    float* ct_q;            /* [2][AB_MAX_TONES][2][ct_stride] */
+    const float* ct_coeff;  /* [n_ctcss][2 detectors][AB_MAX_TONES] */
+    float* ct_q;            /* [n_ctcss][2 detectors][q1|q2][AB_MAX_TONES] */
     uint8_t* trace;         /* [wave_batch][stride] or null */
     const float* sin_lut;   /* 257 */
     const float* cos_lut;   /* 257 */
