@@ -52,8 +52,8 @@ struct airband_hip_handle {
 
     /* geometry */
     int B = 0, R = 0, N = 0;
-    long stride = 0;      /* floats per ring row */
-    int n_slots = 0;
+    int n_slots = 0;      /* demod slots: channels sorted by kind, every kind padded to whole 64-slot blocks */
+    std::vector<int> slot_to_ext, ext_to_slot;
     int64_t hop_bytes = 0, first_batch_bytes = 0, batch_bytes = 0, lookahead_bytes = 0;
     int row0 = 0;
     uint64_t batches_done = 0;
@@ -64,7 +64,8 @@ struct airband_hip_handle {
     DevBuf<DevConst> d_dev;
     DevBuf<ChanConst> d_cc;
     DevBuf<ChanState> d_cs;
-    DevBuf<int> d_slot_to_ext;
+    DevBuf<int> d_slot_to_ext, d_ext_to_slot;
+    DevBuf<uint8_t> d_block_kind;
     DevBuf<float> d_window, d_sin, d_cos;
     DevBuf<float> d_mag, d_wave, d_sqbuf, d_ct_coeff, d_ct_q;
     DevBuf<float2> d_iq, d_iq_out;
@@ -125,7 +126,7 @@ void destroy(airband_hip_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->hip_device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->d_dev.release(); h->d_cc.release(); h->d_cs.release(); h->d_slot_to_ext.release();
+    h->d_dev.release(); h->d_cc.release(); h->d_cs.release(); h->d_slot_to_ext.release(); h->d_ext_to_slot.release(); h->d_block_kind.release();
     h->d_window.release(); h->d_sin.release(); h->d_cos.release();
     h->d_mag.release(); h->d_wave.release(); h->d_sqbuf.release(); h->d_ct_coeff.release(); h->d_ct_q.release();
     h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release();
@@ -164,7 +165,7 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.trace = (h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH) ? h->d_trace.p : nullptr;
     da.sin_lut = h->d_sin.p;
     da.cos_lut = h->d_cos.p;
-    da.stride = h->stride;
+    da.block_kind = h->d_block_kind.p;
     da.ct_stride = h->ct_stride;
     da.n_slots = h->n_slots;
     da.wave_batch = h->B;
@@ -181,7 +182,6 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     ea.out_wave = h->d_out_wave.p;
     ea.out_iq = h->d_out_iq.p;
     ea.out_axc = h->d_out_axc.p;
-    ea.stride = h->stride;
     ea.n_slots = h->n_slots;
     ea.wave_batch = h->B;
     ea.row0 = h->row0;
@@ -274,8 +274,46 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     h->B = p.wave_batch;
     h->R = p.wave_batch + AB_AGC_EXTRA;
     h->N = p.fft_size;
-    h->n_slots = p.total_ch;
-    h->stride = ((long)p.total_ch + 63) / 64 * 64;
+    /* demod slots: sort the channels by demod kind so that a 64-lane wavefront runs ONE code path (AM, NFM,
+     * NFM+lowpass, NFM+CTCSS, everything else); kinds start on 64-slot block boundaries */
+    std::vector<ChanConst> cc_slots;
+    std::vector<ChanState> cs_slots;
+    std::vector<uint8_t> block_kind;
+    {
+        auto kind_of = [](const ChanConst& c) {
+            if (c.flags & AB_F_IQ_OUT) return (int)AB_KIND_GENERIC;
+            const bool nfm = c.flags & AB_F_NFM, raw = c.flags & AB_F_RAW_IQ, lp = c.flags & AB_F_LOWPASS, ct = c.flags & AB_F_CTCSS;
+            if (!nfm) return (!raw && !ct) ? (int)AB_KIND_AM : (int)AB_KIND_GENERIC;
+            if (ct && lp) return (int)AB_KIND_GENERIC;
+            return ct ? (int)AB_KIND_NFM_CTCSS : lp ? (int)AB_KIND_NFM_LOWPASS : (int)AB_KIND_NFM;
+        };
+        h->ext_to_slot.assign(p.total_ch, -1);
+        ChanConst pad_c;
+        ChanState pad_s;
+        std::memset(&pad_c, 0, sizeof(pad_c));
+        std::memset(&pad_s, 0, sizeof(pad_s));
+        pad_c.ct_slot = -1;
+        pad_s.axc = ' ';
+        for (int k = 0; k < AB_KIND_COUNT; k++) {
+            bool any = false;
+            for (int e = 0; e < p.total_ch; e++) {
+                if (kind_of(p.cc[e]) != k) continue;
+                any = true;
+                h->ext_to_slot[e] = (int)cc_slots.size();
+                h->slot_to_ext.push_back(e);
+                cc_slots.push_back(p.cc[e]);
+                cs_slots.push_back(p.cs0[e]);
+            }
+            if (!any) continue;
+            while (cc_slots.size() % AB_SLOT_BLOCK) {
+                h->slot_to_ext.push_back(-1);
+                cc_slots.push_back(pad_c);
+                cs_slots.push_back(pad_s);
+            }
+            while (block_kind.size() < cc_slots.size() / AB_SLOT_BLOCK) block_kind.push_back((uint8_t)k);
+        }
+        h->n_slots = (int)cc_slots.size();
+    }
     h->hop_bytes = 2LL * p.dev[0].bytes_per_sample * p.dev[0].hop_samples;
     h->first_batch_bytes = h->hop_bytes * (h->B + AB_AGC_EXTRA);
     h->batch_bytes = h->hop_bytes * h->B;
@@ -284,13 +322,11 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
 
     /* constants */
     PREP_TRY(upload(h->d_dev, p.dev), AIRBAND_HIP_ENOMEM);
-    PREP_TRY(upload(h->d_cc, p.cc), AIRBAND_HIP_ENOMEM);
-    PREP_TRY(upload(h->d_cs, p.cs0), AIRBAND_HIP_ENOMEM);
-    {
-        std::vector<int> ident(p.total_ch);
-        for (int i = 0; i < p.total_ch; i++) ident[i] = i;
-        PREP_TRY(upload(h->d_slot_to_ext, ident), AIRBAND_HIP_ENOMEM);
-    }
+    PREP_TRY(upload(h->d_cc, cc_slots), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(upload(h->d_cs, cs_slots), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(upload(h->d_slot_to_ext, h->slot_to_ext), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(upload(h->d_ext_to_slot, h->ext_to_slot), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(upload(h->d_block_kind, block_kind), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_window, p.window), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_sin, p.sin_lut), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_cos, p.cos_lut), AIRBAND_HIP_ENOMEM);
@@ -308,21 +344,21 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
         PREP_TRY(hipMemset(h->d_ct_q.p, 0, h->d_ct_q.n * sizeof(float)), AIRBAND_HIP_ENOMEM);
     }
     /* rings, with the reference's config-time prefill of the lead-in (src/config.cpp:313-316) */
-    const size_t ring = (size_t)h->R * h->stride;
+    const size_t ring = (size_t)h->R * h->n_slots; /* blocked: [n_slots/64][R][64] */
     PREP_TRY(h->d_mag.alloc(ring), AIRBAND_HIP_ENOMEM);
     PREP_TRY(h->d_wave.alloc(ring), AIRBAND_HIP_ENOMEM);
     PREP_TRY(h->d_iq.alloc(ring), AIRBAND_HIP_ENOMEM);
-    PREP_TRY(h->d_iq_out.alloc((size_t)h->B * h->stride), AIRBAND_HIP_ENOMEM);
-    PREP_TRY(h->d_sqbuf.alloc((size_t)AB_SQ_BUF * h->stride), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(h->d_iq_out.alloc((size_t)h->B * h->n_slots), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(h->d_sqbuf.alloc((size_t)AB_SQ_BUF * h->n_slots), AIRBAND_HIP_ENOMEM);
     PREP_TRY(fill(h->d_mag.p, ring, 20.0f, h->stream), AIRBAND_HIP_ENOMEM);
     PREP_TRY(fill(h->d_wave.p, ring, 0.5f, h->stream), AIRBAND_HIP_ENOMEM);
     PREP_TRY(hipStreamSynchronize(h->stream), AIRBAND_HIP_ENOMEM);
     PREP_TRY(hipMemset(h->d_iq.p, 0, ring * sizeof(float2)), AIRBAND_HIP_ENOMEM);
-    PREP_TRY(hipMemset(h->d_iq_out.p, 0, (size_t)h->B * h->stride * sizeof(float2)), AIRBAND_HIP_ENOMEM);
-    PREP_TRY(hipMemset(h->d_sqbuf.p, 0, (size_t)AB_SQ_BUF * h->stride * sizeof(float)), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(hipMemset(h->d_iq_out.p, 0, (size_t)h->B * h->n_slots * sizeof(float2)), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(hipMemset(h->d_sqbuf.p, 0, (size_t)AB_SQ_BUF * h->n_slots * sizeof(float)), AIRBAND_HIP_ENOMEM);
     if (h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH) {
-        PREP_TRY(h->d_trace.alloc((size_t)h->B * h->stride), AIRBAND_HIP_ENOMEM);
-        PREP_TRY(hipMemset(h->d_trace.p, 0, (size_t)h->B * h->stride), AIRBAND_HIP_ENOMEM);
+        PREP_TRY(h->d_trace.alloc((size_t)h->B * h->n_slots), AIRBAND_HIP_ENOMEM);
+        PREP_TRY(hipMemset(h->d_trace.p, 0, (size_t)h->B * h->n_slots), AIRBAND_HIP_ENOMEM);
     }
     /* results */
     PREP_TRY(h->d_out_wave.alloc((size_t)p.total_ch * h->B), AIRBAND_HIP_ENOMEM);
@@ -417,13 +453,13 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
         a.iq_stride = (long)stride_bytes;
         a.dev = h->d_dev.p;
         a.cc = h->d_cc.p;
+        a.ext_to_slot = h->d_ext_to_slot.p;
         a.dev_bset = h->d_dev_bset.p;
         a.bfrag = h->d_bfrag.p;
         a.corr = h->d_bcorr.p;
         a.unscale = p.b_unscale;
         a.mag = h->d_mag.p;
         a.iq_bins = h->d_iq.p;
-        a.stride = h->stride;
         a.n_dev = p.n_dev;
         a.n_dev_pad = p.n_dev;
         a.hop_bytes = (int)h->hop_bytes;
@@ -449,11 +485,11 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
     ca.dev = h->d_dev.p;
     ca.cs = h->d_cs.p;
     ca.cc = h->d_cc.p;
+    ca.ext_to_slot = h->d_ext_to_slot.p;
     ca.window = h->d_window.p;
     ca.mag = h->d_mag.p;
     ca.iq_bins = h->d_iq.p;
     ca.last_spectrum = nullptr;
-    ca.stride = h->stride;
     ca.n_dev = p.n_dev;
     ca.fft_log = p.fft_log;
     ca.hop_samples = p.dev[0].hop_samples;
@@ -519,7 +555,7 @@ int airband_hip_process_bins(airband_hip_handle* h, const float* wavein, const f
     HIP_TRY(h, hipMemcpyAsync(h->d_tmp_wavein.p, wavein, n * sizeof(float), hipMemcpyHostToDevice, s), AIRBAND_HIP_ERUNTIME);
     HIP_TRY(h, hipMemcpyAsync(h->d_tmp_iqin.p, iq_in, 2 * n * sizeof(float), hipMemcpyHostToDevice, s), AIRBAND_HIP_ERUNTIME);
     (void)hipEventRecord(h->ev[0], s);
-    launch_scatter_bins(h->d_tmp_wavein.p, h->d_tmp_iqin.p, h->d_slot_to_ext.p, h->d_cc.p, h->d_mag.p, h->d_iq.p, h->stride, h->n_slots, h->B, h->row0, h->R, s);
+    launch_scatter_bins(h->d_tmp_wavein.p, h->d_tmp_iqin.p, h->d_slot_to_ext.p, h->d_cc.p, h->d_mag.p, h->d_iq.p, h->n_slots, h->B, h->row0, h->R, s);
     (void)hipEventRecord(h->ev[1], s);
     return run_back_half(h, s);
 }
@@ -592,7 +628,7 @@ static int gather_last(airband_hip_handle* h, float* wavein, float* iq_in, uint8
     hipStream_t s = h->stream;
     const int prev_row0 = (h->row0 + h->R - h->B) % h->R; /* row0 of the batch just finished */
     launch_gather_bins(h->d_mag.p, h->d_iq.p, h->d_trace.p, h->d_slot_to_ext.p, wavein ? h->d_tmp_wavein.p : nullptr, iq_in ? h->d_tmp_iqin.p : nullptr,
-                       trace ? h->d_tmp_trace.p : nullptr, h->stride, h->n_slots, h->B, prev_row0, h->R, s);
+                       trace ? h->d_tmp_trace.p : nullptr, h->n_slots, h->B, prev_row0, h->R, s);
     if (wavein) HIP_TRY(h, hipMemcpyAsync(wavein, h->d_tmp_wavein.p, n * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
     if (iq_in) HIP_TRY(h, hipMemcpyAsync(iq_in, h->d_tmp_iqin.p, 2 * n * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
     if (trace) HIP_TRY(h, hipMemcpyAsync(trace, h->d_tmp_trace.p, n, hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);

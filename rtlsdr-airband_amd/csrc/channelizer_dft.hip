@@ -47,8 +47,13 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     /* one wavefront per workgroup: waves share nothing, and a 64-thread block lets the LDS budget (two staging
      * buffers per wave) rather than the block shape decide how many waves a CU holds */
     const int lane = threadIdx.x;
+    /* XCD-aware placement: workgroup b runs on XCD b % 8 (observed dispatch order; speed only).  16 consecutive
+     * dongles write neighbouring slots of the same 128-byte lines, so they are given to the SAME XCD and meet in
+     * one L2: inside every group of 128 dongles, workgroup i*8 + x takes dongle x*16 + i. */
     const int wave_global = blockIdx.x;
-    const int d = wave_global % a.n_dev_pad;
+    const int d_lin = wave_global % a.n_dev_pad;
+    const int g128 = d_lin & ~127, in128 = d_lin & 127;
+    const int d = ((a.n_dev_pad - g128) >= 128) ? g128 + (in128 & 7) * 16 + (in128 >> 3) : d_lin;
     const int split = wave_global / a.n_dev_pad;
     if (d >= a.n_dev || split >= a.splits) return;
     const int hop_bytes = a.hop_bytes;
@@ -82,8 +87,9 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     const int ch = col >> 1;
     const DevConst dev = a.dev[d];
     const bool ch_valid = ch < dev.n_ch;
-    const int slot = dev.chan_base + ch;
-    const bool want_iq = ch_valid && ((a.cc[ch_valid ? slot : dev.chan_base].flags & AB_F_RAW_IQ) != 0);
+    const int slot = a.ext_to_slot[dev.chan_base + (ch_valid ? ch : 0)];
+    const bool want_iq = ch_valid && ((a.cc[slot].flags & AB_F_RAW_IQ) != 0);
+    const long slot_base = ab_ring_base(slot, a.ring_rows);
 
     /* ---- raw-byte staging: HBM -> LDS without a register round trip (global_load_lds_dwordx4: every lane
      * supplies its own 16-byte source address, the wave's data lands contiguously at an M0-relative LDS base).
@@ -136,8 +142,8 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
                 int row = a.row0 + a.first_row + hop;
                 if (row >= a.ring_rows) row -= a.ring_rows;
                 const float re = val[r], im = other;
-                a.mag[(long)row * a.stride + slot] = sqrtf(re * re + im * im);
-                if (want_iq) a.iq_bins[(long)row * a.stride + slot] = make_float2(re, im);
+                a.mag[slot_base + (long)row * AB_SLOT_BLOCK] = sqrtf(re * re + im * im);
+                if (want_iq) a.iq_bins[slot_base + (long)row * AB_SLOT_BLOCK] = make_float2(re, im);
             }
         }
         cur ^= 1;

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
     int my_rho = -1, my_src = 0, my_slot = -1;
     bool my_raw = false;
     if (lane < dev.n_ch) {
-        my_slot = dev.chan_base + lane;
+        my_slot = a.ext_to_slot[dev.chan_base + lane];
         const int bin = a.cs[my_slot].bin;
         my_rho = bitrev(bin & (P - 1), LOGP);
         my_src = bitrev(bin >> LOGP, 6);
@@ -201,8 +201,9 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
         if (my_slot >= 0) {
             int row = a.row0 + a.first_row + hop0 + h;
             if (row >= a.ring_rows) row -= a.ring_rows;
-            a.mag[(long)row * a.stride + my_slot] = sqrtf(bre * bre + bim * bim);
-            if (my_raw) a.iq_bins[(long)row * a.stride + my_slot] = make_float2(bre, bim);
+            const long off = ab_ring_base(my_slot, a.ring_rows) + (long)row * AB_SLOT_BLOCK;
+            a.mag[off] = sqrtf(bre * bre + bim * bim);
+            if (my_raw) a.iq_bins[off] = make_float2(bre, bim);
         }
     }
 }

@@ -84,4 +84,19 @@ struct DevConst {
     int32_t pad;
 };
 
+/* Demod kinds: slots are sorted so that the 64 lanes of a demod wavefront run the same code path. */
+enum { AB_KIND_AM = 0, AB_KIND_NFM = 1, AB_KIND_NFM_LOWPASS = 2, AB_KIND_NFM_CTCSS = 3, AB_KIND_GENERIC = 4, AB_KIND_COUNT = 5 };
+
+/* Stage-1/stage-2 exchange buffers are blocked time-major rings: element (row, slot) of a buffer with `rows` rows
+ * lives at ((slot / 64) * rows + row) * 64 + slot % 64.  One demod wavefront (64 slots) therefore streams ONE
+ * contiguous region row by row (256 bytes per row), and a channelizer wavefront writes its dongle's few slots at a
+ * 256-byte row stride inside that same region instead of at a multi-megabyte stride. */
+#define AB_SLOT_BLOCK 64
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define AB_HD __host__ __device__
+#else
+#define AB_HD
+#endif
+static inline AB_HD long ab_ring_base(int slot, int rows) { return ((long)(slot >> 6) * rows) * AB_SLOT_BLOCK + (slot & 63); }
+
 #endif

@@ -233,7 +233,7 @@ struct OutRegs {
 __device__ __forceinline__ void emit_sample(const DemodArgs& a, const ChanConst& cc, OutRegs& o, float* wave, float2* iqout, uint8_t* trace, int j, bool audio, bool fade,
                                             bool tone, int state, float out, float re, float im, bool write_iq_always) {
     const int R = a.ring_rows;
-    const long S = a.stride;
+    constexpr long S = AB_SLOT_BLOCK;
     if (fade) { /* AM, squelch just closing: waveout[k] = waveout[k-1] * 0.94 over the previous AGC_EXTRA-1 samples */
         float prev = wave[(long)ring_row(a.row0 + j, R) * S];
         for (int k = j + 1; k < j + AB_AGC_EXTRA; k++) {
@@ -268,18 +268,31 @@ __device__ __forceinline__ void emit_sample(const DemodArgs& a, const ChanConst&
     if (trace) trace[(long)j * S] = (uint8_t)((state & 7) | (open ? 8 : 0) | (audio ? 16 : 0) | (((cc.flags & AB_F_CTCSS) && tone) ? 32 : 0));
 }
 
-template <bool WAVE_HAS_CTCSS>
-__device__ __forceinline__ void demod_wave(const DemodArgs& a, const ChanConst& cc, ChanState* sp, int slot, float4* lds, float* lds_scratch) {
+/* Feature bits that are compile-time constants inside a specialised kind (everything else stays a run-time flag) */
+constexpr unsigned KIND_MASK = AB_F_NFM | AB_F_RAW_IQ | AB_F_LOWPASS | AB_F_CTCSS | AB_F_IQ_OUT;
+template <int KIND>
+struct KindBits {
+    static constexpr unsigned value = KIND == AB_KIND_NFM           ? (AB_F_NFM | AB_F_RAW_IQ)
+                                      : KIND == AB_KIND_NFM_LOWPASS ? (AB_F_NFM | AB_F_RAW_IQ | AB_F_LOWPASS)
+                                      : KIND == AB_KIND_NFM_CTCSS   ? (AB_F_NFM | AB_F_RAW_IQ | AB_F_CTCSS)
+                                                                    : 0u;
+};
+
+template <int KIND, bool WAVE_HAS_CTCSS>
+__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, float4* lds, float* lds_scratch) {
     const int lane = threadIdx.x & 63;
-    const long S = a.stride;
+    constexpr long S = AB_SLOT_BLOCK;
     const int R = a.ring_rows, B = a.wave_batch;
+    const bool valid = (cc.flags & AB_F_VALID) != 0;
+    /* inside a specialised kind the modulation / filter feature bits are constants: the compiler drops the other paths */
+    if (KIND != AB_KIND_GENERIC) cc.flags = (cc.flags & ~KIND_MASK) | KindBits<KIND>::value;
 
     Lane L;
     L.flags = cc.flags;
     L.manual_level = cc.sq_manual_level;
     L.normal_ratio = cc.sq_normal_ratio;
     L.flappy_ratio = cc.sq_flappy_ratio;
-    L.sqbuf = a.sqbuf + slot;
+    L.sqbuf = a.sqbuf + ab_ring_base(slot, AB_SQ_BUF);
     L.S = S;
 
     SqRegs s;
@@ -300,16 +313,15 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, const ChanConst& 
     int ct_has0 = sp->ct_has_tone[0], ct_has1 = sp->ct_has_tone[1];
     unsigned ct_found0 = sp->ct_found[0], ct_found1 = sp->ct_found[1], ct_nf0 = sp->ct_not_found[0], ct_nf1 = sp->ct_not_found[1];
 
-    const bool valid = (cc.flags & AB_F_VALID) != 0;
     const bool nfm = cc.flags & AB_F_NFM, raw_iq = cc.flags & AB_F_RAW_IQ, lowpass = cc.flags & AB_F_LOWPASS;
     const bool is_ct = valid && (cc.flags & AB_F_CTCSS);
     const float one_minus_alpha = 1.0f - cc.alpha;
 
-    float* mag = a.mag + slot;
-    const float2* iqin = a.iq + slot;
-    float* wave = a.wave + slot;
-    float2* iqout = a.iq_out + slot;
-    uint8_t* trace = a.trace ? a.trace + slot : nullptr;
+    float* mag = a.mag + ab_ring_base(slot, R);
+    const float2* iqin = a.iq + ab_ring_base(slot, R);
+    float* wave = a.wave + ab_ring_base(slot, R);
+    float2* iqout = a.iq_out + ab_ring_base(slot, B);
+    uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
     float4* my = lds + lane;
 
     for (int j0 = 0; j0 < B; j0 += CHUNK) {
@@ -528,23 +540,23 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, const ChanConst& 
 
 __global__ __launch_bounds__(64) void demod_kernel(DemodArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 lds_demod[];
-    const int slot = blockIdx.x * 64 + threadIdx.x;
-    const int lane = threadIdx.x;
-    ChanConst cc;
-    if (slot < a.n_slots) {
-        cc = a.cc[slot];
-    } else {
-        cc.flags = 0; /* padding lanes stay alive: phase 2 needs all 64 lanes of the wave */
-        cc.ct_slot = -1;
-    }
-    (void)lane;
+    const int slot = blockIdx.x * 64 + threadIdx.x; /* n_slots is a multiple of 64: padding slots carry flags == 0 */
+    const ChanConst cc = a.cc[slot];
     float* scratch = reinterpret_cast<float*>(lds_demod + CHUNK * 64);
-    const bool wave_ct = __ballot((cc.flags & AB_F_VALID) && (cc.flags & AB_F_CTCSS)) != 0ull;
-    ChanState* sp = a.cs + (slot < a.n_slots ? slot : 0);
-    if (wave_ct)
-        demod_wave<true>(a, cc, sp, slot, lds_demod, scratch);
-    else
-        demod_wave<false>(a, cc, sp, slot, lds_demod, scratch);
+    ChanState* sp = a.cs + slot;
+    switch (a.block_kind[blockIdx.x]) { /* wave-uniform: slots are sorted by kind */
+        case AB_KIND_AM: demod_wave<AB_KIND_AM, false>(a, cc, sp, slot, lds_demod, scratch); break;
+        case AB_KIND_NFM: demod_wave<AB_KIND_NFM, false>(a, cc, sp, slot, lds_demod, scratch); break;
+        case AB_KIND_NFM_LOWPASS: demod_wave<AB_KIND_NFM_LOWPASS, false>(a, cc, sp, slot, lds_demod, scratch); break;
+        case AB_KIND_NFM_CTCSS: demod_wave<AB_KIND_NFM_CTCSS, true>(a, cc, sp, slot, lds_demod, scratch); break;
+        default: {
+            const bool wave_ct = __ballot((cc.flags & AB_F_VALID) && (cc.flags & AB_F_CTCSS)) != 0ull;
+            if (wave_ct)
+                demod_wave<AB_KIND_GENERIC, true>(a, cc, sp, slot, lds_demod, scratch);
+            else
+                demod_wave<AB_KIND_GENERIC, false>(a, cc, sp, slot, lds_demod, scratch);
+        }
+    }
 }
 
 void launch_demod(const DemodArgs& a, hipStream_t stream) {
@@ -567,7 +579,7 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitArgs a) {
         if (t < a.wave_batch && slot0 + tx < a.n_slots) {
             int pr = a.row0 + t;
             if (pr >= R) pr -= R;
-            v = a.wave[(long)pr * a.stride + slot0 + tx];
+            v = a.wave[((long)blockIdx.x * R + pr) * AB_SLOT_BLOCK + tx];
         }
         tile[r][tx] = v;
     }
@@ -586,7 +598,7 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitArgs a) {
                 const int t = t0 + r;
                 float v = 0.0f;
                 if (t < a.wave_batch && slot0 + tx < a.n_slots) {
-                    const float2 q = a.iq_out[(long)t * a.stride + slot0 + tx];
+                    const float2 q = a.iq_out[((long)blockIdx.x * a.wave_batch + t) * AB_SLOT_BLOCK + tx];
                     v = comp ? q.y : q.x;
                 }
                 tile[r][tx] = v;

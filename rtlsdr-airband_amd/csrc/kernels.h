@@ -10,8 +10,8 @@
 
 namespace airband {
 
-/* Device buffers are time-major rings: logical row r of the current batch lives at physical row
- * (row0 + r) mod ring_rows, ring_rows = WAVE_BATCH + AGC_EXTRA.  Logical rows [0, AGC_EXTRA) are the carry from
+/* Device buffers are blocked time-major rings (see ab_ring_base in common.h): logical row r of the current batch
+ * lives at physical row (row0 + r) mod ring_rows, ring_rows = WAVE_BATCH + AGC_EXTRA.  Logical rows [0, AGC_EXTRA) are the carry from
  * the previous batch (what the reference keeps with its memmove / tail copy, src/rtl_airband.cpp:621-624 and
  * src/output.cpp:920), rows [AGC_EXTRA, AGC_EXTRA + WAVE_BATCH) are this batch's new hops.  Advancing row0 by
  * WAVE_BATCH per batch replaces both copies. */
@@ -22,11 +22,11 @@ struct ChannelizerArgs {
     const DevConst* dev;
     const ChanState* cs;    /* for the (AFC-movable) bin of every slot */
     const ChanConst* cc;
+    const int* ext_to_slot; /* channel (device-major external index) -> demod slot */
     const float* window;    /* fft_size */
     float* mag;             /* [ring_rows][stride] */
     float2* iq_bins;        /* [ring_rows][stride] */
     float* last_spectrum;   /* [n_dev][2*fft_size] full FFT of the batch's last hop (AFC), or null */
-    long stride;
     int n_dev, fft_log;
     int hop_samples, bytes_per_sample, sfmt;
     float scale;
@@ -42,13 +42,13 @@ struct DftArgs {
     long iq_stride;
     const DevConst* dev;
     const ChanConst* cc;
+    const int* ext_to_slot;
     const int* dev_bset;    /* [n_dev] coefficient-table index of every dongle */
     const int8_t* bfrag;    /* [n_bsets][3 digits][16 k-steps][64 lanes][16 bytes] MFMA B fragments */
     const double* corr;     /* [n_bsets][16] offset restoring (b - 127.5) from (b - 128), in table units */
     double unscale;         /* 1 / (table scale * 127.5) */
     float* mag;
     float2* iq_bins;
-    long stride;
     int n_dev, n_dev_pad, splits;
     int hop_bytes, lds_per_buf;
     int row0, ring_rows, first_row, n_hops;
@@ -67,7 +67,7 @@ struct DemodArgs {
     uint8_t* trace;         /* [wave_batch][stride] or null */
     const float* sin_lut;   /* 257 */
     const float* cos_lut;   /* 257 */
-    long stride;
+    const uint8_t* block_kind; /* [n_slots / 64] AB_KIND_* of every slot block */
     int ct_stride;
     int n_slots, wave_batch, row0, ring_rows;
 };
@@ -80,7 +80,6 @@ struct EmitArgs {
     float* out_wave;        /* [total_channels][wave_batch] */
     float* out_iq;          /* [total_channels][2*wave_batch] or null */
     uint8_t* out_axc;       /* [total_channels] */
-    long stride;
     int n_slots, wave_batch, row0, ring_rows;
 };
 
@@ -122,10 +121,10 @@ void launch_mix(const MixArgs& a, hipStream_t stream);
 void launch_stats(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, int n_slots, airband_hip_channel_stats* out, hipStream_t stream);
 void launch_siggen(const SiggenArgs& a, hipStream_t stream);
 /* scatter channel-major host-provided bins into the time-major rings (airband_hip_process_bins) */
-void launch_scatter_bins(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, long stride, int n_slots,
+void launch_scatter_bins(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, int n_slots,
                          int wave_batch, int row0, int ring_rows, hipStream_t stream);
 /* gather the batch's new rows back into channel-major order (airband_hip_read_bins / read_trace) */
-void launch_gather_bins(const float* mag, const float2* iq, const uint8_t* trace, const int* slot_to_ext, float* wavein, float* iqin, uint8_t* trace_out, long stride,
+void launch_gather_bins(const float* mag, const float2* iq, const uint8_t* trace, const int* slot_to_ext, float* wavein, float* iqin, uint8_t* trace_out,
                         int n_slots, int wave_batch, int row0, int ring_rows, hipStream_t stream);
 
 }  // namespace airband

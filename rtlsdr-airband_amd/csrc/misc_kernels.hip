@@ -130,7 +130,7 @@ void launch_mix(const MixArgs& a, hipStream_t stream) {
 }
 
 /* ---- layout shuffles for the introspection entry points -------------------------------------------------- */
-__global__ void scatter_bins_kernel(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, long stride, int n_slots,
+__global__ void scatter_bins_kernel(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, int n_slots,
                                     int wave_batch, int row0, int ring_rows) {
     const int slot = blockIdx.x * 64 + (threadIdx.x & 63);
     const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -139,18 +139,19 @@ __global__ void scatter_bins_kernel(const float* wavein, const float* iqin, cons
     if (ext < 0) return;
     int row = row0 + AB_AGC_EXTRA + t;
     if (row >= ring_rows) row -= ring_rows;
-    mag[(long)row * stride + slot] = wavein[(long)ext * wave_batch + t];
-    if (cc[slot].flags & AB_F_RAW_IQ) iq[(long)row * stride + slot] = make_float2(iqin[((long)ext * wave_batch + t) * 2], iqin[((long)ext * wave_batch + t) * 2 + 1]);
+    const long off = ab_ring_base(slot, ring_rows) + (long)row * AB_SLOT_BLOCK;
+    mag[off] = wavein[(long)ext * wave_batch + t];
+    if (cc[slot].flags & AB_F_RAW_IQ) iq[off] = make_float2(iqin[((long)ext * wave_batch + t) * 2], iqin[((long)ext * wave_batch + t) * 2 + 1]);
 }
 
-void launch_scatter_bins(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, long stride, int n_slots,
+void launch_scatter_bins(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, int n_slots,
                          int wave_batch, int row0, int ring_rows, hipStream_t stream) {
-    hipLaunchKernelGGL(scatter_bins_kernel, dim3((n_slots + 63) / 64, (wave_batch + 3) / 4), dim3(256), 0, stream, wavein, iqin, slot_to_ext, cc, mag, iq, stride, n_slots,
+    hipLaunchKernelGGL(scatter_bins_kernel, dim3((n_slots + 63) / 64, (wave_batch + 3) / 4), dim3(256), 0, stream, wavein, iqin, slot_to_ext, cc, mag, iq, n_slots,
                        wave_batch, row0, ring_rows);
 }
 
 __global__ void gather_bins_kernel(const float* mag, const float2* iq, const uint8_t* trace, const int* slot_to_ext, float* wavein, float* iqin, uint8_t* trace_out,
-                                   long stride, int n_slots, int wave_batch, int row0, int ring_rows) {
+                                   int n_slots, int wave_batch, int row0, int ring_rows) {
     const int slot = blockIdx.x * 64 + (threadIdx.x & 63);
     const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (slot >= n_slots || t >= wave_batch) return;
@@ -158,18 +159,19 @@ __global__ void gather_bins_kernel(const float* mag, const float2* iq, const uin
     if (ext < 0) return;
     int row = row0 + AB_AGC_EXTRA + t;
     if (row >= ring_rows) row -= ring_rows;
-    if (wavein) wavein[(long)ext * wave_batch + t] = mag[(long)row * stride + slot];
+    const long off = ab_ring_base(slot, ring_rows) + (long)row * AB_SLOT_BLOCK;
+    if (wavein) wavein[(long)ext * wave_batch + t] = mag[off];
     if (iqin) {
-        const float2 q = iq[(long)row * stride + slot];
+        const float2 q = iq[off];
         iqin[((long)ext * wave_batch + t) * 2] = q.x;
         iqin[((long)ext * wave_batch + t) * 2 + 1] = q.y;
     }
-    if (trace_out && trace) trace_out[(long)ext * wave_batch + t] = trace[(long)t * stride + slot];
+    if (trace_out && trace) trace_out[(long)ext * wave_batch + t] = trace[ab_ring_base(slot, wave_batch) + (long)t * AB_SLOT_BLOCK];
 }
 
-void launch_gather_bins(const float* mag, const float2* iq, const uint8_t* trace, const int* slot_to_ext, float* wavein, float* iqin, uint8_t* trace_out, long stride,
+void launch_gather_bins(const float* mag, const float2* iq, const uint8_t* trace, const int* slot_to_ext, float* wavein, float* iqin, uint8_t* trace_out,
                         int n_slots, int wave_batch, int row0, int ring_rows, hipStream_t stream) {
-    hipLaunchKernelGGL(gather_bins_kernel, dim3((n_slots + 63) / 64, (wave_batch + 3) / 4), dim3(256), 0, stream, mag, iq, trace, slot_to_ext, wavein, iqin, trace_out, stride,
+    hipLaunchKernelGGL(gather_bins_kernel, dim3((n_slots + 63) / 64, (wave_batch + 3) / 4), dim3(256), 0, stream, mag, iq, trace, slot_to_ext, wavein, iqin, trace_out,
                        n_slots, wave_batch, row0, ring_rows);
 }
 
