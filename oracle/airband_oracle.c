@@ -1020,6 +1020,15 @@ void orc_squelch_raw_audio(void* p, const float* raw, const float* audio, int n,
     }
 }
 
+void orc_squelch_audio_raw(void* p, const float* raw, const float* audio, int n, unsigned char* flags) { /* order of src/test_squelch.cpp:186-189 */
+    squelch_t* s = (squelch_t*)p;
+    for (int i = 0; i < n; i++) {
+        sq_audio(s, audio[i]);
+        sq_raw(s, raw[i]);
+        if (flags) flags[i] = (unsigned char)((sq_is_open(s) ? 1 : 0) | (sq_should_audio(s) ? 2 : 0));
+    }
+}
+
 void orc_squelch_counts(void* p, uint64_t* out4) {
     squelch_t* s = (squelch_t*)p;
     out4[0] = s->open_count;

@@ -36,6 +36,35 @@ def _load(nfm: bool, fast: bool = False) -> C.CDLL:
     return lib
 
 
+def load_units(nfm: bool) -> C.CDLL:
+    """The reference's stand-alone pieces (Squelch, CTCSS, filters, LUTs) for unit-level pinning."""
+    lib = _load(nfm)
+    lib.refh_init(1, 9, 0, -1)  # fft_size 512, sincosf_lut_init()
+    f32, vp, i = C.c_float, C.c_void_p, C.c_int
+    lib.refh_squelch_new.restype = vp
+    lib.refh_squelch_new.argtypes = [f32, i, f32]
+    lib.refh_squelch_raw.argtypes = [vp, vp, i, vp, vp, vp]
+    lib.refh_squelch_raw_audio.argtypes = [vp, vp, vp, i, vp]
+    lib.refh_squelch_audio_raw.argtypes = [vp, vp, vp, i, vp]
+    lib.refh_squelch_counts.argtypes = [vp, vp]
+    lib.refh_squelch_free.argtypes = [vp]
+    lib.refh_ctcss_run.argtypes = [f32, f32, i, vp, i, vp, vp]
+    lib.refh_tone_coeff.restype = f32
+    lib.refh_tone_coeff.argtypes = [f32, f32, i]
+    lib.refh_notch_run.argtypes = [f32, f32, f32, vp, i]
+    lib.refh_lowpass_run.argtypes = [f32, f32, vp, vp, i]
+    lib.refh_sincos_lut.argtypes = [C.c_uint32, C.POINTER(f32), C.POINTER(f32)]
+    lib.refh_dbfs_to_level.restype = f32
+    lib.refh_dbfs_to_level.argtypes = [f32]
+    if nfm:
+        lib.refh_fast_atan2.restype = f32
+        lib.refh_fast_atan2.argtypes = [f32, f32]
+        for n in ("refh_polar_disc_fast", "refh_fm_quadri_demod"):
+            getattr(lib, n).restype = f32
+            getattr(lib, n).argtypes = [f32] * 4
+    return lib
+
+
 TRACE_DT = np.dtype([("raw_input", np.float32), ("filtered_input", np.float32), ("audio_input", np.float32), ("noise_floor", np.float32),
                      ("pre_filter_capped", np.float32), ("post_filter_capped", np.float32), ("current_state", np.intc), ("delay", np.intc),
                      ("low_signalcount", np.intc), ("ctcss_fast_has_tone", np.intc), ("ctcss_slow_has_tone", np.intc)])

@@ -380,6 +380,16 @@ void refh_squelch_raw_audio(void* p, const float* raw, const float* audio, int n
         if (is_open) is_open[i] = (unsigned char)((s->is_open() ? 1 : 0) | (s->should_process_audio() ? 2 : 0));
     }
 }
+/* audio first, then raw, unconditionally: the call order of the reference's own CTCSS squelch tests
+ * (src/test_squelch.cpp:186-189) */
+void refh_squelch_audio_raw(void* p, const float* raw, const float* audio, int n, unsigned char* is_open) {
+    Squelch* s = (Squelch*)p;
+    for (int i = 0; i < n; i++) {
+        s->process_audio_sample(audio[i]);
+        s->process_raw_sample(raw[i]);
+        if (is_open) is_open[i] = (unsigned char)((s->is_open() ? 1 : 0) | (s->should_process_audio() ? 2 : 0));
+    }
+}
 void refh_squelch_counts(void* p, uint64_t* out4) {
     Squelch* s = (Squelch*)p;
     out4[0] = s->open_count();
