@@ -54,6 +54,7 @@ struct airband_hip_handle {
     int B = 0, R = 0, N = 0;
     int n_slots = 0;      /* demod slots: channels sorted by kind, every kind padded to whole 64-slot blocks */
     std::vector<int> slot_to_ext, ext_to_slot;
+    int kind_first_block[AB_KIND_COUNT] = {0}, kind_n_blocks[AB_KIND_COUNT] = {0};
     int64_t hop_bytes = 0, first_batch_bytes = 0, batch_bytes = 0, lookahead_bytes = 0;
     int row0 = 0;
     uint64_t batches_done = 0;
@@ -165,13 +166,12 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.trace = (h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH) ? h->d_trace.p : nullptr;
     da.sin_lut = h->d_sin.p;
     da.cos_lut = h->d_cos.p;
-    da.block_kind = h->d_block_kind.p;
     da.ct_stride = h->ct_stride;
     da.n_slots = h->n_slots;
     da.wave_batch = h->B;
     da.row0 = h->row0;
     da.ring_rows = h->R;
-    launch_demod(da, s);
+    launch_demod(da, h->kind_first_block, h->kind_n_blocks, s);
     (void)hipEventRecord(h->ev[2], s);
 
     EmitArgs ea;
@@ -310,7 +310,9 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
                 cc_slots.push_back(pad_c);
                 cs_slots.push_back(pad_s);
             }
+            h->kind_first_block[k] = (int)block_kind.size();
             while (block_kind.size() < cc_slots.size() / AB_SLOT_BLOCK) block_kind.push_back((uint8_t)k);
+            h->kind_n_blocks[k] = (int)block_kind.size() - h->kind_first_block[k];
         }
         h->n_slots = (int)cc_slots.size();
     }

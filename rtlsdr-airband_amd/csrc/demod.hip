@@ -37,7 +37,6 @@ constexpr int CHUNK = 20; /* divides WAVE_BATCH = 1000 and 2000; 64 lanes x 16 B
 constexpr unsigned FL_AUDIO = 1u;   /* Squelch::should_process_audio()                        */
 constexpr unsigned FL_FADE = 2u;    /* AM last_open_sample(): fade out the previous AGC_EXTRA */
 constexpr unsigned FL_RESET = 4u;   /* squelch went CLOSED on this sample: CTCSS::reset()      */
-constexpr unsigned FL_TONE = 64u;   /* CTCSS tone present (written by phase 2)                 */
 constexpr int FL_STATE_SHIFT = 3;   /* bits 3..5: Squelch::State, for the trace                */
 
 struct SqRegs { /* Squelch members that change per sample (src/squelch.h:117-158) */
@@ -278,8 +277,15 @@ struct KindBits {
                                                                     : 0u;
 };
 
+/* floats parked in LDS per (sample, lane): AM needs only the current and the delayed magnitude */
+template <int KIND>
+struct LdsSlots {
+    static constexpr int value = KIND == AB_KIND_AM ? 2 : 4;
+};
+
 template <int KIND, bool WAVE_HAS_CTCSS>
-__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, float4* lds, float* lds_scratch) {
+__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, float* lds, float* lds_scratch) {
+    constexpr int NS = LdsSlots<KIND>::value;
     const int lane = threadIdx.x & 63;
     constexpr long S = AB_SLOT_BLOCK;
     const int R = a.ring_rows, B = a.wave_batch;
@@ -322,29 +328,41 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     float* wave = a.wave + ab_ring_base(slot, R);
     float2* iqout = a.iq_out + ab_ring_base(slot, B);
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
-    float4* my = lds + lane;
+    float* my = lds + lane * NS; /* element (u, lane) at lds[(u * 64 + lane) * NS ...] */
+    unsigned tone_mask = 0;      /* CTCSS lanes: bit u = tone present at sample u of the chunk (written by phase 2) */
 
     for (int j0 = 0; j0 < B; j0 += CHUNK) {
-        /* ---- phase 0: CHUNK independent row loads per lane, parked in LDS -------------------------------------- */
+        /* ---- phase 0: independent row loads per lane, parked in LDS ------------------------------------------------ */
         if (valid) {
-#pragma unroll
+#pragma unroll 10
             for (int u = 0; u < CHUNK; u++) {
                 const int rc = ring_row(a.row0 + AB_AGC_EXTRA + j0 + u, R); /* current hop */
                 const int rd = ring_row(a.row0 + j0 + u, R);                /* hop AGC_EXTRA earlier */
-                float4 v;
-                v.x = mag[(long)rc * S];
-                v.y = nfm ? 0.0f : mag[(long)rd * S];
-                const float2 q = raw_iq ? iqin[(long)rd * S] : make_float2(0.0f, 0.0f);
-                v.z = q.x;
-                v.w = q.y;
-                my[u * 64] = v;
+                if (NS == 2) {
+                    *reinterpret_cast<float2*>(my + u * 64 * NS) = make_float2(mag[(long)rc * S], mag[(long)rd * S]);
+                } else {
+                    float4 v;
+                    v.x = mag[(long)rc * S];
+                    v.y = nfm ? 0.0f : mag[(long)rd * S];
+                    const float2 q = raw_iq ? iqin[(long)rd * S] : make_float2(0.0f, 0.0f);
+                    v.z = q.x;
+                    v.w = q.y;
+                    *reinterpret_cast<float4*>(my + u * 64 * NS) = v;
+                }
             }
         }
         /* ---- phase 1 (+3 when fused): the sequential per-sample loop ---------------------------------------------- */
         if (valid) {
             for (int u = 0; u < CHUNK; u++) {
                 const int j = j0 + u;
-                const float4 v = my[u * 64];
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (NS == 2) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(my + u * 64 * NS);
+                    v.x = t2.x;
+                    v.y = t2.y;
+                } else {
+                    v = *reinterpret_cast<const float4*>(my + u * 64 * NS);
+                }
                 float cur_mag = v.x, re = v.z, im = v.w;
                 /* stage 2 may have rewritten the delayed magnitude (lowpass channels) less than a chunk ago: those
                  * samples are AGC_EXTRA = 100 > CHUNK steps old, so the value parked in phase 0 is always current */
@@ -428,7 +446,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                     w.y = __uint_as_float((audio ? FL_AUDIO : 0u) | (fade ? FL_FADE : 0u) | (went_closed ? FL_RESET : 0u) | ((unsigned)s.cur << FL_STATE_SHIFT));
                     w.z = re;
                     w.w = im;
-                    my[u * 64] = w;
+                    *reinterpret_cast<float4*>(my + u * 64 * NS) = w;
                     if ((cc.flags & AB_F_IQ_OUT) && audio) iqout[(long)j * S] = make_float2(re, im);
                 } else {
                     emit_sample(a, cc, o, wave, iqout, trace, j, audio, fade, true, s.cur, out, re, im, true);
@@ -441,78 +459,94 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             while (todo) {
                 const int owner = __builtin_ctzll(todo);
                 todo &= todo - 1;
-                const int ct_slot = __builtin_amdgcn_readlane(cc.ct_slot, owner);
-                const int n0 = __builtin_amdgcn_readlane(cc.ct_ntones[0], owner), n1 = __builtin_amdgcn_readlane(cc.ct_ntones[1], owner);
-                const int win0 = __builtin_amdgcn_readlane(cc.ct_window[0], owner), win1 = __builtin_amdgcn_readlane(cc.ct_window[1], owner);
+                /* lane u picks up sample u of the owner's chunk (audio, flags); the loop below reads them back with
+                 * v_readlane, so the serial recurrence never waits on LDS */
+                float ax = 0.0f;
+                unsigned fl = 0;
+                if (lane < CHUNK) {
+                    const float2 af = *reinterpret_cast<const float2*>(lds + ((long)lane * 64 + owner) * NS);
+                    ax = af.x;
+                    fl = __float_as_uint(af.y);
+                }
                 int enough0 = __builtin_amdgcn_readlane(ct_enough0, owner), enough1 = __builtin_amdgcn_readlane(ct_enough1, owner);
-                int count0 = __builtin_amdgcn_readlane(ct_count0, owner), count1 = __builtin_amdgcn_readlane(ct_count1, owner);
                 int has0 = __builtin_amdgcn_readlane(ct_has0, owner), has1 = __builtin_amdgcn_readlane(ct_has1, owner);
-                unsigned found0 = __builtin_amdgcn_readlane(ct_found0, owner), found1 = __builtin_amdgcn_readlane(ct_found1, owner);
-                unsigned nf0 = __builtin_amdgcn_readlane(ct_nf0, owner), nf1 = __builtin_amdgcn_readlane(ct_nf1, owner);
-                /* tone tables: [ct_slot][detector][tone] coefficients, [ct_slot][detector][q1|q2][tone] state */
-                const float* ctab = a.ct_coeff + (long)ct_slot * 2 * AB_MAX_TONES;
-                float* qtab = a.ct_q + (long)ct_slot * 4 * AB_MAX_TONES;
-                const bool t0 = lane < n0, t1 = lane < n1;
-                const float c0 = t0 ? ctab[lane] : 0.0f, c1 = t1 ? ctab[AB_MAX_TONES + lane] : 0.0f;
-                float q1f = t0 ? qtab[lane] : 0.0f, q2f = t0 ? qtab[AB_MAX_TONES + lane] : 0.0f;
-                float q1s = t1 ? qtab[2 * AB_MAX_TONES + lane] : 0.0f, q2s = t1 ? qtab[3 * AB_MAX_TONES + lane] : 0.0f;
-                for (int u = 0; u < CHUNK; u++) {
-                    const float4 w = lds[u * 64 + owner]; /* same address in every lane: LDS broadcast */
-                    const float x = w.x;
-                    unsigned f = __builtin_amdgcn_readfirstlane(__float_as_uint(w.y));
-                    if (f & FL_RESET) { /* CTCSS::reset (src/ctcss.cpp:165-172) on both detectors */
-                        q1f = q2f = q1s = q2s = 0.0f;
-                        enough0 = enough1 = count0 = count1 = has0 = has1 = 0;
-                    }
-                    if (f & FL_AUDIO) { /* Squelch::process_audio_sample (src/squelch.cpp:278-295): slow always, fast until slow has a window */
+                unsigned mask = 0;
+                if (__ballot((fl & (FL_AUDIO | FL_RESET)) != 0) == 0ull) {
+                    /* squelch closed (or nothing to do) for the whole chunk: detector state cannot change */
+                    mask = (enough1 ? has1 : has0) ? 0xffffffffu : 0u;
+                } else {
+                    const int ct_slot = __builtin_amdgcn_readlane(cc.ct_slot, owner);
+                    const int n0 = __builtin_amdgcn_readlane(cc.ct_ntones[0], owner), n1 = __builtin_amdgcn_readlane(cc.ct_ntones[1], owner);
+                    const int win0 = __builtin_amdgcn_readlane(cc.ct_window[0], owner), win1 = __builtin_amdgcn_readlane(cc.ct_window[1], owner);
+                    int count0 = __builtin_amdgcn_readlane(ct_count0, owner), count1 = __builtin_amdgcn_readlane(ct_count1, owner);
+                    unsigned found0 = __builtin_amdgcn_readlane(ct_found0, owner), found1 = __builtin_amdgcn_readlane(ct_found1, owner);
+                    unsigned nf0 = __builtin_amdgcn_readlane(ct_nf0, owner), nf1 = __builtin_amdgcn_readlane(ct_nf1, owner);
+                    /* tone tables: [ct_slot][detector][tone] coefficients, [ct_slot][detector][q1|q2][tone] state */
+                    const float* ctab = a.ct_coeff + (long)ct_slot * 2 * AB_MAX_TONES;
+                    float* qtab = a.ct_q + (long)ct_slot * 4 * AB_MAX_TONES;
+                    const bool t0 = lane < n0, t1 = lane < n1;
+                    const float c0 = t0 ? ctab[lane] : 0.0f, c1 = t1 ? ctab[AB_MAX_TONES + lane] : 0.0f;
+                    float q1f = t0 ? qtab[lane] : 0.0f, q2f = t0 ? qtab[AB_MAX_TONES + lane] : 0.0f;
+                    float q1s = t1 ? qtab[2 * AB_MAX_TONES + lane] : 0.0f, q2s = t1 ? qtab[3 * AB_MAX_TONES + lane] : 0.0f;
 #pragma unroll
-                        for (int k = 1; k >= 0; k--) {
-                            if (k == 0 && enough1) break;
-                            float& q1 = k ? q1s : q1f;
-                            float& q2 = k ? q2s : q2f;
-                            const float co = k ? c1 : c0;
-                            int& count = k ? count1 : count0;
-                            const int win = k ? win1 : win0, n = k ? n1 : n0;
-                            const float q0 = co * q1 - q2 + x; /* ToneDetector::process_sample (src/ctcss.cpp:44-54) */
-                            q2 = q1;
-                            q1 = q0;
-                            if (++count >= win) { /* CTCSS::process_audio_sample window end (src/ctcss.cpp:141-162) */
-                                lds_scratch[lane] = q1 * q1 + q2 * q2 - q1 * q2 * co;
-                                float total = 0.0f, best = 0.0f;
-                                for (int i = 0; i < n; i++) { /* index-order float sum, as ToneDetectorSet::sorted_powers does */
-                                    const float m = lds_scratch[i];
-                                    total += m;
-                                    if (i == 0 || m > best) best = m;
+                    for (int u = 0; u < CHUNK; u++) {
+                        const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
+                        const unsigned f = __builtin_amdgcn_readlane(fl, u);
+                        if (f & FL_RESET) { /* CTCSS::reset (src/ctcss.cpp:165-172) on both detectors */
+                            q1f = q2f = q1s = q2s = 0.0f;
+                            enough0 = enough1 = count0 = count1 = has0 = has1 = 0;
+                        }
+                        if (f & FL_AUDIO) { /* Squelch::process_audio_sample (src/squelch.cpp:278-295): slow always, fast until slow has a window */
+#pragma unroll
+                            for (int k = 1; k >= 0; k--) {
+                                if (k == 0 && enough1) break;
+                                float& q1 = k ? q1s : q1f;
+                                float& q2 = k ? q2s : q2f;
+                                const float co = k ? c1 : c0;
+                                int& count = k ? count1 : count0;
+                                const int win = k ? win1 : win0, n = k ? n1 : n0;
+                                const float q0 = co * q1 - q2 + x; /* ToneDetector::process_sample (src/ctcss.cpp:44-54) */
+                                q2 = q1;
+                                q1 = q0;
+                                if (++count >= win) { /* CTCSS::process_audio_sample window end (src/ctcss.cpp:141-162) */
+                                    lds_scratch[lane] = q1 * q1 + q2 * q2 - q1 * q2 * co;
+                                    float total = 0.0f, best = 0.0f;
+                                    for (int i = 0; i < n; i++) { /* index-order float sum, as ToneDetectorSet::sorted_powers does */
+                                        const float m = lds_scratch[i];
+                                        total += m;
+                                        if (i == 0 || m > best) best = m;
+                                    }
+                                    const float target = lds_scratch[0];
+                                    const float avg = total / (float)n;
+                                    const bool present = __builtin_amdgcn_readfirstlane((int)(target == best && target > avg)) != 0;
+                                    if (k) { enough1 = 1; has1 = present; if (present) found1++; else nf1++; }
+                                    else { enough0 = 1; has0 = present; if (present) found0++; else nf0++; }
+                                    q1 = 0.0f;
+                                    q2 = 0.0f;
+                                    count = 0;
                                 }
-                                const float target = lds_scratch[0];
-                                const float avg = total / (float)n;
-                                const bool present = __builtin_amdgcn_readfirstlane((int)(target == best && target > avg)) != 0;
-                                if (k) { enough1 = 1; has1 = present; if (present) found1++; else nf1++; }
-                                else { enough0 = 1; has0 = present; if (present) found0++; else nf0++; }
-                                q1 = 0.0f;
-                                q2 = 0.0f;
-                                count = 0;
                             }
                         }
+                        const bool tone = enough1 ? (has1 != 0) : (has0 != 0); /* Squelch::is_open's detector choice (src/squelch.cpp:122-130) */
+                        if (tone) mask |= 1u << u;
                     }
-                    const bool tone = enough1 ? (has1 != 0) : (has0 != 0); /* Squelch::is_open's detector choice (src/squelch.cpp:122-130) */
-                    if (tone) f |= FL_TONE;
-                    if (lane == 0) reinterpret_cast<float*>(lds + u * 64 + owner)[1] = __uint_as_float(f);
+                    if (t0) { qtab[lane] = q1f; qtab[AB_MAX_TONES + lane] = q2f; }
+                    if (t1) { qtab[2 * AB_MAX_TONES + lane] = q1s; qtab[3 * AB_MAX_TONES + lane] = q2s; }
+                    const bool mine = lane == owner;
+                    ct_count0 = mine ? count0 : ct_count0; ct_count1 = mine ? count1 : ct_count1;
+                    ct_found0 = mine ? found0 : ct_found0; ct_found1 = mine ? found1 : ct_found1;
+                    ct_nf0 = mine ? nf0 : ct_nf0; ct_nf1 = mine ? nf1 : ct_nf1;
+                    ct_enough0 = mine ? enough0 : ct_enough0; ct_enough1 = mine ? enough1 : ct_enough1;
+                    ct_has0 = mine ? has0 : ct_has0; ct_has1 = mine ? has1 : ct_has1;
                 }
-                if (t0) { qtab[lane] = q1f; qtab[AB_MAX_TONES + lane] = q2f; }
-                if (t1) { qtab[2 * AB_MAX_TONES + lane] = q1s; qtab[3 * AB_MAX_TONES + lane] = q2s; }
-                ct_enough0 = (lane == owner) ? enough0 : ct_enough0; ct_enough1 = (lane == owner) ? enough1 : ct_enough1;
-                ct_count0 = (lane == owner) ? count0 : ct_count0; ct_count1 = (lane == owner) ? count1 : ct_count1;
-                ct_has0 = (lane == owner) ? has0 : ct_has0; ct_has1 = (lane == owner) ? has1 : ct_has1;
-                ct_found0 = (lane == owner) ? found0 : ct_found0; ct_found1 = (lane == owner) ? found1 : ct_found1;
-                ct_nf0 = (lane == owner) ? nf0 : ct_nf0; ct_nf1 = (lane == owner) ? nf1 : ct_nf1;
+                tone_mask = (lane == owner) ? mask : tone_mask;
             }
             /* ---- phase 3: gating + output of the chunk ------------------------------------------------------------- */
             if (valid) {
                 for (int u = 0; u < CHUNK; u++) {
-                    const float4 w = my[u * 64];
+                    const float4 w = *reinterpret_cast<const float4*>(my + u * 64 * NS);
                     const unsigned f = __float_as_uint(w.y);
-                    const bool tone = is_ct ? (f & FL_TONE) != 0 : true;
+                    const bool tone = is_ct ? ((tone_mask >> u) & 1u) != 0 : true;
                     emit_sample(a, cc, o, wave, iqout, trace, j0 + u, (f & FL_AUDIO) != 0, (f & FL_FADE) != 0, tone, (int)((f >> FL_STATE_SHIFT) & 7u), w.x, w.z, w.w, false);
                 }
             }
@@ -538,31 +572,30 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void demod_kernel(DemodArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float4 lds_demod[];
-    const int slot = blockIdx.x * 64 + threadIdx.x; /* n_slots is a multiple of 64: padding slots carry flags == 0 */
+/* One kernel per demod kind: register allocation (hence occupancy) is then set by that kind's code path alone --
+ * the AM kernel does not pay for the CTCSS / lowpass registers.  Slot blocks of one kind are contiguous. */
+template <int KIND, bool WAVE_HAS_CTCSS>
+__global__ __launch_bounds__(64) void demod_kernel(DemodArgs a, int first_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds_demod[];
+    const int slot = (first_block + blockIdx.x) * 64 + threadIdx.x; /* padding slots carry flags == 0 */
     const ChanConst cc = a.cc[slot];
-    float* scratch = reinterpret_cast<float*>(lds_demod + CHUNK * 64);
-    ChanState* sp = a.cs + slot;
-    switch (a.block_kind[blockIdx.x]) { /* wave-uniform: slots are sorted by kind */
-        case AB_KIND_AM: demod_wave<AB_KIND_AM, false>(a, cc, sp, slot, lds_demod, scratch); break;
-        case AB_KIND_NFM: demod_wave<AB_KIND_NFM, false>(a, cc, sp, slot, lds_demod, scratch); break;
-        case AB_KIND_NFM_LOWPASS: demod_wave<AB_KIND_NFM_LOWPASS, false>(a, cc, sp, slot, lds_demod, scratch); break;
-        case AB_KIND_NFM_CTCSS: demod_wave<AB_KIND_NFM_CTCSS, true>(a, cc, sp, slot, lds_demod, scratch); break;
-        default: {
-            const bool wave_ct = __ballot((cc.flags & AB_F_VALID) && (cc.flags & AB_F_CTCSS)) != 0ull;
-            if (wave_ct)
-                demod_wave<AB_KIND_GENERIC, true>(a, cc, sp, slot, lds_demod, scratch);
-            else
-                demod_wave<AB_KIND_GENERIC, false>(a, cc, sp, slot, lds_demod, scratch);
-        }
-    }
+    float* scratch = lds_demod + CHUNK * 64 * LdsSlots<KIND>::value;
+    demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lds_demod, scratch);
 }
 
-void launch_demod(const DemodArgs& a, hipStream_t stream) {
-    const int blocks = (a.n_slots + 63) / 64;
-    const size_t lds = (size_t)CHUNK * 64 * sizeof(float4) + 64 * sizeof(float);
-    hipLaunchKernelGGL(demod_kernel, dim3(blocks), dim3(64), lds, stream, a);
+void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream) {
+    for (int k = 0; k < AB_KIND_COUNT; k++) {
+        const size_t lds = (size_t)CHUNK * 64 * sizeof(float) * (k == AB_KIND_AM ? 2 : 4) + 64 * sizeof(float);
+        const int n = kind_n_blocks[k], f = kind_first_block[k];
+        if (n <= 0) continue;
+        switch (k) {
+            case AB_KIND_AM: hipLaunchKernelGGL((demod_kernel<AB_KIND_AM, false>), dim3(n), dim3(64), lds, stream, a, f); break;
+            case AB_KIND_NFM: hipLaunchKernelGGL((demod_kernel<AB_KIND_NFM, false>), dim3(n), dim3(64), lds, stream, a, f); break;
+            case AB_KIND_NFM_LOWPASS: hipLaunchKernelGGL((demod_kernel<AB_KIND_NFM_LOWPASS, false>), dim3(n), dim3(64), lds, stream, a, f); break;
+            case AB_KIND_NFM_CTCSS: hipLaunchKernelGGL((demod_kernel<AB_KIND_NFM_CTCSS, true>), dim3(n), dim3(64), lds, stream, a, f); break;
+            default: hipLaunchKernelGGL((demod_kernel<AB_KIND_GENERIC, true>), dim3(n), dim3(64), lds, stream, a, f); break;
+        }
+    }
 }
 
 /* ---- emit: time-major device results -> the channel-major layout the output thread consumes -------------

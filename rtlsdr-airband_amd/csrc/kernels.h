@@ -67,7 +67,6 @@ struct DemodArgs {
     uint8_t* trace;         /* [wave_batch][stride] or null */
     const float* sin_lut;   /* 257 */
     const float* cos_lut;   /* 257 */
-    const uint8_t* block_kind; /* [n_slots / 64] AB_KIND_* of every slot block */
     int ct_stride;
     int n_slots, wave_batch, row0, ring_rows;
 };
@@ -115,7 +114,7 @@ void launch_channelizer_fft(const ChannelizerArgs& a, hipStream_t stream);
 bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch);
 int dft_lds_per_buf(int hop_bytes);
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream);
-void launch_demod(const DemodArgs& a, hipStream_t stream);
+void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream);
 void launch_emit(const EmitArgs& a, hipStream_t stream);
 void launch_mix(const MixArgs& a, hipStream_t stream);
 void launch_stats(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, int n_slots, airband_hip_channel_stats* out, hipStream_t stream);

@@ -52,8 +52,9 @@ def test_oracle_reproduces_reference_golden(built, name):
 def test_hip_matches_reference_golden(pkg, built, name):
     z, c, devices, iq = _load(name)
     with pkg.AirbandHip(devices, wave_rate=c["wave_rate"], fm_demod=c["fm_demod"]) as hip:
-        assert hip.submit(0, iq) == iq.nbytes
+        pos = 0
         for b in range(c["n_batches"]):
+            pos += hip.submit(0, iq[pos:])  # the staging ring holds ~5 batches, like the reference's input ring
             assert hip.process()
             out = hip.collect(iq=True, stats=True)
             assert np.array_equal(out["axc"], z["axc"][b]), "batch %d" % b
