@@ -40,7 +40,7 @@ constexpr unsigned FL_RESET = 4u;   /* squelch went CLOSED on this sample: CTCSS
 constexpr int FL_STATE_SHIFT = 3;   /* bits 3..5: Squelch::State, for the trace                */
 
 struct SqRegs { /* Squelch members that change per sample (src/squelch.h:117-158) */
-    float noise_floor, cap, pre_full, pre_capped, post_full, post_capped, level_cache;
+    float noise_floor, cap, pre_full, pre_capped, post_full, post_capped;
     int using_post, next, cur, delay, low_count, head, tail;
     unsigned sample_count, open_count, flappy_count, recent_open, closed_count;
 };
@@ -54,96 +54,71 @@ struct Lane { /* per-lane constants */
 
 __device__ __forceinline__ bool sq_flapping(const SqRegs& s) { return s.recent_open >= 3u; } /* flap_opens_threshold_ */
 
-/* Squelch::squelch_level() (src/squelch.cpp:164-177): cached, 0 means recompute */
-__device__ __forceinline__ float sq_level(SqRegs& s, const Lane& L) {
-    if (L.flags & AB_F_MANUAL) return L.manual_level;
-    if (s.level_cache == 0.0f) {
-        if (sq_flapping(s) && L.flappy_ratio < L.normal_ratio)
-            s.level_cache = L.flappy_ratio * s.noise_floor;
-        else
-            s.level_cache = L.normal_ratio * s.noise_floor;
+/* Squelch::squelch_level() (src/squelch.cpp:164-177).  The reference caches the product and invalidates the cache
+ * whenever one of its inputs (noise_floor_, recent_open_count_) changes (:389,:451,:489), so recomputing it on every
+ * use yields the same float; two VALU ops are cheaper than a divergent cache-hit branch. */
+__device__ __forceinline__ float sq_level(const SqRegs& s, const Lane& L) {
+    const float ratio = (sq_flapping(s) && L.flappy_ratio < L.normal_ratio) ? L.flappy_ratio : L.normal_ratio;
+    const float lvl = ratio * s.noise_floor;
+    return (L.flags & AB_F_MANUAL) ? L.manual_level : lvl;
+}
+
+__device__ __forceinline__ bool sq_has_pre(const SqRegs& s, const Lane& L) { return s.pre_capped >= sq_level(s, L); }
+
+__device__ __forceinline__ bool sq_has_signal(const SqRegs& s, const Lane& L) { /* src/squelch.cpp:462-475 */
+    bool sig = sq_has_pre(s, L);
+    if (L.flags & AB_F_LOWPASS) { /* using_post_filter_ can only ever be set on channels with a lowpass filter */
+        if (s.using_post) sig = sig && (s.post_capped >= L.sqbuf[(long)s.tail * L.S]);
     }
-    return s.level_cache;
+    return sig;
 }
 
-__device__ __forceinline__ bool sq_has_pre(SqRegs& s, const Lane& L) { return s.pre_capped >= sq_level(s, L); }
-
-__device__ __forceinline__ bool sq_has_signal(SqRegs& s, const Lane& L) { /* src/squelch.cpp:462-475 */
-    if (s.using_post) return sq_has_pre(s, L) && (s.post_capped >= L.sqbuf[(long)s.tail * L.S]);
-    return sq_has_pre(s, L);
+/* Squelch::set_state (src/squelch.cpp:297-361) as a select chain: clamp transitions that are not allowed from `cur` */
+__device__ __forceinline__ int sq_clamp(int cur, int want) {
+    const int from_closed = (want == AB_ST_CLOSING || want == AB_ST_ABORT) ? AB_ST_CLOSED : (want == AB_ST_OPEN ? AB_ST_OPENING : want);
+    const int from_opening = want == AB_ST_ABORT ? AB_ST_CLOSED : want;
+    const int from_abort = (want != AB_ST_ABORT && want != AB_ST_CLOSED) ? AB_ST_CLOSED : want;
+    const int from_open = want == AB_ST_CLOSED ? AB_ST_CLOSING : (want == AB_ST_OPENING ? AB_ST_OPEN : want);
+    return cur == AB_ST_CLOSED ? from_closed : cur == AB_ST_OPENING ? from_opening : cur == AB_ST_ABORT ? from_abort : cur == AB_ST_OPEN ? from_open : want;
 }
+__device__ __forceinline__ void sq_request(SqRegs& s, int want) { s.next = sq_clamp(s.cur, want); }
 
-/* Squelch::set_state (src/squelch.cpp:297-361): clamp transitions that are not allowed from the current state */
-__device__ __forceinline__ void sq_request(SqRegs& s, int want) {
-    if (s.cur == AB_ST_CLOSED) {
-        if (want == AB_ST_CLOSING || want == AB_ST_ABORT) want = AB_ST_CLOSED;
-        else if (want == AB_ST_OPEN) want = AB_ST_OPENING;
-    } else if (s.cur == AB_ST_OPENING) {
-        if (want == AB_ST_ABORT) want = AB_ST_CLOSED;
-    } else if (s.cur == AB_ST_ABORT) {
-        if (want != AB_ST_ABORT && want != AB_ST_CLOSED) want = AB_ST_CLOSED;
-    } else if (s.cur == AB_ST_OPEN) {
-        if (want == AB_ST_CLOSED) want = AB_ST_CLOSING;
-        else if (want == AB_ST_OPENING) want = AB_ST_OPEN;
-    }
-    s.next = want;
-}
-
-/* Squelch::update_current_state (src/squelch.cpp:363-460); returns true when the squelch just went CLOSED
- * (the reference resets both CTCSS detectors at that point, :440-441) */
+/* Squelch::update_current_state (src/squelch.cpp:363-460), written without branches: the five-way state machine
+ * diverges on every lane, so selects (a few dozen VALU ops, always) beat exec-masked branches.  Returns true when the
+ * squelch just went CLOSED (the reference resets both CTCSS detectors at that point, :440-441). */
 __device__ __forceinline__ bool sq_advance(SqRegs& s, const Lane& L) {
-    bool went_closed = false;
-    if (s.next == AB_ST_OPENING) {
-        if (s.cur != AB_ST_OPENING) {
-            s.delay = 0;
-            s.low_count = 0;
-            s.using_post = 0;
-            s.cur = AB_ST_OPENING;
-        } else if (++s.delay >= 197) {                 /* open_delay_ */
-            if (s.closed_count < 1000u) {              /* recent_sample_size_ */
-                s.recent_open++;
-                if (sq_flapping(s)) s.flappy_count++;
-                s.level_cache = 0.0f;
-            }
-            s.next = sq_has_signal(s, L) ? AB_ST_OPEN : AB_ST_CLOSED;
-        }
-    } else if (s.next == AB_ST_CLOSING) {
-        if (s.cur != AB_ST_CLOSING) {
-            s.delay = 0;
-            s.cur = AB_ST_CLOSING;
-        } else if (++s.delay >= 197) {                 /* close_delay_ */
-            if (!sq_has_signal(s, L)) {
-                s.next = AB_ST_CLOSED;
-            } else {
-                s.cur = AB_ST_OPEN;
-                s.next = AB_ST_OPEN;
-            }
-        }
-    } else if (s.next == AB_ST_ABORT) {
-        if (s.cur != AB_ST_ABORT) {
-            if (s.cur != AB_ST_CLOSING) s.delay = 0;
-            s.cur = AB_ST_ABORT;
-        } else if (++s.delay >= 197) {
-            s.next = AB_ST_CLOSED;
-        }
-    } else if (s.next == AB_ST_OPEN) {
-        if (s.cur != AB_ST_OPEN) {
-            s.open_count++;
-            s.cur = AB_ST_OPEN;
-        }
-    } else { /* CLOSED */
-        if (s.cur != AB_ST_CLOSED) {
-            s.using_post = 0;
-            s.closed_count = 0;
-            s.cur = AB_ST_CLOSED;
-            went_closed = true;
-        } else if (s.closed_count < 1000u) {
-            s.closed_count++;
-        } else if (s.closed_count == 1000u) {
-            s.recent_open = 0;
-            s.level_cache = 0.0f;
-        }
+    const int n = s.next, c = s.cur;
+    const bool entering = n != c;
+    const bool timed = n == AB_ST_OPENING || n == AB_ST_CLOSING || n == AB_ST_ABORT;
+    const bool staying = timed && !entering;
+    /* delay_: zeroed on entry (ABORT entered from CLOSING keeps CLOSING's running delay), counted while staying */
+    const bool zero_delay = entering && timed && !(n == AB_ST_ABORT && c == AB_ST_CLOSING);
+    const int delay = zero_delay ? 0 : (staying ? s.delay + 1 : s.delay);
+    const bool expired = staying && delay >= 197; /* open_delay_ == close_delay_ == 197 */
+    /* OPENING delay over: count a recent open for flap detection before looking at the signal (:381-392) */
+    const bool bump = expired && n == AB_ST_OPENING && s.closed_count < 1000u;
+    s.recent_open += bump ? 1u : 0u;
+    s.flappy_count += (bump && sq_flapping(s)) ? 1u : 0u;
+    s.delay = delay;
+    const bool sig = sq_has_signal(s, L);
+    int new_cur = entering ? n : c;
+    int new_next = n;
+    if (expired) {
+        if (n == AB_ST_OPENING) new_next = sig ? AB_ST_OPEN : AB_ST_CLOSED;
+        else if (n == AB_ST_CLOSING) {
+            new_next = sig ? AB_ST_OPEN : AB_ST_CLOSED;
+            new_cur = sig ? AB_ST_OPEN : c; /* signal came back: straight to OPEN without counting an open */
+        } else new_next = AB_ST_CLOSED;
     }
+    s.low_count = (entering && n == AB_ST_OPENING) ? 0 : s.low_count;
+    s.using_post = (entering && (n == AB_ST_OPENING || n == AB_ST_CLOSED)) ? 0 : s.using_post;
+    s.open_count += (entering && n == AB_ST_OPEN) ? 1u : 0u;
+    const bool went_closed = entering && n == AB_ST_CLOSED;
+    const bool idle_closed = n == AB_ST_CLOSED && !entering;
+    s.recent_open = (idle_closed && s.closed_count == 1000u) ? 0u : s.recent_open;
+    s.closed_count = went_closed ? 0u : ((idle_closed && s.closed_count < 1000u) ? s.closed_count + 1u : s.closed_count);
+    s.cur = new_cur;
+    s.next = new_next;
     s.tail = s.tail + 1 == AB_SQ_BUF ? 0 : s.tail + 1;
     s.head = s.head + 1 == AB_SQ_BUF ? 0 : s.head + 1;
     return went_closed;
@@ -154,37 +129,34 @@ __device__ __forceinline__ void sq_avg(float cap, float& full, float& capped, fl
     const float decay = 0.99f;
     const float fresh = (float)(1.0 - (double)0.99f);
     full = full * decay + x * fresh;
-    if (capped >= cap && x >= cap) {
-        capped = cap;
-    } else {
-        const float v = capped * decay + x * fresh;
-        capped = cap < v ? cap : v;
-    }
+    const float v = capped * decay + x * fresh;
+    const float vm = cap < v ? cap : v;
+    capped = (capped >= cap && x >= cap) ? cap : vm; /* the reference short-circuits this case; the value is `cap` either way it is written */
 }
 
 /* Squelch::process_raw_sample (src/squelch.cpp:195-246) */
 __device__ __forceinline__ bool sq_raw(SqRegs& s, const Lane& L, float x) {
     const bool went_closed = sq_advance(s, L);
     s.sample_count++;
-    if ((s.sample_count & 15u) == 0u) { /* calculate_noise_floor, :477-490 */
+    if ((s.sample_count & 15u) == 0u) { /* calculate_noise_floor, :477-490; every lane of a wave is on the same sample count */
         const float decay = 0.97f;
         const float fresh = (float)(1.0 - (double)0.97f);
         const float lo = s.pre_capped < s.noise_floor ? s.pre_capped : s.noise_floor;
         s.noise_floor = s.noise_floor * decay + lo * fresh + 1e-6f;
         s.cap = (L.flags & AB_F_MANUAL) ? 1.5f * L.manual_level : 1.5f * L.normal_ratio * s.noise_floor;
-        s.level_cache = 0.0f;
     }
     sq_avg(s.cap, s.pre_full, s.pre_capped, x);
     if (L.flags & AB_F_LOWPASS) L.sqbuf[(long)s.head * L.S] = s.pre_capped * 0.9f; /* only ever read on the post-filter path */
-    if (s.cur == AB_ST_OPEN && !sq_has_signal(s, L)) sq_request(s, AB_ST_CLOSING);
-    if (s.cur == AB_ST_CLOSED && sq_has_signal(s, L)) sq_request(s, AB_ST_OPENING);
-    if (s.cur != AB_ST_CLOSED && s.cur != AB_ST_ABORT) {
-        if (x >= sq_level(s, L)) {
-            s.low_count = 0;
-        } else if (++s.low_count >= 88) { /* low_signal_abort_ */
-            sq_request(s, AB_ST_ABORT);
-        }
-    }
+    const bool sig = sq_has_signal(s, L);
+    int next = s.next;
+    next = (s.cur == AB_ST_OPEN && !sig) ? sq_clamp(s.cur, AB_ST_CLOSING) : next;
+    next = (s.cur == AB_ST_CLOSED && sig) ? sq_clamp(s.cur, AB_ST_OPENING) : next;
+    const bool counting = s.cur != AB_ST_CLOSED && s.cur != AB_ST_ABORT; /* low-signal abort (:233-245) */
+    const bool low = !(x >= sq_level(s, L));
+    const int low_count = counting ? (low ? s.low_count + 1 : 0) : s.low_count;
+    next = (counting && low && low_count >= 88) ? sq_clamp(s.cur, AB_ST_ABORT) : next;
+    s.low_count = low_count;
+    s.next = next;
     return went_closed;
 }
 
@@ -303,7 +275,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
 
     SqRegs s;
     s.noise_floor = sp->noise_floor; s.cap = sp->cap; s.pre_full = sp->pre_full; s.pre_capped = sp->pre_capped;
-    s.post_full = sp->post_full; s.post_capped = sp->post_capped; s.level_cache = sp->level_cache;
+    s.post_full = sp->post_full; s.post_capped = sp->post_capped;
     s.using_post = sp->using_post; s.next = sp->next; s.cur = sp->cur; s.delay = sp->delay; s.low_count = sp->low_count;
     s.head = sp->head; s.tail = sp->tail; s.sample_count = sp->sample_count; s.open_count = sp->open_count;
     s.flappy_count = sp->flappy_count; s.recent_open = sp->recent_open; s.closed_count = sp->closed_count;
@@ -558,7 +530,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     sp->axc = o.axc;
     sp->agcavgfast = agc; sp->pr = pr; sp->pj = pj; sp->prev_waveout = prev_out; sp->dm_phi = dm_phi;
     sp->noise_floor = s.noise_floor; sp->cap = s.cap; sp->pre_full = s.pre_full; sp->pre_capped = s.pre_capped;
-    sp->post_full = s.post_full; sp->post_capped = s.post_capped; sp->level_cache = s.level_cache;
+    sp->post_full = s.post_full; sp->post_capped = s.post_capped;
     sp->using_post = s.using_post; sp->next = s.next; sp->cur = s.cur; sp->delay = s.delay; sp->low_count = s.low_count;
     sp->head = s.head; sp->tail = s.tail; sp->sample_count = s.sample_count; sp->open_count = s.open_count;
     sp->flappy_count = s.flappy_count; sp->recent_open = s.recent_open; sp->closed_count = s.closed_count;
@@ -673,7 +645,6 @@ __global__ void stats_kernel(const ChanConst* cc, const ChanState* cs, const int
     o.signal_level = s.pre_full;
     float lvl;
     if (c.flags & AB_F_MANUAL) lvl = c.sq_manual_level;
-    else if (s.level_cache != 0.0f) lvl = s.level_cache;
     else lvl = ((s.recent_open >= 3u && c.sq_flappy_ratio < c.sq_normal_ratio) ? c.sq_flappy_ratio : c.sq_normal_ratio) * s.noise_floor;
     o.squelch_level = lvl;
     o.agcavgfast = s.agcavgfast;
