@@ -272,7 +272,7 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     for (auto& e : h->ev) PREP_TRY(hipEventCreate(&e), AIRBAND_HIP_ENODEV);
 
     h->B = p.wave_batch;
-    h->R = p.wave_batch + AB_AGC_EXTRA;
+    h->R = (p.wave_batch + AB_AGC_EXTRA + AB_TILE_ROWS - 1) / AB_TILE_ROWS * AB_TILE_ROWS; /* ring rows: whole 16-row tiles */
     h->N = p.fft_size;
     /* demod slots: sort the channels by demod kind so that a 64-lane wavefront runs ONE code path (AM, NFM,
      * NFM+lowpass, NFM+CTCSS, everything else); kinds start on 64-slot block boundaries */

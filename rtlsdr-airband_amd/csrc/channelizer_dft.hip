@@ -62,7 +62,12 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     const int buf_bytes = tile_bytes + carry;
     uint8_t* lds = lds_all;                               /* two buffers of lds_per_buf bytes */
 
-    const int tiles_total = (a.n_hops + TILE_HOPS - 1) / TILE_HOPS;
+    /* MFMA tiles are aligned to the 16-row tiles of the output rings: tile t covers hops [16 t - shift, 16 t - shift + 16);
+     * hops < 0 (first tile) and >= n_hops (last tile) are computed on whatever bytes are there and never stored */
+    const int shift = (a.row0 + a.first_row) & 15;
+    const int ring_tiles = a.ring_rows / AB_TILE_ROWS;
+    const int ptile0 = (a.row0 + a.first_row) >> 4;
+    const int tiles_total = (shift + a.n_hops + TILE_HOPS - 1) / TILE_HOPS;
     const int tiles_per_split = (tiles_total + a.splits - 1) / a.splits;
     const int t_begin = split * tiles_per_split;
     const int t_end = min(tiles_total, t_begin + tiles_per_split);
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     const bool ch_valid = ch < dev.n_ch;
     const int slot = a.ext_to_slot[dev.chan_base + (ch_valid ? ch : 0)];
     const bool want_iq = ch_valid && ((a.cc[slot].flags & AB_F_RAW_IQ) != 0);
-    const long slot_base = ab_ring_base(slot, a.ring_rows);
+    const long slot_base = ab_tile_base(slot, ring_tiles);
 
     /* ---- raw-byte staging: HBM -> LDS without a register round trip (global_load_lds_dwordx4: every lane
      * supplies its own 16-byte source address, the wave's data lands contiguously at an M0-relative LDS base).
@@ -100,10 +105,11 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int n_dma = (buf_bytes + 1023) >> 10;
     auto stage = [&](int tile, uint8_t* buf) {
-        const long base = (long)tile * tile_bytes;
+        const long base = ((long)tile * TILE_HOPS - shift) * hop_bytes;
         for (int i = 0; i < n_dma; i++) {
             long so = base + i * 1024 + lane * 16;
             if (so + 16 > span_end) so = span_end - 16;
+            if (so < 0) so = 0;
             __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(uintptr_t)(buf + i * 1024), 16, 0, 0);
         }
     };
@@ -133,17 +139,34 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
             const double y = ((double)acc2[r] * 65536.0 + (double)acc1[r] * 256.0 + (double)acc0[r] + corr) * unscale;
             val[r] = (float)y;
         }
-        /* lane pairs (2ch, 2ch+1) hold (re, im) of the same hop */
+        /* lane pairs (2ch, 2ch+1) hold (re, im) of the same hop; even lanes write 4 consecutive rows of their slot */
+        float im4[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float other = __shfl_xor(val[r], 1);
-            const int hop = t * TILE_HOPS + grp * 4 + r;
-            if (!(col & 1) && ch_valid && hop < a.n_hops) {
-                int row = a.row0 + a.first_row + hop;
-                if (row >= a.ring_rows) row -= a.ring_rows;
-                const float re = val[r], im = other;
-                a.mag[slot_base + (long)row * AB_SLOT_BLOCK] = sqrtf(re * re + im * im);
-                if (want_iq) a.iq_bins[slot_base + (long)row * AB_SLOT_BLOCK] = make_float2(re, im);
+        for (int r = 0; r < 4; r++) im4[r] = __shfl_xor(val[r], 1);
+        if (!(col & 1) && ch_valid) {
+            int pt = ptile0 + t;
+            pt = pt >= ring_tiles ? pt - ring_tiles : pt;
+            const long off = slot_base + (long)pt * (AB_SLOT_BLOCK * AB_TILE_ROWS) + grp * 4;
+            const int hop_first = t * TILE_HOPS - shift + grp * 4;
+            float m4[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) m4[r] = sqrtf(val[r] * val[r] + im4[r] * im4[r]);
+            if (hop_first >= 0 && hop_first + 3 < a.n_hops) {
+                *reinterpret_cast<float4*>(a.mag + off) = make_float4(m4[0], m4[1], m4[2], m4[3]);
+                if (want_iq) {
+                    float4* q = reinterpret_cast<float4*>(a.iq_bins + off);
+                    q[0] = make_float4(val[0], im4[0], val[1], im4[1]);
+                    q[1] = make_float4(val[2], im4[2], val[3], im4[3]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int hop = hop_first + r;
+                    if (hop >= 0 && hop < a.n_hops) {
+                        a.mag[off + r] = m4[r];
+                        if (want_iq) a.iq_bins[off + r] = make_float2(val[r], im4[r]);
+                    }
+                }
             }
         }
         cur ^= 1;

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
         if (my_slot >= 0) {
             int row = a.row0 + a.first_row + hop0 + h;
             if (row >= a.ring_rows) row -= a.ring_rows;
-            const long off = ab_ring_base(my_slot, a.ring_rows) + (long)row * AB_SLOT_BLOCK;
+            const long off = ab_tile_base(my_slot, a.ring_rows / AB_TILE_ROWS) + ab_tile_off(row);
             a.mag[off] = sqrtf(bre * bre + bim * bim);
             if (my_raw) a.iq_bins[off] = make_float2(bre, bim);
         }

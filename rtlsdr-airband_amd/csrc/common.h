@@ -99,4 +99,13 @@ enum { AB_KIND_AM = 0, AB_KIND_NFM = 1, AB_KIND_NFM_LOWPASS = 2, AB_KIND_NFM_CTC
 #endif
 static inline AB_HD long ab_ring_base(int slot, int rows) { return ((long)(slot >> 6) * rows) * AB_SLOT_BLOCK + (slot & 63); }
 
+/* The two stage-1 -> stage-2 rings (|bin| and raw bin I/Q) are additionally transposed inside 16-row tiles:
+ * element (row, slot) lives at ((slot/64 * tiles + row/16) * 64 + slot%64) * 16 + row%16, tiles = ring_rows / 16.
+ * The matrix-core channelizer produces 16 hops x 16 columns per MFMA tile with 4 consecutive hops per lane, so a lane
+ * stores 16 contiguous bytes and the four lanes of a column complete a 64-byte segment -- full-width HBM writes instead
+ * of 4-byte scatters; the demod kernels fetch the same tiles back 16 bytes (4 rows) per lane. */
+#define AB_TILE_ROWS 16
+static inline AB_HD long ab_tile_base(int slot, int tiles) { return (((long)(slot >> 6) * tiles) * AB_SLOT_BLOCK + (slot & 63)) * AB_TILE_ROWS; }
+static inline AB_HD long ab_tile_off(int row) { return ((long)(row >> 4) * AB_SLOT_BLOCK * AB_TILE_ROWS) + (row & 15); }
+
 #endif

@@ -295,8 +295,8 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     const bool is_ct = valid && (cc.flags & AB_F_CTCSS);
     const float one_minus_alpha = 1.0f - cc.alpha;
 
-    float* mag = a.mag + ab_ring_base(slot, R);
-    const float2* iqin = a.iq + ab_ring_base(slot, R);
+    float* mag = a.mag + ab_tile_base(slot, R / AB_TILE_ROWS);        /* tile-transposed rings: row r at ab_tile_off(r) */
+    const float2* iqin = a.iq + ab_tile_base(slot, R / AB_TILE_ROWS);
     float* wave = a.wave + ab_ring_base(slot, R);
     float2* iqout = a.iq_out + ab_ring_base(slot, B);
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
@@ -304,22 +304,31 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     unsigned tone_mask = 0;      /* CTCSS lanes: bit u = tone present at sample u of the chunk (written by phase 2) */
 
     for (int j0 = 0; j0 < B; j0 += CHUNK) {
-        /* ---- phase 0: independent row loads per lane, parked in LDS ------------------------------------------------ */
+        /* ---- phase 0: the chunk's stage-1 values, 16 bytes (4 rows) per load, parked in LDS -------------------------
+         * row0, AGC_EXTRA, WAVE_BATCH and the chunk start are multiples of 4 and the ring length is a multiple of 16, so
+         * a group of 4 rows is always 16-byte aligned inside one tile and never straddles the ring wrap */
         if (valid) {
-#pragma unroll 10
-            for (int u = 0; u < CHUNK; u++) {
-                const int rc = ring_row(a.row0 + AB_AGC_EXTRA + j0 + u, R); /* current hop */
-                const int rd = ring_row(a.row0 + j0 + u, R);                /* hop AGC_EXTRA earlier */
-                if (NS == 2) {
-                    *reinterpret_cast<float2*>(my + u * 64 * NS) = make_float2(mag[(long)rc * S], mag[(long)rd * S]);
-                } else {
-                    float4 v;
-                    v.x = mag[(long)rc * S];
-                    v.y = nfm ? 0.0f : mag[(long)rd * S];
-                    const float2 q = raw_iq ? iqin[(long)rd * S] : make_float2(0.0f, 0.0f);
-                    v.z = q.x;
-                    v.w = q.y;
-                    *reinterpret_cast<float4*>(my + u * 64 * NS) = v;
+#pragma unroll
+            for (int g = 0; g < CHUNK / 4; g++) {
+                const int rc = ring_row(a.row0 + AB_AGC_EXTRA + j0 + 4 * g, R); /* current hops */
+                const int rd = ring_row(a.row0 + j0 + 4 * g, R);                /* hops AGC_EXTRA earlier */
+                const float4 mc = *reinterpret_cast<const float4*>(mag + ab_tile_off(rc));
+                float4 md = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q01 = md, q23 = md;
+                if (!nfm) md = *reinterpret_cast<const float4*>(mag + ab_tile_off(rd));
+                if (raw_iq) {
+                    const float4* qp = reinterpret_cast<const float4*>(iqin + ab_tile_off(rd));
+                    q01 = qp[0];
+                    q23 = qp[1];
+                }
+                const float mcs[4] = {mc.x, mc.y, mc.z, mc.w}, mds[4] = {md.x, md.y, md.z, md.w};
+                const float qr[4] = {q01.x, q01.z, q23.x, q23.z}, qi[4] = {q01.y, q01.w, q23.y, q23.w};
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float* dst = my + (4 * g + r) * 64 * NS;
+                    if (NS == 2)
+                        *reinterpret_cast<float2*>(dst) = make_float2(mcs[r], mds[r]);
+                    else
+                        *reinterpret_cast<float4*>(dst) = make_float4(mcs[r], mds[r], qr[r], qi[r]);
                 }
             }
         }
@@ -366,7 +375,8 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                     re = tr;
                     im = ti;
                     cur_mag = sqrtf(re * re + im * im); /* double sqrt rounded to float == correctly rounded sqrtf */
-                    mag[(long)ring_row(a.row0 + AB_AGC_EXTRA + j, R) * S] = cur_mag;
+                    /* the reference overwrites wavein[j] here (src/rtl_airband.cpp:524); only AM reads it back later */
+                    if (!nfm) mag[ab_tile_off(ring_row(a.row0 + AB_AGC_EXTRA + j, R))] = cur_mag;
                     if (lowpass) sq_filtered(s, L, cur_mag);
                 }
 
@@ -375,7 +385,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                     if (sq_first_open(s)) {
                         const float lvl = sq_level(s, L);
                         for (int k = j; k < j + AB_AGC_EXTRA; k++) { /* the AGC_EXTRA magnitudes before the current one */
-                            const float w = mag[(long)ring_row(a.row0 + k, R) * S];
+                            const float w = mag[ab_tile_off(ring_row(a.row0 + k, R))];
                             if (w >= lvl) agc = agc * 0.9f + w * 0.1f;
                         }
                     } else if (sq_last_open(s)) {

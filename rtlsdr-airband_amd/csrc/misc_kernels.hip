@@ -139,7 +139,7 @@ __global__ void scatter_bins_kernel(const float* wavein, const float* iqin, cons
     if (ext < 0) return;
     int row = row0 + AB_AGC_EXTRA + t;
     if (row >= ring_rows) row -= ring_rows;
-    const long off = ab_ring_base(slot, ring_rows) + (long)row * AB_SLOT_BLOCK;
+    const long off = ab_tile_base(slot, ring_rows / AB_TILE_ROWS) + ab_tile_off(row);
     mag[off] = wavein[(long)ext * wave_batch + t];
     if (cc[slot].flags & AB_F_RAW_IQ) iq[off] = make_float2(iqin[((long)ext * wave_batch + t) * 2], iqin[((long)ext * wave_batch + t) * 2 + 1]);
 }
@@ -159,7 +159,7 @@ __global__ void gather_bins_kernel(const float* mag, const float2* iq, const uin
     if (ext < 0) return;
     int row = row0 + AB_AGC_EXTRA + t;
     if (row >= ring_rows) row -= ring_rows;
-    const long off = ab_ring_base(slot, ring_rows) + (long)row * AB_SLOT_BLOCK;
+    const long off = ab_tile_base(slot, ring_rows / AB_TILE_ROWS) + ab_tile_off(row);
     if (wavein) wavein[(long)ext * wave_batch + t] = mag[off];
     if (iqin) {
         const float2 q = iq[off];
