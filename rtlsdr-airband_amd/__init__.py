@@ -21,7 +21,7 @@ siggen = importlib.import_module(__name__ + ".siggen")
 _build = importlib.import_module(__name__ + "._build")
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libairband_hip.so")
+LIB_PATH = os.environ.get("AIRBAND_HIP_LIB") or os.path.join(HERE, "libairband_hip.so")  # env override: kernel experiments only
 
 EXPORTS = [
     "airband_hip_prepare", "airband_hip_set_mixers", "airband_hip_release", "airband_hip_get_geometry", "airband_hip_last_error", "airband_hip_submit",

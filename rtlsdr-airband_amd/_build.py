@@ -54,7 +54,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJ, name + ".o")
         objs.append(obj)
         if force or _newer(src, obj):
-            cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + flags + ["-c", src, "-o", obj]
+            extra = os.environ.get("AIRBAND_EXTRA_DEFINES", "").split()  # experiments only (e.g. -DAB_SKIP_PHASE2)
+            cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + flags + extra + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             _run(cmd)

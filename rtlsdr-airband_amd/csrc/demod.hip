@@ -43,10 +43,12 @@ struct SqRegs { /* Squelch members that change per sample (src/squelch.h:117-158
     float noise_floor, cap, pre_full, pre_capped, post_full, post_capped;
     int using_post, next, cur, delay, low_count, head, tail;
     unsigned sample_count, open_count, flappy_count, recent_open, closed_count;
+    float dly; /* buffer_[buffer_tail_] for the current tail, when the kind prefetches the delay line (else unused) */
 };
 
 struct Lane { /* per-lane constants */
     unsigned flags;
+    bool prefetched_delay; /* SqRegs::dly is maintained by the caller instead of reading sqbuf from memory */
     float manual_level, normal_ratio, flappy_ratio;
     float* sqbuf; /* this lane's column of the 102-deep pre-filter delay line, stride S */
     long S;
@@ -68,7 +70,7 @@ __device__ __forceinline__ bool sq_has_pre(const SqRegs& s, const Lane& L) { ret
 __device__ __forceinline__ bool sq_has_signal(const SqRegs& s, const Lane& L) { /* src/squelch.cpp:462-475 */
     bool sig = sq_has_pre(s, L);
     if (L.flags & AB_F_LOWPASS) { /* using_post_filter_ can only ever be set on channels with a lowpass filter */
-        if (s.using_post) sig = sig && (s.post_capped >= L.sqbuf[(long)s.tail * L.S]);
+        if (s.using_post) sig = sig && (s.post_capped >= (L.prefetched_delay ? s.dly : L.sqbuf[(long)s.tail * L.S]));
     }
     return sig;
 }
@@ -135,8 +137,9 @@ __device__ __forceinline__ void sq_avg(float cap, float& full, float& capped, fl
 }
 
 /* Squelch::process_raw_sample (src/squelch.cpp:195-246) */
-__device__ __forceinline__ bool sq_raw(SqRegs& s, const Lane& L, float x) {
-    const bool went_closed = sq_advance(s, L);
+__device__ __forceinline__ bool sq_raw(SqRegs& s, const Lane& L, float x, float dly_new) {
+    const bool went_closed = sq_advance(s, L); /* evaluates the post-filter gate against buffer_[tail] BEFORE the tail moves */
+    s.dly = dly_new;                           /* ... everything after it sees the entry under the advanced tail */
     s.sample_count++;
     if ((s.sample_count & 15u) == 0u) { /* calculate_noise_floor, :477-490; every lane of a wave is on the same sample count */
         const float decay = 0.97f;
@@ -170,7 +173,7 @@ __device__ __forceinline__ bool sq_last_open(const SqRegs& s) {
 /* Squelch::process_filtered_sample (src/squelch.cpp:248-276) */
 __device__ __forceinline__ void sq_filtered(SqRegs& s, const Lane& L, float x) {
     if (!sq_should_filter(s, L)) return;
-    const float delayed = L.sqbuf[(long)s.tail * L.S];
+    const float delayed = L.prefetched_delay ? s.dly : L.sqbuf[(long)s.tail * L.S];
     if (s.cur == AB_ST_OPENING) {
         if (s.delay < AB_SQ_BUF) return;
         if (s.delay == AB_SQ_BUF) s.post_full = s.post_capped = delayed;
@@ -272,6 +275,9 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     L.flappy_ratio = cc.sq_flappy_ratio;
     L.sqbuf = a.sqbuf + ab_ring_base(slot, AB_SQ_BUF);
     L.S = S;
+    /* NFM+lowpass kind: the 102-deep delay line is read 101 samples after it is written, so a chunk's reads can be
+     * fetched up front with the other inputs (LDS slot .y, unused by NFM) instead of one dependent L2 round trip per sample */
+    L.prefetched_delay = (KIND == AB_KIND_NFM_LOWPASS);
 
     SqRegs s;
     s.noise_floor = sp->noise_floor; s.cap = sp->cap; s.pre_full = sp->pre_full; s.pre_capped = sp->pre_capped;
@@ -279,6 +285,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     s.using_post = sp->using_post; s.next = sp->next; s.cur = sp->cur; s.delay = sp->delay; s.low_count = sp->low_count;
     s.head = sp->head; s.tail = sp->tail; s.sample_count = sp->sample_count; s.open_count = sp->open_count;
     s.flappy_count = sp->flappy_count; s.recent_open = sp->recent_open; s.closed_count = sp->closed_count;
+    s.dly = (KIND == AB_KIND_NFM_LOWPASS && valid) ? L.sqbuf[(long)s.tail * S] : 0.0f;
     float agc = sp->agcavgfast, pr = sp->pr, pj = sp->pj, prev_out = sp->prev_waveout;
     unsigned dm_phi = sp->dm_phi;
     OutRegs o;
@@ -320,6 +327,16 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                     q01 = qp[0];
                     q23 = qp[1];
                 }
+                if (KIND == AB_KIND_NFM_LOWPASS) { /* delay-line entries the 4 samples will see after their tail increment */
+                    float dv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        int e = s.tail + 1 + 4 * g + r;
+                        e = e >= AB_SQ_BUF ? e - AB_SQ_BUF : e;
+                        dv[r] = L.sqbuf[(long)e * S];
+                    }
+                    md = make_float4(dv[0], dv[1], dv[2], dv[3]);
+                }
                 const float mcs[4] = {mc.x, mc.y, mc.z, mc.w}, mds[4] = {md.x, md.y, md.z, md.w};
                 const float qr[4] = {q01.x, q01.z, q23.x, q23.z}, qi[4] = {q01.y, q01.w, q23.y, q23.w};
 #pragma unroll
@@ -349,7 +366,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                  * samples are AGC_EXTRA = 100 > CHUNK steps old, so the value parked in phase 0 is always current */
                 const float delayed_mag = v.y;
 
-                const bool went_closed = sq_raw(s, L, cur_mag);
+                const bool went_closed = sq_raw(s, L, cur_mag, delayed_mag /* = prefetched delay-line entry for the lowpass kind */);
 
                 if (raw_iq && sq_should_filter(s, L)) { /* src/rtl_airband.cpp:510-530 */
                     const unsigned idx = dm_phi >> 16; /* sincosf_lut (src/util.cpp:113-127) */
@@ -436,40 +453,95 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             }
         }
         if (WAVE_HAS_CTCSS) {
-            /* ---- phase 2: every CTCSS channel of the wave in turn; lanes = tones ------------------------------------ */
+            /* ---- phase 2: every CTCSS channel of the wave in turn; lanes = tones ------------------------------------
+             * Software-pipelined over the channels: while channel k runs its recurrences, channel k+1's chunk samples
+             * (LDS) and tone state (L2) are already on their way, so the serial loop never sits on a load. */
             unsigned long long todo = __ballot(is_ct);
-            while (todo) {
-                const int owner = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                /* lane u picks up sample u of the owner's chunk (audio, flags); the loop below reads them back with
-                 * v_readlane, so the serial recurrence never waits on LDS */
-                float ax = 0.0f;
-                unsigned fl = 0;
-                if (lane < CHUNK) {
-                    const float2 af = *reinterpret_cast<const float2*>(lds + ((long)lane * 64 + owner) * NS);
-                    ax = af.x;
-                    fl = __float_as_uint(af.y);
+#ifdef AB_SKIP_PHASE2
+            todo = 0; /* timing experiment only */
+#endif
+            int owner = todo ? __builtin_ctzll(todo) : -1;
+            todo &= todo - 1;
+            struct ToneRegs { float ax; unsigned fl; float c0, c1, q1f, q2f, q1s, q2s; };
+            auto fetch = [&](int who) {
+                ToneRegs t;
+                t.ax = 0.0f;
+                t.fl = 0;
+                if (lane < CHUNK) { /* lane u picks up sample u of the channel's chunk: (audio, flags) */
+                    const float2 af = *reinterpret_cast<const float2*>(lds + ((long)lane * 64 + who) * NS);
+                    t.ax = af.x;
+                    t.fl = __float_as_uint(af.y);
                 }
+                /* tone tables: [ct_slot][detector][tone] coefficients, [ct_slot][detector][q1|q2][tone] state */
+                const int ct_slot = __builtin_amdgcn_readlane(cc.ct_slot, who);
+                const float* ctab = a.ct_coeff + (long)ct_slot * 2 * AB_MAX_TONES;
+                const float* qtab = a.ct_q + (long)ct_slot * 4 * AB_MAX_TONES;
+                const bool tl = lane < AB_MAX_TONES;
+                t.c0 = tl ? ctab[lane] : 0.0f;
+                t.c1 = tl ? ctab[AB_MAX_TONES + lane] : 0.0f;
+                t.q1f = tl ? qtab[lane] : 0.0f;
+                t.q2f = tl ? qtab[AB_MAX_TONES + lane] : 0.0f;
+                t.q1s = tl ? qtab[2 * AB_MAX_TONES + lane] : 0.0f;
+                t.q2s = tl ? qtab[3 * AB_MAX_TONES + lane] : 0.0f;
+                return t;
+            };
+            ToneRegs T;
+            if (owner >= 0) T = fetch(owner);
+            while (owner >= 0) {
+                const int next_owner = todo ? __builtin_ctzll(todo) : -1;
+                todo &= todo - 1;
+                ToneRegs TN = T;
+                if (next_owner >= 0) TN = fetch(next_owner);
+
+                const float ax = T.ax;
+                const unsigned fl = T.fl;
                 int enough0 = __builtin_amdgcn_readlane(ct_enough0, owner), enough1 = __builtin_amdgcn_readlane(ct_enough1, owner);
                 int has0 = __builtin_amdgcn_readlane(ct_has0, owner), has1 = __builtin_amdgcn_readlane(ct_has1, owner);
+                int count0 = __builtin_amdgcn_readlane(ct_count0, owner), count1 = __builtin_amdgcn_readlane(ct_count1, owner);
+                const int win0 = __builtin_amdgcn_readlane(cc.ct_window[0], owner), win1 = __builtin_amdgcn_readlane(cc.ct_window[1], owner);
+                const int n0 = __builtin_amdgcn_readlane(cc.ct_ntones[0], owner), n1 = __builtin_amdgcn_readlane(cc.ct_ntones[1], owner);
+                const int ct_slot = __builtin_amdgcn_readlane(cc.ct_slot, owner);
+                float* qtab = a.ct_q + (long)ct_slot * 4 * AB_MAX_TONES;
+                const bool t0 = lane < n0, t1 = lane < n1;
+                const float c0 = T.c0, c1 = T.c1;
+                float q1f = T.q1f, q2f = T.q2f, q1s = T.q1s, q2s = T.q2s;
                 unsigned mask = 0;
-                if (__ballot((fl & (FL_AUDIO | FL_RESET)) != 0) == 0ull) {
+                const bool idle = __ballot((fl & (FL_AUDIO | FL_RESET)) != 0) == 0ull;
+                const bool all_audio = __ballot(lane < CHUNK && (fl & (FL_AUDIO | FL_RESET)) != FL_AUDIO) == 0ull;
+                if (idle) {
                     /* squelch closed (or nothing to do) for the whole chunk: detector state cannot change */
                     mask = (enough1 ? has1 : has0) ? 0xffffffffu : 0u;
+                } else if (all_audio && count1 + CHUNK < win1 && (enough1 || count0 + CHUNK < win0)) {
+                    /* steady state (most of a transmission): squelch open for the whole chunk and no detector window ends inside
+                     * it -> nothing but the Goertzel recurrences (ToneDetector::process_sample, src/ctcss.cpp:44-54) */
+                    if (enough1) {
+#pragma unroll
+                        for (int u = 0; u < CHUNK; u++) {
+                            const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
+                            const float q0 = c1 * q1s - q2s + x;
+                            q2s = q1s;
+                            q1s = q0;
+                        }
+                    } else { /* the fast detector runs too until the slow one has a full window (src/squelch.cpp:288-293) */
+#pragma unroll
+                        for (int u = 0; u < CHUNK; u++) {
+                            const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
+                            const float q0 = c1 * q1s - q2s + x;
+                            q2s = q1s;
+                            q1s = q0;
+                            const float p0 = c0 * q1f - q2f + x;
+                            q2f = q1f;
+                            q1f = p0;
+                        }
+                        count0 += CHUNK;
+                        if (t0) { qtab[lane] = q1f; qtab[AB_MAX_TONES + lane] = q2f; }
+                    }
+                    count1 += CHUNK;
+                    if (t1) { qtab[2 * AB_MAX_TONES + lane] = q1s; qtab[3 * AB_MAX_TONES + lane] = q2s; }
+                    mask = (enough1 ? has1 : has0) ? 0xffffffffu : 0u;
                 } else {
-                    const int ct_slot = __builtin_amdgcn_readlane(cc.ct_slot, owner);
-                    const int n0 = __builtin_amdgcn_readlane(cc.ct_ntones[0], owner), n1 = __builtin_amdgcn_readlane(cc.ct_ntones[1], owner);
-                    const int win0 = __builtin_amdgcn_readlane(cc.ct_window[0], owner), win1 = __builtin_amdgcn_readlane(cc.ct_window[1], owner);
-                    int count0 = __builtin_amdgcn_readlane(ct_count0, owner), count1 = __builtin_amdgcn_readlane(ct_count1, owner);
                     unsigned found0 = __builtin_amdgcn_readlane(ct_found0, owner), found1 = __builtin_amdgcn_readlane(ct_found1, owner);
                     unsigned nf0 = __builtin_amdgcn_readlane(ct_nf0, owner), nf1 = __builtin_amdgcn_readlane(ct_nf1, owner);
-                    /* tone tables: [ct_slot][detector][tone] coefficients, [ct_slot][detector][q1|q2][tone] state */
-                    const float* ctab = a.ct_coeff + (long)ct_slot * 2 * AB_MAX_TONES;
-                    float* qtab = a.ct_q + (long)ct_slot * 4 * AB_MAX_TONES;
-                    const bool t0 = lane < n0, t1 = lane < n1;
-                    const float c0 = t0 ? ctab[lane] : 0.0f, c1 = t1 ? ctab[AB_MAX_TONES + lane] : 0.0f;
-                    float q1f = t0 ? qtab[lane] : 0.0f, q2f = t0 ? qtab[AB_MAX_TONES + lane] : 0.0f;
-                    float q1s = t1 ? qtab[2 * AB_MAX_TONES + lane] : 0.0f, q2s = t1 ? qtab[3 * AB_MAX_TONES + lane] : 0.0f;
 #pragma unroll
                     for (int u = 0; u < CHUNK; u++) {
                         const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
@@ -515,16 +587,26 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                     if (t0) { qtab[lane] = q1f; qtab[AB_MAX_TONES + lane] = q2f; }
                     if (t1) { qtab[2 * AB_MAX_TONES + lane] = q1s; qtab[3 * AB_MAX_TONES + lane] = q2s; }
                     const bool mine = lane == owner;
-                    ct_count0 = mine ? count0 : ct_count0; ct_count1 = mine ? count1 : ct_count1;
                     ct_found0 = mine ? found0 : ct_found0; ct_found1 = mine ? found1 : ct_found1;
                     ct_nf0 = mine ? nf0 : ct_nf0; ct_nf1 = mine ? nf1 : ct_nf1;
                     ct_enough0 = mine ? enough0 : ct_enough0; ct_enough1 = mine ? enough1 : ct_enough1;
                     ct_has0 = mine ? has0 : ct_has0; ct_has1 = mine ? has1 : ct_has1;
                 }
-                tone_mask = (lane == owner) ? mask : tone_mask;
+                {
+                    const bool mine = lane == owner;
+                    ct_count0 = mine ? count0 : ct_count0;
+                    ct_count1 = mine ? count1 : ct_count1;
+                    tone_mask = mine ? mask : tone_mask;
+                }
+                T = TN;
+                owner = next_owner;
             }
             /* ---- phase 3: gating + output of the chunk ------------------------------------------------------------- */
+#ifdef AB_SKIP_PHASE3
+            if (false) {
+#else
             if (valid) {
+#endif
                 for (int u = 0; u < CHUNK; u++) {
                     const float4 w = *reinterpret_cast<const float4*>(my + u * 64 * NS);
                     const unsigned f = __float_as_uint(w.y);
