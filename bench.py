@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--mixers", type=int, default=-1, help="number of mixers (default: 64 when --gpus > 1, else 0)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise a process group even at world size 1 (plumbing check of the RCCL leg)")
     args = ap.parse_args()
 
     import numpy as np
@@ -106,15 +107,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libairband_hip has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     pkg = importlib.import_module("rtlsdr-airband_amd")
     wl = WORKLOADS[args.workload]
     D = args.dongles or wl["dongles"]
     mixed, wave_rate = wl["mixed"], wl["wave_rate"]
-    n_mixers = args.mixers if args.mixers >= 0 else (64 if world > 1 else 0)
+    n_mixers = args.mixers if args.mixers >= 0 else (64 if use_dist else 0)
 
     chans, carriers = pkg.siggen.baseline_plan(mixed=mixed)
     devices = [dict(channels=chans) for _ in range(D)]
@@ -136,7 +139,7 @@ def main():
 
     res = hip.device_results()
     mix_t = None
-    if n_mixers and world > 1:
+    if n_mixers and use_dist:
         # torch views over the library's device-side mixer sums, for the RCCL all-reduce
         class _Ptr:  # __cuda_array_interface__ shim
             def __init__(self, ptr, shape, typestr):
@@ -158,7 +161,7 @@ def main():
     def sync():
         hip.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for i in range(args.warmup):
@@ -173,7 +176,7 @@ def main():
             chan_ms.append(t["channelizer_ms"]); demod_ms.append(t["demod_ms"]); emit_ms.append(t["emit_ms"])
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -212,7 +215,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     hip.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -19,7 +19,7 @@ ARCH = "gfx950"
 HIP_SOURCES = {
     "channelizer_fft.hip": ["-O3"],
     "channelizer_dft.hip": ["-O3"],
-    "misc_kernels.hip": ["-O3"],
+    "misc_kernels.hip": ["-O3", "-ffp-contract=off"],  # mixer sums: the reference's multiply-then-add, no FMA
     "demod.hip": ["-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "airband_hip.cpp": ["-O2", "-x", "hip"],
 }
@@ -30,7 +30,7 @@ def _newer(src: str, dst: str) -> bool:
     if not os.path.exists(dst):
         return True
     t = os.path.getmtime(dst)
-    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "airband_hip.h")]
+    deps = [src, os.path.abspath(__file__)] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "airband_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

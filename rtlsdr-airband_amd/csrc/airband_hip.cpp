@@ -91,7 +91,10 @@ struct airband_hip_handle {
 
     /* mixers */
     int n_mixers = 0;
-    DevBuf<int> d_mix_chan, d_mix_first;
+    int n_mix_runs = 0;
+    DevBuf<int> d_mix_chan, d_mix_first, d_mix_run_first, d_mix_run_mixer, d_mix_first_run;
+    DevBuf<float> d_mix_run_left, d_mix_run_right;
+    DevBuf<uint8_t> d_mix_run_signal;
     DevBuf<float> d_mix_ml, d_mix_mr, d_mix_left, d_mix_right;
     DevBuf<uint8_t> d_mix_stereo, d_mix_signal;
 
@@ -138,6 +141,8 @@ void destroy(airband_hip_handle* h) {
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     h->d_mix_chan.release(); h->d_mix_first.release(); h->d_mix_ml.release(); h->d_mix_mr.release();
     h->d_mix_left.release(); h->d_mix_right.release(); h->d_mix_stereo.release(); h->d_mix_signal.release();
+    h->d_mix_run_first.release(); h->d_mix_run_mixer.release(); h->d_mix_first_run.release();
+    h->d_mix_run_left.release(); h->d_mix_run_right.release(); h->d_mix_run_signal.release();
     h->d_sin_tab.release(); h->d_carriers.release();
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
@@ -194,8 +199,14 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
         ma.in_chan = h->d_mix_chan.p;
         ma.in_ml = h->d_mix_ml.p;
         ma.in_mr = h->d_mix_mr.p;
-        ma.mixer_first = h->d_mix_first.p;
+        ma.run_first = h->d_mix_run_first.p;
+        ma.run_mixer = h->d_mix_run_mixer.p;
+        ma.mixer_first_run = h->d_mix_first_run.p;
         ma.mixer_stereo = h->d_mix_stereo.p;
+        ma.run_left = h->d_mix_run_left.p;
+        ma.run_right = h->d_mix_run_right.p;
+        ma.run_signal = h->d_mix_run_signal.p;
+        ma.n_runs = h->n_mix_runs;
         ma.left = h->d_mix_left.p;
         ma.right = h->d_mix_right.p;
         ma.has_signal = h->d_mix_signal.p;
@@ -431,6 +442,25 @@ int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const air
     }
     h->d_mix_chan.release(); h->d_mix_first.release(); h->d_mix_ml.release(); h->d_mix_mr.release();
     h->d_mix_left.release(); h->d_mix_right.release(); h->d_mix_stereo.release(); h->d_mix_signal.release();
+    h->d_mix_run_first.release(); h->d_mix_run_mixer.release(); h->d_mix_first_run.release();
+    h->d_mix_run_left.release(); h->d_mix_run_right.release(); h->d_mix_run_signal.release();
+    std::vector<int> run_first, run_mixer, first_run(mixer_count + 1, 0);
+    for (int m = 0; m < mixer_count; m++) {
+        first_run[m] = (int)run_mixer.size();
+        for (int i = first[m]; i < first[m + 1]; i += AB_MIX_RUN) {
+            run_first.push_back(i);
+            run_mixer.push_back(m);
+        }
+    }
+    first_run[mixer_count] = (int)run_mixer.size();
+    run_first.push_back(n_in);
+    h->n_mix_runs = (int)run_mixer.size();
+    HIP_TRY(h, upload(h->d_mix_run_first, run_first), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, upload(h->d_mix_run_mixer, run_mixer), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, upload(h->d_mix_first_run, first_run), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, h->d_mix_run_left.alloc((size_t)h->n_mix_runs * h->B), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, h->d_mix_run_right.alloc((size_t)h->n_mix_runs * h->B), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, h->d_mix_run_signal.alloc((size_t)h->n_mix_runs), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, upload(h->d_mix_chan, chan), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, upload(h->d_mix_first, first), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, upload(h->d_mix_ml, ml), AIRBAND_HIP_ENOMEM);

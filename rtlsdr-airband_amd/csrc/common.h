@@ -14,6 +14,7 @@
 #define AB_SQ_BUF 102     /* Squelch::buffer_size_, src/squelch.cpp:66 */
 #define AB_MAX_TONES 52   /* target + 51 standard CTCSS tones, src/ctcss.cpp:101-122 */
 #define AB_MAX_CH_PER_DEV 64
+#define AB_MIX_RUN 64       /* mixer inputs summed sequentially by one stage-A run */
 
 /* Squelch::State numeric values (src/squelch.h:102-108) */
 enum { AB_ST_CLOSED = 0, AB_ST_OPENING = 1, AB_ST_CLOSING = 2, AB_ST_ABORT = 3, AB_ST_OPEN = 4 };

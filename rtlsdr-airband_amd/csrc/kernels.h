@@ -88,12 +88,17 @@ struct MixArgs {
     const int* in_chan;     /* [n_inputs] external channel index, grouped by mixer */
     const float* in_ml;     /* ampfactor * ampl */
     const float* in_mr;     /* ampfactor * ampr */
-    const int* mixer_first; /* [n_mixers + 1] offsets into the input arrays */
+    const int* run_first;       /* [n_runs + 1] offsets into the input arrays: runs of <= AB_MIX_RUN inputs of one mixer */
+    const int* run_mixer;       /* [n_runs] */
+    const int* mixer_first_run; /* [n_mixers + 1] */
     const uint8_t* mixer_stereo;
+    float* run_left;            /* [n_runs][wave_batch] stage-A sums */
+    float* run_right;
+    uint8_t* run_signal;        /* [n_runs] */
     float* left;            /* [n_mixers][wave_batch] */
     float* right;
     uint8_t* has_signal;    /* [n_mixers] */
-    int n_mixers, wave_batch;
+    int n_mixers, n_runs, wave_batch;
 };
 
 struct SiggenArgs {

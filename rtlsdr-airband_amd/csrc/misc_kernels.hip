@@ -99,14 +99,17 @@ void launch_siggen(const SiggenArgs& a, hipStream_t stream) {
     }
 }
 
-/* ---- mixer sum (reference: src/mixer.cpp:133-140 mix_waveforms, :201-214) ------------------------------- */
-__global__ __launch_bounds__(256) void mix_kernel(MixArgs a) {
-    const int m = blockIdx.y;
+/* ---- mixer sum (reference: src/mixer.cpp:133-140 mix_waveforms, :201-214) -------------------------------
+ * Two stages so that mixers with hundreds of thousands of inputs (BASELINE config #5) parallelise: stage A sums runs of
+ * up to MIX_RUN consecutive inputs of one mixer in connection order, stage B adds the run sums in order.  A mixer with
+ * <= MIX_RUN inputs (every mixer in the reference's example configs) is therefore summed in exactly the reference's order. */
+__global__ __launch_bounds__(256) void mix_runs_kernel(MixArgs a) {
+    const int run = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
-    const int first = a.mixer_first[m], last = a.mixer_first[m + 1];
+    const int first = a.run_first[run], last = a.run_first[run + 1];
+    const bool stereo = a.mixer_stereo[a.run_mixer[run]] != 0;
     float l = 0.0f, r = 0.0f;
     bool any = false;
-    const bool stereo = a.mixer_stereo[m] != 0;
     for (int i = first; i < last; i++) {
         const int ch = a.in_chan[i];
         if (a.out_axc[ch] == ' ') continue; /* has_signal == false: nothing is added (src/mixer.cpp:119-122,203) */
@@ -119,6 +122,31 @@ __global__ __launch_bounds__(256) void mix_kernel(MixArgs a) {
         }
     }
     if (t < a.wave_batch) {
+        a.run_left[(long)run * a.wave_batch + t] = l;
+        a.run_right[(long)run * a.wave_batch + t] = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.run_signal[run] = any ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void mix_final_kernel(MixArgs a) {
+    const int m = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int first = a.mixer_first_run[m], last = a.mixer_first_run[m + 1];
+    float l = 0.0f, r = 0.0f;
+    bool any = false;
+    for (int k = first; k < last; k++) {
+        any = any || a.run_signal[k] != 0;
+        if (t < a.wave_batch) {
+            if (k == first) { /* keeps a single-run mixer bit-identical to the sequential sum (0 + x is exact, but -0.0 would not survive) */
+                l = a.run_left[(long)k * a.wave_batch + t];
+                r = a.run_right[(long)k * a.wave_batch + t];
+            } else {
+                l += a.run_left[(long)k * a.wave_batch + t];
+                r += a.run_right[(long)k * a.wave_batch + t];
+            }
+        }
+    }
+    if (t < a.wave_batch) {
         a.left[(long)m * a.wave_batch + t] = l;
         a.right[(long)m * a.wave_batch + t] = r;
     }
@@ -126,7 +154,9 @@ __global__ __launch_bounds__(256) void mix_kernel(MixArgs a) {
 }
 
 void launch_mix(const MixArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(mix_kernel, dim3((a.wave_batch + 255) / 256, a.n_mixers), dim3(256), 0, stream, a);
+    const int bx = (a.wave_batch + 255) / 256;
+    hipLaunchKernelGGL(mix_runs_kernel, dim3(bx, a.n_runs), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(mix_final_kernel, dim3(bx, a.n_mixers), dim3(256), 0, stream, a);
 }
 
 /* ---- layout shuffles for the introspection entry points -------------------------------------------------- */
