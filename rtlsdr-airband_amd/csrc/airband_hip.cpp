@@ -496,14 +496,15 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
         a.n_dev_pad = p.n_dev;
         a.hop_bytes = (int)h->hop_bytes;
         a.lds_per_buf = dft_lds_per_buf((int)h->hop_bytes);
+        a.sub = dft_sub_tiles((int)h->hop_bytes);
         a.row0 = h->row0;
         a.ring_rows = h->R;
         a.first_row = first ? 0 : AB_AGC_EXTRA;
         a.n_hops = first ? h->B + AB_AGC_EXTRA : h->B;
         /* enough waves to fill 256 CUs x 8 waves even with few dongles: split each dongle's tiles */
-        const int tiles = (a.n_hops + 15) / 16;
+        const int steps = ((a.n_hops + 15) / 16 + 1 + a.sub - 1) / a.sub;
         int splits = (8192 + a.n_dev_pad - 1) / a.n_dev_pad;
-        if (splits > tiles / 4) splits = tiles / 4;
+        if (splits > steps / 4) splits = steps / 4;
         if (splits < 1) splits = 1;
         a.splits = splits;
         (void)hipEventRecord(h->ev[0], s);

@@ -57,9 +57,11 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     const int split = wave_global / a.n_dev_pad;
     if (d >= a.n_dev || split >= a.splits) return;
     const int hop_bytes = a.hop_bytes;
-    const int tile_bytes = TILE_HOPS * hop_bytes;         /* new stream bytes per tile */
-    const int carry = WIN_BYTES - hop_bytes;              /* bytes a tile shares with the next one */
-    const int buf_bytes = tile_bytes + carry;
+    /* a staging step feeds `sub` consecutive 16-hop MFMA tiles: ~10 KiB of stream per step whatever the hop size, so
+     * the bytes a wave keeps in flight (one step ahead) do not shrink when the hop does */
+    const int sub = a.sub;
+    const int step_hops = TILE_HOPS * sub;
+    const int buf_bytes = (step_hops - 1) * hop_bytes + WIN_BYTES;
     uint8_t* lds = lds_all;                               /* two buffers of lds_per_buf bytes */
 
     /* MFMA tiles are aligned to the 16-row tiles of the output rings: tile t covers hops [16 t - shift, 16 t - shift + 16);
@@ -68,10 +70,11 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     const int ring_tiles = a.ring_rows / AB_TILE_ROWS;
     const int ptile0 = (a.row0 + a.first_row) >> 4;
     const int tiles_total = (shift + a.n_hops + TILE_HOPS - 1) / TILE_HOPS;
-    const int tiles_per_split = (tiles_total + a.splits - 1) / a.splits;
-    const int t_begin = split * tiles_per_split;
-    const int t_end = min(tiles_total, t_begin + tiles_per_split);
-    if (t_begin >= t_end) return;
+    const int steps_total = (tiles_total + sub - 1) / sub;
+    const int steps_per_split = (steps_total + a.splits - 1) / a.splits;
+    const int st_begin = split * steps_per_split;
+    const int st_end = min(steps_total, st_begin + steps_per_split);
+    if (st_begin >= st_end) return;
 
     const uint8_t* src = a.iq + (long)d * a.iq_stride;    /* first byte of this batch's first hop */
     const long span_end = (long)(a.n_hops - 1) * hop_bytes + WIN_BYTES; /* bytes of the batch span that may be read */
@@ -98,14 +101,14 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
 
     /* ---- raw-byte staging: HBM -> LDS without a register round trip (global_load_lds_dwordx4: every lane
      * supplies its own 16-byte source address, the wave's data lands contiguously at an M0-relative LDS base).
-     * A tile needs stream bytes [t*tile_bytes, t*tile_bytes + buf_bytes); the first `carry` of them were already
-     * fetched for the previous tile, so that part is an L2 hit -- HBM sees every byte once. Lanes past the end of
+     * A step needs buf_bytes of stream; its first WIN_BYTES - hop_bytes were already fetched for the previous step,
+     * so that part is an L2 hit -- HBM sees every byte once. Lanes past the end of
      * the batch span re-read its last 16 bytes: they only feed hops >= n_hops, which are never stored. */
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int n_dma = (buf_bytes + 1023) >> 10;
-    auto stage = [&](int tile, uint8_t* buf) {
-        const long base = ((long)tile * TILE_HOPS - shift) * hop_bytes;
+    auto stage = [&](int step, uint8_t* buf) {
+        const long base = ((long)step * step_hops - shift) * hop_bytes;
         for (int i = 0; i < n_dma; i++) {
             long so = base + i * 1024 + lane * 16;
             if (so + 16 > span_end) so = span_end - 16;
@@ -114,16 +117,19 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
         }
     };
     int cur = 0;
-    stage(t_begin, lds);
+    stage(st_begin, lds);
 
     const int row_l = lane & 15, grp = lane >> 4;
-    for (int t = t_begin; t < t_end; t++) {
+    for (int st = st_begin; st < st_end; st++) {
         uint8_t* buf = lds + cur * a.lds_per_buf;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this tile's bytes have landed in LDS */
-        if (t + 1 < t_end) stage(t + 1, lds + (cur ^ 1) * a.lds_per_buf); /* next tile streams in under this tile's MFMAs */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this step's bytes have landed in LDS */
+        if (st + 1 < st_end) stage(st + 1, lds + (cur ^ 1) * a.lds_per_buf); /* next step streams in under this step's MFMAs */
+      for (int sb = 0; sb < sub; sb++) {
+        const int t = st * sub + sb;
+        if (t >= tiles_total) break;
 
         v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-        const uint8_t* arow = buf + row_l * hop_bytes + grp * 16;
+        const uint8_t* arow = buf + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 16;
 #pragma unroll
         for (int s = 0; s < KSTEPS; s++) {
             v4i av = *reinterpret_cast<const v4i*>(arow + s * 64);
@@ -169,6 +175,7 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
                 }
             }
         }
+      }
         cur ^= 1;
     }
 }
@@ -180,7 +187,11 @@ bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch) {
 }
 
 /* whole 1 KiB DMA pieces: the last piece of a tile may run past the bytes the tile needs, never past its buffer */
-int dft_lds_per_buf(int hop_bytes) { return (TILE_HOPS * hop_bytes + 1024 - hop_bytes + 1023) / 1024 * 1024; }
+int dft_sub_tiles(int hop_bytes) {
+    int sub = 640 / hop_bytes;
+    return sub < 1 ? 1 : (sub > 4 ? 4 : sub);
+}
+int dft_lds_per_buf(int hop_bytes) { return ((TILE_HOPS * dft_sub_tiles(hop_bytes) - 1) * hop_bytes + 1024 + 1023) / 1024 * 1024; }
 
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream) {
     const long waves = (long)a.n_dev_pad * a.splits;
