@@ -490,13 +490,15 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
         a.bfrag = h->d_bfrag.p;
         a.corr = h->d_bcorr.p;
         a.unscale = p.b_unscale;
+        a.edge_hi_zero = p.b_edge_hi_zero ? 1 : 0;
         a.mag = h->d_mag.p;
         a.iq_bins = h->d_iq.p;
         a.n_dev = p.n_dev;
         a.n_dev_pad = p.n_dev;
         a.hop_bytes = (int)h->hop_bytes;
         a.lds_per_buf = dft_lds_per_buf((int)h->hop_bytes);
-        a.sub = dft_sub_tiles((int)h->hop_bytes);
+        a.nbuf = dft_nbuf((int)h->hop_bytes);
+        a.sub = a.nbuf == 3 ? 1 : dft_sub_tiles((int)h->hop_bytes);
         a.row0 = h->row0;
         a.ring_rows = h->R;
         a.first_row = first ? 0 : AB_AGC_EXTRA;

@@ -37,7 +37,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int TILE_HOPS = 16;
 
-template <int FFT_N>
+/* EDGE_HI_ZERO: the most significant coefficient digit is zero for every k-step in which the window is below 2^-8
+ * (steps 0,1,14,15 of the 7-term cosine window at N = 512 -- checked on the host, see build_dft_tables): those four
+ * MFMAs and their 16 VGPRs are dropped. */
+template <int FFT_N, bool EDGE_HI_ZERO>
 __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     constexpr int WIN_BYTES = 2 * FFT_N;          /* bytes per window (u8/s8 I/Q)      */
     constexpr int KSTEPS = WIN_BYTES / 64;        /* MFMA k-steps per window           */
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     for (int s = 0; s < KSTEPS; s++) {
         b0[s] = btab[(0 * KSTEPS + s) * 64];
         b1[s] = btab[(1 * KSTEPS + s) * 64];
-        b2[s] = btab[(2 * KSTEPS + s) * 64];
+        if (!(EDGE_HI_ZERO && (s < 2 || s >= KSTEPS - 2))) b2[s] = btab[(2 * KSTEPS + s) * 64];
     }
     const int col = lane & 15;
     const double corr = a.corr[bset * 16 + col];
@@ -116,27 +119,59 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
             __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(uintptr_t)(buf + i * 1024), 16, 0, 0);
         }
     };
-    int cur = 0;
+    /* staging ring of nbuf buffers: step st lives in buffer (st - st_begin) % nbuf; nbuf - 1 steps are in flight */
+    const int nbuf = a.nbuf;
     stage(st_begin, lds);
+    if (nbuf == 3 && st_begin + 1 < st_end) stage(st_begin + 1, lds + a.lds_per_buf);
+    int cur = 0;
 
     const int row_l = lane & 15, grp = lane >> 4;
     for (int st = st_begin; st < st_end; st++) {
         uint8_t* buf = lds + cur * a.lds_per_buf;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this step's bytes have landed in LDS */
-        if (st + 1 < st_end) stage(st + 1, lds + (cur ^ 1) * a.lds_per_buf); /* next step streams in under this step's MFMAs */
+        if (nbuf == 3) {
+            /* Loads complete in issue order, so once at most n_dma vector-memory operations are outstanding none of them
+             * can belong to step st: the step-(st+1) transfer alone has n_dma pieces, all younger.  (Stores issued in
+             * between only add to the count, i.e. make this wait conservative.) */
+            switch (n_dma) {
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+            if (st + 1 >= st_end) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* last step: nothing younger to hide behind */
+            int nb = cur + 2;
+            nb = nb >= 3 ? nb - 3 : nb;
+            if (st + 2 < st_end) stage(st + 2, lds + nb * a.lds_per_buf); /* two steps ahead: the buffer step st-1 just left */
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this step's bytes have landed in LDS */
+            if (st + 1 < st_end) stage(st + 1, lds + (cur ^ 1) * a.lds_per_buf); /* next step streams in under this step's MFMAs */
+        }
       for (int sb = 0; sb < sub; sb++) {
         const int t = st * sub + sb;
         if (t >= tiles_total) break;
 
         v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
         const uint8_t* arow = buf + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 16;
+        /* A fragments are fetched two k-steps ahead of the MFMAs that consume them, so the LDS latency (and the 2-way
+         * bank conflict of the strided rows) hides behind six MFMAs instead of stalling in front of them */
+        v4i av[KSTEPS];
+        av[0] = *reinterpret_cast<const v4i*>(arow);
+        av[1] = *reinterpret_cast<const v4i*>(arow + 64);
+        av[2] = *reinterpret_cast<const v4i*>(arow + 128);
+        av[3] = *reinterpret_cast<const v4i*>(arow + 192);
 #pragma unroll
         for (int s = 0; s < KSTEPS; s++) {
-            v4i av = *reinterpret_cast<const v4i*>(arow + s * 64);
-            av.x ^= 0x80808080; av.y ^= 0x80808080; av.z ^= 0x80808080; av.w ^= 0x80808080; /* u8 -> b - 128 as int8 */
-            acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b0[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b1[s], acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b2[s], acc2, 0, 0, 0);
+            if ((s & 1) == 0 && s + 4 < KSTEPS) {
+                av[s + 4] = *reinterpret_cast<const v4i*>(arow + (s + 4) * 64);
+                av[s + 5] = *reinterpret_cast<const v4i*>(arow + (s + 5) * 64);
+            }
+            v4i x = av[s];
+            x.x ^= 0x80808080; x.y ^= 0x80808080; x.z ^= 0x80808080; x.w ^= 0x80808080; /* u8 -> b - 128 as int8 */
+            acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b0[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b1[s], acc1, 0, 0, 0);
+            if (!(EDGE_HI_ZERO && (s < 2 || s >= KSTEPS - 2))) acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b2[s], acc2, 0, 0, 0);
+            if (s & 1) __builtin_amdgcn_sched_barrier(0); /* keep the prefetch distance the source order spells out */
         }
         /* recombine the digits exactly, restore the -127.5 offset of the reference's LUT, undo the fixed-point scale */
         float val[4];
@@ -149,21 +184,35 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
         float im4[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) im4[r] = __shfl_xor(val[r], 1);
+#ifdef AB_DFT_NO_STORE
+        if (!(col & 1) && ch_valid && val[0] == 1.2345e-30f) {
+#else
         if (!(col & 1) && ch_valid) {
+#endif
             int pt = ptile0 + t;
             pt = pt >= ring_tiles ? pt - ring_tiles : pt;
             const long off = slot_base + (long)pt * (AB_SLOT_BLOCK * AB_TILE_ROWS) + grp * 4;
             const int hop_first = t * TILE_HOPS - shift + grp * 4;
             float m4[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) m4[r] = sqrtf(val[r] * val[r] + im4[r] * im4[r]);
+            for (int r = 0; r < 4; r++) m4[r] = __builtin_amdgcn_sqrtf(val[r] * val[r] + im4[r] * im4[r]); /* v_sqrt_f32, 1 ulp: stage 1 is tolerance-bound anyway */
             if (hop_first >= 0 && hop_first + 3 < a.n_hops) {
+#ifdef AB_DFT_NT_STORE
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store((v4f){m4[0], m4[1], m4[2], m4[3]}, reinterpret_cast<v4f*>(a.mag + off));
+                if (want_iq) {
+                    v4f* q = reinterpret_cast<v4f*>(a.iq_bins + off);
+                    __builtin_nontemporal_store((v4f){val[0], im4[0], val[1], im4[1]}, q);
+                    __builtin_nontemporal_store((v4f){val[2], im4[2], val[3], im4[3]}, q + 1);
+                }
+#else
                 *reinterpret_cast<float4*>(a.mag + off) = make_float4(m4[0], m4[1], m4[2], m4[3]);
                 if (want_iq) {
                     float4* q = reinterpret_cast<float4*>(a.iq_bins + off);
                     q[0] = make_float4(val[0], im4[0], val[1], im4[1]);
                     q[1] = make_float4(val[2], im4[2], val[3], im4[3]);
                 }
+#endif
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -176,7 +225,7 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
             }
         }
       }
-        cur ^= 1;
+        cur = cur + 1 == nbuf ? 0 : cur + 1;
     }
 }
 
@@ -191,12 +240,18 @@ int dft_sub_tiles(int hop_bytes) {
     int sub = 640 / hop_bytes;
     return sub < 1 ? 1 : (sub > 4 ? 4 : sub);
 }
-int dft_lds_per_buf(int hop_bytes) { return ((TILE_HOPS * dft_sub_tiles(hop_bytes) - 1) * hop_bytes + 1024 + 1023) / 1024 * 1024; }
+static int lds_for(int hop_bytes, int sub) { return ((TILE_HOPS * sub - 1) * hop_bytes + 1024 + 1023) / 1024 * 1024; }
+/* three small buffers (two steps in flight) when eight waves of them fit a CU's 160 KiB, else two larger ones */
+int dft_nbuf(int hop_bytes) { return 3 * lds_for(hop_bytes, 1) * 8 <= 160 * 1024 ? 3 : 2; }
+int dft_lds_per_buf(int hop_bytes) { return dft_nbuf(hop_bytes) == 3 ? lds_for(hop_bytes, 1) : lds_for(hop_bytes, dft_sub_tiles(hop_bytes)); }
 
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream) {
     const long waves = (long)a.n_dev_pad * a.splits;
-    const size_t lds = (size_t)2 * a.lds_per_buf;
-    hipLaunchKernelGGL(channelizer_dft_kernel<512>, dim3((unsigned)waves), dim3(64), lds, stream, a);
+    const size_t lds = (size_t)a.nbuf * a.lds_per_buf;
+    if (a.edge_hi_zero)
+        hipLaunchKernelGGL((channelizer_dft_kernel<512, true>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+    else
+        hipLaunchKernelGGL((channelizer_dft_kernel<512, false>), dim3((unsigned)waves), dim3(64), lds, stream, a);
 }
 
 }  // namespace airband

@@ -50,7 +50,8 @@ struct DftArgs {
     float* mag;
     float2* iq_bins;
     int n_dev, n_dev_pad, splits;
-    int hop_bytes, lds_per_buf, sub; /* sub = 16-hop MFMA tiles per staging step */
+    int edge_hi_zero;                /* most significant digit is zero in k-steps 0,1,14,15 for every coefficient table */
+    int hop_bytes, lds_per_buf, sub, nbuf; /* sub = 16-hop MFMA tiles per staging step; nbuf staging buffers */
     int row0, ring_rows, first_row, n_hops;
 };
 
@@ -119,6 +120,7 @@ void launch_channelizer_fft(const ChannelizerArgs& a, hipStream_t stream);
 bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch);
 int dft_lds_per_buf(int hop_bytes);
 int dft_sub_tiles(int hop_bytes);
+int dft_nbuf(int hop_bytes);
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream);
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream);
 void launch_emit(const EmitArgs& a, hipStream_t stream);

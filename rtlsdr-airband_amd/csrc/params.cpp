@@ -346,6 +346,12 @@ void build_dft_tables(Plan& p) {
         p.dev_bset[d] = found;
     }
     p.n_bsets = (int)keys.size();
+    /* the window is below 2^-8 of full scale in the outer k-steps, so the top digit vanishes there: verify, don't assume */
+    p.b_edge_hi_zero = true;
+    for (int b = 0; b < p.n_bsets && p.b_edge_hi_zero; b++)
+        for (int s : {0, 1, KS - 2, KS - 1})
+            for (int i = 0; i < 64 * 16; i++)
+                if (p.bfrag[(size_t)b * 3 * KS * 64 * 16 + ((size_t)2 * KS + s) * 64 * 16 + i] != 0) p.b_edge_hi_zero = false;
 }
 
 void channel_constants(const Plan& p, int i, double* v) {

@@ -34,6 +34,7 @@ struct Plan {
     std::vector<int8_t> bfrag;         /* [n_bsets][3][16][64][16] */
     std::vector<double> bcorr;         /* [n_bsets][16] */
     double b_unscale = 0.0;
+    bool b_edge_hi_zero = false;       /* digit 2 is zero in k-steps 0,1,14,15 of every table */
     int n_bsets = 0;
     int64_t hop_bytes_max = 0;
     bool uniform_hop = true;           /* every dongle has the same sfmt / hop (needed by the batched launch) */
