@@ -69,7 +69,9 @@ struct airband_hip_handle {
     DevBuf<uint8_t> d_block_kind;
     DevBuf<float> d_window, d_sin, d_cos;
     DevBuf<float> d_mag, d_wave, d_sqbuf, d_ct_coeff, d_ct_q;
-    DevBuf<float2> d_iq, d_iq_out;
+    DevBuf<float2> d_iq, d_iq_out, d_ct_af;
+    DevBuf<unsigned long long> d_ct_mask;
+    int ct_first_block = 0, ct_n_blocks = 0;
     DevBuf<uint8_t> d_trace;
     DevBuf<float> d_out_wave, d_out_iq;
     DevBuf<uint8_t> d_out_axc;
@@ -133,7 +135,7 @@ void destroy(airband_hip_handle* h) {
     h->d_dev.release(); h->d_cc.release(); h->d_cs.release(); h->d_slot_to_ext.release(); h->d_ext_to_slot.release(); h->d_block_kind.release();
     h->d_window.release(); h->d_sin.release(); h->d_cos.release();
     h->d_mag.release(); h->d_wave.release(); h->d_sqbuf.release(); h->d_ct_coeff.release(); h->d_ct_q.release();
-    h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release();
+    h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release(); h->d_ct_af.release(); h->d_ct_mask.release();
     h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
     h->d_tmp_wavein.release(); h->d_tmp_iqin.release(); h->d_tmp_trace.release();
     h->d_dev_bset.release(); h->d_bfrag.release(); h->d_bcorr.release();
@@ -169,6 +171,10 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.ct_coeff = h->d_ct_coeff.p;
     da.ct_q = h->d_ct_q.p;
     da.trace = (h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH) ? h->d_trace.p : nullptr;
+    da.ct_af = h->d_ct_af.p;
+    da.ct_mask = h->d_ct_mask.p;
+    da.ct_first_block = h->ct_first_block;
+    da.ct_n_blocks = h->ct_n_blocks;
     da.sin_lut = h->d_sin.p;
     da.cos_lut = h->d_cos.p;
     da.ct_stride = h->ct_stride;
@@ -369,6 +375,13 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     PREP_TRY(hipMemset(h->d_iq.p, 0, ring * sizeof(float2)), AIRBAND_HIP_ENOMEM);
     PREP_TRY(hipMemset(h->d_iq_out.p, 0, (size_t)h->B * h->n_slots * sizeof(float2)), AIRBAND_HIP_ENOMEM);
     PREP_TRY(hipMemset(h->d_sqbuf.p, 0, (size_t)AB_SQ_BUF * h->n_slots * sizeof(float)), AIRBAND_HIP_ENOMEM);
+    /* hand-off buffers of the split kinds (NFM+CTCSS and generic are adjacent in slot order) */
+    h->ct_n_blocks = h->kind_n_blocks[AB_KIND_NFM_CTCSS] + h->kind_n_blocks[AB_KIND_GENERIC];
+    h->ct_first_block = h->kind_n_blocks[AB_KIND_NFM_CTCSS] ? h->kind_first_block[AB_KIND_NFM_CTCSS] : h->kind_first_block[AB_KIND_GENERIC];
+    if (h->ct_n_blocks > 0) {
+        PREP_TRY(h->d_ct_af.alloc((size_t)h->ct_n_blocks * h->B * AB_SLOT_BLOCK), AIRBAND_HIP_ENOMEM);
+        PREP_TRY(h->d_ct_mask.alloc((size_t)h->ct_n_blocks * (h->B / 50) * AB_SLOT_BLOCK), AIRBAND_HIP_ENOMEM);
+    }
     if (h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH) {
         PREP_TRY(h->d_trace.alloc((size_t)h->B * h->n_slots), AIRBAND_HIP_ENOMEM);
         PREP_TRY(hipMemset(h->d_trace.p, 0, (size_t)h->B * h->n_slots), AIRBAND_HIP_ENOMEM);

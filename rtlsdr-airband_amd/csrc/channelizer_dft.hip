@@ -99,7 +99,11 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     const DevConst dev = a.dev[d];
     const bool ch_valid = ch < dev.n_ch;
     const int slot = a.ext_to_slot[dev.chan_base + (ch_valid ? ch : 0)];
-    const bool want_iq = ch_valid && ((a.cc[slot].flags & AB_F_RAW_IQ) != 0);
+    const unsigned ch_flags = a.cc[slot].flags;
+    const bool want_iq = ch_valid && ((ch_flags & AB_F_RAW_IQ) != 0);
+    /* NFM channels never read |bin| back except as sqrt(re^2 + im^2) of the very I/Q written next to it: stage 2 recomputes it,
+     * and stage 1 saves the bytes (writes are the expensive half of this kernel's HBM traffic) */
+    const bool want_mag = !(ch_flags & AB_F_NFM);
     const long slot_base = ab_tile_base(slot, ring_tiles);
 
     /* ---- raw-byte staging: HBM -> LDS without a register round trip (global_load_lds_dwordx4: every lane
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
                     __builtin_nontemporal_store((v4f){val[2], im4[2], val[3], im4[3]}, q + 1);
                 }
 #else
-                *reinterpret_cast<float4*>(a.mag + off) = make_float4(m4[0], m4[1], m4[2], m4[3]);
+                if (want_mag) *reinterpret_cast<float4*>(a.mag + off) = make_float4(m4[0], m4[1], m4[2], m4[3]);
                 if (want_iq) {
                     float4* q = reinterpret_cast<float4*>(a.iq_bins + off);
                     q[0] = make_float4(val[0], im4[0], val[1], im4[1]);
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
                 for (int r = 0; r < 4; r++) {
                     const int hop = hop_first + r;
                     if (hop >= 0 && hop < a.n_hops) {
-                        a.mag[off + r] = m4[r];
+                        if (want_mag) a.mag[off + r] = m4[r];
                         if (want_iq) a.iq_bins[off + r] = make_float2(val[r], im4[r]);
                     }
                 }

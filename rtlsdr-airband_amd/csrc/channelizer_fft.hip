@@ -90,13 +90,14 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
     }
     /* which (register, lane) holds this lane's channel bin */
     int my_rho = -1, my_src = 0, my_slot = -1;
-    bool my_raw = false;
+    bool my_raw = false, my_mag = true; /* NFM channels: stage 2 recomputes |bin| from the raw I/Q */
     if (lane < dev.n_ch) {
         my_slot = a.ext_to_slot[dev.chan_base + lane];
         const int bin = a.cs[my_slot].bin;
         my_rho = bitrev(bin & (P - 1), LOGP);
         my_src = bitrev(bin >> LOGP, 6);
         my_raw = (a.cc[my_slot].flags & AB_F_RAW_IQ) != 0;
+        my_mag = (a.cc[my_slot].flags & AB_F_NFM) == 0;
     }
     __syncthreads();
 
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
             int row = a.row0 + a.first_row + hop0 + h;
             if (row >= a.ring_rows) row -= a.ring_rows;
             const long off = ab_tile_base(my_slot, a.ring_rows / AB_TILE_ROWS) + ab_tile_off(row);
-            a.mag[off] = sqrtf(bre * bre + bim * bim);
+            if (my_mag) a.mag[off] = sqrtf(bre * bre + bim * bim);
             if (my_raw) a.iq_bins[off] = make_float2(bre, bim);
         }
     }

@@ -293,13 +293,8 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     o.axc = ' ';
     float lxr0 = sp->lxr[0], lxr1 = sp->lxr[1], lxr2 = sp->lxr[2], lxi0 = sp->lxi[0], lxi1 = sp->lxi[1], lxi2 = sp->lxi[2];
     float lyr0 = sp->lyr[0], lyr1 = sp->lyr[1], lyr2 = sp->lyr[2], lyi0 = sp->lyi[0], lyi1 = sp->lyi[1], lyi2 = sp->lyi[2];
-    /* CTCSS bookkeeping of this lane's channel: [0] fast, [1] slow (src/ctcss.h:84-95); used only in phase 2 */
-    int ct_enough0 = sp->ct_enough[0], ct_enough1 = sp->ct_enough[1], ct_count0 = sp->ct_count[0], ct_count1 = sp->ct_count[1];
-    int ct_has0 = sp->ct_has_tone[0], ct_has1 = sp->ct_has_tone[1];
-    unsigned ct_found0 = sp->ct_found[0], ct_found1 = sp->ct_found[1], ct_nf0 = sp->ct_not_found[0], ct_nf1 = sp->ct_not_found[1];
 
     const bool nfm = cc.flags & AB_F_NFM, raw_iq = cc.flags & AB_F_RAW_IQ, lowpass = cc.flags & AB_F_LOWPASS;
-    const bool is_ct = valid && (cc.flags & AB_F_CTCSS);
     const float one_minus_alpha = 1.0f - cc.alpha;
 
     float* mag = a.mag + ab_tile_base(slot, R / AB_TILE_ROWS);        /* tile-transposed rings: row r at ab_tile_off(r) */
@@ -308,7 +303,8 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     float2* iqout = a.iq_out + ab_ring_base(slot, B);
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
     float* my = lds + lane * NS; /* element (u, lane) at lds[(u * 64 + lane) * NS ...] */
-    unsigned tone_mask = 0;      /* CTCSS lanes: bit u = tone present at sample u of the chunk (written by phase 2) */
+    /* split kinds: (audio, flags) rows for the tone / back kernels, [ct block][sample][64 lanes] */
+    float2* ct_af = WAVE_HAS_CTCSS ? a.ct_af + ((long)((slot >> 6) - a.ct_first_block) * B) * S + lane : nullptr;
 
     for (int j0 = 0; j0 < B; j0 += CHUNK) {
         /* ---- phase 0: the chunk's stage-1 values, 16 bytes (4 rows) per load, parked in LDS -------------------------
@@ -319,8 +315,15 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             for (int g = 0; g < CHUNK / 4; g++) {
                 const int rc = ring_row(a.row0 + AB_AGC_EXTRA + j0 + 4 * g, R); /* current hops */
                 const int rd = ring_row(a.row0 + j0 + 4 * g, R);                /* hops AGC_EXTRA earlier */
-                const float4 mc = *reinterpret_cast<const float4*>(mag + ab_tile_off(rc));
-                float4 md = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q01 = md, q23 = md;
+                float4 mc, md = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q01 = md, q23 = md;
+                if (!nfm) {
+                    mc = *reinterpret_cast<const float4*>(mag + ab_tile_off(rc));
+                } else { /* NFM: wavein[j] = sqrtf(re^2 + im^2) of the current hop's raw bin (src/rtl_airband.cpp:484-487), recomputed here */
+                    const float4* cp = reinterpret_cast<const float4*>(iqin + ab_tile_off(rc));
+                    const float4 c01 = cp[0], c23 = cp[1];
+                    mc = make_float4(sqrtf(c01.x * c01.x + c01.y * c01.y), sqrtf(c01.z * c01.z + c01.w * c01.w), sqrtf(c23.x * c23.x + c23.y * c23.y),
+                                     sqrtf(c23.z * c23.z + c23.w * c23.w));
+                }
                 if (!nfm) md = *reinterpret_cast<const float4*>(mag + ab_tile_off(rd));
                 if (raw_iq) {
                     const float4* qp = reinterpret_cast<const float4*>(iqin + ab_tile_off(rd));
@@ -438,206 +441,42 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                     }
                 }
                 if (WAVE_HAS_CTCSS) {
-                    /* park audio + flags; CTCSS channels finish in phases 2/3.  Raw I/Q of an open sample is written now
-                     * (phase 3 zeroes it again if the tone gate turns out closed). */
-                    float4 w;
-                    w.x = out;
-                    w.y = __uint_as_float((audio ? FL_AUDIO : 0u) | (fade ? FL_FADE : 0u) | (went_closed ? FL_RESET : 0u) | ((unsigned)s.cur << FL_STATE_SHIFT));
-                    w.z = re;
-                    w.w = im;
-                    *reinterpret_cast<float4*>(my + u * 64 * NS) = w;
+                    /* front half of a CTCSS-capable kind: hand (pre-notch audio, flags) to the tone and back kernels.  Raw I/Q of
+                     * an open sample is written now; the back kernel zeroes it again if the tone gate turns out closed. */
+                    const unsigned f = (audio ? FL_AUDIO : 0u) | (fade ? FL_FADE : 0u) | (went_closed ? FL_RESET : 0u) | ((unsigned)s.cur << FL_STATE_SHIFT);
+                    ct_af[(long)j * S] = make_float2(out, __uint_as_float(f));
                     if ((cc.flags & AB_F_IQ_OUT) && audio) iqout[(long)j * S] = make_float2(re, im);
                 } else {
                     emit_sample(a, cc, o, wave, iqout, trace, j, audio, fade, true, s.cur, out, re, im, true);
                 }
             }
         }
-        if (WAVE_HAS_CTCSS) {
-            /* ---- phase 2: every CTCSS channel of the wave in turn; lanes = tones ------------------------------------
-             * Software-pipelined over the channels: while channel k runs its recurrences, channel k+1's chunk samples
-             * (LDS) and tone state (L2) are already on their way, so the serial loop never sits on a load. */
-            unsigned long long todo = __ballot(is_ct);
-#ifdef AB_SKIP_PHASE2
-            todo = 0; /* timing experiment only */
-#endif
-            int owner = todo ? __builtin_ctzll(todo) : -1;
-            todo &= todo - 1;
-            struct ToneRegs { float ax; unsigned fl; float c0, c1, q1f, q2f, q1s, q2s; };
-            auto fetch = [&](int who) {
-                ToneRegs t;
-                t.ax = 0.0f;
-                t.fl = 0;
-                if (lane < CHUNK) { /* lane u picks up sample u of the channel's chunk: (audio, flags) */
-                    const float2 af = *reinterpret_cast<const float2*>(lds + ((long)lane * 64 + who) * NS);
-                    t.ax = af.x;
-                    t.fl = __float_as_uint(af.y);
-                }
-                /* tone tables: [ct_slot][detector][tone] coefficients, [ct_slot][detector][q1|q2][tone] state */
-                const int ct_slot = __builtin_amdgcn_readlane(cc.ct_slot, who);
-                const float* ctab = a.ct_coeff + (long)ct_slot * 2 * AB_MAX_TONES;
-                const float* qtab = a.ct_q + (long)ct_slot * 4 * AB_MAX_TONES;
-                const bool tl = lane < AB_MAX_TONES;
-                t.c0 = tl ? ctab[lane] : 0.0f;
-                t.c1 = tl ? ctab[AB_MAX_TONES + lane] : 0.0f;
-                t.q1f = tl ? qtab[lane] : 0.0f;
-                t.q2f = tl ? qtab[AB_MAX_TONES + lane] : 0.0f;
-                t.q1s = tl ? qtab[2 * AB_MAX_TONES + lane] : 0.0f;
-                t.q2s = tl ? qtab[3 * AB_MAX_TONES + lane] : 0.0f;
-                return t;
-            };
-            ToneRegs T;
-            if (owner >= 0) T = fetch(owner);
-            while (owner >= 0) {
-                const int next_owner = todo ? __builtin_ctzll(todo) : -1;
-                todo &= todo - 1;
-                ToneRegs TN = T;
-                if (next_owner >= 0) TN = fetch(next_owner);
-
-                const float ax = T.ax;
-                const unsigned fl = T.fl;
-                int enough0 = __builtin_amdgcn_readlane(ct_enough0, owner), enough1 = __builtin_amdgcn_readlane(ct_enough1, owner);
-                int has0 = __builtin_amdgcn_readlane(ct_has0, owner), has1 = __builtin_amdgcn_readlane(ct_has1, owner);
-                int count0 = __builtin_amdgcn_readlane(ct_count0, owner), count1 = __builtin_amdgcn_readlane(ct_count1, owner);
-                const int win0 = __builtin_amdgcn_readlane(cc.ct_window[0], owner), win1 = __builtin_amdgcn_readlane(cc.ct_window[1], owner);
-                const int n0 = __builtin_amdgcn_readlane(cc.ct_ntones[0], owner), n1 = __builtin_amdgcn_readlane(cc.ct_ntones[1], owner);
-                const int ct_slot = __builtin_amdgcn_readlane(cc.ct_slot, owner);
-                float* qtab = a.ct_q + (long)ct_slot * 4 * AB_MAX_TONES;
-                const bool t0 = lane < n0, t1 = lane < n1;
-                const float c0 = T.c0, c1 = T.c1;
-                float q1f = T.q1f, q2f = T.q2f, q1s = T.q1s, q2s = T.q2s;
-                unsigned mask = 0;
-                const bool idle = __ballot((fl & (FL_AUDIO | FL_RESET)) != 0) == 0ull;
-                const bool all_audio = __ballot(lane < CHUNK && (fl & (FL_AUDIO | FL_RESET)) != FL_AUDIO) == 0ull;
-                if (idle) {
-                    /* squelch closed (or nothing to do) for the whole chunk: detector state cannot change */
-                    mask = (enough1 ? has1 : has0) ? 0xffffffffu : 0u;
-                } else if (all_audio && count1 + CHUNK < win1 && (enough1 || count0 + CHUNK < win0)) {
-                    /* steady state (most of a transmission): squelch open for the whole chunk and no detector window ends inside
-                     * it -> nothing but the Goertzel recurrences (ToneDetector::process_sample, src/ctcss.cpp:44-54) */
-                    if (enough1) {
-#pragma unroll
-                        for (int u = 0; u < CHUNK; u++) {
-                            const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
-                            const float q0 = c1 * q1s - q2s + x;
-                            q2s = q1s;
-                            q1s = q0;
-                        }
-                    } else { /* the fast detector runs too until the slow one has a full window (src/squelch.cpp:288-293) */
-#pragma unroll
-                        for (int u = 0; u < CHUNK; u++) {
-                            const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
-                            const float q0 = c1 * q1s - q2s + x;
-                            q2s = q1s;
-                            q1s = q0;
-                            const float p0 = c0 * q1f - q2f + x;
-                            q2f = q1f;
-                            q1f = p0;
-                        }
-                        count0 += CHUNK;
-                        if (t0) { qtab[lane] = q1f; qtab[AB_MAX_TONES + lane] = q2f; }
-                    }
-                    count1 += CHUNK;
-                    if (t1) { qtab[2 * AB_MAX_TONES + lane] = q1s; qtab[3 * AB_MAX_TONES + lane] = q2s; }
-                    mask = (enough1 ? has1 : has0) ? 0xffffffffu : 0u;
-                } else {
-                    unsigned found0 = __builtin_amdgcn_readlane(ct_found0, owner), found1 = __builtin_amdgcn_readlane(ct_found1, owner);
-                    unsigned nf0 = __builtin_amdgcn_readlane(ct_nf0, owner), nf1 = __builtin_amdgcn_readlane(ct_nf1, owner);
-#pragma unroll
-                    for (int u = 0; u < CHUNK; u++) {
-                        const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
-                        const unsigned f = __builtin_amdgcn_readlane(fl, u);
-                        if (f & FL_RESET) { /* CTCSS::reset (src/ctcss.cpp:165-172) on both detectors */
-                            q1f = q2f = q1s = q2s = 0.0f;
-                            enough0 = enough1 = count0 = count1 = has0 = has1 = 0;
-                        }
-                        if (f & FL_AUDIO) { /* Squelch::process_audio_sample (src/squelch.cpp:278-295): slow always, fast until slow has a window */
-#pragma unroll
-                            for (int k = 1; k >= 0; k--) {
-                                if (k == 0 && enough1) break;
-                                float& q1 = k ? q1s : q1f;
-                                float& q2 = k ? q2s : q2f;
-                                const float co = k ? c1 : c0;
-                                int& count = k ? count1 : count0;
-                                const int win = k ? win1 : win0, n = k ? n1 : n0;
-                                const float q0 = co * q1 - q2 + x; /* ToneDetector::process_sample (src/ctcss.cpp:44-54) */
-                                q2 = q1;
-                                q1 = q0;
-                                if (++count >= win) { /* CTCSS::process_audio_sample window end (src/ctcss.cpp:141-162) */
-                                    lds_scratch[lane] = q1 * q1 + q2 * q2 - q1 * q2 * co;
-                                    float total = 0.0f, best = 0.0f;
-                                    for (int i = 0; i < n; i++) { /* index-order float sum, as ToneDetectorSet::sorted_powers does */
-                                        const float m = lds_scratch[i];
-                                        total += m;
-                                        if (i == 0 || m > best) best = m;
-                                    }
-                                    const float target = lds_scratch[0];
-                                    const float avg = total / (float)n;
-                                    const bool present = __builtin_amdgcn_readfirstlane((int)(target == best && target > avg)) != 0;
-                                    if (k) { enough1 = 1; has1 = present; if (present) found1++; else nf1++; }
-                                    else { enough0 = 1; has0 = present; if (present) found0++; else nf0++; }
-                                    q1 = 0.0f;
-                                    q2 = 0.0f;
-                                    count = 0;
-                                }
-                            }
-                        }
-                        const bool tone = enough1 ? (has1 != 0) : (has0 != 0); /* Squelch::is_open's detector choice (src/squelch.cpp:122-130) */
-                        if (tone) mask |= 1u << u;
-                    }
-                    if (t0) { qtab[lane] = q1f; qtab[AB_MAX_TONES + lane] = q2f; }
-                    if (t1) { qtab[2 * AB_MAX_TONES + lane] = q1s; qtab[3 * AB_MAX_TONES + lane] = q2s; }
-                    const bool mine = lane == owner;
-                    ct_found0 = mine ? found0 : ct_found0; ct_found1 = mine ? found1 : ct_found1;
-                    ct_nf0 = mine ? nf0 : ct_nf0; ct_nf1 = mine ? nf1 : ct_nf1;
-                    ct_enough0 = mine ? enough0 : ct_enough0; ct_enough1 = mine ? enough1 : ct_enough1;
-                    ct_has0 = mine ? has0 : ct_has0; ct_has1 = mine ? has1 : ct_has1;
-                }
-                {
-                    const bool mine = lane == owner;
-                    ct_count0 = mine ? count0 : ct_count0;
-                    ct_count1 = mine ? count1 : ct_count1;
-                    tone_mask = mine ? mask : tone_mask;
-                }
-                T = TN;
-                owner = next_owner;
-            }
-            /* ---- phase 3: gating + output of the chunk ------------------------------------------------------------- */
-#ifdef AB_SKIP_PHASE3
-            if (false) {
-#else
-            if (valid) {
-#endif
-                for (int u = 0; u < CHUNK; u++) {
-                    const float4 w = *reinterpret_cast<const float4*>(my + u * 64 * NS);
-                    const unsigned f = __float_as_uint(w.y);
-                    const bool tone = is_ct ? ((tone_mask >> u) & 1u) != 0 : true;
-                    emit_sample(a, cc, o, wave, iqout, trace, j0 + u, (f & FL_AUDIO) != 0, (f & FL_FADE) != 0, tone, (int)((f >> FL_STATE_SHIFT) & 7u), w.x, w.z, w.w, false);
-                }
-            }
-        }
     }
 
     if (!valid) return;
-    if (o.axc != ' ') sp->active_counter++;
-    sp->axc = o.axc;
+    if (!WAVE_HAS_CTCSS) { /* the back kernel owns these in the split kinds */
+        if (o.axc != ' ') sp->active_counter++;
+        sp->axc = o.axc;
+        sp->nx[0] = o.nx0; sp->nx[1] = o.nx1; sp->nx[2] = o.nx2; sp->ny[0] = o.ny0; sp->ny[1] = o.ny1; sp->ny[2] = o.ny2;
+    }
     sp->agcavgfast = agc; sp->pr = pr; sp->pj = pj; sp->prev_waveout = prev_out; sp->dm_phi = dm_phi;
     sp->noise_floor = s.noise_floor; sp->cap = s.cap; sp->pre_full = s.pre_full; sp->pre_capped = s.pre_capped;
     sp->post_full = s.post_full; sp->post_capped = s.post_capped;
     sp->using_post = s.using_post; sp->next = s.next; sp->cur = s.cur; sp->delay = s.delay; sp->low_count = s.low_count;
     sp->head = s.head; sp->tail = s.tail; sp->sample_count = s.sample_count; sp->open_count = s.open_count;
     sp->flappy_count = s.flappy_count; sp->recent_open = s.recent_open; sp->closed_count = s.closed_count;
-    sp->nx[0] = o.nx0; sp->nx[1] = o.nx1; sp->nx[2] = o.nx2; sp->ny[0] = o.ny0; sp->ny[1] = o.ny1; sp->ny[2] = o.ny2;
     sp->lxr[0] = lxr0; sp->lxr[1] = lxr1; sp->lxr[2] = lxr2; sp->lxi[0] = lxi0; sp->lxi[1] = lxi1; sp->lxi[2] = lxi2;
     sp->lyr[0] = lyr0; sp->lyr[1] = lyr1; sp->lyr[2] = lyr2; sp->lyi[0] = lyi0; sp->lyi[1] = lyi1; sp->lyi[2] = lyi2;
-    sp->ct_enough[0] = ct_enough0; sp->ct_enough[1] = ct_enough1; sp->ct_count[0] = ct_count0; sp->ct_count[1] = ct_count1;
-    sp->ct_has_tone[0] = ct_has0; sp->ct_has_tone[1] = ct_has1;
-    sp->ct_found[0] = ct_found0; sp->ct_found[1] = ct_found1; sp->ct_not_found[0] = ct_nf0; sp->ct_not_found[1] = ct_nf1;
 }
+
+constexpr int TONE_GROUP = 50; /* samples per tone-kernel step; divides WAVE_BATCH = 1000 and 2000, fits one wavefront's lanes */
 
 }  // namespace
 
 /* One kernel per demod kind: register allocation (hence occupancy) is then set by that kind's code path alone --
- * the AM kernel does not pay for the CTCSS / lowpass registers.  Slot blocks of one kind are contiguous. */
+ * the AM kernel does not pay for the lowpass registers.  Slot blocks of one kind are contiguous.
+ * CTCSS-capable kinds are split in three: this "front" (squelch + discriminator -> audio, flags), the tone kernel
+ * (Goertzel banks, one wavefront per channel) and the back kernel (gate, notch, output). */
 template <int KIND, bool WAVE_HAS_CTCSS>
 __global__ __launch_bounds__(64) void demod_kernel(DemodArgs a, int first_block) {
     extern __shared__ __attribute__((aligned(16))) float lds_demod[];
@@ -645,6 +484,169 @@ __global__ __launch_bounds__(64) void demod_kernel(DemodArgs a, int first_block)
     const ChanConst cc = a.cc[slot];
     float* scratch = lds_demod + CHUNK * 64 * LdsSlots<KIND>::value;
     demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lds_demod, scratch);
+}
+
+/* CTCSS tone detection (reference: src/ctcss.cpp, driven by Squelch::process_audio_sample src/squelch.cpp:278-295).
+ * One wavefront per channel; lane t is tone t of the fast (0.05 s) and of the slow (0.4 s) Goertzel bank, so the
+ * reference's ~104 multiply-adds per audio sample are one 3-op recurrence per lane.  The channel's whole batch is walked
+ * with the state in registers; audio and flags come from the front kernel 50 samples at a time (lane u fetches sample u,
+ * v_readlane feeds the serial loop), the verdict leaves as a 50-bit mask per step.  Tiny register footprint -> 8 waves per
+ * SIMD hide the dependent-issue latency of the recurrence. */
+__global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
+    __shared__ float power[4][64];
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= a.ct_n_blocks * 64) return;
+    const int slot = a.ct_first_block * 64 + wave;
+    const unsigned flags = a.cc[slot].flags;
+    if (!(flags & AB_F_VALID) || !(flags & AB_F_CTCSS)) return;
+    const ChanConst cc = a.cc[slot];
+    ChanState* sp = a.cs + slot;
+    float* scratch = power[threadIdx.x >> 6];
+    const int B = a.wave_batch, NG = B / TONE_GROUP;
+    int enough0 = sp->ct_enough[0], enough1 = sp->ct_enough[1], count0 = sp->ct_count[0], count1 = sp->ct_count[1];
+    int has0 = sp->ct_has_tone[0], has1 = sp->ct_has_tone[1];
+    unsigned found0 = sp->ct_found[0], found1 = sp->ct_found[1], nf0 = sp->ct_not_found[0], nf1 = sp->ct_not_found[1];
+    const int n0 = cc.ct_ntones[0], n1 = cc.ct_ntones[1], win0 = cc.ct_window[0], win1 = cc.ct_window[1];
+    /* tone tables: [ct_slot][detector][tone] coefficients, [ct_slot][detector][q1|q2][tone] state */
+    const float* ctab = a.ct_coeff + (long)cc.ct_slot * 2 * AB_MAX_TONES;
+    float* qtab = a.ct_q + (long)cc.ct_slot * 4 * AB_MAX_TONES;
+    const bool t0 = lane < n0, t1 = lane < n1;
+    const float c0 = t0 ? ctab[lane] : 0.0f, c1 = t1 ? ctab[AB_MAX_TONES + lane] : 0.0f;
+    float q1f = t0 ? qtab[lane] : 0.0f, q2f = t0 ? qtab[AB_MAX_TONES + lane] : 0.0f;
+    float q1s = t1 ? qtab[2 * AB_MAX_TONES + lane] : 0.0f, q2s = t1 ? qtab[3 * AB_MAX_TONES + lane] : 0.0f;
+
+    const long blk = wave >> 6;
+    const float2* af = a.ct_af + (blk * B) * AB_SLOT_BLOCK + (wave & 63);
+    unsigned long long* maskp = a.ct_mask + (blk * NG) * AB_SLOT_BLOCK + (wave & 63);
+    float2 cur = lane < TONE_GROUP ? af[(long)lane * AB_SLOT_BLOCK] : make_float2(0.0f, 0.0f);
+    for (int g = 0; g < NG; g++) {
+        float2 nxt = make_float2(0.0f, 0.0f);
+        if (g + 1 < NG && lane < TONE_GROUP) nxt = af[((long)(g + 1) * TONE_GROUP + lane) * AB_SLOT_BLOCK];
+        const float ax = cur.x;
+        const unsigned fl = __float_as_uint(cur.y);
+        unsigned long long mask = 0;
+        const bool idle = __ballot((fl & (FL_AUDIO | FL_RESET)) != 0) == 0ull;
+        const bool all_audio = __ballot(lane < TONE_GROUP && (fl & (FL_AUDIO | FL_RESET)) != FL_AUDIO) == 0ull;
+        if (idle) {
+            /* squelch closed for the whole step: detector state cannot change */
+            mask = (enough1 ? has1 : has0) ? ~0ull : 0ull;
+        } else if (all_audio && count1 + TONE_GROUP < win1 && (enough1 || count0 + TONE_GROUP < win0)) {
+            /* steady state: squelch open throughout and no detector window ends inside the step -> only the recurrences
+             * (ToneDetector::process_sample, src/ctcss.cpp:44-54) */
+            if (enough1) {
+                for (int u = 0; u < TONE_GROUP; u++) {
+                    const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
+                    const float q0 = c1 * q1s - q2s + x;
+                    q2s = q1s;
+                    q1s = q0;
+                }
+            } else { /* the fast detector runs until the slow one has a full window (src/squelch.cpp:288-293) */
+                for (int u = 0; u < TONE_GROUP; u++) {
+                    const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
+                    const float q0 = c1 * q1s - q2s + x;
+                    q2s = q1s;
+                    q1s = q0;
+                    const float p0 = c0 * q1f - q2f + x;
+                    q2f = q1f;
+                    q1f = p0;
+                }
+                count0 += TONE_GROUP;
+            }
+            count1 += TONE_GROUP;
+            mask = (enough1 ? has1 : has0) ? ~0ull : 0ull;
+        } else {
+            for (int u = 0; u < TONE_GROUP; u++) {
+                const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
+                const unsigned f = __builtin_amdgcn_readlane(fl, u);
+                if (f & FL_RESET) { /* CTCSS::reset (src/ctcss.cpp:165-172) on both detectors, at the squelch's transition to CLOSED */
+                    q1f = q2f = q1s = q2s = 0.0f;
+                    enough0 = enough1 = count0 = count1 = has0 = has1 = 0;
+                }
+                if (f & FL_AUDIO) { /* Squelch::process_audio_sample: slow always, fast until slow has a window */
+#pragma unroll
+                    for (int k = 1; k >= 0; k--) {
+                        if (k == 0 && enough1) break;
+                        float& q1 = k ? q1s : q1f;
+                        float& q2 = k ? q2s : q2f;
+                        const float co = k ? c1 : c0;
+                        int& count = k ? count1 : count0;
+                        const int win = k ? win1 : win0, n = k ? n1 : n0;
+                        const float q0 = co * q1 - q2 + x;
+                        q2 = q1;
+                        q1 = q0;
+                        if (++count >= win) { /* CTCSS::process_audio_sample window end (src/ctcss.cpp:141-162) */
+                            scratch[lane] = q1 * q1 + q2 * q2 - q1 * q2 * co;
+                            float total = 0.0f, best = 0.0f;
+                            for (int i = 0; i < n; i++) { /* index-order float sum, as ToneDetectorSet::sorted_powers does */
+                                const float m = scratch[i];
+                                total += m;
+                                if (i == 0 || m > best) best = m;
+                            }
+                            const float target = scratch[0];
+                            const float avg = total / (float)n;
+                            const bool present = __builtin_amdgcn_readfirstlane((int)(target == best && target > avg)) != 0;
+                            if (k) { enough1 = 1; has1 = present; if (present) found1++; else nf1++; }
+                            else { enough0 = 1; has0 = present; if (present) found0++; else nf0++; }
+                            q1 = 0.0f;
+                            q2 = 0.0f;
+                            count = 0;
+                        }
+                    }
+                }
+                const bool tone = enough1 ? (has1 != 0) : (has0 != 0); /* Squelch::is_open's detector choice (src/squelch.cpp:122-130) */
+                if (tone) mask |= 1ull << u;
+            }
+        }
+        if (lane == 0) maskp[(long)g * AB_SLOT_BLOCK] = mask;
+        cur = nxt;
+    }
+    if (t0) { qtab[lane] = q1f; qtab[AB_MAX_TONES + lane] = q2f; }
+    if (t1) { qtab[2 * AB_MAX_TONES + lane] = q1s; qtab[3 * AB_MAX_TONES + lane] = q2s; }
+    if (lane == 0) {
+        sp->ct_enough[0] = enough0; sp->ct_enough[1] = enough1; sp->ct_count[0] = count0; sp->ct_count[1] = count1;
+        sp->ct_has_tone[0] = has0; sp->ct_has_tone[1] = has1;
+        sp->ct_found[0] = found0; sp->ct_found[1] = found1; sp->ct_not_found[0] = nf0; sp->ct_not_found[1] = nf1;
+    }
+}
+
+/* Back half of the split kinds: output gating (squelch open AND tone present), notch, ampfactor, clamp, AM fade-out
+ * (reference: src/rtl_airband.cpp:532-547,589-620), one lane per channel, samples staged through LDS 25 at a time. */
+__global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
+    constexpr int SUBCHUNK = 25;
+    __shared__ float2 stage[SUBCHUNK][64];
+    const int lane = threadIdx.x;
+    const int slot = (a.ct_first_block + blockIdx.x) * 64 + lane;
+    const ChanConst cc = a.cc[slot];
+    if (!(cc.flags & AB_F_VALID)) return;
+    ChanState* sp = a.cs + slot;
+    const int R = a.ring_rows, B = a.wave_batch, NG = B / TONE_GROUP;
+    OutRegs o;
+    o.nx0 = sp->nx[0]; o.nx1 = sp->nx[1]; o.nx2 = sp->nx[2]; o.ny0 = sp->ny[0]; o.ny1 = sp->ny[1]; o.ny2 = sp->ny[2];
+    o.axc = ' ';
+    float* wave = a.wave + ab_ring_base(slot, R);
+    float2* iqout = a.iq_out + ab_ring_base(slot, B);
+    uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
+    const float2* af = a.ct_af + ((long)blockIdx.x * B) * AB_SLOT_BLOCK + lane;
+    const unsigned long long* maskp = a.ct_mask + ((long)blockIdx.x * NG) * AB_SLOT_BLOCK + lane;
+    const bool is_ct = (cc.flags & AB_F_CTCSS) != 0;
+    for (int g = 0; g < NG; g++) {
+        const unsigned long long mask = is_ct ? maskp[(long)g * AB_SLOT_BLOCK] : ~0ull;
+        for (int h = 0; h < TONE_GROUP / SUBCHUNK; h++) {
+            const int j0 = g * TONE_GROUP + h * SUBCHUNK;
+#pragma unroll
+            for (int u = 0; u < SUBCHUNK; u++) stage[u][lane] = af[(long)(j0 + u) * AB_SLOT_BLOCK];
+            for (int u = 0; u < SUBCHUNK; u++) {
+                const float2 w = stage[u][lane];
+                const unsigned f = __float_as_uint(w.y);
+                const bool tone = ((mask >> (h * SUBCHUNK + u)) & 1ull) != 0;
+                emit_sample(a, cc, o, wave, iqout, trace, j0 + u, (f & FL_AUDIO) != 0, (f & FL_FADE) != 0, tone, (int)((f >> FL_STATE_SHIFT) & 7u), w.x, 0.0f, 0.0f, false);
+            }
+        }
+    }
+    if (o.axc != ' ') sp->active_counter++;
+    sp->axc = o.axc;
+    sp->nx[0] = o.nx0; sp->nx[1] = o.nx1; sp->nx[2] = o.nx2; sp->ny[0] = o.ny0; sp->ny[1] = o.ny1; sp->ny[2] = o.ny2;
 }
 
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream) {
@@ -660,7 +662,14 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
             default: hipLaunchKernelGGL((demod_kernel<AB_KIND_GENERIC, true>), dim3(n), dim3(64), lds, stream, a, f); break;
         }
     }
+    if (a.ct_n_blocks > 0) {
+        hipLaunchKernelGGL(tone_kernel, dim3((a.ct_n_blocks * 64 * 64 + 255) / 256), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(back_kernel, dim3(a.ct_n_blocks), dim3(64), 0, stream, a);
+    }
 }
+
+namespace {
+}  // namespace
 
 /* ---- emit: time-major device results -> the channel-major layout the output thread consumes -------------
  * (reference: src/output.cpp:460,521,535 read channel->waveout[0..WAVE_BATCH) / iq_out; :920 tail copy is implicit
