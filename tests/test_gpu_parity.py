@@ -184,3 +184,69 @@ def test_mixers_match_reference_order_sum(pkg, built):
             assert not left[2].any() and not sig[2]
             seen |= bool(ws.any())
         assert seen
+
+
+def _convert(iq_u8, sfmt, capi):
+    """Re-express the synthetic u8 stream in the other sample formats the input drivers deliver (src/input-soapysdr.cpp:45-64)."""
+    x = iq_u8.astype(np.float32) - 127.5
+    if sfmt == capi.SFMT_U8:
+        return iq_u8
+    if sfmt == capi.SFMT_S8:
+        return np.clip(np.round(x), -127, 127).astype(np.int8)  # -128 indexes a table entry the reference never initialises
+    if sfmt == capi.SFMT_S16:
+        return np.round(x * 200.0).astype(np.int16)
+    return (x / 127.5).astype(np.float32)
+
+
+@pytest.mark.parametrize("sfmt_name,fft_log,sample_rate,wave_rate", [
+    ("SFMT_S8", 9, 2_560_000, 8000), ("SFMT_S16", 9, 2_560_000, 16000), ("SFMT_F32", 9, 2_560_000, 16000),
+    ("SFMT_U8", 8, 2_560_000, 16000), ("SFMT_U8", 10, 2_560_000, 8000), ("SFMT_U8", 11, 2_560_000, 16000), ("SFMT_S16", 13, 2_560_000, 8000),
+    ("SFMT_U8", 9, 2_400_000, 16000), ("SFMT_U8", 9, 1_024_000, 8000)])
+def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sample_rate, wave_rate):
+    """Everything the matrix-core path does not take (s8/s16/f32, fft sizes 256..8192, hops that are not a multiple of 16 bytes)
+    runs on the wavefront-FFT channelizer: same parity bars."""
+    capi = pkg.capi
+    sfmt = getattr(capi, sfmt_name)
+    mixed = wave_rate == 16000
+    n_dev, n_batches = 2, 7
+    chans, _ = pkg.siggen.baseline_plan(mixed=mixed)
+    scale = sample_rate / 2_560_000
+    for c in chans:  # keep every channel inside the dongle's (possibly narrower) passband
+        c["frequency"] = 120_000_000 + int((c["frequency"] - 120_000_000) * scale * 0.8)
+    carriers = []
+    probe = [dict(channels=[dict(c) for c in chans], sample_rate=sample_rate)]
+    for k, c in enumerate(chans):
+        # put the transmitter where the reference LOOKS: its bin formula divides by the integer sample_rate / fft_size
+        # (src/config.cpp:666-667), which is off by many bins when that quotient is not exact (e.g. 2.56 MS/s / 8192)
+        b = int(pkg.derive_constants(probe, k, wave_rate=wave_rate, fft_log=fft_log)[0])
+        n_fft = 1 << fft_log
+        off = (b if b < n_fft // 2 else b - n_fft) * sample_rate / n_fft
+        kind = c["modulation"]
+        carriers.append(pkg.siggen.make_carrier(off, sample_rate, kind=kind, ctcss_hz=c["ctcss_freq"], key_slot=k, key_period_s=0.5, key_on_s=0.3, key_slot_s=0.04))
+    fullscale = 0.0 if sfmt != capi.SFMT_S16 else 127.5 * 200.0
+    devices = [dict(channels=[dict(c) for c in chans], sample_rate=sample_rate, sfmt=sfmt, fullscale=fullscale) for _ in range(n_dev)]
+    hop = round(sample_rate / wave_rate)
+    n_samples = (n_batches * (wave_rate // 8) + 100) * hop + (1 << fft_log)
+    iq = [_convert(pkg.siggen.generate_u8(d, 0, n_samples, carriers), sfmt, capi) for d in range(n_dev)]
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fft_log=fft_log)
+    ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
+    assert all(r["n_batches"] == n_batches for r in ref)
+    opened = 0
+    with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=capi.FLAG_TRACE_SQUELCH) as hip:
+        expect_dft = sfmt == capi.SFMT_U8 and fft_log == 9 and (2 * hop) % 16 == 0 and 64 <= 2 * hop <= 640
+        assert hip.channelizer_name() == ("dft_mfma_i8" if expect_dft else "fft_wave64")
+        pos = [0] * n_dev
+        for b in range(n_batches):
+            for d in range(n_dev):
+                raw = iq[d].view(np.uint8)
+                pos[d] += hip.submit(d, raw[pos[d]:])
+            assert hip.process(), "batch %d: not enough input queued" % b
+            out = hip.collect()
+            tr = hip.read_trace()
+            want_t = np.concatenate([r["trace"][b] for r in ref])
+            assert np.array_equal(out["axc"], np.concatenate([r["axc"][b] for r in ref])), "batch %d axc" % b
+            assert np.array_equal(tr, want_t), "batch %d: %d squelch-state mismatches" % (b, int((tr != want_t).sum()))
+            ww = np.concatenate([r["waveout"][b] for r in ref])
+            assert helpers.rms(out["waveout"] - ww) <= 1e-4
+            opened += int((out["axc"] == ord("*")).sum())
+    assert opened > 0
