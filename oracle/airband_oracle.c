@@ -754,9 +754,9 @@ static void afc_finalize(const orc_t* o, odev_t* dev, chan_t* c, char prev_axc) 
         if (c->bin != bin) {
             c->bin = bin;
             if (bin > base)
-                c->axc = '>';
+                c->axc = '<'; /* AFC_UP, src/rtl_airband.h:99 */
             else if (bin < base)
-                c->axc = '<';
+                c->axc = '>'; /* AFC_DOWN */
         }
     } else if (c->axc == ' ' && prev_axc != ' ') {
         c->bin = c->base_bin;

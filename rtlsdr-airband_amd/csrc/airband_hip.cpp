@@ -76,7 +76,8 @@ struct airband_hip_handle {
     DevBuf<float> d_out_wave, d_out_iq;
     DevBuf<uint8_t> d_out_axc;
     DevBuf<airband_hip_channel_stats> d_stats;
-    DevBuf<float> d_tmp_wavein, d_tmp_iqin;
+    DevBuf<float> d_tmp_wavein, d_tmp_iqin, d_spectrum;
+    bool any_afc = false, afc_spectrum_valid = false; /* process_bins() has no spectrum: AFC is skipped there */
     DevBuf<uint8_t> d_tmp_trace;
     int ct_stride = 0;
     /* matrix-core channelizer */
@@ -137,7 +138,7 @@ void destroy(airband_hip_handle* h) {
     h->d_mag.release(); h->d_wave.release(); h->d_sqbuf.release(); h->d_ct_coeff.release(); h->d_ct_q.release();
     h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release(); h->d_ct_af.release(); h->d_ct_mask.release();
     h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
-    h->d_tmp_wavein.release(); h->d_tmp_iqin.release(); h->d_tmp_trace.release();
+    h->d_tmp_wavein.release(); h->d_tmp_iqin.release(); h->d_tmp_trace.release(); h->d_spectrum.release();
     h->d_dev_bset.release(); h->d_bfrag.release(); h->d_bcorr.release();
     h->d_stage.release();
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -183,6 +184,7 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.row0 = h->row0;
     da.ring_rows = h->R;
     launch_demod(da, h->kind_first_block, h->kind_n_blocks, s);
+    if (h->any_afc && h->afc_spectrum_valid) launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, s); /* afc.finalize(), src/rtl_airband.cpp:626-630 */
     (void)hipEventRecord(h->ev[2], s);
 
     EmitArgs ea;
@@ -263,11 +265,8 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
         delete h;
         return fail(nullptr, AIRBAND_HIP_EINVAL, "all dongles of one handle must share sample format and sample_rate/WAVE_RATE hop; use one handle per class");
     }
-    for (const ChanConst& c : p.cc)
-        if (c.afc != 0) {
-            delete h;
-            return fail(nullptr, AIRBAND_HIP_EINVAL, "afc is not implemented by this backend yet (reference default is afc=0, src/config.cpp:352)");
-        }
+    bool any_afc = false;
+    for (const ChanConst& c : p.cc) any_afc |= c.afc != 0;
     h->flags = cfg->flags;
     h->hip_device = cfg->hip_device;
     int ndev = 0;
@@ -396,7 +395,10 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
         PREP_TRY(hipMemset(h->d_out_iq.p, 0, h->d_out_iq.n * sizeof(float)), AIRBAND_HIP_ENOMEM);
     }
     /* channelizer variant: matrix-core pruned DFT when the configuration qualifies, wavefront FFT otherwise */
-    h->use_dft = !(h->flags & AIRBAND_HIP_FLAG_FORCE_FFT) && dft_supported(p.fft_size, (int)h->hop_bytes, p.dev[0].sfmt, p.max_ch);
+    /* AFC moves bins at run time and needs the full spectrum of each batch's last hop: that is the FFT kernel's job */
+    h->any_afc = any_afc;
+    if (any_afc) PREP_TRY(h->d_spectrum.alloc((size_t)p.n_dev * p.fft_size * 2), AIRBAND_HIP_ENOMEM);
+    h->use_dft = !any_afc && !(h->flags & AIRBAND_HIP_FLAG_FORCE_FFT) && dft_supported(p.fft_size, (int)h->hop_bytes, p.dev[0].sfmt, p.max_ch);
     if (h->use_dft) {
         build_dft_tables(h->plan);
         if (p.n_bsets > 4096) {
@@ -537,7 +539,7 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
     ca.window = h->d_window.p;
     ca.mag = h->d_mag.p;
     ca.iq_bins = h->d_iq.p;
-    ca.last_spectrum = nullptr;
+    ca.last_spectrum = h->any_afc ? h->d_spectrum.p : nullptr;
     ca.n_dev = p.n_dev;
     ca.fft_log = p.fft_log;
     ca.hop_samples = p.dev[0].hop_samples;
@@ -550,6 +552,7 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
     ca.n_hops = first ? h->B + AB_AGC_EXTRA : h->B;
     ca.max_ch = p.max_ch;
     (void)hipEventRecord(h->ev[0], s);
+    h->afc_spectrum_valid = h->any_afc;
     launch_channelizer_fft(ca, s);
     (void)hipEventRecord(h->ev[1], s);
     return run_back_half(h, s);
@@ -603,6 +606,7 @@ int airband_hip_process_bins(airband_hip_handle* h, const float* wavein, const f
     HIP_TRY(h, hipMemcpyAsync(h->d_tmp_wavein.p, wavein, n * sizeof(float), hipMemcpyHostToDevice, s), AIRBAND_HIP_ERUNTIME);
     HIP_TRY(h, hipMemcpyAsync(h->d_tmp_iqin.p, iq_in, 2 * n * sizeof(float), hipMemcpyHostToDevice, s), AIRBAND_HIP_ERUNTIME);
     (void)hipEventRecord(h->ev[0], s);
+    h->afc_spectrum_valid = false;
     launch_scatter_bins(h->d_tmp_wavein.p, h->d_tmp_iqin.p, h->d_slot_to_ext.p, h->d_cc.p, h->d_mag.p, h->d_iq.p, h->n_slots, h->B, h->row0, h->R, s);
     (void)hipEventRecord(h->ev[1], s);
     return run_back_half(h, s);

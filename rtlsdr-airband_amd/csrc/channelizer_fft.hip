@@ -188,6 +188,12 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
                 xi[rho] = tr * cwi[st] + ti * cwr[st];
             }
         }
+        /* AFC looks at the whole spectrum of the batch's last hop (afc.finalize(dev, i, fftout), src/rtl_airband.cpp:626-630) */
+        if (a.last_spectrum && hop0 + h == a.n_hops - 1) {
+            float2* sp = reinterpret_cast<float2*>(a.last_spectrum) + (long)d * N;
+#pragma unroll
+            for (int rho = 0; rho < P; rho++) sp[bitrev(rho, LOGP) + P * bitrev(lane, 6)] = make_float2(xr[rho], xi[rho]);
+        }
         /* channel lanes fetch their bin (src/rtl_airband.cpp:483-489) */
         float bre = 0.0f, bim = 0.0f;
 #pragma unroll

@@ -70,7 +70,8 @@ struct ChanState {
     /* CTCSS detectors: [0] fast, [1] slow (src/ctcss.h:84-95) */
     int32_t ct_enough[2], ct_count[2], ct_has_tone[2];
     uint32_t ct_found[2], ct_not_found[2];
-    int32_t pad[3];
+    int32_t axc_prev; /* axcindicate before the last batch (what `AFC afc(dev, i)` captures, src/rtl_airband.cpp:222,496) */
+    int32_t pad[2];
 };
 
 /* Per-dongle constants for the channelizer. */

@@ -456,6 +456,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     if (!valid) return;
     if (!WAVE_HAS_CTCSS) { /* the back kernel owns these in the split kinds */
         if (o.axc != ' ') sp->active_counter++;
+        sp->axc_prev = sp->axc;
         sp->axc = o.axc;
         sp->nx[0] = o.nx0; sp->nx[1] = o.nx1; sp->nx[2] = o.nx2; sp->ny[0] = o.ny0; sp->ny[1] = o.ny1; sp->ny[2] = o.ny2;
     }
@@ -645,6 +646,7 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
         }
     }
     if (o.axc != ' ') sp->active_counter++;
+    sp->axc_prev = sp->axc;
     sp->axc = o.axc;
     sp->nx[0] = o.nx0; sp->nx[1] = o.nx1; sp->nx[2] = o.nx2; sp->ny[0] = o.ny0; sp->ny[1] = o.ny1; sp->ny[2] = o.ny2;
 }

@@ -131,6 +131,7 @@ void launch_emit(const EmitArgs& a, hipStream_t stream);
 void launch_mix(const MixArgs& a, hipStream_t stream);
 void launch_stats(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, int n_slots, airband_hip_channel_stats* out, hipStream_t stream);
 void launch_siggen(const SiggenArgs& a, hipStream_t stream);
+void launch_afc(const ChanConst* cc, ChanState* cs, const float* spectrum, int fft_size, int n_slots, hipStream_t stream);
 /* scatter channel-major host-provided bins into the time-major rings (airband_hip_process_bins) */
 void launch_scatter_bins(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, int n_slots,
                          int wave_batch, int row0, int ring_rows, hipStream_t stream);

@@ -159,6 +159,59 @@ void launch_mix(const MixArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(mix_final_kernel, dim3(bx, a.n_mixers), dim3(256), 0, stream, a);
 }
 
+/* ---- AFC (reference: class AFC, src/rtl_airband.cpp:180-251) ------------------------------------------------
+ * After a batch: on a NO_SIGNAL -> signal edge walk to a stronger neighbouring bin of the batch's last FFT (downwards
+ * first, then upwards), with the reference's growing threshold; on a signal -> NO_SIGNAL edge return to the base bin. */
+__device__ int afc_walk(const float2* fft, int fft_size, int base, float base_value, int afc, int step) {
+    float threshold = 0;
+    int bin;
+    for (bin = base;; bin += step) {
+        if (step < 0) {
+            if (bin < -step) break;
+        } else if (bin + step >= fft_size) {
+            break;
+        }
+        const float2 v = fft[bin + step];
+        const float value = v.x * v.x + v.y * v.y;
+        if (value <= base_value) break;
+        if (base == bin) {
+            threshold = (value - base_value) / (float)afc;
+        } else {
+            if ((value - base_value) < threshold) break;
+            threshold = (float)((double)threshold + (double)threshold / 10.0);
+        }
+    }
+    return bin;
+}
+
+__global__ void afc_kernel(const ChanConst* cc, ChanState* cs, const float2* spectrum, int fft_size, int n_slots) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots) return;
+    const ChanConst c = cc[slot];
+    if (!(c.flags & AB_F_VALID) || c.afc == 0) return;
+    ChanState* s = cs + slot;
+    const int axc = s->axc, prev = s->axc_prev;
+    const float2* fft = spectrum + (long)c.dev * fft_size;
+    if (axc != ' ' && prev == ' ') {
+        const int base = c.base_bin;
+        const float2 b = fft[base];
+        const float base_value = b.x * b.x + b.y * b.y;
+        int bin = afc_walk(fft, fft_size, base, base_value, c.afc, -1);
+        if (bin == base) bin = afc_walk(fft, fft_size, base, base_value, c.afc, 1);
+        if (s->bin != bin) {
+            s->bin = bin;
+            if (bin > base) s->axc = '<';      /* AFC_UP   (enum status, src/rtl_airband.h:99) */
+            else if (bin < base) s->axc = '>'; /* AFC_DOWN */
+        }
+    } else if (axc == ' ' && prev != ' ') {
+        s->bin = c.base_bin;
+    }
+}
+
+void launch_afc(const ChanConst* cc, ChanState* cs, const float* spectrum, int fft_size, int n_slots, hipStream_t stream) {
+    hipLaunchKernelGGL(afc_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, cc, cs, reinterpret_cast<const float2*>(spectrum), fft_size, n_slots);
+}
+
 /* ---- layout shuffles for the introspection entry points -------------------------------------------------- */
 __global__ void scatter_bins_kernel(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, int n_slots,
                                     int wave_batch, int row0, int ring_rows) {

@@ -40,3 +40,18 @@ def rms(a: np.ndarray) -> float:
 
 def axc_str(axc: np.ndarray) -> str:
     return "\n".join("".join(chr(v) for v in row) for row in np.asarray(axc).T)
+
+
+def afc_case(n_dev: int = 1):
+    """Channels with AFC enabled whose transmitters sit a few FFT bins off the configured frequency
+    (reference: class AFC, src/rtl_airband.cpp:180-251).  Returns (devices, carriers)."""
+    chans, carriers = sg.baseline_plan(mixed=False)
+    shifts = [+3, -2, 0, +5, -4, +1, 0, -1]           # in 5 kHz bins
+    afcs = [2, 1, 3, 10, 2, 255, 0, 0]
+    bin_hz = sg.SAMPLE_RATE / 512
+    out = []
+    for k, (c, car) in enumerate(zip(chans, carriers)):
+        c["afc"] = afcs[k]
+        off = sg.PLAN_OFFSETS_HZ[k] + shifts[k] * bin_hz
+        out.append(sg.make_carrier(off, sg.SAMPLE_RATE, kind=0, key_slot=k, key_period_s=0.75, key_on_s=0.4, key_slot_s=0.05))
+    return [dict(channels=[dict(c) for c in chans]) for _ in range(n_dev)], out

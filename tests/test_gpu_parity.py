@@ -250,3 +250,33 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
             assert helpers.rms(out["waveout"] - ww) <= 1e-4
             opened += int((out["axc"] == ord("*")).sum())
     assert opened > 0
+
+
+def test_afc(pkg, built):
+    """AFC-enabled channels (wavefront-FFT path: needs the whole spectrum of each batch's last hop)."""
+    n_dev, n_batches = 3, 14
+    devices, carriers = helpers.afc_case(n_dev)
+    nbytes = helpers.stream_bytes(n_batches, 8000)
+    iq = [pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)]
+    orc = pyoracle.Oracle(devices, wave_rate=8000)
+    ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
+    moved = 0
+    with pkg.AirbandHip(devices, wave_rate=8000, flags=pkg.capi.FLAG_TRACE_SQUELCH) as hip:
+        assert hip.channelizer_name() == "fft_wave64"
+        pos = [0] * n_dev
+        for b in range(n_batches):
+            for d in range(n_dev):
+                pos[d] += hip.submit(d, iq[d][pos[d]:])
+            assert hip.process()
+            out = hip.collect(stats=True)
+            want_a = np.concatenate([r["axc"][b] for r in ref])
+            assert np.array_equal(out["axc"], want_a), "batch %d: %s vs %s" % (b, bytes(out["axc"]), bytes(want_a))
+            assert np.array_equal(hip.read_trace(), np.concatenate([r["trace"][b] for r in ref]))
+            assert helpers.rms(out["waveout"] - np.concatenate([r["waveout"][b] for r in ref])) <= 1e-4
+            moved += int(((out["axc"] == ord("<")) | (out["axc"] == ord(">"))).sum())
+        k = 0
+        for d in range(n_dev):
+            for j in range(8):
+                assert out["stats"][k]["bin"] == orc.stats(d, j)["bin"], (d, j)
+                k += 1
+    assert moved > 0

@@ -132,3 +132,19 @@ def test_squelch_object_bit_exact(built, ctcss):
     assert np.array_equal(c1, c2) and c1[0] > 0
     ref.refh_squelch_free(a)
     L.orc_squelch_free(b)
+
+
+@need_ref
+def test_afc_bit_exact(pkg, built):
+    """AFC on: bins move at squelch-open edges ('<' / '>' in axcindicate) and return afterwards -- oracle == reference."""
+    devices, carriers = helpers.afc_case(1)
+    n_batches = 14
+    iq = pkg.siggen.generate_u8(1, 0, helpers.stream_bytes(n_batches, 8000) // 2, carriers)
+    ref = pyref.run_reference(devices, [iq], n_batches, nfm=False)[0]
+    orc = pyoracle.Oracle(devices, wave_rate=8000)
+    got = orc.run_device(0, iq, n_batches)
+    assert np.array_equal(ref["axc"], got["axc"])
+    assert np.array_equal(ref["waveout"].view(np.uint32), got["waveout"].view(np.uint32))
+    assert (ref["axc"] == ord(">")).any() and (ref["axc"] == ord("<")).any(), "test signal never triggered AFC"
+    for j in range(8):
+        assert ref["stats"][j]["bin"] == orc.stats(0, j)["bin"]
