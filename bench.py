@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--mixers", type=int, default=-1, help="number of mixers (default: 64 when --gpus > 1, else 0)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-path", action="store_true", help="additionally time the host-buffer path (submit over PCIe) on a small slice; reported separately, never as value")
     ap.add_argument("--force-dist", action="store_true", help="initialise a process group even at world size 1 (plumbing check of the RCCL leg)")
     args = ap.parse_args()
 
@@ -207,6 +208,26 @@ def main():
                roofline=roofline,
                stage_ms=dict(channelizer=ch_ms, demod=float(np.mean(demod_ms)) if demod_ms else None, emit=float(np.mean(emit_ms)) if emit_ms else None),
                realtime_dongles=int(value / 2.56))
+    if rank == 0 and world == 1 and args.host_path:
+        # host-buffer path: the shim of INTEGRATION.md feeding pageable host memory through submit()/process()
+        nd = min(D, 512)
+        sub = pkg.AirbandHip(devices[:nd], wave_rate=wave_rate, hip_device=local_rank)
+        gg = sub.geometry
+        host = iq[:nd, :gg.first_batch_bytes + 3 * gg.batch_bytes + gg.lookahead_bytes].cpu().numpy()
+        for d in range(nd):
+            sub.submit(d, host[d, :gg.first_batch_bytes + gg.lookahead_bytes])
+        sub.process(); sub.synchronize()
+        t1 = time.perf_counter()
+        off = gg.first_batch_bytes + gg.lookahead_bytes
+        for k in range(3):
+            for d in range(nd):
+                sub.submit(d, host[d, off:off + gg.batch_bytes])
+            sub.process()
+            off += gg.batch_bytes
+        sub.synchronize()
+        el = time.perf_counter() - t1
+        out["host_path"] = dict(value=round(nd * SAMPLES_PER_BATCH * 3 / el / 1e6, 1), unit="Msamples/s", dongles=nd, note="pageable host buffers -> pinned staging -> PCIe; includes the H2D copy")
+        sub.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(pkg, hip, devices, wave_rate, mixed, args.cpu_seconds)
