@@ -164,3 +164,54 @@ def reference_throughput(devices, iq_list, seconds: float, threads: int, *, nfm:
     if status != "ok":
         raise RuntimeError(res)
     return res
+
+
+def _all_worker(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib):
+    try:
+        lib = _load(nfm)
+        lib.refh_run_all.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        lib.refh_start_hip.argtypes = [C.c_char_p]
+        lib.refh_hip_channel_stats.argtypes = [C.c_int, C.c_int, C.POINTER(capi.ChannelStats)]
+        wb = lib.refh_wave_batch()
+        lib.refh_init(len(devices), fft_log, fm_demod, -1)
+        keep = []
+        for d, dev in enumerate(devices):
+            dc, arr = capi.device_cfg(**dev)
+            keep.append(arr)
+            assert lib.refh_add_device(d, C.byref(dc)) == 0
+        rc = lib.refh_start_hip(hip_lib.encode()) if hip_lib else lib.refh_start(1)
+        assert rc == 0, rc
+        nd, nch = len(devices), len(devices[0]["channels"])
+        wave = np.zeros((nd, n_batches, nch, wb), np.float32)
+        iqo = np.zeros((nd, n_batches, nch, 2 * wb), np.float32)
+        axc = np.zeros((nd, n_batches, nch), np.uint8)
+        bufs = [np.ascontiguousarray(x) for x in iq_list]
+        ptrs = (C.c_void_p * nd)(*[b.ctypes.data for b in bufs])
+        got = lib.refh_run_all(ptrs, bufs[0].nbytes, n_batches, wave.ctypes.data, iqo.ctypes.data, axc.ctypes.data, 120.0)
+        stats = []
+        for d in range(nd):
+            row = []
+            for j in range(nch):
+                st = capi.ChannelStats()
+                (lib.refh_hip_channel_stats if hip_lib else lib.refh_channel_stats)(d, j, C.byref(st))
+                row.append({f[0]: getattr(st, f[0]) for f in capi.ChannelStats._fields_})
+            stats.append(row)
+        lib.refh_stop()
+        q.put(("ok", dict(n_batches=got, waveout=wave, iq_out=iqo, axc=axc, stats=stats)))
+    except BaseException as e:  # noqa: BLE001
+        q.put(("err", repr(e)))
+
+
+def run_reference_all(devices, iq_list, n_batches, *, nfm: bool, fft_log: int = 9, fm_demod: int = 0, hip_lib: str | None = None):
+    """All devices fed concurrently through the reference's own rings.  hip_lib=None: the reference's demodulate();
+    hip_lib=path to libairband_hip.so: the SAME harness with demodulate() swapped for the drop-in shim (oracle/ref_harness.cpp
+    demodulate_hip, the code INTEGRATION.md shows)."""
+    ctx = mp.get_context("spawn" if hip_lib else "fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=_all_worker, args=(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib))
+    p.start()
+    status, res = q.get()
+    p.join()
+    if status != "ok":
+        raise RuntimeError(res)
+    return res

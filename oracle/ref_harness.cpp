@@ -23,8 +23,11 @@
 #include "rtl_airband.cpp" /* found through -I/root/reference/src */
 #undef main
 
+#include <dlfcn.h>
 #include <limits.h>
 #include <sched.h>
+
+#include <vector>
 
 #include "../include/airband_hip.h"
 #include "input-helpers.h"
@@ -55,6 +58,10 @@ static demod_params_t g_demod_params[REFH_MAX_THREADS];
 static Signal g_signal;
 static size_t* g_hops_fed_bytes = NULL;  /* total bytes fed per device */
 static char g_trace_dir[512] = "";
+/* config-level values per device, kept next to the objects built from them (what a maintainer's shim would keep) */
+static std::vector<airband_hip_device_cfg> g_dev_cfg;
+static std::vector<std::vector<airband_hip_channel_cfg> > g_ch_cfg;
+static int g_fm_demod_algo = 0;
 
 extern "C" {
 
@@ -79,6 +86,9 @@ int refh_init(int n_devices, int fft_log, int fm_demod_algo, int global_tau_us) 
     device_count = n_devices;
     devices = (device_t*)XCALLOC(n_devices, sizeof(device_t));
     g_hops_fed_bytes = (size_t*)XCALLOC(n_devices, sizeof(size_t));
+    g_dev_cfg.assign(n_devices, airband_hip_device_cfg());
+    g_ch_cfg.assign(n_devices, std::vector<airband_hip_channel_cfg>());
+    g_fm_demod_algo = fm_demod_algo;
     mixer_count = 0;
     do_exit = 0;
 #ifdef NFM
@@ -96,6 +106,9 @@ int refh_init(int n_devices, int fft_log, int fm_demod_algo, int global_tau_us) 
 
 int refh_add_device(int d, const airband_hip_device_cfg* cfg) {
     device_t* dev = devices + d;
+    g_ch_cfg[d].assign(cfg->channels, cfg->channels + cfg->channel_count);
+    g_dev_cfg[d] = *cfg;
+    g_dev_cfg[d].channels = g_ch_cfg[d].data();
     input_t* input = (input_t*)XCALLOC(1, sizeof(input_t));
     input->state = INPUT_RUNNING;
     input->sfmt = (sample_format_t)cfg->sfmt;
@@ -235,6 +248,126 @@ int refh_add_device(int d, const airband_hip_device_cfg* cfg) {
     return 0;
 }
 
+/* ---- the reference-side shim of INTEGRATION.md, for real: demodulate()'s replacement driving libairband_hip.so through
+ * its C ABI from the reference's own device_t / channel_t / input_t objects.  The library is dlopen()ed so that the oracle
+ * build never links against the product. ------------------------------------------------------------------------------ */
+struct HipApi {
+    void* dl;
+    int (*prepare)(const airband_hip_config*, airband_hip_handle**);
+    void (*release)(airband_hip_handle*);
+    int (*get_geometry)(const airband_hip_handle*, airband_hip_geometry*);
+    const char* (*last_error)(const airband_hip_handle*);
+    int64_t (*submit)(airband_hip_handle*, int32_t, const void*, size_t);
+    int (*process)(airband_hip_handle*);
+    int (*collect)(airband_hip_handle*, float*, float*, char*, airband_hip_channel_stats*);
+};
+static HipApi g_hip;
+static std::vector<airband_hip_channel_stats> g_hip_stats; /* last batch's statistics mirror, device-major */
+
+static void* demodulate_hip(void* params) {
+    demod_params_t* dp = (demod_params_t*)params;
+    const int n = dp->device_end - dp->device_start;
+    airband_hip_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.abi_version = AIRBAND_HIP_ABI_VERSION;
+    cfg.fft_size_log = (int32_t)fft_size_log;
+    cfg.wave_rate = WAVE_RATE;
+    cfg.fm_demod = g_fm_demod_algo ? AIRBAND_FM_QUADRI_DEMOD : AIRBAND_FM_FAST_ATAN2;
+    cfg.hip_device = 0;
+    cfg.device_count = n;
+    cfg.devices = g_dev_cfg.data() + dp->device_start;
+    airband_hip_handle* h = NULL;
+    int rc = g_hip.prepare(&cfg, &h);
+    if (rc != 0) { /* same reaction as to gpu_fft_prepare() failures, src/rtl_airband.cpp:297-310 */
+        fprintf(stderr, "demodulate_hip: airband_hip_prepare failed (%d): %s\n", rc, g_hip.last_error(NULL));
+        do_exit = 1;
+        return NULL;
+    }
+    airband_hip_geometry g;
+    g_hip.get_geometry(h, &g);
+    std::vector<float> wave((size_t)g.total_channels * g.wave_batch), iq((size_t)g.total_channels * g.wave_batch * 2);
+    std::vector<char> axc(g.total_channels);
+    g_hip_stats.assign(g.total_channels, airband_hip_channel_stats());
+    while (!do_exit) {
+        /* hand over what the rx side appended (circbuffer_append); same cursor discipline as src/rtl_airband.cpp:370-375,:669 */
+        for (int i = 0; i < n; i++) {
+            input_t* in = devices[dp->device_start + i].input;
+            pthread_mutex_lock(&in->buffer_lock);
+            const size_t bufe = in->bufe;
+            pthread_mutex_unlock(&in->buffer_lock);
+            while (in->bufs != bufe) {
+                const size_t run = (bufe > in->bufs ? bufe : in->buf_size) - in->bufs;
+                const int64_t took = g_hip.submit(h, i, in->buffer + in->bufs, run);
+                if (took <= 0) break;
+                in->bufs = (in->bufs + (size_t)took) % in->buf_size;
+            }
+        }
+        bool busy = false;
+        for (int i = 0; i < n; i++) busy |= devices[dp->device_start + i].waveavail != 0;
+        if (busy) { /* the consumer has not drained the previous batch yet: do not overwrite it */
+            sched_yield();
+            continue;
+        }
+        rc = g_hip.process(h);
+        if (rc == AIRBAND_HIP_EAGAIN) {
+            SLEEP(1);
+            continue;
+        }
+        if (rc < 0) {
+            fprintf(stderr, "demodulate_hip: %s\n", g_hip.last_error(h));
+            do_exit = 1;
+            break;
+        }
+        g_hip.collect(h, wave.data(), iq.data(), axc.data(), g_hip_stats.data());
+        size_t k = 0;
+        for (int i = 0; i < n; i++) { /* publish what the per-channel loop publishes (src/rtl_airband.cpp:549-619,:645-655) */
+            device_t* dev = devices + dp->device_start + i;
+            for (int j = 0; j < dev->channel_count; j++, k++) {
+                channel_t* c = dev->channels + j;
+                memcpy(c->waveout, &wave[k * g.wave_batch], sizeof(float) * g.wave_batch);
+                if (c->has_iq_outputs) memcpy(c->iq_out, &iq[k * g.wave_batch * 2], sizeof(float) * 2 * g.wave_batch);
+                c->axcindicate = (status)axc[k];
+                c->freqlist->active_counter = g_hip_stats[k].active_counter;
+            }
+            dev->waveavail = 1;
+        }
+        dp->mp3_signal->send();
+    }
+    g_hip.release(h);
+    return NULL;
+}
+
+/* statistics as the stats file would see them with the HIP backend (mirror of Squelch getters, src/output.cpp:617-761) */
+int refh_hip_channel_stats(int d, int j, airband_hip_channel_stats* out) {
+    size_t k = 0;
+    for (int i = 0; i < d; i++) k += devices[i].channel_count;
+    if (k + j >= g_hip_stats.size()) return -1;
+    *out = g_hip_stats[k + j];
+    return 0;
+}
+
+/* Starts ONE demodulate_hip thread over all devices (instead of demodulate()). */
+int refh_start_hip(const char* lib_path) {
+    g_hip.dl = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
+    if (!g_hip.dl) {
+        fprintf(stderr, "refh_start_hip: %s\n", dlerror());
+        return -1;
+    }
+#define REFH_SYM(field, name)                                   \
+    *(void**)(&g_hip.field) = dlsym(g_hip.dl, "airband_hip_" name); \
+    if (!g_hip.field) return -2;
+    REFH_SYM(prepare, "prepare") REFH_SYM(release, "release") REFH_SYM(get_geometry, "get_geometry") REFH_SYM(last_error, "last_error")
+    REFH_SYM(submit, "submit") REFH_SYM(process, "process") REFH_SYM(collect, "collect")
+#undef REFH_SYM
+    devices_running = device_count;
+    g_demod_params[0].mp3_signal = &g_signal;
+    g_demod_params[0].device_start = 0;
+    g_demod_params[0].device_end = device_count;
+    if (pthread_create(&g_demod_thread[0], NULL, &demodulate_hip, &g_demod_params[0]) != 0) return -1;
+    g_threads_running = 1;
+    return 0;
+}
+
 /* n_threads demodulate() instances over contiguous device shards: the reference's own
  * multiple_demod_threads model (src/rtl_airband.cpp:1052-1086,1110-1112), 1 = its default. */
 int refh_start(int n_threads) {
@@ -316,6 +449,49 @@ int refh_run_device(int d, const unsigned char* iq, size_t nbytes, int max_batch
     }
     g_hops_fed_bytes[d] += off;
     return nb;
+}
+
+/* Streams nbytes of I/Q into EVERY device concurrently (round-robin, like independent rx threads) and collects batches until each
+ * device produced n_batches (or `timeout_s` passes).  Works with demodulate() and with demodulate_hip().
+ * waveout [device][n_batches][C][WAVE_BATCH] with C = the (common) channel count, etc.  Returns the minimum batch count reached. */
+int refh_run_all(const unsigned char* const* iq, size_t nbytes, int n_batches, float* waveout, float* iq_out, char* axc, double timeout_s) {
+    std::vector<size_t> off(device_count, 0);
+    std::vector<int> nb(device_count, 0);
+    struct timeval t0, t1;
+    gettimeofday(&t0, NULL);
+    const int C = devices[0].channel_count;
+    for (;;) {
+        bool done = true;
+        for (int d = 0; d < device_count; d++) {
+            device_t* dev = devices + d;
+            input_t* in = dev->input;
+            if (dev->waveavail && nb[d] < n_batches) {
+                const size_t o = ((size_t)d * n_batches + nb[d]) * C;
+                refh_drain(d, waveout ? waveout + o * WAVE_BATCH : NULL, iq_out ? iq_out + o * 2 * WAVE_BATCH : NULL, axc ? axc + o : NULL);
+                nb[d]++;
+            }
+            /* Never queue more than the batch that is about to be drained needs: the reference's hand-off (waveavail flag, tail
+             * copy by the consumer, src/output.cpp:917-922) is racy by design when the demod thread can run a whole batch ahead of
+             * the output thread, and a deterministic harness must not depend on who wins. */
+            const size_t cap = ((size_t)(nb[d] + 1) * WAVE_BATCH + AGC_EXTRA + 1) * refh_bps(in) + fft_size * in->bytes_per_sample * 2;
+            if (off[d] < nbytes && off[d] < cap) {
+                const size_t room = in->buf_size - 1 - refh_available(in);
+                const size_t n = std::min(std::min(nbytes, cap) - off[d], std::min(room, refh_bps(in) * (size_t)WAVE_BATCH / 4));
+                if (n > 0) {
+                    circbuffer_append(in, const_cast<unsigned char*>(iq[d]) + off[d], n);
+                    off[d] += n;
+                }
+            }
+            if (nb[d] < n_batches) done = false;
+        }
+        if (done) break;
+        gettimeofday(&t1, NULL);
+        if ((t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec) > timeout_s) break;
+        sched_yield();
+    }
+    int mn = n_batches;
+    for (int d = 0; d < device_count; d++) mn = std::min(mn, nb[d]);
+    return mn;
 }
 
 /* stats mirror: what src/output.cpp:617-761 and the TUI read */
