@@ -31,7 +31,10 @@ namespace airband {
 
 namespace {
 
-constexpr int CHUNK = 20; /* divides WAVE_BATCH = 1000 and 2000; 64 lanes x 16 B x CHUNK = 20 KiB of LDS per wave */
+#ifndef AB_DEMOD_CHUNK
+#define AB_DEMOD_CHUNK 8
+#endif
+constexpr int CHUNK = AB_DEMOD_CHUNK; /* multiple of 4 dividing WAVE_BATCH = 1000 and 2000; 64 lanes x 16 B x CHUNK of LDS per wave */
 
 /* per-sample flag word parked in LDS between the phases */
 constexpr unsigned FL_AUDIO = 1u;   /* Squelch::should_process_audio()                        */
