@@ -481,8 +481,11 @@ constexpr int TONE_GROUP = 50; /* samples per tone-kernel step; divides WAVE_BAT
  * the AM kernel does not pay for the lowpass registers.  Slot blocks of one kind are contiguous.
  * CTCSS-capable kinds are split in three: this "front" (squelch + discriminator -> audio, flags), the tone kernel
  * (Goertzel banks, one wavefront per channel) and the back kernel (gate, notch, output). */
+#ifndef AB_DEMOD_WAVES
+#define AB_DEMOD_WAVES 4
+#endif
 template <int KIND, bool WAVE_HAS_CTCSS>
-__global__ __launch_bounds__(64) void demod_kernel(DemodArgs a, int first_block) {
+__global__ __launch_bounds__(64, AB_DEMOD_WAVES) void demod_kernel(DemodArgs a, int first_block) {
     extern __shared__ __attribute__((aligned(16))) float lds_demod[];
     const int slot = (first_block + blockIdx.x) * 64 + threadIdx.x; /* padding slots carry flags == 0 */
     const ChanConst cc = a.cc[slot];
@@ -680,46 +683,68 @@ namespace {
  * (reference: src/output.cpp:460,521,535 read channel->waveout[0..WAVE_BATCH) / iq_out; :920 tail copy is implicit
  * in the ring rotation).  64 slots x 64 samples per block, transposed through LDS so both sides are coalesced. */
 __global__ __launch_bounds__(256) void emit_kernel(EmitArgs a) {
-    __shared__ float tile[64][65];
-    const int slot0 = blockIdx.x * 64, t0 = blockIdx.y * 64;
+    __shared__ float tile[2][64][65];
+    const int slot0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int R = a.ring_rows;
-    for (int r = ty; r < 64; r += 4) {
-        const int t = t0 + r;
-        float v = 0.0f;
-        if (t < a.wave_batch && slot0 + tx < a.n_slots) {
-            int pr = a.row0 + t;
-            if (pr >= R) pr -= R;
-            v = a.wave[((long)blockIdx.x * R + pr) * AB_SLOT_BLOCK + tx];
+    const int R = a.ring_rows, B = a.wave_batch;
+    const int n_tiles = (B + 63) / 64;
+    /* blockIdx.y splits the batch's time tiles; every block walks its share with the next tile's loads in flight */
+    const int per = (n_tiles + gridDim.y - 1) / gridDim.y;
+    const int tile_begin = blockIdx.y * per, tile_end = min(n_tiles, tile_begin + per);
+    const int ext_w = a.slot_to_ext[min(slot0 + ty, a.n_slots - 1)]; /* dummy read keeps the table warm */
+    (void)ext_w;
+    float v[16];
+    auto load = [&](int tl) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int t = tl * 64 + ty + 4 * k;
+            float x = 0.0f;
+            if (t < B) {
+                int pr = a.row0 + t;
+                if (pr >= R) pr -= R;
+                x = a.wave[((long)blockIdx.x * R + pr) * AB_SLOT_BLOCK + tx];
+            }
+            v[k] = x;
         }
-        tile[r][tx] = v;
-    }
-    __syncthreads();
-    for (int r = ty; r < 64; r += 4) {
-        const int slot = slot0 + r, t = t0 + tx;
-        if (slot < a.n_slots && t < a.wave_batch) {
-            const int ext = a.slot_to_ext[slot];
-            if (ext >= 0) a.out_wave[(long)ext * a.wave_batch + t] = tile[tx][r];
+    };
+    if (tile_begin < tile_end) load(tile_begin);
+    int buf = 0;
+    for (int tl = tile_begin; tl < tile_end; tl++) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) tile[buf][ty + 4 * k][tx] = v[k];
+        __syncthreads();
+        if (tl + 1 < tile_end) load(tl + 1);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int r = ty + 4 * k;
+            const int slot = slot0 + r, t = tl * 64 + tx;
+            if (slot < a.n_slots && t < B) {
+                const int ext = a.slot_to_ext[slot];
+                if (ext >= 0) a.out_wave[(long)ext * B + t] = tile[buf][tx][r];
+            }
         }
+        buf ^= 1; /* the other buffer is free: its readers passed the barrier above one iteration ago */
     }
     if (a.out_iq) {
-        for (int comp = 0; comp < 2; comp++) {
-            __syncthreads();
-            for (int r = ty; r < 64; r += 4) {
-                const int t = t0 + r;
-                float v = 0.0f;
-                if (t < a.wave_batch && slot0 + tx < a.n_slots) {
-                    const float2 q = a.iq_out[((long)blockIdx.x * a.wave_batch + t) * AB_SLOT_BLOCK + tx];
-                    v = comp ? q.y : q.x;
+        for (int tl = tile_begin; tl < tile_end; tl++) {
+            for (int comp = 0; comp < 2; comp++) {
+                __syncthreads();
+                for (int r = ty; r < 64; r += 4) {
+                    const int t = tl * 64 + r;
+                    float x = 0.0f;
+                    if (t < B && slot0 + tx < a.n_slots) {
+                        const float2 q = a.iq_out[((long)blockIdx.x * B + t) * AB_SLOT_BLOCK + tx];
+                        x = comp ? q.y : q.x;
+                    }
+                    tile[0][r][tx] = x;
                 }
-                tile[r][tx] = v;
-            }
-            __syncthreads();
-            for (int r = ty; r < 64; r += 4) {
-                const int slot = slot0 + r, t = t0 + tx;
-                if (slot < a.n_slots && t < a.wave_batch) {
-                    const int ext = a.slot_to_ext[slot];
-                    if (ext >= 0) a.out_iq[((long)ext * a.wave_batch + t) * 2 + comp] = tile[tx][r];
+                __syncthreads();
+                for (int r = ty; r < 64; r += 4) {
+                    const int slot = slot0 + r, t = tl * 64 + tx;
+                    if (slot < a.n_slots && t < B) {
+                        const int ext = a.slot_to_ext[slot];
+                        if (ext >= 0) a.out_iq[((long)ext * B + t) * 2 + comp] = tile[0][tx][r];
+                    }
                 }
             }
         }
@@ -734,8 +759,12 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitArgs a) {
 }
 
 void launch_emit(const EmitArgs& a, hipStream_t stream) {
-    dim3 grid((a.n_slots + 63) / 64, (a.wave_batch + 63) / 64);
-    hipLaunchKernelGGL(emit_kernel, grid, dim3(256), 0, stream, a);
+    const int blocks = (a.n_slots + 63) / 64;
+    const int n_tiles = (a.wave_batch + 63) / 64;
+    int ysplit = blocks >= 4096 ? 2 : (16384 / (blocks > 0 ? blocks : 1)); /* few slot blocks: split time instead, to fill the chip */
+    if (ysplit < 1) ysplit = 1;
+    if (ysplit > n_tiles) ysplit = n_tiles;
+    hipLaunchKernelGGL(emit_kernel, dim3(blocks, ysplit), dim3(256), 0, stream, a);
 }
 
 /* ---- stats mirror (reference getters: src/output.cpp:617-761) ---------------------------------------------- */
