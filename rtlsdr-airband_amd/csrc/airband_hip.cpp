@@ -495,6 +495,8 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
     const Plan& p = h->plan;
     const bool first = h->batches_done == 0;
     if (h->use_dft) {
+        if ((((uintptr_t)d_iq) | (uintptr_t)stride_bytes) & 15)
+            return fail(h, AIRBAND_HIP_EINVAL, "d_iq and stride_bytes must be multiples of 16 (the channelizer fetches 16 bytes per lane)");
         DftArgs a;
         a.iq = (const uint8_t*)d_iq;
         a.iq_stride = (long)stride_bytes;

@@ -108,3 +108,23 @@ def test_no_cpu_fallback(pkg, built):
     with pytest.raises(pkg.AirbandError) as e:
         pkg.AirbandHip(devices, wave_rate=8000)
     assert e.value.code == pkg.capi.ENODEV
+
+
+def test_null_and_misuse_do_not_crash(pkg, built):
+    """Every entry point checks its arguments (C callers get error codes, not segfaults)."""
+    L = pkg.load_library()
+    capi = pkg.capi
+    assert L.airband_hip_prepare(None, None) == capi.EINVAL
+    h = C.c_void_p()
+    assert L.airband_hip_prepare(None, C.byref(h)) == capi.EINVAL and not h.value
+    assert b"NULL" in L.airband_hip_last_error(None)
+    L.airband_hip_release(None)
+    for fn in ("airband_hip_process", "airband_hip_synchronize"):
+        assert getattr(L, fn)(None) == capi.EINVAL
+    assert L.airband_hip_get_geometry(None, None) == capi.EINVAL
+    assert L.airband_hip_submit(None, 0, None, 0) == capi.EINVAL
+    assert L.airband_hip_collect(None, None, None, None, None) == capi.EINVAL
+    assert L.airband_hip_process_device(None, None, 0, None) == capi.EINVAL
+    assert L.airband_hip_channelizer_name(None) == b"fft_wave64"
+    bad = capi.Config(capi.ABI_VERSION + 7, 0, 9, 8000, 0, 0, 0, None)
+    assert L.airband_hip_prepare(C.byref(bad), C.byref(h)) == capi.EINVAL
