@@ -57,6 +57,8 @@ extern "C" {
                                                src/squelch.cpp:593-633)                                 */
 #define AIRBAND_HIP_FLAG_KEEP_BINS 0x2u     /* keep stage-1 output (wavein/iq_in) readable after a batch */
 #define AIRBAND_HIP_FLAG_FORCE_FFT 0x4u     /* always use the full wavefront-FFT channelizer             */
+#define AIRBAND_HIP_FLAG_SERIAL_DEMOD 0x8u  /* run the per-kind demod kernels one after another instead   \
+                                               of side by side on forked streams (profiling aid)          */
 
 /* Per-channel configuration: the values a multichannel-mode `channels` entry carries after
  * parse_channels() (reference: src/config.cpp:306-726).  The library derives bin index, derotation

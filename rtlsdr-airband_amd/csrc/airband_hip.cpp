@@ -47,6 +47,8 @@ struct airband_hip_handle {
     int hip_device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side[3] = {nullptr, nullptr, nullptr}; /* fused demod kinds run beside the CTCSS chain */
+    hipEvent_t fork_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timings_valid = false;
     std::string error;
 
@@ -149,6 +151,10 @@ void destroy(airband_hip_handle* h) {
     h->d_sin_tab.release(); h->d_carriers.release();
     for (auto& e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : h->fork_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& st : h->side)
+        if (st) (void)hipStreamDestroy(st);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -183,7 +189,7 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.wave_batch = h->B;
     da.row0 = h->row0;
     da.ring_rows = h->R;
-    launch_demod(da, h->kind_first_block, h->kind_n_blocks, s);
+    launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
     if (h->any_afc && h->afc_spectrum_valid) launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, s); /* afc.finalize(), src/rtl_airband.cpp:626-630 */
     (void)hipEventRecord(h->ev[2], s);
 
@@ -286,6 +292,8 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     PREP_TRY(hipSetDevice(cfg->hip_device), AIRBAND_HIP_ENODEV);
     PREP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), AIRBAND_HIP_ENODEV);
     for (auto& e : h->ev) PREP_TRY(hipEventCreate(&e), AIRBAND_HIP_ENODEV);
+    for (auto& e : h->fork_ev) PREP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
+    for (auto& st : h->side) PREP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), AIRBAND_HIP_ENODEV);
 
     h->B = p.wave_batch;
     h->R = (p.wave_batch + AB_AGC_EXTRA + AB_TILE_ROWS - 1) / AB_TILE_ROWS * AB_TILE_ROWS; /* ring rows: whole 16-row tiles */

@@ -657,22 +657,45 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
     sp->nx[0] = o.nx0; sp->nx[1] = o.nx1; sp->nx[2] = o.nx2; sp->ny[0] = o.ny0; sp->ny[1] = o.ny1; sp->ny[2] = o.ny2;
 }
 
-void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream) {
-    for (int k = 0; k < AB_KIND_COUNT; k++) {
+/* The kinds are independent of each other (different channels), and none of their kernels fills the chip on its own: a
+ * lane-per-channel kernel holds at most 4 waves per SIMD and the NFM kinds have only half that many wavefronts at BASELINE
+ * config #3.  So the split chain (front -> tone -> back, the longest) goes on the caller's stream and the fused kinds run
+ * beside it on side streams, forked and joined with events (works the same under graph capture). */
+void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev) {
+    auto launch_kind = [&](int k, hipStream_t s) {
         const size_t lds = (size_t)CHUNK * 64 * sizeof(float) * (k == AB_KIND_AM ? 2 : 4) + 64 * sizeof(float);
         const int n = kind_n_blocks[k], f = kind_first_block[k];
-        if (n <= 0) continue;
+        if (n <= 0) return;
         switch (k) {
-            case AB_KIND_AM: hipLaunchKernelGGL((demod_kernel<AB_KIND_AM, false>), dim3(n), dim3(64), lds, stream, a, f); break;
-            case AB_KIND_NFM: hipLaunchKernelGGL((demod_kernel<AB_KIND_NFM, false>), dim3(n), dim3(64), lds, stream, a, f); break;
-            case AB_KIND_NFM_LOWPASS: hipLaunchKernelGGL((demod_kernel<AB_KIND_NFM_LOWPASS, false>), dim3(n), dim3(64), lds, stream, a, f); break;
-            case AB_KIND_NFM_CTCSS: hipLaunchKernelGGL((demod_kernel<AB_KIND_NFM_CTCSS, true>), dim3(n), dim3(64), lds, stream, a, f); break;
-            default: hipLaunchKernelGGL((demod_kernel<AB_KIND_GENERIC, true>), dim3(n), dim3(64), lds, stream, a, f); break;
+            case AB_KIND_AM: hipLaunchKernelGGL((demod_kernel<AB_KIND_AM, false>), dim3(n), dim3(64), lds, s, a, f); break;
+            case AB_KIND_NFM: hipLaunchKernelGGL((demod_kernel<AB_KIND_NFM, false>), dim3(n), dim3(64), lds, s, a, f); break;
+            case AB_KIND_NFM_LOWPASS: hipLaunchKernelGGL((demod_kernel<AB_KIND_NFM_LOWPASS, false>), dim3(n), dim3(64), lds, s, a, f); break;
+            case AB_KIND_NFM_CTCSS: hipLaunchKernelGGL((demod_kernel<AB_KIND_NFM_CTCSS, true>), dim3(n), dim3(64), lds, s, a, f); break;
+            default: hipLaunchKernelGGL((demod_kernel<AB_KIND_GENERIC, true>), dim3(n), dim3(64), lds, s, a, f); break;
+        }
+    };
+    const bool fork = side != nullptr && ev != nullptr;
+    const int fused[3] = {AB_KIND_NFM_LOWPASS, AB_KIND_AM, AB_KIND_NFM};
+    if (fork) {
+        (void)hipEventRecord(ev[0], stream); /* stage 1 is done at this point of the caller's stream */
+        for (int i = 0; i < 3; i++) {
+            if (kind_n_blocks[fused[i]] <= 0) continue;
+            (void)hipStreamWaitEvent(side[i], ev[0], 0);
+            launch_kind(fused[i], side[i]);
+            (void)hipEventRecord(ev[1 + i], side[i]);
         }
     }
+    launch_kind(AB_KIND_NFM_CTCSS, stream);
+    launch_kind(AB_KIND_GENERIC, stream);
     if (a.ct_n_blocks > 0) {
         hipLaunchKernelGGL(tone_kernel, dim3((a.ct_n_blocks * 64 * 64 + 255) / 256), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(back_kernel, dim3(a.ct_n_blocks), dim3(64), 0, stream, a);
+    }
+    if (fork) {
+        for (int i = 0; i < 3; i++)
+            if (kind_n_blocks[fused[i]] > 0) (void)hipStreamWaitEvent(stream, ev[1 + i], 0);
+    } else {
+        for (int i = 0; i < 3; i++) launch_kind(fused[i], stream);
     }
 }
 
