@@ -122,7 +122,8 @@ def main():
 
     chans, carriers = pkg.siggen.baseline_plan(mixed=mixed)
     devices = [dict(channels=chans) for _ in range(D)]
-    hip = pkg.AirbandHip(devices, wave_rate=wave_rate, hip_device=local_rank)
+    # AIRBAND_BENCH_FLAGS: AIRBAND_HIP_FLAG_* bits for experiments (e.g. 8 = demod kinds one after the other, for per-kernel profiles)
+    hip = pkg.AirbandHip(devices, wave_rate=wave_rate, hip_device=local_rank, flags=int(os.environ.get("AIRBAND_BENCH_FLAGS", "0"), 0))
     g = hip.geometry
     if n_mixers:
         base = rank * D

@@ -1011,6 +1011,19 @@ void orc_squelch_raw(void* p, const float* x, int n, unsigned char* flags, float
     }
 }
 
+/* raw + filtered path in the order of the demod loop (src/rtl_airband.cpp:507,510,526): process_raw_sample, then, when
+ * should_filter_sample(), process_filtered_sample of the lowpass-filtered magnitude */
+void orc_squelch_raw_filtered(void* p, const float* raw, const float* filtered, int n, unsigned char* flags, float* noise, float* level) {
+    squelch_t* s = (squelch_t*)p;
+    for (int i = 0; i < n; i++) {
+        sq_raw(s, raw[i]);
+        if (sq_should_filter(s)) sq_filtered(s, filtered[i]);
+        if (flags) flags[i] = sq_flags(s);
+        if (noise) noise[i] = s->noise_floor;
+        if (level) level[i] = sq_level(s);
+    }
+}
+
 void orc_squelch_raw_audio(void* p, const float* raw, const float* audio, int n, unsigned char* flags) {
     squelch_t* s = (squelch_t*)p;
     for (int i = 0; i < n; i++) {

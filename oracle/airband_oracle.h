@@ -49,6 +49,7 @@ void orc_lowpass_run(float freq, float rate, float* re, float* im, int n); /* sr
 void orc_ctcss_run(float ctcss_freq, float sample_rate, int window, const float* x, int n, unsigned char* has_tone, uint64_t* counts2);
 void* orc_squelch_new(float snr_db, int manual_dbfs, float ctcss_freq, int wave_rate, int fft_size);
 void orc_squelch_raw(void* s, const float* x, int n, unsigned char* flags, float* noise, float* level);
+void orc_squelch_raw_filtered(void* s, const float* raw, const float* filtered, int n, unsigned char* flags, float* noise, float* level);
 void orc_squelch_raw_audio(void* s, const float* raw, const float* audio, int n, unsigned char* flags);
 void orc_squelch_audio_raw(void* s, const float* raw, const float* audio, int n, unsigned char* flags);
 void orc_squelch_counts(void* s, uint64_t* out4);

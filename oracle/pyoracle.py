@@ -47,6 +47,7 @@ def lib() -> C.CDLL:
         L.orc_squelch_new.restype = C.c_void_p
         L.orc_squelch_new.argtypes = [C.c_float, C.c_int, C.c_float, C.c_int, C.c_int]
         L.orc_squelch_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_squelch_raw_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_squelch_raw_audio.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_squelch_audio_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_squelch_counts.argtypes = [C.c_void_p, C.c_void_p]

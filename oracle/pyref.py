@@ -44,6 +44,7 @@ def load_units(nfm: bool) -> C.CDLL:
     lib.refh_squelch_new.restype = vp
     lib.refh_squelch_new.argtypes = [f32, i, f32]
     lib.refh_squelch_raw.argtypes = [vp, vp, i, vp, vp, vp]
+    lib.refh_squelch_raw_filtered.argtypes = [vp, vp, vp, i, vp, vp, vp]
     lib.refh_squelch_raw_audio.argtypes = [vp, vp, vp, i, vp]
     lib.refh_squelch_audio_raw.argtypes = [vp, vp, vp, i, vp]
     lib.refh_squelch_counts.argtypes = [vp, vp]

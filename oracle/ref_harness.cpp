@@ -547,6 +547,18 @@ void refh_squelch_raw(void* p, const float* x, int n, unsigned char* is_open, fl
         if (level) level[i] = s->squelch_level();
     }
 }
+/* raw + filtered path in the order demodulate() calls them (src/rtl_airband.cpp:507,510,526) */
+void refh_squelch_raw_filtered(void* p, const float* raw, const float* filtered, int n, unsigned char* is_open, float* noise, float* level) {
+    Squelch* s = (Squelch*)p;
+    for (int i = 0; i < n; i++) {
+        s->process_raw_sample(raw[i]);
+        if (s->should_filter_sample()) s->process_filtered_sample(filtered[i]);
+        if (is_open) is_open[i] = (unsigned char)((s->is_open() ? 1 : 0) | (s->should_process_audio() ? 2 : 0) | (s->should_filter_sample() ? 4 : 0) |
+                                                  (s->first_open_sample() ? 8 : 0) | (s->last_open_sample() ? 16 : 0));
+        if (noise) noise[i] = s->noise_level();
+        if (level) level[i] = s->squelch_level();
+    }
+}
 /* raw + audio path as the ctcss squelch tests do (src/test_squelch.cpp:167-281) */
 void refh_squelch_raw_audio(void* p, const float* raw, const float* audio, int n, unsigned char* is_open) {
     Squelch* s = (Squelch*)p;

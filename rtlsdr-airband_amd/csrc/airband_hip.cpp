@@ -189,10 +189,6 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.wave_batch = h->B;
     da.row0 = h->row0;
     da.ring_rows = h->R;
-    launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
-    if (h->any_afc && h->afc_spectrum_valid) launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, s); /* afc.finalize(), src/rtl_airband.cpp:626-630 */
-    (void)hipEventRecord(h->ev[2], s);
-
     EmitArgs ea;
     ea.wave = h->d_wave.p;
     ea.iq_out = h->d_iq_out.p;
@@ -205,7 +201,14 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     ea.wave_batch = h->B;
     ea.row0 = h->row0;
     ea.ring_rows = h->R;
-    launch_emit(ea, s);
+    /* The emit transposes are HBM-bound, the demod kernels are not: each kind's slots are emitted on that kind's stream, under the
+     * other kinds' demod work.  AFC rewrites axcindicate after ALL of stage 2 (afc.finalize(), src/rtl_airband.cpp:626-630), so
+     * with AFC channels the emit stays behind it. */
+    const bool emit_per_kind = !(h->any_afc && h->afc_spectrum_valid);
+    launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev, emit_per_kind ? &ea : nullptr);
+    if (!emit_per_kind) launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, s);
+    (void)hipEventRecord(h->ev[2], s);
+    if (!emit_per_kind) launch_emit(ea, s);
     if (h->n_mixers > 0) {
         MixArgs ma;
         ma.out_wave = h->d_out_wave.p;

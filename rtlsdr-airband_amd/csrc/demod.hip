@@ -26,6 +26,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "squelch_fsm.h"
 
 namespace airband {
 
@@ -41,150 +42,6 @@ constexpr unsigned FL_AUDIO = 1u;   /* Squelch::should_process_audio()          
 constexpr unsigned FL_FADE = 2u;    /* AM last_open_sample(): fade out the previous AGC_EXTRA */
 constexpr unsigned FL_RESET = 4u;   /* squelch went CLOSED on this sample: CTCSS::reset()      */
 constexpr int FL_STATE_SHIFT = 3;   /* bits 3..5: Squelch::State, for the trace                */
-
-struct SqRegs { /* Squelch members that change per sample (src/squelch.h:117-158) */
-    float noise_floor, cap, pre_full, pre_capped, post_full, post_capped;
-    int using_post, next, cur, delay, low_count, head, tail;
-    unsigned sample_count, open_count, flappy_count, recent_open, closed_count;
-    float dly; /* buffer_[buffer_tail_] for the current tail, when the kind prefetches the delay line (else unused) */
-};
-
-struct Lane { /* per-lane constants */
-    unsigned flags;
-    bool prefetched_delay; /* SqRegs::dly is maintained by the caller instead of reading sqbuf from memory */
-    float manual_level, normal_ratio, flappy_ratio;
-    float* sqbuf; /* this lane's column of the 102-deep pre-filter delay line, stride S */
-    long S;
-};
-
-__device__ __forceinline__ bool sq_flapping(const SqRegs& s) { return s.recent_open >= 3u; } /* flap_opens_threshold_ */
-
-/* Squelch::squelch_level() (src/squelch.cpp:164-177).  The reference caches the product and invalidates the cache
- * whenever one of its inputs (noise_floor_, recent_open_count_) changes (:389,:451,:489), so recomputing it on every
- * use yields the same float; two VALU ops are cheaper than a divergent cache-hit branch. */
-__device__ __forceinline__ float sq_level(const SqRegs& s, const Lane& L) {
-    const float ratio = (sq_flapping(s) && L.flappy_ratio < L.normal_ratio) ? L.flappy_ratio : L.normal_ratio;
-    const float lvl = ratio * s.noise_floor;
-    return (L.flags & AB_F_MANUAL) ? L.manual_level : lvl;
-}
-
-__device__ __forceinline__ bool sq_has_pre(const SqRegs& s, const Lane& L) { return s.pre_capped >= sq_level(s, L); }
-
-__device__ __forceinline__ bool sq_has_signal(const SqRegs& s, const Lane& L) { /* src/squelch.cpp:462-475 */
-    bool sig = sq_has_pre(s, L);
-    if (L.flags & AB_F_LOWPASS) { /* using_post_filter_ can only ever be set on channels with a lowpass filter */
-        if (s.using_post) sig = sig && (s.post_capped >= (L.prefetched_delay ? s.dly : L.sqbuf[(long)s.tail * L.S]));
-    }
-    return sig;
-}
-
-/* Squelch::set_state (src/squelch.cpp:297-361) as a select chain: clamp transitions that are not allowed from `cur` */
-__device__ __forceinline__ int sq_clamp(int cur, int want) {
-    const int from_closed = (want == AB_ST_CLOSING || want == AB_ST_ABORT) ? AB_ST_CLOSED : (want == AB_ST_OPEN ? AB_ST_OPENING : want);
-    const int from_opening = want == AB_ST_ABORT ? AB_ST_CLOSED : want;
-    const int from_abort = (want != AB_ST_ABORT && want != AB_ST_CLOSED) ? AB_ST_CLOSED : want;
-    const int from_open = want == AB_ST_CLOSED ? AB_ST_CLOSING : (want == AB_ST_OPENING ? AB_ST_OPEN : want);
-    return cur == AB_ST_CLOSED ? from_closed : cur == AB_ST_OPENING ? from_opening : cur == AB_ST_ABORT ? from_abort : cur == AB_ST_OPEN ? from_open : want;
-}
-__device__ __forceinline__ void sq_request(SqRegs& s, int want) { s.next = sq_clamp(s.cur, want); }
-
-/* Squelch::update_current_state (src/squelch.cpp:363-460), written without branches: the five-way state machine
- * diverges on every lane, so selects (a few dozen VALU ops, always) beat exec-masked branches.  Returns true when the
- * squelch just went CLOSED (the reference resets both CTCSS detectors at that point, :440-441). */
-__device__ __forceinline__ bool sq_advance(SqRegs& s, const Lane& L) {
-    const int n = s.next, c = s.cur;
-    const bool entering = n != c;
-    const bool timed = n == AB_ST_OPENING || n == AB_ST_CLOSING || n == AB_ST_ABORT;
-    const bool staying = timed && !entering;
-    /* delay_: zeroed on entry (ABORT entered from CLOSING keeps CLOSING's running delay), counted while staying */
-    const bool zero_delay = entering && timed && !(n == AB_ST_ABORT && c == AB_ST_CLOSING);
-    const int delay = zero_delay ? 0 : (staying ? s.delay + 1 : s.delay);
-    const bool expired = staying && delay >= 197; /* open_delay_ == close_delay_ == 197 */
-    /* OPENING delay over: count a recent open for flap detection before looking at the signal (:381-392) */
-    const bool bump = expired && n == AB_ST_OPENING && s.closed_count < 1000u;
-    s.recent_open += bump ? 1u : 0u;
-    s.flappy_count += (bump && sq_flapping(s)) ? 1u : 0u;
-    s.delay = delay;
-    const bool sig = sq_has_signal(s, L);
-    int new_cur = entering ? n : c;
-    int new_next = n;
-    if (expired) {
-        if (n == AB_ST_OPENING) new_next = sig ? AB_ST_OPEN : AB_ST_CLOSED;
-        else if (n == AB_ST_CLOSING) {
-            new_next = sig ? AB_ST_OPEN : AB_ST_CLOSED;
-            new_cur = sig ? AB_ST_OPEN : c; /* signal came back: straight to OPEN without counting an open */
-        } else new_next = AB_ST_CLOSED;
-    }
-    s.low_count = (entering && n == AB_ST_OPENING) ? 0 : s.low_count;
-    s.using_post = (entering && (n == AB_ST_OPENING || n == AB_ST_CLOSED)) ? 0 : s.using_post;
-    s.open_count += (entering && n == AB_ST_OPEN) ? 1u : 0u;
-    const bool went_closed = entering && n == AB_ST_CLOSED;
-    const bool idle_closed = n == AB_ST_CLOSED && !entering;
-    s.recent_open = (idle_closed && s.closed_count == 1000u) ? 0u : s.recent_open;
-    s.closed_count = went_closed ? 0u : ((idle_closed && s.closed_count < 1000u) ? s.closed_count + 1u : s.closed_count);
-    s.cur = new_cur;
-    s.next = new_next;
-    s.tail = s.tail + 1 == AB_SQ_BUF ? 0 : s.tail + 1;
-    s.head = s.head + 1 == AB_SQ_BUF ? 0 : s.head + 1;
-    return went_closed;
-}
-
-/* Squelch::update_moving_avg (src/squelch.cpp:501-514) */
-__device__ __forceinline__ void sq_avg(float cap, float& full, float& capped, float x) {
-    const float decay = 0.99f;
-    const float fresh = (float)(1.0 - (double)0.99f);
-    full = full * decay + x * fresh;
-    const float v = capped * decay + x * fresh;
-    const float vm = cap < v ? cap : v;
-    capped = (capped >= cap && x >= cap) ? cap : vm; /* the reference short-circuits this case; the value is `cap` either way it is written */
-}
-
-/* Squelch::process_raw_sample (src/squelch.cpp:195-246) */
-__device__ __forceinline__ bool sq_raw(SqRegs& s, const Lane& L, float x, float dly_new) {
-    const bool went_closed = sq_advance(s, L); /* evaluates the post-filter gate against buffer_[tail] BEFORE the tail moves */
-    s.dly = dly_new;                           /* ... everything after it sees the entry under the advanced tail */
-    s.sample_count++;
-    if ((s.sample_count & 15u) == 0u) { /* calculate_noise_floor, :477-490; every lane of a wave is on the same sample count */
-        const float decay = 0.97f;
-        const float fresh = (float)(1.0 - (double)0.97f);
-        const float lo = s.pre_capped < s.noise_floor ? s.pre_capped : s.noise_floor;
-        s.noise_floor = s.noise_floor * decay + lo * fresh + 1e-6f;
-        s.cap = (L.flags & AB_F_MANUAL) ? 1.5f * L.manual_level : 1.5f * L.normal_ratio * s.noise_floor;
-    }
-    sq_avg(s.cap, s.pre_full, s.pre_capped, x);
-    if (L.flags & AB_F_LOWPASS) L.sqbuf[(long)s.head * L.S] = s.pre_capped * 0.9f; /* only ever read on the post-filter path */
-    const bool sig = sq_has_signal(s, L);
-    int next = s.next;
-    next = (s.cur == AB_ST_OPEN && !sig) ? sq_clamp(s.cur, AB_ST_CLOSING) : next;
-    next = (s.cur == AB_ST_CLOSED && sig) ? sq_clamp(s.cur, AB_ST_OPENING) : next;
-    const bool counting = s.cur != AB_ST_CLOSED && s.cur != AB_ST_ABORT; /* low-signal abort (:233-245) */
-    const bool low = !(x >= sq_level(s, L));
-    const int low_count = counting ? (low ? s.low_count + 1 : 0) : s.low_count;
-    next = (counting && low && low_count >= 88) ? sq_clamp(s.cur, AB_ST_ABORT) : next;
-    s.low_count = low_count;
-    s.next = next;
-    return went_closed;
-}
-
-__device__ __forceinline__ bool sq_should_filter(SqRegs& s, const Lane& L) { return (sq_has_pre(s, L) || s.cur != AB_ST_CLOSED) && s.cur != AB_ST_ABORT; }
-__device__ __forceinline__ bool sq_should_audio(const SqRegs& s) { return s.cur == AB_ST_OPEN || s.cur == AB_ST_CLOSING; }
-__device__ __forceinline__ bool sq_first_open(const SqRegs& s) { return s.cur != AB_ST_OPEN && s.next == AB_ST_OPEN; }
-__device__ __forceinline__ bool sq_last_open(const SqRegs& s) {
-    return (s.cur == AB_ST_CLOSING && s.next == AB_ST_CLOSED) || (s.cur != AB_ST_ABORT && s.next == AB_ST_ABORT);
-}
-
-/* Squelch::process_filtered_sample (src/squelch.cpp:248-276) */
-__device__ __forceinline__ void sq_filtered(SqRegs& s, const Lane& L, float x) {
-    if (!sq_should_filter(s, L)) return;
-    const float delayed = L.prefetched_delay ? s.dly : L.sqbuf[(long)s.tail * L.S];
-    if (s.cur == AB_ST_OPENING) {
-        if (s.delay < AB_SQ_BUF) return;
-        if (s.delay == AB_SQ_BUF) s.post_full = s.post_capped = delayed;
-    }
-    s.using_post = 1;
-    sq_avg(s.cap, s.post_full, s.post_capped, x);
-    if (s.post_capped < delayed) sq_request(s, AB_ST_CLOSED);
-}
 
 /* fast_atan2 / polar_disc_fast / fm_quadri_demod (src/rtl_airband.cpp:141-176) */
 __device__ __forceinline__ float fast_atan2_dev(float y, float x) {
@@ -262,8 +119,12 @@ struct LdsSlots {
 };
 
 template <int KIND, bool WAVE_HAS_CTCSS>
-__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, float* lds, float* lds_scratch) {
+__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, float* lds, const float2* lut) {
     constexpr int NS = LdsSlots<KIND>::value;
+#ifndef AB_DEMOD_UNROLL
+#define AB_DEMOD_UNROLL 2
+#endif
+    constexpr int UNROLL = KIND == AB_KIND_AM ? CHUNK : AB_DEMOD_UNROLL; /* per-sample loop: how many samples share one loop body */
     const int lane = threadIdx.x & 63;
     constexpr long S = AB_SLOT_BLOCK;
     const int R = a.ring_rows, B = a.wave_batch;
@@ -271,24 +132,30 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     /* inside a specialised kind the modulation / filter feature bits are constants: the compiler drops the other paths */
     if (KIND != AB_KIND_GENERIC) cc.flags = (cc.flags & ~KIND_MASK) | KindBits<KIND>::value;
 
+    if (!valid) return; /* padding slots of the last block: lanes share nothing (no barriers, per-lane LDS columns) */
+
+    const bool nfm = cc.flags & AB_F_NFM, raw_iq = cc.flags & AB_F_RAW_IQ, lowpass = cc.flags & AB_F_LOWPASS;
+    /* feature bits as lane masks (compile-time all-or-nothing inside a specialised kind) */
+    const lmask m_am = ab_ballot(!nfm), m_raw_iq = ab_ballot(raw_iq);
+
     Lane L;
-    L.flags = cc.flags;
+    L.m_lowpass = ab_ballot(lowpass);
+    L.m_manual = ab_ballot((cc.flags & AB_F_MANUAL) != 0);
     L.manual_level = cc.sq_manual_level;
     L.normal_ratio = cc.sq_normal_ratio;
     L.flappy_ratio = cc.sq_flappy_ratio;
+    L.m_flappy_lower = ab_ballot(cc.sq_flappy_ratio < cc.sq_normal_ratio);
     L.sqbuf = a.sqbuf + ab_ring_base(slot, AB_SQ_BUF);
     L.S = S;
     /* NFM+lowpass kind: the 102-deep delay line is read 101 samples after it is written, so a chunk's reads can be
      * fetched up front with the other inputs (LDS slot .y, unused by NFM) instead of one dependent L2 round trip per sample */
     L.prefetched_delay = (KIND == AB_KIND_NFM_LOWPASS);
+    /* only channels with a lowpass filter ever touch the delay line: the other kinds move head/tail once per batch */
+    L.track_delay_line = (KIND == AB_KIND_NFM_LOWPASS || KIND == AB_KIND_GENERIC);
 
     SqRegs s;
-    s.noise_floor = sp->noise_floor; s.cap = sp->cap; s.pre_full = sp->pre_full; s.pre_capped = sp->pre_capped;
-    s.post_full = sp->post_full; s.post_capped = sp->post_capped;
-    s.using_post = sp->using_post; s.next = sp->next; s.cur = sp->cur; s.delay = sp->delay; s.low_count = sp->low_count;
-    s.head = sp->head; s.tail = sp->tail; s.sample_count = sp->sample_count; s.open_count = sp->open_count;
-    s.flappy_count = sp->flappy_count; s.recent_open = sp->recent_open; s.closed_count = sp->closed_count;
-    s.dly = (KIND == AB_KIND_NFM_LOWPASS && valid) ? L.sqbuf[(long)s.tail * S] : 0.0f;
+    sq_load(s, L, sp, true);
+    s.dly = (KIND == AB_KIND_NFM_LOWPASS) ? L.sqbuf[(long)s.tail * S] : 0.0f;
     float agc = sp->agcavgfast, pr = sp->pr, pj = sp->pj, prev_out = sp->prev_waveout;
     unsigned dm_phi = sp->dm_phi;
     OutRegs o;
@@ -297,7 +164,6 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     float lxr0 = sp->lxr[0], lxr1 = sp->lxr[1], lxr2 = sp->lxr[2], lxi0 = sp->lxi[0], lxi1 = sp->lxi[1], lxi2 = sp->lxi[2];
     float lyr0 = sp->lyr[0], lyr1 = sp->lyr[1], lyr2 = sp->lyr[2], lyi0 = sp->lyi[0], lyi1 = sp->lyi[1], lyi2 = sp->lyi[2];
 
-    const bool nfm = cc.flags & AB_F_NFM, raw_iq = cc.flags & AB_F_RAW_IQ, lowpass = cc.flags & AB_F_LOWPASS;
     const float one_minus_alpha = 1.0f - cc.alpha;
 
     float* mag = a.mag + ab_tile_base(slot, R / AB_TILE_ROWS);        /* tile-transposed rings: row r at ab_tile_off(r) */
@@ -313,7 +179,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         /* ---- phase 0: the chunk's stage-1 values, 16 bytes (4 rows) per load, parked in LDS -------------------------
          * row0, AGC_EXTRA, WAVE_BATCH and the chunk start are multiples of 4 and the ring length is a multiple of 16, so
          * a group of 4 rows is always 16-byte aligned inside one tile and never straddles the ring wrap */
-        if (valid) {
+        {
 #pragma unroll
             for (int g = 0; g < CHUNK / 4; g++) {
                 const int rc = ring_row(a.row0 + AB_AGC_EXTRA + j0 + 4 * g, R); /* current hops */
@@ -356,7 +222,8 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             }
         }
         /* ---- phase 1 (+3 when fused): the sequential per-sample loop ---------------------------------------------- */
-        if (valid) {
+        {
+#pragma unroll UNROLL
             for (int u = 0; u < CHUNK; u++) {
                 const int j = j0 + u;
                 float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -372,55 +239,59 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                  * samples are AGC_EXTRA = 100 > CHUNK steps old, so the value parked in phase 0 is always current */
                 const float delayed_mag = v.y;
 
-                const bool went_closed = sq_raw(s, L, cur_mag, delayed_mag /* = prefetched delay-line entry for the lowpass kind */);
+                const lmask went_closed = sq_raw(s, L, cur_mag, delayed_mag /* = prefetched delay-line entry for the lowpass kind */);
 
-                if (raw_iq && sq_should_filter(s, L)) { /* src/rtl_airband.cpp:510-530 */
-                    const unsigned idx = dm_phi >> 16; /* sincosf_lut (src/util.cpp:113-127) */
-                    const float fract = (float)(dm_phi & 0xffffu) / 65536.0f;
-                    const float s0 = a.sin_lut[idx], s1 = a.sin_lut[idx + 1], c0 = a.cos_lut[idx], c1 = a.cos_lut[idx + 1];
-                    const float swf = s0 + (s1 - s0) * fract;
-                    const float cwf = c0 + (c1 - c0) * fract;
-                    const float nswf = -swf;
-                    float tr = re * cwf - im * nswf; /* multiply(real, imag, cwf, -swf) */
-                    float ti = im * cwf + re * nswf;
-                    dm_phi = (dm_phi + cc.dm_dphi) & 0xffffffu;
-                    if (lowpass) { /* LowpassFilter::apply (src/filters.cpp:146-163) */
-                        lxr0 = lxr1; lxi0 = lxi1;
-                        lxr1 = lxr2; lxi1 = lxi2;
-                        lxr2 = tr / cc.lp_gain; lxi2 = ti / cc.lp_gain;
-                        lyr0 = lyr1; lyi0 = lyi1;
-                        lyr1 = lyr2; lyi1 = lyi2;
-                        lyr2 = (lxr0 + lxr2) + (2.0f * lxr1) + (cc.lp_yc0 * lyr0) + (cc.lp_yc1 * lyr1);
-                        lyi2 = (lxi0 + lxi2) + (2.0f * lxi1) + (cc.lp_yc0 * lyi0) + (cc.lp_yc1 * lyi1);
-                        tr = lyr2;
-                        ti = lyi2;
+                if (ab_any(m_raw_iq)) { /* src/rtl_airband.cpp:510-530 */
+                    const lmask filt = sq_should_filter(s) & m_raw_iq;
+                    if (ab_lane(filt)) { /* per-lane float work only: lane masks are not touched inside divergent code */
+                        const unsigned idx = dm_phi >> 16; /* sincosf_lut (src/util.cpp:113-127) */
+                        const float fract = (float)(dm_phi & 0xffffu) / 65536.0f;
+                        const float2 e0 = lut[idx], e1 = lut[idx + 1];
+                        const float s0 = e0.x, s1 = e1.x, c0 = e0.y, c1 = e1.y;
+                        const float swf = s0 + (s1 - s0) * fract;
+                        const float cwf = c0 + (c1 - c0) * fract;
+                        const float nswf = -swf;
+                        float tr = re * cwf - im * nswf; /* multiply(real, imag, cwf, -swf) */
+                        float ti = im * cwf + re * nswf;
+                        dm_phi = (dm_phi + cc.dm_dphi) & 0xffffffu;
+                        if (lowpass) { /* LowpassFilter::apply (src/filters.cpp:146-163) */
+                            lxr0 = lxr1; lxi0 = lxi1;
+                            lxr1 = lxr2; lxi1 = lxi2;
+                            lxr2 = tr / cc.lp_gain; lxi2 = ti / cc.lp_gain;
+                            lyr0 = lyr1; lyi0 = lyi1;
+                            lyr1 = lyr2; lyi1 = lyi2;
+                            lyr2 = (lxr0 + lxr2) + (2.0f * lxr1) + (cc.lp_yc0 * lyr0) + (cc.lp_yc1 * lyr1);
+                            lyi2 = (lxi0 + lxi2) + (2.0f * lxi1) + (cc.lp_yc0 * lyi0) + (cc.lp_yc1 * lyi1);
+                            tr = lyr2;
+                            ti = lyi2;
+                        }
+                        re = tr;
+                        im = ti;
+                        cur_mag = sqrtf(re * re + im * im); /* double sqrt rounded to float == correctly rounded sqrtf */
+                        /* the reference overwrites wavein[j] here (src/rtl_airband.cpp:524); only AM reads it back later */
+                        if (!nfm) mag[ab_tile_off(ring_row(a.row0 + AB_AGC_EXTRA + j, R))] = cur_mag;
                     }
-                    re = tr;
-                    im = ti;
-                    cur_mag = sqrtf(re * re + im * im); /* double sqrt rounded to float == correctly rounded sqrtf */
-                    /* the reference overwrites wavein[j] here (src/rtl_airband.cpp:524); only AM reads it back later */
-                    if (!nfm) mag[ab_tile_off(ring_row(a.row0 + AB_AGC_EXTRA + j, R))] = cur_mag;
-                    if (lowpass) sq_filtered(s, L, cur_mag);
+                    sq_filtered(s, L, filt, cur_mag); /* process_filtered_sample for the lanes with a lowpass filter */
                 }
 
-                bool fade = false;
-                if (!nfm) { /* src/rtl_airband.cpp:532-547 */
-                    if (sq_first_open(s)) {
-                        const float lvl = sq_level(s, L);
+                lmask fade_m = 0;
+                if (ab_any(m_am)) { /* src/rtl_airband.cpp:532-547 */
+                    if (ab_lane(sq_first_open(s) & m_am)) {
+                        const float lvl = sq_level(s);
                         for (int k = j; k < j + AB_AGC_EXTRA; k++) { /* the AGC_EXTRA magnitudes before the current one */
                             const float w = mag[ab_tile_off(ring_row(a.row0 + k, R))];
                             if (w >= lvl) agc = agc * 0.9f + w * 0.1f;
                         }
-                    } else if (sq_last_open(s)) {
-                        fade = true;
                     }
+                    fade_m = sq_last_open(s) & m_am;
                 }
+                const bool fade = ab_lane(fade_m);
 
                 float out = 0.0f;
-                const bool audio = sq_should_audio(s);
+                const bool audio = ab_lane(sq_should_audio(s));
                 if (audio) {
                     if (!nfm) { /* AM: src/rtl_airband.cpp:553-563 */
-                        if (cur_mag > sq_level(s, L)) agc = agc * 0.995f + cur_mag * 0.005f;
+                        if (cur_mag > sq_level(s)) agc = agc * 0.995f + cur_mag * 0.005f;
                         out = (delayed_mag - agc) / (agc * 1.5f);
                         if (fabsf(out) > 0.8f) {
                             out *= 0.85f;
@@ -446,17 +317,16 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                 if (WAVE_HAS_CTCSS) {
                     /* front half of a CTCSS-capable kind: hand (pre-notch audio, flags) to the tone and back kernels.  Raw I/Q of
                      * an open sample is written now; the back kernel zeroes it again if the tone gate turns out closed. */
-                    const unsigned f = (audio ? FL_AUDIO : 0u) | (fade ? FL_FADE : 0u) | (went_closed ? FL_RESET : 0u) | ((unsigned)s.cur << FL_STATE_SHIFT);
+                    const unsigned f = (audio ? FL_AUDIO : 0u) | (fade ? FL_FADE : 0u) | (ab_lane(went_closed) ? FL_RESET : 0u) | (a.trace ? (unsigned)sq_cur(s) << FL_STATE_SHIFT : 0u);
                     ct_af[(long)j * S] = make_float2(out, __uint_as_float(f));
                     if ((cc.flags & AB_F_IQ_OUT) && audio) iqout[(long)j * S] = make_float2(re, im);
                 } else {
-                    emit_sample(a, cc, o, wave, iqout, trace, j, audio, fade, true, s.cur, out, re, im, true);
+                    emit_sample(a, cc, o, wave, iqout, trace, j, audio, fade, true, trace ? sq_cur(s) : 0, out, re, im, true);
                 }
             }
         }
     }
 
-    if (!valid) return;
     if (!WAVE_HAS_CTCSS) { /* the back kernel owns these in the split kinds */
         if (o.axc != ' ') sp->active_counter++;
         sp->axc_prev = sp->axc;
@@ -464,11 +334,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         sp->nx[0] = o.nx0; sp->nx[1] = o.nx1; sp->nx[2] = o.nx2; sp->ny[0] = o.ny0; sp->ny[1] = o.ny1; sp->ny[2] = o.ny2;
     }
     sp->agcavgfast = agc; sp->pr = pr; sp->pj = pj; sp->prev_waveout = prev_out; sp->dm_phi = dm_phi;
-    sp->noise_floor = s.noise_floor; sp->cap = s.cap; sp->pre_full = s.pre_full; sp->pre_capped = s.pre_capped;
-    sp->post_full = s.post_full; sp->post_capped = s.post_capped;
-    sp->using_post = s.using_post; sp->next = s.next; sp->cur = s.cur; sp->delay = s.delay; sp->low_count = s.low_count;
-    sp->head = s.head; sp->tail = s.tail; sp->sample_count = s.sample_count; sp->open_count = s.open_count;
-    sp->flappy_count = s.flappy_count; sp->recent_open = s.recent_open; sp->closed_count = s.closed_count;
+    sq_store(s, L, sp, B);
     sp->lxr[0] = lxr0; sp->lxr[1] = lxr1; sp->lxr[2] = lxr2; sp->lxi[0] = lxi0; sp->lxi[1] = lxi1; sp->lxi[2] = lxi2;
     sp->lyr[0] = lyr0; sp->lyr[1] = lyr1; sp->lyr[2] = lyr2; sp->lyi[0] = lyi0; sp->lyi[1] = lyi1; sp->lyi[2] = lyi2;
 }
@@ -489,8 +355,14 @@ __global__ __launch_bounds__(64, AB_DEMOD_WAVES) void demod_kernel(DemodArgs a, 
     extern __shared__ __attribute__((aligned(16))) float lds_demod[];
     const int slot = (first_block + blockIdx.x) * 64 + threadIdx.x; /* padding slots carry flags == 0 */
     const ChanConst cc = a.cc[slot];
-    float* scratch = lds_demod + CHUNK * 64 * LdsSlots<KIND>::value;
-    demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lds_demod, scratch);
+    /* behind the sample staging area: the (sin, cos) table of sincosf_lut (src/util.cpp:105-127), 257 float2 -- a sample's
+     * derotation then costs one LDS read instead of four dependent trips to L2 on the serial path */
+    float2* lut = reinterpret_cast<float2*>(lds_demod + CHUNK * 64 * LdsSlots<KIND>::value);
+    if (KIND != AB_KIND_AM) {
+        for (int i = threadIdx.x; i < 257; i += 64) lut[i] = make_float2(a.sin_lut[i], a.cos_lut[i]);
+        __syncthreads(); /* one wavefront per block: orders the table writes before any lane's reads */
+    }
+    demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lds_demod, lut);
 }
 
 /* CTCSS tone detection (reference: src/ctcss.cpp, driven by Squelch::process_audio_sample src/squelch.cpp:278-295).
@@ -661,9 +533,9 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
  * lane-per-channel kernel holds at most 4 waves per SIMD and the NFM kinds have only half that many wavefronts at BASELINE
  * config #3.  So the split chain (front -> tone -> back, the longest) goes on the caller's stream and the fused kinds run
  * beside it on side streams, forked and joined with events (works the same under graph capture). */
-void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev) {
+void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev, const EmitArgs* emit) {
     auto launch_kind = [&](int k, hipStream_t s) {
-        const size_t lds = (size_t)CHUNK * 64 * sizeof(float) * (k == AB_KIND_AM ? 2 : 4) + 64 * sizeof(float);
+        const size_t lds = (size_t)CHUNK * 64 * sizeof(float) * (k == AB_KIND_AM ? 2 : 4) + (k == AB_KIND_AM ? 0 : 257 * sizeof(float2));
         const int n = kind_n_blocks[k], f = kind_first_block[k];
         if (n <= 0) return;
         switch (k) {
@@ -682,6 +554,7 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
             if (kind_n_blocks[fused[i]] <= 0) continue;
             (void)hipStreamWaitEvent(side[i], ev[0], 0);
             launch_kind(fused[i], side[i]);
+            if (emit) launch_emit(*emit, side[i], kind_first_block[fused[i]], kind_n_blocks[fused[i]]);
             (void)hipEventRecord(ev[1 + i], side[i]);
         }
     }
@@ -691,11 +564,18 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
         hipLaunchKernelGGL(tone_kernel, dim3((a.ct_n_blocks * 64 * 64 + 255) / 256), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(back_kernel, dim3(a.ct_n_blocks), dim3(64), 0, stream, a);
     }
+    if (emit) { /* the split kinds' slots (their blocks are contiguous: CTCSS kind, then generic) */
+        launch_emit(*emit, stream, kind_first_block[AB_KIND_NFM_CTCSS], kind_n_blocks[AB_KIND_NFM_CTCSS]);
+        launch_emit(*emit, stream, kind_first_block[AB_KIND_GENERIC], kind_n_blocks[AB_KIND_GENERIC]);
+    }
     if (fork) {
         for (int i = 0; i < 3; i++)
             if (kind_n_blocks[fused[i]] > 0) (void)hipStreamWaitEvent(stream, ev[1 + i], 0);
     } else {
-        for (int i = 0; i < 3; i++) launch_kind(fused[i], stream);
+        for (int i = 0; i < 3; i++) {
+            launch_kind(fused[i], stream);
+            if (emit) launch_emit(*emit, stream, kind_first_block[fused[i]], kind_n_blocks[fused[i]]);
+        }
     }
 }
 
@@ -705,9 +585,10 @@ namespace {
 /* ---- emit: time-major device results -> the channel-major layout the output thread consumes -------------
  * (reference: src/output.cpp:460,521,535 read channel->waveout[0..WAVE_BATCH) / iq_out; :920 tail copy is implicit
  * in the ring rotation).  64 slots x 64 samples per block, transposed through LDS so both sides are coalesced. */
-__global__ __launch_bounds__(256) void emit_kernel(EmitArgs a) {
+__global__ __launch_bounds__(256) void emit_kernel(EmitArgs a, int first_block) {
     __shared__ float tile[2][64][65];
-    const int slot0 = blockIdx.x * 64;
+    const int blk = first_block + blockIdx.x;
+    const int slot0 = blk * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int R = a.ring_rows, B = a.wave_batch;
     const int n_tiles = (B + 63) / 64;
@@ -725,7 +606,7 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitArgs a) {
             if (t < B) {
                 int pr = a.row0 + t;
                 if (pr >= R) pr -= R;
-                x = a.wave[((long)blockIdx.x * R + pr) * AB_SLOT_BLOCK + tx];
+                x = a.wave[((long)blk * R + pr) * AB_SLOT_BLOCK + tx];
             }
             v[k] = x;
         }
@@ -756,7 +637,7 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitArgs a) {
                     const int t = tl * 64 + r;
                     float x = 0.0f;
                     if (t < B && slot0 + tx < a.n_slots) {
-                        const float2 q = a.iq_out[((long)blockIdx.x * B + t) * AB_SLOT_BLOCK + tx];
+                        const float2 q = a.iq_out[((long)blk * B + t) * AB_SLOT_BLOCK + tx];
                         x = comp ? q.y : q.x;
                     }
                     tile[0][r][tx] = x;
@@ -781,13 +662,14 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitArgs a) {
     }
 }
 
-void launch_emit(const EmitArgs& a, hipStream_t stream) {
-    const int blocks = (a.n_slots + 63) / 64;
+void launch_emit(const EmitArgs& a, hipStream_t stream, int first_block, int n_blocks) {
+    const int blocks = n_blocks >= 0 ? n_blocks : (a.n_slots + 63) / 64;
+    if (blocks <= 0) return;
     const int n_tiles = (a.wave_batch + 63) / 64;
     int ysplit = blocks >= 4096 ? 2 : (16384 / (blocks > 0 ? blocks : 1)); /* few slot blocks: split time instead, to fill the chip */
     if (ysplit < 1) ysplit = 1;
     if (ysplit > n_tiles) ysplit = n_tiles;
-    hipLaunchKernelGGL(emit_kernel, dim3(blocks, ysplit), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(emit_kernel, dim3(blocks, ysplit), dim3(256), 0, stream, a, first_block);
 }
 
 /* ---- stats mirror (reference getters: src/output.cpp:617-761) ---------------------------------------------- */

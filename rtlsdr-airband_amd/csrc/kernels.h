@@ -127,8 +127,10 @@ int dft_sub_tiles(int hop_bytes);
 int dft_nbuf(int hop_bytes);
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream);
 /* side: 3 extra streams, ev: 4 events (fork + 3 joins); both may be null -> everything on `stream` */
-void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev);
-void launch_emit(const EmitArgs& a, hipStream_t stream);
+/* `emit` != nullptr: every kind's slots are emitted on that kind's own stream as soon as its demod kernels are done */
+void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev, const EmitArgs* emit);
+/* slot blocks [first_block, first_block + n_blocks) (n_blocks < 0: all) */
+void launch_emit(const EmitArgs& a, hipStream_t stream, int first_block = 0, int n_blocks = -1);
 void launch_mix(const MixArgs& a, hipStream_t stream);
 void launch_stats(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, int n_slots, airband_hip_channel_stats* out, hipStream_t stream);
 void launch_siggen(const SiggenArgs& a, hipStream_t stream);

@@ -1,0 +1,268 @@
+/* csrc/squelch_fsm.h -- the reference's Squelch (src/squelch.cpp, state list src/squelch.h:117-158) as the demod kernels run it:
+ * one lane per channel, no divergent control flow around the state machine.
+ *
+ * Shape of the code, and why:
+ *  - Every per-channel BOOLEAN (which Squelch::State, using_post_filter_, every predicate) is kept as a wave-wide LANE MASK
+ *    (`lmask`, bit l = lane l's value) instead of a per-lane variable.  Lane masks live in scalar register pairs, so the
+ *    whole five-way state machine -- which transition is legal, which predicate the caller sees -- is scalar-unit bit
+ *    arithmetic and costs no vector-ALU slot.  The lane-per-channel kernels are vector-ALU bound (a wave64 VALU instruction
+ *    occupies the SIMD for four cycles), so this is where the time goes.  Only counters, float compares (one v_cmp each,
+ *    `ab_ballot`) and the moving averages remain vector work; a mask steers a per-lane select through `ab_lane`
+ *    (v_cndmask with the scalar pair as its condition).
+ *  - Lane masks are wave-uniform values: they are only ever assigned in wave-uniform control flow.  Per-lane conditions
+ *    are folded in with mask arithmetic, never with an `if` around a mask update.
+ *  - Rare events (a state change, a timer running out, the flap counter being cleared) sit behind wave-uniform
+ *    `ab_any()` branches: the body is written with per-lane selects and is correct for every lane whenever it runs, so it
+ *    is skipped exactly when no lane of the wavefront needs it.
+ *  - squelch_level() is kept as an always-valid cache `lvl`: the reference invalidates its cache exactly when
+ *    noise_floor_ or recent_open_count_ change (:389,:451,:489) and recomputes the same product, so refreshing the value at
+ *    those three places yields the float every call of the reference would see.
+ *
+ * The header also compiles as plain C++, where a "wavefront" is one lane and a lane mask is one bit: tests/ builds it with
+ * g++ and checks it sample by sample against the oracle (tests/test_host_fsm.py) -- that is a test of this logic, not a CPU
+ * code path of the product; nothing in the library calls it on the host.
+ */
+#ifndef AIRBAND_CSRC_SQUELCH_FSM_H
+#define AIRBAND_CSRC_SQUELCH_FSM_H
+
+#include "common.h"
+
+namespace airband {
+
+typedef unsigned long long lmask;
+
+#if defined(__HIPCC__)
+#define AB_FSM_FN __device__ __forceinline__
+AB_FSM_FN lmask ab_ballot(bool b) { return __ballot(b); }                                   /* per-lane bool -> lane mask (one v_cmp) */
+AB_FSM_FN bool ab_lane(lmask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }          /* lane mask -> this lane's bool        */
+AB_FSM_FN bool ab_any(lmask m) { return m != 0ull; }
+#else
+#define AB_FSM_FN static inline
+AB_FSM_FN lmask ab_ballot(bool b) { return b ? 1ull : 0ull; }
+AB_FSM_FN bool ab_lane(lmask m) { return (m & 1ull) != 0ull; }
+AB_FSM_FN bool ab_any(lmask m) { return (m & 1ull) != 0ull; }
+#endif
+
+struct SqRegs { /* Squelch members that change per sample */
+    float noise_floor, cap, pre_full, pre_capped, post_full, post_capped;
+    float lvl;                    /* squelch_level() of the current noise_floor_ / recent_open_count_ */
+    lmask active;                 /* lanes that own a channel */
+    lmask using_post;             /* using_post_filter_ */
+    lmask cC, cOg, cCg, cA, cO;   /* current_state_ == CLOSED / OPENING / CLOSING / LOW_SIGNAL_ABORT / OPEN */
+    lmask nC, nOg, nCg, nA, nO;   /* next_state_ */
+    int delay, low_count, head, tail;
+    unsigned sample_count, open_count, flappy_count, recent_open, closed_count;
+    float dly; /* buffer_[buffer_tail_] for the current tail, when the kind prefetches the delay line (else unused) */
+};
+
+struct Lane { /* per-lane constants */
+    bool prefetched_delay; /* SqRegs::dly is maintained by the caller instead of reading sqbuf from memory (compile-time per kind) */
+    bool track_delay_line; /* head/tail advance per sample (only kinds that touch the delay line need them inside a batch) */
+    lmask m_lowpass, m_manual, m_flappy_lower;
+    float manual_level, normal_ratio, flappy_ratio;
+    float* sqbuf; /* this lane's column of the 102-deep pre-filter delay line, stride S */
+    long S;
+};
+
+AB_FSM_FN void sq_set_cur(SqRegs& s, int st) {
+    s.cC = ab_ballot(st == AB_ST_CLOSED); s.cOg = ab_ballot(st == AB_ST_OPENING); s.cCg = ab_ballot(st == AB_ST_CLOSING);
+    s.cA = ab_ballot(st == AB_ST_ABORT); s.cO = ab_ballot(st == AB_ST_OPEN);
+}
+AB_FSM_FN void sq_set_next(SqRegs& s, int st) {
+    s.nC = ab_ballot(st == AB_ST_CLOSED); s.nOg = ab_ballot(st == AB_ST_OPENING); s.nCg = ab_ballot(st == AB_ST_CLOSING);
+    s.nA = ab_ballot(st == AB_ST_ABORT); s.nO = ab_ballot(st == AB_ST_OPEN);
+}
+AB_FSM_FN int sq_cur(const SqRegs& s) {
+    return ab_lane(s.cO) ? AB_ST_OPEN : ab_lane(s.cA) ? AB_ST_ABORT : ab_lane(s.cCg) ? AB_ST_CLOSING : ab_lane(s.cOg) ? AB_ST_OPENING : AB_ST_CLOSED;
+}
+AB_FSM_FN int sq_next(const SqRegs& s) {
+    return ab_lane(s.nO) ? AB_ST_OPEN : ab_lane(s.nA) ? AB_ST_ABORT : ab_lane(s.nCg) ? AB_ST_CLOSING : ab_lane(s.nOg) ? AB_ST_OPENING : AB_ST_CLOSED;
+}
+
+/* Squelch::squelch_level() (src/squelch.cpp:164-177) */
+AB_FSM_FN float sq_level_compute(const SqRegs& s, const Lane& L) {
+    const lmask flappy = ab_ballot(s.recent_open >= 3u /* flap_opens_threshold_ */) & L.m_flappy_lower;
+    const float ratio = ab_lane(flappy) ? L.flappy_ratio : L.normal_ratio;
+    const float lvl = ratio * s.noise_floor;
+    return ab_lane(L.m_manual) ? L.manual_level : lvl;
+}
+AB_FSM_FN float sq_level(const SqRegs& s) { return s.lvl; }
+
+AB_FSM_FN float sq_delayed(const SqRegs& s, const Lane& L) { return L.prefetched_delay ? s.dly : L.sqbuf[(long)s.tail * L.S]; }
+
+AB_FSM_FN lmask sq_has_pre(const SqRegs& s) { return ab_ballot(s.pre_capped >= s.lvl); }
+
+AB_FSM_FN lmask sq_has_signal(const SqRegs& s, const Lane& L) { /* src/squelch.cpp:462-475 */
+    lmask sig = sq_has_pre(s);
+    /* using_post_filter_ can only ever be set on channels with a lowpass filter */
+    if (ab_any(s.using_post)) sig &= ~s.using_post | ab_ballot(s.post_capped >= sq_delayed(s, L));
+    return sig;
+}
+
+/* Squelch::update_current_state (src/squelch.cpp:363-460).  Returns the lanes whose squelch just went CLOSED (the reference
+ * resets both CTCSS detectors at that point, :440-441). */
+AB_FSM_FN lmask sq_advance(SqRegs& s, const Lane& L) {
+    const lmask same = (s.nC & s.cC) | (s.nOg & s.cOg) | (s.nCg & s.cCg) | (s.nA & s.cA) | (s.nO & s.cO);
+    const lmask entering = s.active & ~same;
+    const lmask timed = s.nOg | s.nCg | s.nA;
+    const lmask staying = timed & same;
+    const lmask idle_closed = s.nC & same;
+    lmask went_closed = 0;
+    s.delay += ab_lane(staying) ? 1 : 0; /* the timer of OPENING / CLOSING / LOW_SIGNAL_ABORT */
+    if (ab_any(entering)) {
+        /* delay_ is zeroed on entry to a timed state, except that ABORT entered from CLOSING keeps CLOSING's running delay */
+        const lmask zero_delay = entering & timed & ~(s.nA & s.cCg);
+        s.delay = ab_lane(zero_delay) ? 0 : s.delay;
+        s.low_count = ab_lane(entering & s.nOg) ? 0 : s.low_count;
+        s.using_post &= ~(entering & (s.nOg | s.nC));
+        s.open_count += ab_lane(entering & s.nO) ? 1u : 0u;
+        went_closed = entering & s.nC;
+        s.closed_count = ab_lane(went_closed) ? 0u : s.closed_count;
+    }
+    /* current_state_ = next_state_ (when nothing is entered the two are equal already) */
+    s.cC = s.nC; s.cOg = s.nOg; s.cCg = s.nCg; s.cA = s.nA; s.cO = s.nO;
+    const lmask expired = staying & ab_ballot(s.delay >= 197); /* open_delay_ == close_delay_ == 197 */
+    if (ab_any(expired)) {
+        /* OPENING delay over: count a recent open for flap detection before looking at the signal (:381-392) */
+        const lmask bump = expired & s.nOg & ab_ballot(s.closed_count < 1000u);
+        s.recent_open += ab_lane(bump) ? 1u : 0u;
+        s.flappy_count += ab_lane(bump & ab_ballot(s.recent_open >= 3u)) ? 1u : 0u;
+        s.lvl = sq_level_compute(s, L);
+        const lmask sig = sq_has_signal(s, L);
+        const lmask to_open = expired & (s.nOg | s.nCg) & sig; /* OPENING -> OPEN; CLOSING with the signal back -> OPEN */
+        const lmask reopen = expired & s.nCg & sig;            /* ... the latter straight away, without counting an open */
+        s.cCg &= ~reopen;
+        s.cO |= reopen;
+        s.nO |= to_open;
+        s.nC |= expired & ~to_open;
+        s.nOg &= ~expired;
+        s.nCg &= ~expired;
+        s.nA &= ~expired;
+    }
+    /* CLOSED and staying there: count closed samples up to recent_sample_size_ = 1000, then forget the recent opens */
+    const lmask below = ab_ballot(s.closed_count < 1000u);
+    const lmask forget = idle_closed & ~below & ab_ballot(s.recent_open != 0u);
+    s.closed_count += ab_lane(idle_closed & below) ? 1u : 0u;
+    if (ab_any(forget)) {
+        s.recent_open = ab_lane(forget) ? 0u : s.recent_open;
+        s.lvl = sq_level_compute(s, L);
+    }
+    if (L.track_delay_line) {
+        s.tail = s.tail + 1 == AB_SQ_BUF ? 0 : s.tail + 1;
+        s.head = s.head + 1 == AB_SQ_BUF ? 0 : s.head + 1;
+    }
+    return went_closed;
+}
+
+/* Squelch::update_moving_avg (src/squelch.cpp:501-514) */
+AB_FSM_FN void sq_avg(float cap, float& full, float& capped, float x) {
+    const float decay = 0.99f;
+    const float fresh = (float)(1.0 - (double)0.99f);
+    const float xf = x * fresh;
+    full = full * decay + xf;
+    const float v = capped * decay + xf;
+    const float vm = cap < v ? cap : v;
+    capped = (capped >= cap && x >= cap) ? cap : vm; /* the reference short-circuits this case; the value is `cap` either way it is written */
+}
+
+/* Squelch::process_raw_sample (src/squelch.cpp:195-246) */
+AB_FSM_FN lmask sq_raw(SqRegs& s, const Lane& L, float x, float dly_new) {
+    const lmask went_closed = sq_advance(s, L); /* evaluates the post-filter gate against buffer_[tail] BEFORE the tail moves */
+    s.dly = dly_new;                            /* ... everything after it sees the entry under the advanced tail */
+    s.sample_count++;
+    const lmask sweep = ab_ballot((s.sample_count & 15u) == 0u); /* calculate_noise_floor every 16th sample, :477-490 */
+    if (ab_any(sweep)) {
+        const float decay = 0.97f;
+        const float fresh = (float)(1.0 - (double)0.97f);
+        const float lo = s.pre_capped < s.noise_floor ? s.pre_capped : s.noise_floor;
+        const float nf = s.noise_floor * decay + lo * fresh + 1e-6f;
+        s.noise_floor = ab_lane(sweep) ? nf : s.noise_floor;
+        const float cap = ab_lane(L.m_manual) ? 1.5f * L.manual_level : 1.5f * L.normal_ratio * s.noise_floor;
+        s.cap = ab_lane(sweep) ? cap : s.cap;
+        s.lvl = sq_level_compute(s, L);
+    }
+    sq_avg(s.cap, s.pre_full, s.pre_capped, x);
+    if (ab_any(L.m_lowpass)) {
+        if (ab_lane(L.m_lowpass)) L.sqbuf[(long)s.head * L.S] = s.pre_capped * 0.9f; /* only ever read on the post-filter path */
+    }
+    const lmask sig = sq_has_signal(s, L);
+    /* set_state() requests (:297-361), already clamped: OPEN -> CLOSING, CLOSED -> OPENING are legal as asked */
+    const lmask to_closing = s.cO & ~sig;
+    const lmask to_opening = s.cC & sig;
+    /* low-signal abort (:233-245): LOW_SIGNAL_ABORT asked from OPENING is clamped to CLOSED, from CLOSING / OPEN it stands */
+    const lmask counting = s.cOg | s.cCg | s.cO;
+    const lmask low = counting & ab_ballot(!(x >= s.lvl));
+    s.low_count = ab_lane(low) ? s.low_count + 1 : (ab_lane(counting) ? 0 : s.low_count);
+    const lmask abort_now = low & ab_ballot(s.low_count >= 88); /* low_signal_abort_ */
+    const lmask any_req = to_closing | to_opening | abort_now;
+    if (ab_any(any_req)) {
+        s.nC = (s.nC & ~any_req) | (abort_now & s.cOg);
+        s.nA = (s.nA & ~any_req) | (abort_now & ~s.cOg);
+        s.nCg = (s.nCg & ~any_req) | (to_closing & ~abort_now);
+        s.nOg = (s.nOg & ~any_req) | (to_opening & ~abort_now);
+        s.nO &= ~any_req;
+    }
+    return went_closed;
+}
+
+AB_FSM_FN lmask sq_should_filter(const SqRegs& s) { return (sq_has_pre(s) | ~s.cC) & ~s.cA & s.active; } /* :136-138 */
+AB_FSM_FN lmask sq_should_audio(const SqRegs& s) { return s.cO | s.cCg; }                                /* :140-142 */
+AB_FSM_FN lmask sq_first_open(const SqRegs& s) { return ~s.cO & s.nO; }                                  /* :144-146 */
+AB_FSM_FN lmask sq_last_open(const SqRegs& s) { return (s.cCg & s.nC) | (~s.cA & s.nA); }                /* :148-150 */
+
+/* Squelch::process_filtered_sample (src/squelch.cpp:248-276) for the lanes in `filt` (= should_filter_sample() lanes that
+ * have a lowpass filter; the caller ran the filter for them and hands over the filtered magnitude) */
+AB_FSM_FN void sq_filtered(SqRegs& s, const Lane& L, lmask filt, float x) {
+    filt &= L.m_lowpass;
+    if (!ab_any(filt)) return;
+    const float delayed = sq_delayed(s, L);
+    /* OPENING: nothing until the delay line holds post-opening samples, then the averages start from its oldest entry */
+    const lmask run = filt & ~(s.cOg & ab_ballot(s.delay < AB_SQ_BUF));
+    const lmask seed = run & s.cOg & ab_ballot(s.delay == AB_SQ_BUF);
+    float full = ab_lane(seed) ? delayed : s.post_full, capped = ab_lane(seed) ? delayed : s.post_capped;
+    s.using_post |= run;
+    sq_avg(s.cap, full, capped, x);
+    s.post_full = ab_lane(run) ? full : s.post_full;
+    s.post_capped = ab_lane(run) ? capped : s.post_capped;
+    const lmask close = run & ab_ballot(capped < delayed);
+    if (ab_any(close)) { /* set_state(CLOSED): from OPEN that is clamped to CLOSING, from anywhere else it stands */
+        s.nC = (s.nC & ~close) | (close & ~s.cO);
+        s.nCg = (s.nCg & ~close) | (close & s.cO);
+        s.nOg &= ~close;
+        s.nA &= ~close;
+        s.nO &= ~close;
+    }
+}
+
+/* ChanState <-> registers; `valid` = this lane owns a channel */
+AB_FSM_FN void sq_load(SqRegs& s, const Lane& L, const ChanState* sp, bool valid) {
+    s.active = ab_ballot(valid);
+    s.noise_floor = sp->noise_floor; s.cap = sp->cap; s.pre_full = sp->pre_full; s.pre_capped = sp->pre_capped;
+    s.post_full = sp->post_full; s.post_capped = sp->post_capped;
+    s.using_post = ab_ballot(valid && sp->using_post != 0);
+    sq_set_next(s, valid ? sp->next : -1);
+    sq_set_cur(s, valid ? sp->cur : -1);
+    s.delay = sp->delay; s.low_count = sp->low_count;
+    s.head = sp->head; s.tail = sp->tail; s.sample_count = sp->sample_count; s.open_count = sp->open_count;
+    s.flappy_count = sp->flappy_count; s.recent_open = sp->recent_open; s.closed_count = sp->closed_count;
+    s.lvl = sq_level_compute(s, L);
+    s.dly = 0.0f;
+}
+
+/* `samples` = how many process_raw_sample calls ran since sq_load (head/tail advance once per call, :453-456) */
+AB_FSM_FN void sq_store(const SqRegs& s, const Lane& L, ChanState* sp, int samples) {
+    sp->noise_floor = s.noise_floor; sp->cap = s.cap; sp->pre_full = s.pre_full; sp->pre_capped = s.pre_capped;
+    sp->post_full = s.post_full; sp->post_capped = s.post_capped;
+    sp->using_post = ab_lane(s.using_post) ? 1 : 0; sp->next = sq_next(s); sp->cur = sq_cur(s); sp->delay = s.delay; sp->low_count = s.low_count;
+    int head = s.head, tail = s.tail;
+    if (!L.track_delay_line) {
+        head = (head + samples) % AB_SQ_BUF;
+        tail = (tail + samples) % AB_SQ_BUF;
+    }
+    sp->head = head; sp->tail = tail; sp->sample_count = s.sample_count; sp->open_count = s.open_count;
+    sp->flappy_count = s.flappy_count; sp->recent_open = s.recent_open; sp->closed_count = s.closed_count;
+}
+
+}  // namespace airband
+
+#endif
