@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-path", action="store_true", help="additionally time the host-buffer path (submit over PCIe) on a small slice; reported separately, never as value")
+    ap.add_argument("--sequential", action="store_true", help="one batch at a time (stage 1, then stage 2) instead of the pipelined throughput mode: "
+                    "the channelizer kernel then runs alone on the chip, which is what the committed kernel profiles and PMC traffic figures describe")
     ap.add_argument("--force-dist", action="store_true", help="initialise a process group even at world size 1 (plumbing check of the RCCL leg)")
     args = ap.parse_args()
 
@@ -122,8 +124,11 @@ def main():
 
     chans, carriers = pkg.siggen.baseline_plan(mixed=mixed)
     devices = [dict(channels=chans) for _ in range(D)]
-    # AIRBAND_BENCH_FLAGS: AIRBAND_HIP_FLAG_* bits for experiments (e.g. 8 = demod kinds one after the other, for per-kernel profiles)
-    hip = pkg.AirbandHip(devices, wave_rate=wave_rate, hip_device=local_rank, flags=int(os.environ.get("AIRBAND_BENCH_FLAGS", "0"), 0))
+    # Throughput mode (AIRBAND_HIP_FLAG_PIPELINE): a step enqueues stage 1 of its batch beside stage 2 of the previous one -- every step
+    # still does one full stage 1 and one full stage 2, of consecutive batches.  AIRBAND_BENCH_FLAGS adds AIRBAND_HIP_FLAG_* bits for
+    # experiments (e.g. 8 = demod kinds one after the other, for per-kernel profiles).
+    flags = int(os.environ.get("AIRBAND_BENCH_FLAGS", "0"), 0) | (0 if args.sequential else pkg.capi.FLAG_PIPELINE)
+    hip = pkg.AirbandHip(devices, wave_rate=wave_rate, hip_device=local_rank, flags=flags)
     g = hip.geometry
     if n_mixers:
         base = rank * D
@@ -149,14 +154,18 @@ def main():
         mix_t = torch.as_tensor(_Ptr(res["mix_left"], (n_mixers, hip.B), "<f4"), device="cuda")
         sig_t = torch.as_tensor(_Ptr(res["mix_signal"], (n_mixers,), "|u1"), device="cuda")
 
+    # the RCCL all-reduce is issued on torch's stream: that stream waits (on the GPU) for the batch's mixer sums, and the next
+    # process call orders its overwrite of them behind the all-reduce -- no host synchronisation inside a step
+    consumer = torch.cuda.current_stream().cuda_stream if mix_t is not None else 0
+
     def step(i):
         if i == 0:
             off = 0
         else:
             off = g.first_batch_bytes + ((i - 1) % args.ring) * g.batch_bytes
-        hip.process_device(iq.data_ptr() + off, stride)
+        hip.process_device(iq.data_ptr() + off, stride, consumer)
         if mix_t is not None:
-            hip.synchronize()
+            hip.stream_wait_results(consumer)
             dist.all_reduce(mix_t, op=dist.ReduceOp.SUM)      # mixer sum over xGMI (src/mixer.cpp:133-140)
             dist.all_reduce(sig_t, op=dist.ReduceOp.MAX)      # axcindicate of the mixer (src/mixer.cpp:209)
 
@@ -169,15 +178,18 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync()
-    chan_ms, demod_ms, emit_ms = [], [], []
+    hip.timing_totals(reset=True)
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
-        if os.environ.get("AIRBAND_BENCH_STAGE_TIMES", "1") == "1":
-            t = hip.last_timings()  # HIP events recorded on the handle's stream around each kernel
-            chan_ms.append(t["channelizer_ms"]); demod_ms.append(t["demod_ms"]); emit_ms.append(t["emit_ms"])
     sync()
     elapsed = time.perf_counter() - t0
+    # HIP events the library records around each kernel on the stream it runs on, read once after the timed region
+    tt = hip.timing_totals()
+    nb = max(1, tt["batches"])
+    chan_ms, demod_ms, emit_ms = [tt["channelizer_ms"] / nb], [tt["demod_ms"] / nb], [tt["emit_ms"] / nb]
+    hip.flush()
+    sync()
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -204,6 +216,7 @@ def main():
                warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
                data="synthetic", config=dict(workload=wl["desc"], dongles_per_gpu=D, channels_per_dongle=8, fft_size=g.fft_size, wave_rate=wave_rate,
                                                sample_format="u8", iq_resident="HBM", ring_batches=args.ring, mixers=n_mixers,
+                                               schedule="sequential" if args.sequential else "pipelined: stage 1 of batch k beside stage 2 of batch k-1",
                                                parallelism="dongle-sharded x%d, %s" % (world, "RCCL all-reduce of mixer sums" if mix_t is not None else "no collective"),
                                                channelizer=hip.channelizer_name()),
                roofline=roofline,

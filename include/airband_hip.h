@@ -59,6 +59,13 @@ extern "C" {
 #define AIRBAND_HIP_FLAG_FORCE_FFT 0x4u     /* always use the full wavefront-FFT channelizer             */
 #define AIRBAND_HIP_FLAG_SERIAL_DEMOD 0x8u  /* run the per-kind demod kernels one after another instead   \
                                                of side by side on forked streams (profiling aid)          */
+#define AIRBAND_HIP_FLAG_PIPELINE 0x10u     /* throughput mode: a process call enqueues stage 1 of ITS batch \
+                                               beside stage 2 of the PREVIOUS batch (the channelizer is       \
+                                               HBM-bound, the demod kernels are not).  Results lag one batch: \
+                                               the first call produces none, airband_hip_flush() drains the   \
+                                               last.  Same values, bit for bit, as the sequential mode.       \
+                                               Ignored when a channel has AFC (stage 1 of the next batch needs \
+                                               stage 2's verdict, src/rtl_airband.cpp:222-251).               */
 
 /* Per-channel configuration: the values a multichannel-mode `channels` entry carries after
  * parse_channels() (reference: src/config.cpp:306-726).  The library derives bin index, derotation
@@ -212,6 +219,15 @@ int airband_hip_collect_mixers(airband_hip_handle* h, float* left, float* right,
 int airband_hip_device_results(airband_hip_handle* h, float** d_waveout, float** d_iq_out, uint8_t** d_axc, float** d_mix_left, float** d_mix_right,
                                uint8_t** d_mix_signal);
 
+/* Makes `stream` (a hipStream_t of a GPU-side consumer, e.g. the stream an RCCL all-reduce of the mixer sums is issued on)
+ * wait for the results of the batch the last process call completed -- no host synchronisation.  The consumer hands its
+ * stream to the next airband_hip_process_device() call, which then orders the overwrite of the result buffers behind it. */
+int airband_hip_stream_wait_results(airband_hip_handle* h, void* stream);
+
+/* AIRBAND_HIP_FLAG_PIPELINE handles: enqueues stage 2 of the batch whose stage 1 the last process call started, so that its
+ * results can be collected without feeding another batch (end of stream).  No-op otherwise. */
+int airband_hip_flush(airband_hip_handle* h);
+
 /* Blocks until everything enqueued on the handle has finished. */
 int airband_hip_synchronize(airband_hip_handle* h);
 
@@ -242,9 +258,14 @@ int airband_hip_channel_constants(const airband_hip_handle* h, int32_t channel_i
 /* Same slots, computed without any GPU (pure host arithmetic): lets CPU-only tests pin the derivations. */
 int airband_hip_derive_constants(const airband_hip_config* cfg, int32_t channel_index, double* out_vals);
 
-/* Milliseconds the GPU spent in each stage during the last process call (HIP events on the handle's
- * stream): [0] channelizer kernel, [1] demod kernel(s), [2] emit/transposes, [3] whole batch. */
+/* Milliseconds the GPU spent on the last finished batch (HIP events on the streams the kernels run on):
+ * [0] channelizer kernel, [1] demod kernels (+ per-kind emit), [2] joint emit / mixers, [3] their sum.  Waits for the
+ * enqueued batches. */
 int airband_hip_last_timings(airband_hip_handle* h, float* ms4);
+
+/* Sums of the same four figures over every batch that has FINISHED since the last reset, and how many batches that is.
+ * Waits for the enqueued batches; callers that must not stall inside a run call it once, after airband_hip_synchronize(). */
+int airband_hip_timing_totals(airband_hip_handle* h, double* ms4_sum, int64_t* n_batches, int32_t reset);
 
 /* Name of the channelizer variant the handle selected ("fft_wave64" / "dft_mfma_i8"). */
 const char* airband_hip_channelizer_name(const airband_hip_handle* h);

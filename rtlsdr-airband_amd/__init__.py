@@ -28,6 +28,7 @@ EXPORTS = [
     "airband_hip_process", "airband_hip_process_device", "airband_hip_collect", "airband_hip_collect_mixers", "airband_hip_device_results",
     "airband_hip_synchronize", "airband_hip_process_bins", "airband_hip_read_bins", "airband_hip_read_trace", "airband_hip_channel_constants",
     "airband_hip_derive_constants", "airband_hip_last_timings", "airband_hip_channelizer_name", "airband_hip_set_signal_plan", "airband_hip_generate_iq",
+    "airband_hip_flush", "airband_hip_timing_totals", "airband_hip_stream_wait_results",
 ]
 
 _lib = None
@@ -80,6 +81,9 @@ def load_library() -> C.CDLL:
     L.airband_hip_channelizer_name.restype = C.c_char_p
     L.airband_hip_set_signal_plan.argtypes = [vp, vp, i32, i32, vp]
     L.airband_hip_generate_iq.argtypes = [vp, vp, sz, u64, sz, u64, i32, vp]
+    L.airband_hip_flush.argtypes = [vp]
+    L.airband_hip_stream_wait_results.argtypes = [vp, vp]
+    L.airband_hip_timing_totals.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     _lib = L
     return L
 
@@ -184,6 +188,14 @@ class AirbandHip:
     def synchronize(self):
         self._check(self.L.airband_hip_synchronize(self.h))
 
+    def stream_wait_results(self, stream_ptr: int):
+        """Make a consumer's hipStream_t wait (on the GPU) for the results of the last completed batch."""
+        self._check(self.L.airband_hip_stream_wait_results(self.h, C.c_void_p(stream_ptr)))
+
+    def flush(self):
+        """Pipelined handles (FLAG_PIPELINE): run stage 2 of the batch the last process call started."""
+        self._check(self.L.airband_hip_flush(self.h))
+
     def process_bins(self, wavein: np.ndarray, iq_in: np.ndarray):
         wavein = np.ascontiguousarray(wavein, np.float32)
         iq_in = np.ascontiguousarray(iq_in, np.float32)
@@ -211,6 +223,13 @@ class AirbandHip:
         v = (C.c_float * 4)()
         self._check(self.L.airband_hip_last_timings(self.h, v))
         return dict(channelizer_ms=v[0], demod_ms=v[1], emit_ms=v[2], batch_ms=v[3])
+
+    def timing_totals(self, reset: bool = False):
+        """Sums of the per-stage GPU times over the batches finished since the last reset (waits for the enqueued ones)."""
+        v = (C.c_double * 4)()
+        n = C.c_int64(0)
+        self._check(self.L.airband_hip_timing_totals(self.h, v, C.byref(n), 1 if reset else 0))
+        return dict(channelizer_ms=v[0], demod_ms=v[1], emit_ms=v[2], batch_ms=v[3], batches=int(n.value))
 
     def channelizer_name(self) -> str:
         return self.L.airband_hip_channelizer_name(self.h).decode()

@@ -46,9 +46,23 @@ struct airband_hip_handle {
     uint32_t flags = 0;
     int hip_device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t side[3] = {nullptr, nullptr, nullptr}; /* fused demod kinds run beside the CTCSS chain */
     hipEvent_t fork_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    /* AIRBAND_HIP_FLAG_PIPELINE: stage 1 of batch k runs on `front` while stage 2 of batch k-1 runs on `stream` */
+    bool pipeline = false;
+    hipStream_t front = nullptr;
+    hipEvent_t ev_in = nullptr, ev_back = nullptr, ev_wait = nullptr, front_done[2] = {nullptr, nullptr};
+    hipStream_t last_stream = nullptr; /* stream the last sequential batch ran on (the caller's or ours) */
+    int row0_front = 0;            /* ring row of the batch stage 1 writes next (== row0 when not pipelined) */
+    uint64_t front_batches = 0;    /* batches whose stage 1 has been enqueued */
+    /* per-stage GPU time: a pool of event sets (one per process call) harvested lazily, so that nobody has to
+     * synchronise inside a run to read timings */
+    static constexpr int EV_POOL = 16;
+    hipEvent_t evp[EV_POOL][5] = {}; /* stage 1 begin / end, stage 2 begin, demod end, batch end */
+    uint8_t evp_state[EV_POOL] = {0}; /* bit 0: stage-1 pair recorded, bit 1: stage-2 pair recorded */
+    double t_sum[4] = {0, 0, 0, 0};
+    int64_t t_n[2] = {0, 0};          /* harvested stage-1 / stage-2 pairs */
+    float t_last[4] = {0, 0, 0, 0};
     bool timings_valid = false;
     std::string error;
 
@@ -149,8 +163,15 @@ void destroy(airband_hip_handle* h) {
     h->d_mix_run_first.release(); h->d_mix_run_mixer.release(); h->d_mix_first_run.release();
     h->d_mix_run_left.release(); h->d_mix_run_right.release(); h->d_mix_run_signal.release();
     h->d_sin_tab.release(); h->d_carriers.release();
-    for (auto& e : h->ev)
+    for (auto& set : h->evp)
+        for (auto& e : set)
+            if (e) (void)hipEventDestroy(e);
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+    if (h->ev_back) (void)hipEventDestroy(h->ev_back);
+    if (h->ev_wait) (void)hipEventDestroy(h->ev_wait);
+    for (auto& e : h->front_done)
         if (e) (void)hipEventDestroy(e);
+    if (h->front) (void)hipStreamDestroy(h->front);
     for (auto& e : h->fork_ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& st : h->side)
@@ -165,8 +186,41 @@ hipError_t fill(T* p, size_t n, T value, hipStream_t s) {
     return hipMemcpyAsync(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice, s);
 }
 
+/* Per-stage GPU times: every batch records into its own event set; finished sets are folded into running sums here. */
+void harvest_timings(airband_hip_handle* h, bool wait) {
+    for (int i = 0; i < airband_hip_handle::EV_POOL; i++) {
+        if (h->evp_state[i] != 3) continue;
+        hipEvent_t* e = h->evp[i];
+        if (wait) {
+            if (hipEventSynchronize(e[4]) != hipSuccess || hipEventSynchronize(e[1]) != hipSuccess) continue;
+        } else if (hipEventQuery(e[4]) != hipSuccess || hipEventQuery(e[1]) != hipSuccess) {
+            continue;
+        }
+        float a = 0, b = 0, c = 0;
+        if (hipEventElapsedTime(&a, e[0], e[1]) == hipSuccess && hipEventElapsedTime(&b, e[2], e[3]) == hipSuccess && hipEventElapsedTime(&c, e[3], e[4]) == hipSuccess) {
+            h->t_last[0] = a; h->t_last[1] = b; h->t_last[2] = c; h->t_last[3] = a + b + c;
+            for (int k = 0; k < 4; k++) h->t_sum[k] += h->t_last[k];
+            h->t_n[0]++;
+            h->timings_valid = true;
+        }
+        h->evp_state[i] = 0;
+    }
+}
+
+hipEvent_t* event_set(airband_hip_handle* h, uint64_t batch, int half) {
+    const int i = (int)(batch % airband_hip_handle::EV_POOL);
+    if (half == 0 && h->evp_state[i] != 0) { /* the pool wrapped around a set nobody has read yet */
+        harvest_timings(h, true);
+        h->evp_state[i] = 0;
+    }
+    h->evp_state[i] |= (uint8_t)(1u << half);
+    return h->evp[i];
+}
+
 /* stage 2 + emit (+ mixers) of the batch whose stage-1 rows are already in the rings */
 int run_back_half(airband_hip_handle* h, hipStream_t s) {
+    hipEvent_t* ev = event_set(h, h->batches_done, 1);
+    (void)hipEventRecord(ev[2], s);
     DemodArgs da;
     da.cc = h->d_cc.p;
     da.cs = h->d_cs.p;
@@ -207,7 +261,7 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     const bool emit_per_kind = !(h->any_afc && h->afc_spectrum_valid);
     launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev, emit_per_kind ? &ea : nullptr);
     if (!emit_per_kind) launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, s);
-    (void)hipEventRecord(h->ev[2], s);
+    (void)hipEventRecord(ev[3], s);
     if (!emit_per_kind) launch_emit(ea, s);
     if (h->n_mixers > 0) {
         MixArgs ma;
@@ -231,7 +285,7 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
         ma.wave_batch = h->B;
         launch_mix(ma, s);
     }
-    (void)hipEventRecord(h->ev[3], s);
+    (void)hipEventRecord(ev[4], s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, AIRBAND_HIP_ERUNTIME, std::string("kernel launch: ") + hipGetErrorString(e));
     /* rotate the rings: this batch's last AGC_EXTRA rows become the next batch's carry */
@@ -239,7 +293,7 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     h->batches_done++;
     if (h->results_ready) h->overruns++; /* like dev->output_overrun_count (src/rtl_airband.cpp:649-654) */
     h->results_ready = true;
-    h->timings_valid = true;
+    harvest_timings(h, false);
     return AIRBAND_HIP_OK;
 }
 
@@ -293,13 +347,27 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
         }                                                                                    \
     } while (0)
     PREP_TRY(hipSetDevice(cfg->hip_device), AIRBAND_HIP_ENODEV);
-    PREP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking), AIRBAND_HIP_ENODEV);
-    for (auto& e : h->ev) PREP_TRY(hipEventCreate(&e), AIRBAND_HIP_ENODEV);
+    int prio_lo = 0, prio_hi = 0; /* numerically lower = more urgent */
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    PREP_TRY(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi), AIRBAND_HIP_ENODEV);
+    for (auto& set : h->evp)
+        for (auto& e : set) PREP_TRY(hipEventCreate(&e), AIRBAND_HIP_ENODEV);
+    /* AFC needs stage 2's verdict on batch k before stage 1 of batch k+1 picks its bins (src/rtl_airband.cpp:222-251):
+     * such handles stay sequential */
+    h->pipeline = (cfg->flags & AIRBAND_HIP_FLAG_PIPELINE) && !any_afc;
+    if (h->pipeline) {
+        PREP_TRY(hipStreamCreateWithFlags(&h->front, hipStreamNonBlocking), AIRBAND_HIP_ENODEV);
+        PREP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
+        PREP_TRY(hipEventCreateWithFlags(&h->ev_back, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
+        for (auto& e : h->front_done) PREP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
+    }
     for (auto& e : h->fork_ev) PREP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
-    for (auto& st : h->side) PREP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), AIRBAND_HIP_ENODEV);
+    for (auto& st : h->side) PREP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_lo), AIRBAND_HIP_ENODEV);
 
     h->B = p.wave_batch;
-    h->R = (p.wave_batch + AB_AGC_EXTRA + AB_TILE_ROWS - 1) / AB_TILE_ROWS * AB_TILE_ROWS; /* ring rows: whole 16-row tiles */
+    /* ring rows, whole 16-row tiles: one batch plus its AGC_EXTRA carry -- or two batches deep when stage 1 of the next batch
+     * is written while stage 2 still reads this one */
+    h->R = ((h->pipeline ? 2 : 1) * p.wave_batch + AB_AGC_EXTRA + AB_TILE_ROWS - 1) / AB_TILE_ROWS * AB_TILE_ROWS;
     h->N = p.fft_size;
     /* demod slots: sort the channels by demod kind so that a 64-lane wavefront runs ONE code path (AM, NFM,
      * NFM+lowpass, NFM+CTCSS, everything else); kinds start on 64-slot block boundaries */
@@ -389,7 +457,7 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     h->ct_n_blocks = h->kind_n_blocks[AB_KIND_NFM_CTCSS] + h->kind_n_blocks[AB_KIND_GENERIC];
     h->ct_first_block = h->kind_n_blocks[AB_KIND_NFM_CTCSS] ? h->kind_first_block[AB_KIND_NFM_CTCSS] : h->kind_first_block[AB_KIND_GENERIC];
     if (h->ct_n_blocks > 0) {
-        PREP_TRY(h->d_ct_af.alloc((size_t)h->ct_n_blocks * h->B * AB_SLOT_BLOCK), AIRBAND_HIP_ENOMEM);
+        PREP_TRY(h->d_ct_af.alloc((size_t)h->ct_n_blocks * AB_SLOT_BLOCK * h->B), AIRBAND_HIP_ENOMEM);
         PREP_TRY(h->d_ct_mask.alloc((size_t)h->ct_n_blocks * (h->B / 50) * AB_SLOT_BLOCK), AIRBAND_HIP_ENOMEM);
     }
     if (h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH) {
@@ -499,15 +567,12 @@ int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const air
     return AIRBAND_HIP_OK;
 }
 
-int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t stride_bytes, void* stream) {
-    if (!h || !d_iq) return fail(h, AIRBAND_HIP_EINVAL, "NULL argument");
-    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+/* stage 1 of the next batch (index front_batches, ring rows from row0_front) on stream s */
+static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_bytes, hipStream_t s) {
     const Plan& p = h->plan;
-    const bool first = h->batches_done == 0;
+    const bool first = h->front_batches == 0;
+    hipEvent_t* ev = event_set(h, h->front_batches, 0);
     if (h->use_dft) {
-        if ((((uintptr_t)d_iq) | (uintptr_t)stride_bytes) & 15)
-            return fail(h, AIRBAND_HIP_EINVAL, "d_iq and stride_bytes must be multiples of 16 (the channelizer fetches 16 bytes per lane)");
         DftArgs a;
         a.iq = (const uint8_t*)d_iq;
         a.iq_stride = (long)stride_bytes;
@@ -527,7 +592,7 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
         a.lds_per_buf = dft_lds_per_buf((int)h->hop_bytes);
         a.nbuf = dft_nbuf((int)h->hop_bytes);
         a.sub = a.nbuf == 3 ? 1 : dft_sub_tiles((int)h->hop_bytes);
-        a.row0 = h->row0;
+        a.row0 = h->row0_front;
         a.ring_rows = h->R;
         a.first_row = first ? 0 : AB_AGC_EXTRA;
         a.n_hops = first ? h->B + AB_AGC_EXTRA : h->B;
@@ -537,38 +602,91 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
         if (splits > steps / 4) splits = steps / 4;
         if (splits < 1) splits = 1;
         a.splits = splits;
-        (void)hipEventRecord(h->ev[0], s);
+        (void)hipEventRecord(ev[0], s);
         launch_channelizer_dft(a, s);
-        (void)hipEventRecord(h->ev[1], s);
+        (void)hipEventRecord(ev[1], s);
+    } else {
+        ChannelizerArgs ca;
+        ca.iq = (const uint8_t*)d_iq;
+        ca.iq_stride = (long)stride_bytes;
+        ca.dev = h->d_dev.p;
+        ca.cs = h->d_cs.p;
+        ca.cc = h->d_cc.p;
+        ca.ext_to_slot = h->d_ext_to_slot.p;
+        ca.window = h->d_window.p;
+        ca.mag = h->d_mag.p;
+        ca.iq_bins = h->d_iq.p;
+        ca.last_spectrum = h->any_afc ? h->d_spectrum.p : nullptr;
+        ca.n_dev = p.n_dev;
+        ca.fft_log = p.fft_log;
+        ca.hop_samples = p.dev[0].hop_samples;
+        ca.bytes_per_sample = p.dev[0].bytes_per_sample;
+        ca.sfmt = p.dev[0].sfmt;
+        ca.scale = p.dev[0].scale;
+        ca.row0 = h->row0_front;
+        ca.ring_rows = h->R;
+        ca.first_row = first ? 0 : AB_AGC_EXTRA; /* the first batch also produces the AGC_EXTRA lead-in hops (waveend starts at 0, src/config.cpp:805) */
+        ca.n_hops = first ? h->B + AB_AGC_EXTRA : h->B;
+        ca.max_ch = p.max_ch;
+        (void)hipEventRecord(ev[0], s);
+        h->afc_spectrum_valid = h->any_afc;
+        launch_channelizer_fft(ca, s);
+        (void)hipEventRecord(ev[1], s);
+    }
+    h->row0_front = (h->row0_front + h->B) % h->R;
+    h->front_batches++;
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t stride_bytes, void* stream) {
+    if (!h || !d_iq) return fail(h, AIRBAND_HIP_EINVAL, "NULL argument");
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    if (h->use_dft && ((((uintptr_t)d_iq) | (uintptr_t)stride_bytes) & 15))
+        return fail(h, AIRBAND_HIP_EINVAL, "d_iq and stride_bytes must be multiples of 16 (the channelizer fetches 16 bytes per lane)");
+    if (!h->pipeline) {
+        hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+        h->last_stream = s;
+        launch_front(h, d_iq, stride_bytes, s);
         return run_back_half(h, s);
     }
-    ChannelizerArgs ca;
-    ca.iq = (const uint8_t*)d_iq;
-    ca.iq_stride = (long)stride_bytes;
-    ca.dev = h->d_dev.p;
-    ca.cs = h->d_cs.p;
-    ca.cc = h->d_cc.p;
-    ca.ext_to_slot = h->d_ext_to_slot.p;
-    ca.window = h->d_window.p;
-    ca.mag = h->d_mag.p;
-    ca.iq_bins = h->d_iq.p;
-    ca.last_spectrum = h->any_afc ? h->d_spectrum.p : nullptr;
-    ca.n_dev = p.n_dev;
-    ca.fft_log = p.fft_log;
-    ca.hop_samples = p.dev[0].hop_samples;
-    ca.bytes_per_sample = p.dev[0].bytes_per_sample;
-    ca.sfmt = p.dev[0].sfmt;
-    ca.scale = p.dev[0].scale;
-    ca.row0 = h->row0;
-    ca.ring_rows = h->R;
-    ca.first_row = first ? 0 : AB_AGC_EXTRA; /* the first batch also produces the AGC_EXTRA lead-in hops (waveend starts at 0, src/config.cpp:805) */
-    ca.n_hops = first ? h->B + AB_AGC_EXTRA : h->B;
-    ca.max_ch = p.max_ch;
-    (void)hipEventRecord(h->ev[0], s);
-    h->afc_spectrum_valid = h->any_afc;
-    launch_channelizer_fft(ca, s);
-    (void)hipEventRecord(h->ev[1], s);
-    return run_back_half(h, s);
+    /* Pipelined: stage 1 of this batch (k) goes on the front stream and runs beside stage 2 of batch k-1, which is enqueued
+     * right after it on the handle's stream.  Stage 1 (k) overwrites the ring rows stage 2 (k-2) read, and may use the
+     * caller's input as soon as the caller's stream (or everything enqueued on the handle so far) has produced it. */
+    hipStream_t in = stream ? (hipStream_t)stream : h->stream;
+    HIP_TRY(h, hipEventRecord(h->ev_in, in), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipStreamWaitEvent(h->front, h->ev_in, 0), AIRBAND_HIP_ERUNTIME);
+    if (in != h->stream) {
+        /* a caller stream orders BOTH halves: its earlier work (producing this input, consuming the previous results) is done
+         * before stage 1 reads and before stage 2 overwrites the result buffers */
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_in, 0), AIRBAND_HIP_ERUNTIME);
+        HIP_TRY(h, hipEventRecord(h->ev_back, h->stream), AIRBAND_HIP_ERUNTIME);
+        HIP_TRY(h, hipStreamWaitEvent(h->front, h->ev_back, 0), AIRBAND_HIP_ERUNTIME);
+    }
+    const uint64_t k = h->front_batches;
+    launch_front(h, d_iq, stride_bytes, h->front);
+    HIP_TRY(h, hipEventRecord(h->front_done[k & 1], h->front), AIRBAND_HIP_ERUNTIME);
+    if (k == 0) return AIRBAND_HIP_OK; /* nothing to demodulate yet: the first results appear with the second call (or flush) */
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->front_done[(k - 1) & 1], 0), AIRBAND_HIP_ERUNTIME);
+    return run_back_half(h, h->stream);
+}
+
+int airband_hip_stream_wait_results(airband_hip_handle* h, void* stream) {
+    if (!h || !stream) return fail(h, AIRBAND_HIP_EINVAL, "NULL argument");
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    if (!h->ev_wait) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_wait, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
+    hipStream_t res = h->pipeline ? h->stream : (h->last_stream ? h->last_stream : h->stream);
+    if (res == (hipStream_t)stream) return AIRBAND_HIP_OK;
+    HIP_TRY(h, hipEventRecord(h->ev_wait, res), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipStreamWaitEvent((hipStream_t)stream, h->ev_wait, 0), AIRBAND_HIP_ERUNTIME);
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_flush(airband_hip_handle* h) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    if (!h->pipeline || h->front_batches == h->batches_done) return AIRBAND_HIP_OK;
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->front_done[(h->front_batches - 1) & 1], 0), AIRBAND_HIP_ERUNTIME);
+    return run_back_half(h, h->stream);
 }
 
 int64_t airband_hip_submit(airband_hip_handle* h, int32_t dev, const void* iq, size_t nbytes) {
@@ -587,7 +705,7 @@ int64_t airband_hip_submit(airband_hip_handle* h, int32_t dev, const void* iq, s
 int airband_hip_process(airband_hip_handle* h) {
     if (!h) return AIRBAND_HIP_EINVAL;
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
-    const bool first = h->batches_done == 0;
+    const bool first = h->front_batches == 0;
     const int64_t consume = first ? h->first_batch_bytes : h->batch_bytes;
     const int64_t need = consume + h->lookahead_bytes; /* availability rule (src/rtl_airband.cpp:394-400) applied to a whole batch */
     for (auto& q : h->pending)
@@ -598,6 +716,7 @@ int airband_hip_process(airband_hip_handle* h) {
         HIP_TRY(h, hipHostMalloc((void**)&h->h_stage, (size_t)h->stage_stride * h->plan.n_dev, hipHostMallocDefault), AIRBAND_HIP_ENOMEM);
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream), AIRBAND_HIP_ERUNTIME); /* previous batch may still read the staging buffer */
+    if (h->pipeline) HIP_TRY(h, hipStreamSynchronize(h->front), AIRBAND_HIP_ERUNTIME);
     for (int d = 0; d < h->plan.n_dev; d++) {
         std::vector<uint8_t>& q = h->pending[d];
         std::memcpy(h->h_stage + (size_t)d * h->stage_stride, q.data(), (size_t)need);
@@ -609,6 +728,7 @@ int airband_hip_process(airband_hip_handle* h) {
 
 int airband_hip_process_bins(airband_hip_handle* h, const float* wavein, const float* iq_in) {
     if (!h || !wavein || !iq_in) return fail(h, AIRBAND_HIP_EINVAL, "NULL argument");
+    if (h->pipeline) return fail(h, AIRBAND_HIP_EINVAL, "process_bins (stage 2 only) is not available on a pipelined handle");
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
     const size_t n = (size_t)h->plan.total_ch * h->B;
     if (!h->d_tmp_wavein.p) {
@@ -618,16 +738,20 @@ int airband_hip_process_bins(airband_hip_handle* h, const float* wavein, const f
     hipStream_t s = h->stream;
     HIP_TRY(h, hipMemcpyAsync(h->d_tmp_wavein.p, wavein, n * sizeof(float), hipMemcpyHostToDevice, s), AIRBAND_HIP_ERUNTIME);
     HIP_TRY(h, hipMemcpyAsync(h->d_tmp_iqin.p, iq_in, 2 * n * sizeof(float), hipMemcpyHostToDevice, s), AIRBAND_HIP_ERUNTIME);
-    (void)hipEventRecord(h->ev[0], s);
+    hipEvent_t* ev = event_set(h, h->front_batches, 0);
+    (void)hipEventRecord(ev[0], s);
     h->afc_spectrum_valid = false;
     launch_scatter_bins(h->d_tmp_wavein.p, h->d_tmp_iqin.p, h->d_slot_to_ext.p, h->d_cc.p, h->d_mag.p, h->d_iq.p, h->n_slots, h->B, h->row0, h->R, s);
-    (void)hipEventRecord(h->ev[1], s);
+    (void)hipEventRecord(ev[1], s);
+    h->row0_front = (h->row0_front + h->B) % h->R;
+    h->front_batches++;
     return run_back_half(h, s);
 }
 
 int airband_hip_synchronize(airband_hip_handle* h) {
     if (!h) return AIRBAND_HIP_EINVAL;
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    if (h->front) HIP_TRY(h, hipStreamSynchronize(h->front), AIRBAND_HIP_ERUNTIME);
     HIP_TRY(h, hipStreamSynchronize(h->stream), AIRBAND_HIP_ERUNTIME);
     return AIRBAND_HIP_OK;
 }
@@ -720,13 +844,24 @@ int airband_hip_channel_constants(const airband_hip_handle* h, int32_t channel_i
 
 int airband_hip_last_timings(airband_hip_handle* h, float* ms4) {
     if (!h || !ms4) return AIRBAND_HIP_EINVAL;
-    if (!h->timings_valid) return AIRBAND_HIP_EAGAIN;
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
-    HIP_TRY(h, hipEventSynchronize(h->ev[3]), AIRBAND_HIP_ERUNTIME);
-    HIP_TRY(h, hipEventElapsedTime(&ms4[0], h->ev[0], h->ev[1]), AIRBAND_HIP_ERUNTIME);
-    HIP_TRY(h, hipEventElapsedTime(&ms4[1], h->ev[1], h->ev[2]), AIRBAND_HIP_ERUNTIME);
-    HIP_TRY(h, hipEventElapsedTime(&ms4[2], h->ev[2], h->ev[3]), AIRBAND_HIP_ERUNTIME);
-    HIP_TRY(h, hipEventElapsedTime(&ms4[3], h->ev[0], h->ev[3]), AIRBAND_HIP_ERUNTIME);
+    harvest_timings(h, true);
+    if (!h->timings_valid) return AIRBAND_HIP_EAGAIN;
+    for (int k = 0; k < 4; k++) ms4[k] = h->t_last[k];
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_timing_totals(airband_hip_handle* h, double* ms4_sum, int64_t* n_batches, int32_t reset) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    harvest_timings(h, true);
+    if (ms4_sum)
+        for (int k = 0; k < 4; k++) ms4_sum[k] = h->t_sum[k];
+    if (n_batches) *n_batches = h->t_n[0];
+    if (reset) {
+        for (double& v : h->t_sum) v = 0.0;
+        h->t_n[0] = 0;
+    }
     return AIRBAND_HIP_OK;
 }
 

@@ -24,6 +24,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 #include "squelch_fsm.h"
@@ -45,15 +47,21 @@ constexpr int FL_STATE_SHIFT = 3;   /* bits 3..5: Squelch::State, for the trace 
 
 /* fast_atan2 / polar_disc_fast / fm_quadri_demod (src/rtl_airband.cpp:141-176) */
 __device__ __forceinline__ float fast_atan2_dev(float y, float x) {
+    /* The reference picks one of  pi/4 - pi/4 * (x - |y|) / (x + |y|)   (x >= 0)
+     *                             3pi/4 - pi/4 * (x + |y|) / (|y| - x)   (x <  0).
+     * The sign of x differs from lane to lane, so both arms would run under masks -- two IEEE divisions.  Selecting the
+     * operands instead leaves one: same operations on the same values in either case (|y| - x is the exact negation of
+     * x - |y|), hence the same float. */
     const float pi4 = (float)0.78539816339744830962, pi34 = (float)(3 * 0.78539816339744830962);
-    if (x == 0.0f && y == 0.0f) return 0.0f;
     const float ay = y < 0.0f ? -y : y;
-    float a;
-    if (x >= 0.0f)
-        a = pi4 - pi4 * (x - ay) / (x + ay);
-    else
-        a = pi34 - pi4 * (x + ay) / (ay - x);
-    return y < 0.0f ? -a : a;
+    const float diff = x - ay, sum = x + ay;
+    const bool right = x >= 0.0f;
+    const float num = right ? diff : sum;
+    const float den = right ? sum : -diff;
+    const float base = right ? pi4 : pi34;
+    const float a = base - pi4 * num / den;
+    const float r = y < 0.0f ? -a : a;
+    return (x == 0.0f && y == 0.0f) ? 0.0f : r;
 }
 
 __device__ __forceinline__ int ring_row(int r, int R) { return r >= R ? r - R : r; }
@@ -124,7 +132,10 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
 #ifndef AB_DEMOD_UNROLL
 #define AB_DEMOD_UNROLL 2
 #endif
-    constexpr int UNROLL = KIND == AB_KIND_AM ? CHUNK : AB_DEMOD_UNROLL; /* per-sample loop: how many samples share one loop body */
+#ifndef AB_DEMOD_UNROLL_AM
+#define AB_DEMOD_UNROLL_AM CHUNK
+#endif
+    constexpr int UNROLL = KIND == AB_KIND_AM ? AB_DEMOD_UNROLL_AM : AB_DEMOD_UNROLL; /* per-sample loop: how many samples share one loop body */
     const int lane = threadIdx.x & 63;
     constexpr long S = AB_SLOT_BLOCK;
     const int R = a.ring_rows, B = a.wave_batch;
@@ -173,7 +184,8 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
     float* my = lds + lane * NS; /* element (u, lane) at lds[(u * 64 + lane) * NS ...] */
     /* split kinds: (audio, flags) rows for the tone / back kernels, [ct block][sample][64 lanes] */
-    float2* ct_af = WAVE_HAS_CTCSS ? a.ct_af + ((long)((slot >> 6) - a.ct_first_block) * B) * S + lane : nullptr;
+    /* split kinds: (audio, flags) for the tone / back kernels, channel-major [ct slot][sample] */
+    float2* ct_af = WAVE_HAS_CTCSS ? a.ct_af + (long)(slot - a.ct_first_block * 64) * B : nullptr;
 
     for (int j0 = 0; j0 < B; j0 += CHUNK) {
         /* ---- phase 0: the chunk's stage-1 values, 16 bytes (4 rows) per load, parked in LDS -------------------------
@@ -318,10 +330,19 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                     /* front half of a CTCSS-capable kind: hand (pre-notch audio, flags) to the tone and back kernels.  Raw I/Q of
                      * an open sample is written now; the back kernel zeroes it again if the tone gate turns out closed. */
                     const unsigned f = (audio ? FL_AUDIO : 0u) | (fade ? FL_FADE : 0u) | (ab_lane(went_closed) ? FL_RESET : 0u) | (a.trace ? (unsigned)sq_cur(s) << FL_STATE_SHIFT : 0u);
-                    ct_af[(long)j * S] = make_float2(out, __uint_as_float(f));
+                    /* parked in the (consumed) LDS slot of this sample; the chunk leaves as one 64-byte run per lane below */
+                    *reinterpret_cast<float2*>(my + u * 64 * NS) = make_float2(out, __uint_as_float(f));
                     if ((cc.flags & AB_F_IQ_OUT) && audio) iqout[(long)j * S] = make_float2(re, im);
                 } else {
                     emit_sample(a, cc, o, wave, iqout, trace, j, audio, fade, true, trace ? sq_cur(s) : 0, out, re, im, true);
+                }
+            }
+            if (WAVE_HAS_CTCSS) {
+                float4* dst = reinterpret_cast<float4*>(ct_af + j0); /* 16-byte aligned: wave_batch and the chunk start are even */
+#pragma unroll
+                for (int q = 0; q < CHUNK / 2; q++) {
+                    const float2 p0 = *reinterpret_cast<const float2*>(my + (2 * q) * 64 * NS), p1 = *reinterpret_cast<const float2*>(my + (2 * q + 1) * 64 * NS);
+                    dst[q] = make_float4(p0.x, p0.y, p1.x, p1.y);
                 }
             }
         }
@@ -396,12 +417,12 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
     float q1s = t1 ? qtab[2 * AB_MAX_TONES + lane] : 0.0f, q2s = t1 ? qtab[3 * AB_MAX_TONES + lane] : 0.0f;
 
     const long blk = wave >> 6;
-    const float2* af = a.ct_af + (blk * B) * AB_SLOT_BLOCK + (wave & 63);
+    const float2* af = a.ct_af + (long)wave * B; /* this channel's batch, contiguous: 50 lanes fetch 400 consecutive bytes */
     unsigned long long* maskp = a.ct_mask + (blk * NG) * AB_SLOT_BLOCK + (wave & 63);
-    float2 cur = lane < TONE_GROUP ? af[(long)lane * AB_SLOT_BLOCK] : make_float2(0.0f, 0.0f);
+    float2 cur = lane < TONE_GROUP ? af[lane] : make_float2(0.0f, 0.0f);
     for (int g = 0; g < NG; g++) {
         float2 nxt = make_float2(0.0f, 0.0f);
-        if (g + 1 < NG && lane < TONE_GROUP) nxt = af[((long)(g + 1) * TONE_GROUP + lane) * AB_SLOT_BLOCK];
+        if (g + 1 < NG && lane < TONE_GROUP) nxt = af[(g + 1) * TONE_GROUP + lane];
         const float ax = cur.x;
         const unsigned fl = __float_as_uint(cur.y);
         unsigned long long mask = 0;
@@ -492,8 +513,7 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
 /* Back half of the split kinds: output gating (squelch open AND tone present), notch, ampfactor, clamp, AM fade-out
  * (reference: src/rtl_airband.cpp:532-547,589-620), one lane per channel, samples staged through LDS 25 at a time. */
 __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
-    constexpr int SUBCHUNK = 25;
-    __shared__ float2 stage[SUBCHUNK][64];
+    constexpr int PIECE = 10; /* samples fetched ahead per lane: 5 x 16 bytes of the lane's own (channel-major) hand-off row */
     const int lane = threadIdx.x;
     const int slot = (a.ct_first_block + blockIdx.x) * 64 + lane;
     const ChanConst cc = a.cc[slot];
@@ -506,20 +526,31 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
     float* wave = a.wave + ab_ring_base(slot, R);
     float2* iqout = a.iq_out + ab_ring_base(slot, B);
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
-    const float2* af = a.ct_af + ((long)blockIdx.x * B) * AB_SLOT_BLOCK + lane;
+    /* every lane walks its own contiguous row: all bytes of the lines it touches are its own, the re-use is served by L2 */
+    const float4* af = reinterpret_cast<const float4*>(a.ct_af + (long)(slot - a.ct_first_block * 64) * B);
     const unsigned long long* maskp = a.ct_mask + ((long)blockIdx.x * NG) * AB_SLOT_BLOCK + lane;
     const bool is_ct = (cc.flags & AB_F_CTCSS) != 0;
+    float4 nxt[PIECE / 2];
+#pragma unroll
+    for (int q = 0; q < PIECE / 2; q++) nxt[q] = af[q];
     for (int g = 0; g < NG; g++) {
         const unsigned long long mask = is_ct ? maskp[(long)g * AB_SLOT_BLOCK] : ~0ull;
-        for (int h = 0; h < TONE_GROUP / SUBCHUNK; h++) {
-            const int j0 = g * TONE_GROUP + h * SUBCHUNK;
+        for (int h = 0; h < TONE_GROUP / PIECE; h++) {
+            const int j0 = g * TONE_GROUP + h * PIECE;
+            float4 cur[PIECE / 2];
 #pragma unroll
-            for (int u = 0; u < SUBCHUNK; u++) stage[u][lane] = af[(long)(j0 + u) * AB_SLOT_BLOCK];
-            for (int u = 0; u < SUBCHUNK; u++) {
-                const float2 w = stage[u][lane];
-                const unsigned f = __float_as_uint(w.y);
-                const bool tone = ((mask >> (h * SUBCHUNK + u)) & 1ull) != 0;
-                emit_sample(a, cc, o, wave, iqout, trace, j0 + u, (f & FL_AUDIO) != 0, (f & FL_FADE) != 0, tone, (int)((f >> FL_STATE_SHIFT) & 7u), w.x, 0.0f, 0.0f, false);
+            for (int q = 0; q < PIECE / 2; q++) cur[q] = nxt[q];
+            if (j0 + PIECE < B) {
+#pragma unroll
+                for (int q = 0; q < PIECE / 2; q++) nxt[q] = af[(j0 + PIECE) / 2 + q];
+            }
+#pragma unroll
+            for (int u = 0; u < PIECE; u++) {
+                const float4 p = cur[u >> 1];
+                const float w = (u & 1) ? p.z : p.x;
+                const unsigned f = __float_as_uint((u & 1) ? p.w : p.y);
+                const bool tone = ((mask >> (h * PIECE + u)) & 1ull) != 0;
+                emit_sample(a, cc, o, wave, iqout, trace, j0 + u, (f & FL_AUDIO) != 0, (f & FL_FADE) != 0, tone, (int)((f >> FL_STATE_SHIFT) & 7u), w, 0.0f, 0.0f, false);
             }
         }
     }
@@ -533,9 +564,16 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
  * lane-per-channel kernel holds at most 4 waves per SIMD and the NFM kinds have only half that many wavefronts at BASELINE
  * config #3.  So the split chain (front -> tone -> back, the longest) goes on the caller's stream and the fused kinds run
  * beside it on side streams, forked and joined with events (works the same under graph capture). */
+/* experiment knob: extra LDS per AM block caps how many of the (cheap, register-hungry in aggregate) AM waves a CU holds */
+static size_t am_lds_pad() {
+    static const size_t v = [] { const char* e = getenv("AIRBAND_AM_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+    return v;
+}
+
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev, const EmitArgs* emit) {
     auto launch_kind = [&](int k, hipStream_t s) {
-        const size_t lds = (size_t)CHUNK * 64 * sizeof(float) * (k == AB_KIND_AM ? 2 : 4) + (k == AB_KIND_AM ? 0 : 257 * sizeof(float2));
+        size_t lds = (size_t)CHUNK * 64 * sizeof(float) * (k == AB_KIND_AM ? 2 : 4) + (k == AB_KIND_AM ? 0 : 257 * sizeof(float2));
+        if (k == AB_KIND_AM) lds += am_lds_pad();
         const int n = kind_n_blocks[k], f = kind_first_block[k];
         if (n <= 0) return;
         switch (k) {
@@ -547,17 +585,10 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
         }
     };
     const bool fork = side != nullptr && ev != nullptr;
-    const int fused[3] = {AB_KIND_NFM_LOWPASS, AB_KIND_AM, AB_KIND_NFM};
-    if (fork) {
-        (void)hipEventRecord(ev[0], stream); /* stage 1 is done at this point of the caller's stream */
-        for (int i = 0; i < 3; i++) {
-            if (kind_n_blocks[fused[i]] <= 0) continue;
-            (void)hipStreamWaitEvent(side[i], ev[0], 0);
-            launch_kind(fused[i], side[i]);
-            if (emit) launch_emit(*emit, side[i], kind_first_block[fused[i]], kind_n_blocks[fused[i]]);
-            (void)hipEventRecord(ev[1 + i], side[i]);
-        }
-    }
+    const int fused[3] = {AB_KIND_NFM_LOWPASS, AB_KIND_NFM, AB_KIND_AM};
+    if (fork) (void)hipEventRecord(ev[0], stream); /* stage 1 is done at this point of the caller's stream */
+    /* the split chain is the longest dependent sequence of stage 2: it is enqueued first (and its stream has the higher
+     * priority), the fused kinds fill in beside it -- heaviest first, the cheap AM kernel last */
     launch_kind(AB_KIND_NFM_CTCSS, stream);
     launch_kind(AB_KIND_GENERIC, stream);
     if (a.ct_n_blocks > 0) {
@@ -568,13 +599,15 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
         launch_emit(*emit, stream, kind_first_block[AB_KIND_NFM_CTCSS], kind_n_blocks[AB_KIND_NFM_CTCSS]);
         launch_emit(*emit, stream, kind_first_block[AB_KIND_GENERIC], kind_n_blocks[AB_KIND_GENERIC]);
     }
-    if (fork) {
-        for (int i = 0; i < 3; i++)
-            if (kind_n_blocks[fused[i]] > 0) (void)hipStreamWaitEvent(stream, ev[1 + i], 0);
-    } else {
-        for (int i = 0; i < 3; i++) {
-            launch_kind(fused[i], stream);
-            if (emit) launch_emit(*emit, stream, kind_first_block[fused[i]], kind_n_blocks[fused[i]]);
+    for (int i = 0; i < 3; i++) {
+        if (kind_n_blocks[fused[i]] <= 0) continue;
+        hipStream_t s = fork ? side[i] : stream;
+        if (fork) (void)hipStreamWaitEvent(s, ev[0], 0);
+        launch_kind(fused[i], s);
+        if (emit) launch_emit(*emit, s, kind_first_block[fused[i]], kind_n_blocks[fused[i]]);
+        if (fork) {
+            (void)hipEventRecord(ev[1 + i], s);
+            (void)hipStreamWaitEvent(stream, ev[1 + i], 0);
         }
     }
 }

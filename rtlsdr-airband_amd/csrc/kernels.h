@@ -67,7 +67,7 @@ struct DemodArgs {
     float* ct_q;            /* [n_ctcss][2 detectors][q1|q2][AB_MAX_TONES] */
     uint8_t* trace;         /* [wave_batch][stride] or null */
     /* split (CTCSS-capable) kinds: front -> tone -> back hand-off */
-    float2* ct_af;                 /* [ct blocks][wave_batch][64] (pre-notch audio, flag word) */
+    float2* ct_af;                 /* [ct slots][wave_batch] (pre-notch audio, flag word), channel-major: the tone kernel reads a channel's samples across its lanes */
     unsigned long long* ct_mask;   /* [ct blocks][wave_batch / 50][64] tone-present bits */
     int ct_first_block, ct_n_blocks;
     const float* sin_lut;   /* 257 */

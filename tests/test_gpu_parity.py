@@ -139,6 +139,89 @@ def test_zero_copy_device_path_matches_host_ring_path(pkg, built):
             off += g.first_batch_bytes if k == 0 else g.batch_bytes
 
 
+@pytest.mark.parametrize("mixed,wave_rate", [(False, 8000), (True, 16000)])
+def test_pipelined_mode_is_the_sequential_mode_one_batch_late(pkg, built, mixed, wave_rate):
+    """AIRBAND_HIP_FLAG_PIPELINE (stage 1 of batch k beside stage 2 of batch k-1, two-batch-deep rings, two streams):
+    every output is bit-identical to the sequential handle's, one process call later; flush() drains the last batch.
+    Both entry points are covered: the zero-copy device path and the host-ring path."""
+    torch = pytest.importorskip("torch")
+    n_dev, n_batches = 5, 9
+    devices, carriers = helpers.plan_devices(n_dev, mixed, _tweak if mixed else None)
+    nbytes = helpers.stream_bytes(n_batches, wave_rate)
+    iq = np.stack([pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)])
+    mix = [(d, c, (d * 8 + c) % 3, 1.0 + 0.1 * c, 0.0) for d in range(n_dev) for c in range(8)]
+    P = pkg.capi.FLAG_PIPELINE | pkg.capi.FLAG_TRACE_SQUELCH
+    with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=pkg.capi.FLAG_TRACE_SQUELCH) as seq, pkg.AirbandHip(devices, wave_rate=wave_rate, flags=P) as pip, \
+            pkg.AirbandHip(devices, wave_rate=wave_rate, flags=P) as pip_host:
+        for h in (seq, pip, pip_host):
+            h.set_mixers(3, mix)
+        g = seq.geometry
+        assert pip.geometry.first_batch_bytes == g.first_batch_bytes and pip.geometry.lookahead_bytes == g.lookahead_bytes
+        dbuf = torch.from_numpy(iq).cuda()
+        want = []
+        off = 0
+        opened = 0
+        for k in range(n_batches):
+            seq.process_device(dbuf.data_ptr() + off, dbuf.stride(0))
+            r = seq.collect(iq=True, stats=True)
+            r["trace"] = seq.read_trace()
+            r["mix"] = seq.collect_mixers()
+            want.append(r)
+            opened += int((r["axc"] == ord("*")).sum())
+            off += g.first_batch_bytes if k == 0 else g.batch_bytes
+        assert opened > 0
+
+        def check(got, k, what):
+            w = want[k]
+            assert np.array_equal(got["axc"], w["axc"]), "%s batch %d axc" % (what, k)
+            assert np.array_equal(got["waveout"].view(np.uint32), w["waveout"].view(np.uint32)), "%s batch %d waveout" % (what, k)
+            assert np.array_equal(got["iq_out"].view(np.uint32), w["iq_out"].view(np.uint32)), "%s batch %d iq_out" % (what, k)
+            assert np.array_equal(got["trace"], w["trace"]), "%s batch %d trace" % (what, k)
+            for a, b in zip(got["mix"], w["mix"]):
+                assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8)), "%s batch %d mixers" % (what, k)
+            for x, y in zip(got["stats"], w["stats"]):
+                for f in ("noise_level", "signal_level", "squelch_level", "agcavgfast", "open_count", "flappy_count", "ctcss_count", "no_ctcss_count",
+                          "active_counter", "bin", "squelch_state"):
+                    assert x[f] == y[f], (what, k, f)
+
+        def grab(h):
+            r = h.collect(iq=True, stats=True)
+            r["trace"] = h.read_trace()
+            r["mix"] = h.collect_mixers()
+            return r
+
+        # zero-copy device path
+        off = 0
+        for k in range(n_batches):
+            pip.process_device(dbuf.data_ptr() + off, dbuf.stride(0))
+            if k == 0:
+                with pytest.raises(pkg.AirbandError) as e:  # nothing to collect yet
+                    pip.collect()
+                assert e.value.code == pkg.capi.EAGAIN
+            else:
+                check(grab(pip), k - 1, "device path")
+            off += g.first_batch_bytes if k == 0 else g.batch_bytes
+        pip.flush()
+        check(grab(pip), n_batches - 1, "device path (flush)")
+        pip.flush()  # idempotent
+        # host-ring path, fed in ragged pieces
+        pos = [0] * n_dev
+        done = started = 0
+        while done < n_batches - 1:
+            for d in range(n_dev):
+                if pos[d] < nbytes:
+                    pos[d] += pip_host.submit(d, iq[d][pos[d]:pos[d] + 250_003 + 16 * d])
+            while pip_host.process():
+                started += 1
+                if started >= 2:
+                    check(grab(pip_host), done, "host path")
+                    done += 1
+        pip_host.flush()
+        check(grab(pip_host), done, "host path (flush)")
+        t = pip.timing_totals()
+        assert t["batches"] == n_batches and t["channelizer_ms"] > 0 and t["demod_ms"] > 0
+
+
 def test_mixers_match_reference_order_sum(pkg, built):
     """GPU-side mixer sums (src/mixer.cpp:133-140,201-214) vs the oracle's restatement: small mixers bit-exact (same
     summation order), a many-input mixer within float tolerance; stereo via balance."""
