@@ -129,7 +129,7 @@ typedef struct airband_hip_geometry {
     int32_t total_channels;    /* sum of channel_count                                                */
     int32_t max_channels;      /* max channel_count                                                   */
     int32_t mixer_count;
-    int32_t reserved;
+    int32_t wave_stride;       /* floats between two channels' rows in the DEVICE waveout buffer (airband_hip_device_results) */
     int64_t first_batch_bytes; /* per device: IQ bytes the first batch consumes (incl. AGC_EXTRA hops) */
     int64_t batch_bytes;       /* per device: IQ bytes every later batch consumes                     */
     int64_t lookahead_bytes;   /* per device: bytes past the batch the last FFT window still reads    */
@@ -215,7 +215,9 @@ int airband_hip_collect(airband_hip_handle* h, float* waveout, float* iq_out, ch
 int airband_hip_collect_mixers(airband_hip_handle* h, float* left, float* right, uint8_t* has_signal);
 
 /* Device-side views of the current result buffers (valid until the next process call), for consumers
- * that stay on the GPU (e.g. an RCCL all-reduce of the mixer sums).  Any out-pointer may be NULL. */
+ * that stay on the GPU (e.g. an RCCL all-reduce of the mixer sums).  Any out-pointer may be NULL.
+ * d_waveout is laid out like the reference's channel->waveout arrays: channel c's WAVE_BATCH samples start at
+ * d_waveout + c * geometry.wave_stride (the AGC_EXTRA floats behind them are the carry into the next batch). */
 int airband_hip_device_results(airband_hip_handle* h, float** d_waveout, float** d_iq_out, uint8_t** d_axc, float** d_mix_left, float** d_mix_right,
                                uint8_t** d_mix_signal);
 

@@ -36,7 +36,7 @@ class MixerInput(C.Structure):
 
 class Geometry(C.Structure):
     _fields_ = [("fft_size", C.c_int32), ("wave_rate", C.c_int32), ("wave_batch", C.c_int32), ("device_count", C.c_int32), ("total_channels", C.c_int32),
-                ("max_channels", C.c_int32), ("mixer_count", C.c_int32), ("reserved", C.c_int32), ("first_batch_bytes", C.c_int64),
+                ("max_channels", C.c_int32), ("mixer_count", C.c_int32), ("wave_stride", C.c_int32), ("first_batch_bytes", C.c_int64),
                 ("batch_bytes", C.c_int64), ("lookahead_bytes", C.c_int64)]
 
 

@@ -73,6 +73,7 @@ struct airband_hip_handle {
     int kind_first_block[AB_KIND_COUNT] = {0}, kind_n_blocks[AB_KIND_COUNT] = {0};
     int64_t hop_bytes = 0, first_batch_bytes = 0, batch_bytes = 0, lookahead_bytes = 0;
     int row0 = 0;
+    int wave_stride = 0;   /* floats between two channels' rows of d_out_wave */
     uint64_t batches_done = 0;
     bool results_ready = false;
     uint64_t overruns = 0;
@@ -84,7 +85,7 @@ struct airband_hip_handle {
     DevBuf<int> d_slot_to_ext, d_ext_to_slot;
     DevBuf<uint8_t> d_block_kind;
     DevBuf<float> d_window, d_sin, d_cos;
-    DevBuf<float> d_mag, d_wave, d_sqbuf, d_ct_coeff, d_ct_q;
+    DevBuf<float> d_mag, d_sqbuf, d_ct_coeff, d_ct_q;
     DevBuf<float2> d_iq, d_iq_out, d_ct_af;
     DevBuf<unsigned long long> d_ct_mask;
     int ct_first_block = 0, ct_n_blocks = 0;
@@ -151,7 +152,7 @@ void destroy(airband_hip_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_dev.release(); h->d_cc.release(); h->d_cs.release(); h->d_slot_to_ext.release(); h->d_ext_to_slot.release(); h->d_block_kind.release();
     h->d_window.release(); h->d_sin.release(); h->d_cos.release();
-    h->d_mag.release(); h->d_wave.release(); h->d_sqbuf.release(); h->d_ct_coeff.release(); h->d_ct_q.release();
+    h->d_mag.release(); h->d_sqbuf.release(); h->d_ct_coeff.release(); h->d_ct_q.release();
     h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release(); h->d_ct_af.release(); h->d_ct_mask.release();
     h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
     h->d_tmp_wavein.release(); h->d_tmp_iqin.release(); h->d_tmp_trace.release(); h->d_spectrum.release();
@@ -226,7 +227,11 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.cs = h->d_cs.p;
     da.mag = h->d_mag.p;
     da.iq = h->d_iq.p;
-    da.wave = h->d_wave.p;
+    da.out_wave = h->d_out_wave.p; /* row starts; the kernels skip AB_OUT_PAD themselves */
+    da.out_axc = h->d_out_axc.p;
+    da.slot_to_ext = h->d_slot_to_ext.p;
+    da.wave_stride = h->wave_stride;
+    da.tail_copy = h->batches_done > 0 ? 1 : 0; /* the consumer's tail copy (src/output.cpp:920) happens after it has read a batch */
     da.iq_out = h->d_iq_out.p;
     da.sqbuf = h->d_sqbuf.p;
     da.ct_coeff = h->d_ct_coeff.p;
@@ -243,29 +248,25 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.wave_batch = h->B;
     da.row0 = h->row0;
     da.ring_rows = h->R;
-    EmitArgs ea;
-    ea.wave = h->d_wave.p;
-    ea.iq_out = h->d_iq_out.p;
-    ea.cs = h->d_cs.p;
-    ea.slot_to_ext = h->d_slot_to_ext.p;
-    ea.out_wave = h->d_out_wave.p;
-    ea.out_iq = h->d_out_iq.p;
-    ea.out_axc = h->d_out_axc.p;
-    ea.n_slots = h->n_slots;
-    ea.wave_batch = h->B;
-    ea.row0 = h->row0;
-    ea.ring_rows = h->R;
-    /* The emit transposes are HBM-bound, the demod kernels are not: each kind's slots are emitted on that kind's stream, under the
-     * other kinds' demod work.  AFC rewrites axcindicate after ALL of stage 2 (afc.finalize(), src/rtl_airband.cpp:626-630), so
-     * with AFC channels the emit stays behind it. */
-    const bool emit_per_kind = !(h->any_afc && h->afc_spectrum_valid);
-    launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev, emit_per_kind ? &ea : nullptr);
-    if (!emit_per_kind) launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, s);
+    launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
+    if (h->any_afc && h->afc_spectrum_valid) { /* afc.finalize(), src/rtl_airband.cpp:626-630: may turn '*' into '<' / '>' */
+        launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, s);
+        launch_axc(h->d_cs.p, h->d_slot_to_ext.p, h->d_out_axc.p, h->n_slots, s);
+    }
     (void)hipEventRecord(ev[3], s);
-    if (!emit_per_kind) launch_emit(ea, s);
+    if (h->d_out_iq.p) { /* handles with has_iq_outputs channels: raw I/Q rows -> channel-major */
+        EmitArgs ea;
+        ea.iq_out = h->d_iq_out.p;
+        ea.slot_to_ext = h->d_slot_to_ext.p;
+        ea.out_iq = h->d_out_iq.p;
+        ea.n_slots = h->n_slots;
+        ea.wave_batch = h->B;
+        launch_emit_iq(ea, s);
+    }
     if (h->n_mixers > 0) {
         MixArgs ma;
-        ma.out_wave = h->d_out_wave.p;
+        ma.out_wave = h->d_out_wave.p + AB_OUT_PAD;
+        ma.wave_stride = h->wave_stride;
         ma.out_axc = h->d_out_axc.p;
         ma.in_chan = h->d_mix_chan.p;
         ma.in_ml = h->d_mix_ml.p;
@@ -443,12 +444,10 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     /* rings, with the reference's config-time prefill of the lead-in (src/config.cpp:313-316) */
     const size_t ring = (size_t)h->R * h->n_slots; /* blocked: [n_slots/64][R][64] */
     PREP_TRY(h->d_mag.alloc(ring), AIRBAND_HIP_ENOMEM);
-    PREP_TRY(h->d_wave.alloc(ring), AIRBAND_HIP_ENOMEM);
     PREP_TRY(h->d_iq.alloc(ring), AIRBAND_HIP_ENOMEM);
     PREP_TRY(h->d_iq_out.alloc((size_t)h->B * h->n_slots), AIRBAND_HIP_ENOMEM);
     PREP_TRY(h->d_sqbuf.alloc((size_t)AB_SQ_BUF * h->n_slots), AIRBAND_HIP_ENOMEM);
     PREP_TRY(fill(h->d_mag.p, ring, 20.0f, h->stream), AIRBAND_HIP_ENOMEM);
-    PREP_TRY(fill(h->d_wave.p, ring, 0.5f, h->stream), AIRBAND_HIP_ENOMEM);
     PREP_TRY(hipStreamSynchronize(h->stream), AIRBAND_HIP_ENOMEM);
     PREP_TRY(hipMemset(h->d_iq.p, 0, ring * sizeof(float2)), AIRBAND_HIP_ENOMEM);
     PREP_TRY(hipMemset(h->d_iq_out.p, 0, (size_t)h->B * h->n_slots * sizeof(float2)), AIRBAND_HIP_ENOMEM);
@@ -465,7 +464,15 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
         PREP_TRY(hipMemset(h->d_trace.p, 0, (size_t)h->B * h->n_slots), AIRBAND_HIP_ENOMEM);
     }
     /* results */
-    PREP_TRY(h->d_out_wave.alloc((size_t)p.total_ch * h->B), AIRBAND_HIP_ENOMEM);
+    /* channel->waveout rows (src/rtl_airband.h:230): [AGC_EXTRA tail of the previous batch][WAVE_BATCH]; the consumer reads the first
+     * WAVE_BATCH entries.  Config-time prefill of the lead-in as in src/config.cpp:313-316 (waveout[0..AGC_EXTRA) = 0.5). */
+    h->wave_stride = (AB_OUT_PAD + AB_AGC_EXTRA + h->B + AB_OUT_RUN - 1) / AB_OUT_RUN * AB_OUT_RUN; /* whole 128-byte lines per row */
+    {
+        std::vector<float> rows((size_t)p.total_ch * h->wave_stride, 0.0f);
+        for (int c = 0; c < p.total_ch; c++)
+            for (int k = 0; k < AB_AGC_EXTRA; k++) rows[(size_t)c * h->wave_stride + AB_OUT_PAD + k] = 0.5f;
+        PREP_TRY(upload(h->d_out_wave, rows), AIRBAND_HIP_ENOMEM);
+    }
     PREP_TRY(h->d_out_axc.alloc((size_t)p.total_ch), AIRBAND_HIP_ENOMEM);
     bool any_iq_out = false;
     for (const ChanConst& c : p.cc) any_iq_out |= (c.flags & AB_F_IQ_OUT) != 0;
@@ -505,7 +512,7 @@ int airband_hip_get_geometry(const airband_hip_handle* h, airband_hip_geometry* 
     g->total_channels = h->plan.total_ch;
     g->max_channels = h->plan.max_ch;
     g->mixer_count = h->n_mixers;
-    g->reserved = 0;
+    g->wave_stride = h->wave_stride;
     g->first_batch_bytes = h->first_batch_bytes;
     g->batch_bytes = h->batch_bytes;
     g->lookahead_bytes = h->lookahead_bytes;
@@ -767,7 +774,9 @@ int airband_hip_collect(airband_hip_handle* h, float* waveout, float* iq_out, ch
         launch_stats(h->d_cc.p, h->d_cs.p, h->d_slot_to_ext.p, h->n_slots, h->d_stats.p, s);
         HIP_TRY(h, hipMemcpyAsync(stats, h->d_stats.p, nch * sizeof(airband_hip_channel_stats), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
     }
-    if (waveout) HIP_TRY(h, hipMemcpyAsync(waveout, h->d_out_wave.p, nch * h->B * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
+    if (waveout)
+        HIP_TRY(h, hipMemcpy2DAsync(waveout, h->B * sizeof(float), h->d_out_wave.p + AB_OUT_PAD, (size_t)h->wave_stride * sizeof(float), h->B * sizeof(float), nch, hipMemcpyDeviceToHost, s),
+                AIRBAND_HIP_ERUNTIME);
     if (iq_out) {
         if (h->d_out_iq.p)
             HIP_TRY(h, hipMemcpyAsync(iq_out, h->d_out_iq.p, nch * h->B * 2 * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
@@ -796,7 +805,7 @@ int airband_hip_collect_mixers(airband_hip_handle* h, float* left, float* right,
 int airband_hip_device_results(airband_hip_handle* h, float** d_waveout, float** d_iq_out, uint8_t** d_axc, float** d_mix_left, float** d_mix_right,
                                uint8_t** d_mix_signal) {
     if (!h) return AIRBAND_HIP_EINVAL;
-    if (d_waveout) *d_waveout = h->d_out_wave.p;
+    if (d_waveout) *d_waveout = h->d_out_wave.p + AB_OUT_PAD;
     if (d_iq_out) *d_iq_out = h->d_out_iq.p;
     if (d_axc) *d_axc = h->d_out_axc.p;
     if (d_mix_left) *d_mix_left = h->d_mix_left.p;

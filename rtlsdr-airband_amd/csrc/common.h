@@ -15,6 +15,10 @@
 #define AB_MAX_TONES 52   /* target + 51 standard CTCSS tones, src/ctcss.cpp:101-122 */
 #define AB_MAX_CH_PER_DEV 64
 #define AB_MIX_RUN 64       /* mixer inputs summed sequentially by one stage-A run */
+/* Result rows (channel->waveout): AB_OUT_PAD floats of padding, the AGC_EXTRA carry, then the batch -- so that the batch's
+ * samples start on a 128-byte boundary and leave the demod kernels as whole cache lines (AB_OUT_RUN floats per lane) */
+#define AB_OUT_RUN 32
+#define AB_OUT_PAD (128 - AB_AGC_EXTRA)
 
 /* Squelch::State numeric values (src/squelch.h:102-108) */
 enum { AB_ST_CLOSED = 0, AB_ST_OPENING = 1, AB_ST_CLOSING = 2, AB_ST_ABORT = 3, AB_ST_OPEN = 4 };

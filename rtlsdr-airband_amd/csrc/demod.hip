@@ -38,6 +38,7 @@ namespace {
 #define AB_DEMOD_CHUNK 8
 #endif
 constexpr int CHUNK = AB_DEMOD_CHUNK; /* multiple of 4 dividing WAVE_BATCH = 1000 and 2000; 64 lanes x 16 B x CHUNK of LDS per wave */
+static_assert(CHUNK == 8, "output runs (RUN) and the hand-off stores are sized for 8-sample chunks");
 
 /* per-sample flag word parked in LDS between the phases */
 constexpr unsigned FL_AUDIO = 1u;   /* Squelch::should_process_audio()                        */
@@ -66,21 +67,55 @@ __device__ __forceinline__ float fast_atan2_dev(float y, float x) {
 
 __device__ __forceinline__ int ring_row(int r, int R) { return r >= R ? r - R : r; }
 
-/* Output path of one sample (src/rtl_airband.cpp:532-547 fade-out, :589-620 gating): shared by the fused loop and phase 3 */
+/* Output path of one sample (src/rtl_airband.cpp:532-547 fade-out, :589-620 gating): shared by the fused loop and the back kernel */
 struct OutRegs {
     float nx0, nx1, nx2, ny0, ny1, ny2; /* NotchFilter delay line */
     int axc;
 };
 
-__device__ __forceinline__ void emit_sample(const DemodArgs& a, const ChanConst& cc, OutRegs& o, float* wave, float2* iqout, uint8_t* trace, int j, bool audio, bool fade,
+/* Where a lane's audio goes: its channel's row of the result buffer, laid out like the reference's channel->waveout
+ * (src/rtl_airband.h:230): row[k], k in [0, WAVE_BATCH + AGC_EXTRA); sample j of the batch lands at k = j + AGC_EXTRA, the
+ * consumer reads [0, WAVE_BATCH), and the last AGC_EXTRA entries are copied to the front when the next batch starts -- the
+ * output thread's tail copy (src/output.cpp:920).  Samples leave in runs of RUN through the lane's LDS column (stride 64
+ * floats): a lane stores whole 128-byte lines of its own row (rows are padded so that k = AGC_EXTRA is line-aligned). */
+constexpr int RUN = AB_OUT_RUN; /* 32 floats = one 128-byte cache line of the lane's row per flush (64-byte runs: 10.6 ms of stage 2, 32-byte runs: 11.5 ms, whole lines: 9.9 ms) */
+struct WaveRow {
+    float* row;
+    float* staged; /* LDS, element i of the current run at staged[i * stride] */
+    int stride;
+    int j0;        /* first sample of the current run */
+};
+
+__device__ __forceinline__ void wave_tail_copy(float* row, int B) {
+    const float4* src = reinterpret_cast<const float4*>(row + B);
+    float4* dst = reinterpret_cast<float4*>(row);
+    float4 t[AB_AGC_EXTRA / 4];
+#pragma unroll
+    for (int q = 0; q < AB_AGC_EXTRA / 4; q++) t[q] = src[q];
+#pragma unroll
+    for (int q = 0; q < AB_AGC_EXTRA / 4; q++) dst[q] = t[q];
+}
+
+__device__ __forceinline__ void wave_flush(const WaveRow& w, int n = RUN) { /* the finished run (n samples) -> row[j0 + AGC_EXTRA ...): 16-byte aligned by construction */
+    float4* dst = reinterpret_cast<float4*>(w.row + AB_AGC_EXTRA + w.j0);
+#pragma unroll
+    for (int q = 0; q < RUN / 4; q++)
+        if (4 * q < n)
+        dst[q] = make_float4(w.staged[(4 * q) * w.stride], w.staged[(4 * q + 1) * w.stride], w.staged[(4 * q + 2) * w.stride], w.staged[(4 * q + 3) * w.stride]);
+}
+
+__device__ __forceinline__ void emit_sample(const DemodArgs& a, const ChanConst& cc, OutRegs& o, const WaveRow& w, float2* iqout, uint8_t* trace, int j, bool audio, bool fade,
                                             bool tone, int state, float out, float re, float im, bool write_iq_always) {
-    const int R = a.ring_rows;
     constexpr long S = AB_SLOT_BLOCK;
     if (fade) { /* AM, squelch just closing: waveout[k] = waveout[k-1] * 0.94 over the previous AGC_EXTRA-1 samples */
-        float prev = wave[(long)ring_row(a.row0 + j, R) * S];
+        float prev = w.row[j]; /* = output of sample j - AGC_EXTRA: left its run long ago */
         for (int k = j + 1; k < j + AB_AGC_EXTRA; k++) {
             prev = prev * 0.94f;
-            wave[(long)ring_row(a.row0 + k, R) * S] = prev;
+            const int i = k - AB_AGC_EXTRA - w.j0; /* position in the run still parked in LDS, if it is that recent */
+            if (i >= 0)
+                w.staged[i * w.stride] = prev;
+            else
+                w.row[k] = prev;
         }
     }
     const bool open = audio && tone; /* Squelch::is_open (src/squelch.cpp:118-134) */
@@ -99,7 +134,7 @@ __device__ __forceinline__ void emit_sample(const DemodArgs& a, const ChanConst&
     } else {
         out = 0.0f;
     }
-    wave[(long)ring_row(a.row0 + AB_AGC_EXTRA + j, R) * S] = out;
+    w.staged[(j - w.j0) * w.stride] = out;
     if (cc.flags & AB_F_IQ_OUT) {
         if (open) {
             if (write_iq_always) iqout[(long)j * S] = make_float2(re, im);
@@ -127,7 +162,7 @@ struct LdsSlots {
 };
 
 template <int KIND, bool WAVE_HAS_CTCSS>
-__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, float* lds, const float2* lut) {
+__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, float* lds, const float2* lut, float* ostage) {
     constexpr int NS = LdsSlots<KIND>::value;
 #ifndef AB_DEMOD_UNROLL
 #define AB_DEMOD_UNROLL 2
@@ -179,10 +214,16 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
 
     float* mag = a.mag + ab_tile_base(slot, R / AB_TILE_ROWS);        /* tile-transposed rings: row r at ab_tile_off(r) */
     const float2* iqin = a.iq + ab_tile_base(slot, R / AB_TILE_ROWS);
-    float* wave = a.wave + ab_ring_base(slot, R);
+    const int ext = a.slot_to_ext[slot];
+    WaveRow wrow;
+    wrow.row = a.out_wave + (long)ext * a.wave_stride + AB_OUT_PAD;
+    wrow.stride = 64;
+    wrow.j0 = 0;
     float2* iqout = a.iq_out + ab_ring_base(slot, B);
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
-    float* my = lds + lane * NS; /* element (u, lane) at lds[(u * 64 + lane) * NS ...] */
+    float* my = lds + lane * NS;
+    wrow.staged = ostage + lane; /* [RUN][64] floats behind the input staging area (and the sincos table) */
+    if (!WAVE_HAS_CTCSS && a.tail_copy) wave_tail_copy(wrow.row, B); /* src/output.cpp:920; the back kernel does it for the split kinds */ /* element (u, lane) at lds[(u * 64 + lane) * NS ...] */
     /* split kinds: (audio, flags) rows for the tone / back kernels, [ct block][sample][64 lanes] */
     /* split kinds: (audio, flags) for the tone / back kernels, channel-major [ct slot][sample] */
     float2* ct_af = WAVE_HAS_CTCSS ? a.ct_af + (long)(slot - a.ct_first_block * 64) * B : nullptr;
@@ -233,6 +274,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                 }
             }
         }
+        if ((j0 % RUN) == 0) wrow.j0 = j0;
         /* ---- phase 1 (+3 when fused): the sequential per-sample loop ---------------------------------------------- */
         {
 #pragma unroll UNROLL
@@ -334,9 +376,10 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                     *reinterpret_cast<float2*>(my + u * 64 * NS) = make_float2(out, __uint_as_float(f));
                     if ((cc.flags & AB_F_IQ_OUT) && audio) iqout[(long)j * S] = make_float2(re, im);
                 } else {
-                    emit_sample(a, cc, o, wave, iqout, trace, j, audio, fade, true, trace ? sq_cur(s) : 0, out, re, im, true);
+                    emit_sample(a, cc, o, wrow, iqout, trace, j, audio, fade, true, trace ? sq_cur(s) : 0, out, re, im, true);
                 }
             }
+            if (!WAVE_HAS_CTCSS && ((j0 + CHUNK) % RUN) == 0) wave_flush(wrow);
             if (WAVE_HAS_CTCSS) {
                 float4* dst = reinterpret_cast<float4*>(ct_af + j0); /* 16-byte aligned: wave_batch and the chunk start are even */
 #pragma unroll
@@ -348,10 +391,12 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         }
     }
 
+    if (!WAVE_HAS_CTCSS && (B % RUN) != 0) wave_flush(wrow, B % RUN); /* WAVE_BATCH = 1000: the last run is a short one */
     if (!WAVE_HAS_CTCSS) { /* the back kernel owns these in the split kinds */
         if (o.axc != ' ') sp->active_counter++;
         sp->axc_prev = sp->axc;
         sp->axc = o.axc;
+        a.out_axc[ext] = (uint8_t)o.axc;
         sp->nx[0] = o.nx0; sp->nx[1] = o.nx1; sp->nx[2] = o.nx2; sp->ny[0] = o.ny0; sp->ny[1] = o.ny1; sp->ny[2] = o.ny2;
     }
     sp->agcavgfast = agc; sp->pr = pr; sp->pj = pj; sp->prev_waveout = prev_out; sp->dm_phi = dm_phi;
@@ -383,7 +428,8 @@ __global__ __launch_bounds__(64, AB_DEMOD_WAVES) void demod_kernel(DemodArgs a, 
         for (int i = threadIdx.x; i < 257; i += 64) lut[i] = make_float2(a.sin_lut[i], a.cos_lut[i]);
         __syncthreads(); /* one wavefront per block: orders the table writes before any lane's reads */
     }
-    demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lds_demod, lut);
+    float* ostage = reinterpret_cast<float*>(lut + (KIND == AB_KIND_AM ? 0 : 258));
+    demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lds_demod, lut, ostage);
 }
 
 /* CTCSS tone detection (reference: src/ctcss.cpp, driven by Squelch::process_audio_sample src/squelch.cpp:278-295).
@@ -513,50 +559,66 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
 /* Back half of the split kinds: output gating (squelch open AND tone present), notch, ampfactor, clamp, AM fade-out
  * (reference: src/rtl_airband.cpp:532-547,589-620), one lane per channel, samples staged through LDS 25 at a time. */
 __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
-    constexpr int PIECE = 10; /* samples fetched ahead per lane: 5 x 16 bytes of the lane's own (channel-major) hand-off row */
+    __shared__ float staged[RUN][64];
     const int lane = threadIdx.x;
     const int slot = (a.ct_first_block + blockIdx.x) * 64 + lane;
     const ChanConst cc = a.cc[slot];
     if (!(cc.flags & AB_F_VALID)) return;
     ChanState* sp = a.cs + slot;
-    const int R = a.ring_rows, B = a.wave_batch, NG = B / TONE_GROUP;
+    const int B = a.wave_batch, NG = B / TONE_GROUP;
     OutRegs o;
     o.nx0 = sp->nx[0]; o.nx1 = sp->nx[1]; o.nx2 = sp->nx[2]; o.ny0 = sp->ny[0]; o.ny1 = sp->ny[1]; o.ny2 = sp->ny[2];
     o.axc = ' ';
-    float* wave = a.wave + ab_ring_base(slot, R);
+    const int ext = a.slot_to_ext[slot];
+    WaveRow w;
+    w.row = a.out_wave + (long)ext * a.wave_stride + AB_OUT_PAD;
+    w.staged = &staged[0][lane];
+    w.stride = 64;
+    w.j0 = 0;
+    if (a.tail_copy) wave_tail_copy(w.row, B); /* src/output.cpp:920 */
     float2* iqout = a.iq_out + ab_ring_base(slot, B);
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
-    /* every lane walks its own contiguous row: all bytes of the lines it touches are its own, the re-use is served by L2 */
+    /* every lane walks its own contiguous (channel-major) hand-off row, 8 samples = 4 x 16 bytes ahead: all bytes of the
+     * lines it touches are its own, the re-use is served by L2 */
     const float4* af = reinterpret_cast<const float4*>(a.ct_af + (long)(slot - a.ct_first_block * 64) * B);
     const unsigned long long* maskp = a.ct_mask + ((long)blockIdx.x * NG) * AB_SLOT_BLOCK + lane;
     const bool is_ct = (cc.flags & AB_F_CTCSS) != 0;
+    constexpr int PIECE = 8; /* samples fetched ahead */
     float4 nxt[PIECE / 2];
 #pragma unroll
     for (int q = 0; q < PIECE / 2; q++) nxt[q] = af[q];
-    for (int g = 0; g < NG; g++) {
-        const unsigned long long mask = is_ct ? maskp[(long)g * AB_SLOT_BLOCK] : ~0ull;
-        for (int h = 0; h < TONE_GROUP / PIECE; h++) {
-            const int j0 = g * TONE_GROUP + h * PIECE;
-            float4 cur[PIECE / 2];
+    unsigned long long mask = ~0ull;
+    int g = -1, jg = TONE_GROUP; /* tone-kernel step of the current sample and the sample's position in it */
+    for (int j0 = 0; j0 < B; j0 += PIECE) {
+        float4 cur[PIECE / 2];
 #pragma unroll
-            for (int q = 0; q < PIECE / 2; q++) cur[q] = nxt[q];
-            if (j0 + PIECE < B) {
+        for (int q = 0; q < PIECE / 2; q++) cur[q] = nxt[q];
+        if (j0 + PIECE < B) {
 #pragma unroll
-                for (int q = 0; q < PIECE / 2; q++) nxt[q] = af[(j0 + PIECE) / 2 + q];
-            }
-#pragma unroll
-            for (int u = 0; u < PIECE; u++) {
-                const float4 p = cur[u >> 1];
-                const float w = (u & 1) ? p.z : p.x;
-                const unsigned f = __float_as_uint((u & 1) ? p.w : p.y);
-                const bool tone = ((mask >> (h * PIECE + u)) & 1ull) != 0;
-                emit_sample(a, cc, o, wave, iqout, trace, j0 + u, (f & FL_AUDIO) != 0, (f & FL_FADE) != 0, tone, (int)((f >> FL_STATE_SHIFT) & 7u), w, 0.0f, 0.0f, false);
-            }
+            for (int q = 0; q < PIECE / 2; q++) nxt[q] = af[(j0 + PIECE) / 2 + q];
         }
+        if ((j0 % RUN) == 0) w.j0 = j0;
+#pragma unroll
+        for (int u = 0; u < PIECE; u++) {
+            if (jg == TONE_GROUP) { /* wave-uniform: every lane is on the same sample */
+                jg = 0;
+                g++;
+                mask = is_ct ? maskp[(long)g * AB_SLOT_BLOCK] : ~0ull;
+            }
+            const float4 p = cur[u >> 1];
+            const float x = (u & 1) ? p.z : p.x;
+            const unsigned f = __float_as_uint((u & 1) ? p.w : p.y);
+            const bool tone = ((mask >> jg) & 1ull) != 0;
+            emit_sample(a, cc, o, w, iqout, trace, j0 + u, (f & FL_AUDIO) != 0, (f & FL_FADE) != 0, tone, (int)((f >> FL_STATE_SHIFT) & 7u), x, 0.0f, 0.0f, false);
+            jg++;
+        }
+        if (((j0 + PIECE) % RUN) == 0) wave_flush(w);
     }
+    if ((B % RUN) != 0) wave_flush(w, B % RUN);
     if (o.axc != ' ') sp->active_counter++;
     sp->axc_prev = sp->axc;
     sp->axc = o.axc;
+    a.out_axc[ext] = (uint8_t)o.axc;
     sp->nx[0] = o.nx0; sp->nx[1] = o.nx1; sp->nx[2] = o.nx2; sp->ny[0] = o.ny0; sp->ny[1] = o.ny1; sp->ny[2] = o.ny2;
 }
 
@@ -570,9 +632,9 @@ static size_t am_lds_pad() {
     return v;
 }
 
-void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev, const EmitArgs* emit) {
+void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev) {
     auto launch_kind = [&](int k, hipStream_t s) {
-        size_t lds = (size_t)CHUNK * 64 * sizeof(float) * (k == AB_KIND_AM ? 2 : 4) + (k == AB_KIND_AM ? 0 : 257 * sizeof(float2));
+        size_t lds = (size_t)CHUNK * 64 * sizeof(float) * (k == AB_KIND_AM ? 2 : 4) + (k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)RUN * 64 * sizeof(float);
         if (k == AB_KIND_AM) lds += am_lds_pad();
         const int n = kind_n_blocks[k], f = kind_first_block[k];
         if (n <= 0) return;
@@ -595,16 +657,11 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
         hipLaunchKernelGGL(tone_kernel, dim3((a.ct_n_blocks * 64 * 64 + 255) / 256), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(back_kernel, dim3(a.ct_n_blocks), dim3(64), 0, stream, a);
     }
-    if (emit) { /* the split kinds' slots (their blocks are contiguous: CTCSS kind, then generic) */
-        launch_emit(*emit, stream, kind_first_block[AB_KIND_NFM_CTCSS], kind_n_blocks[AB_KIND_NFM_CTCSS]);
-        launch_emit(*emit, stream, kind_first_block[AB_KIND_GENERIC], kind_n_blocks[AB_KIND_GENERIC]);
-    }
     for (int i = 0; i < 3; i++) {
         if (kind_n_blocks[fused[i]] <= 0) continue;
         hipStream_t s = fork ? side[i] : stream;
         if (fork) (void)hipStreamWaitEvent(s, ev[0], 0);
         launch_kind(fused[i], s);
-        if (emit) launch_emit(*emit, s, kind_first_block[fused[i]], kind_n_blocks[fused[i]]);
         if (fork) {
             (void)hipEventRecord(ev[1 + i], s);
             (void)hipStreamWaitEvent(stream, ev[1 + i], 0);
@@ -615,94 +672,62 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
 namespace {
 }  // namespace
 
-/* ---- emit: time-major device results -> the channel-major layout the output thread consumes -------------
- * (reference: src/output.cpp:460,521,535 read channel->waveout[0..WAVE_BATCH) / iq_out; :920 tail copy is implicit
- * in the ring rotation).  64 slots x 64 samples per block, transposed through LDS so both sides are coalesced. */
-__global__ __launch_bounds__(256) void emit_kernel(EmitArgs a, int first_block) {
-    __shared__ float tile[2][64][65];
-    const int blk = first_block + blockIdx.x;
-    const int slot0 = blk * 64;
+/* ---- raw I/Q outputs: time-major device rows -> the channel-major layout the output thread consumes (reference:
+ * src/output.cpp:521,535 read channel->iq_out).  Only handles with has_iq_outputs channels run this; audio needs no
+ * such pass, the demod kernels write channel->waveout rows directly.  64 slots x 64 samples per block, transposed
+ * through LDS so both sides are coalesced. */
+__global__ __launch_bounds__(256) void emit_iq_kernel(EmitArgs a) {
+    __shared__ float tile[64][65];
+    const int slot0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int R = a.ring_rows, B = a.wave_batch;
+    const int B = a.wave_batch;
     const int n_tiles = (B + 63) / 64;
-    /* blockIdx.y splits the batch's time tiles; every block walks its share with the next tile's loads in flight */
     const int per = (n_tiles + gridDim.y - 1) / gridDim.y;
     const int tile_begin = blockIdx.y * per, tile_end = min(n_tiles, tile_begin + per);
-    const int ext_w = a.slot_to_ext[min(slot0 + ty, a.n_slots - 1)]; /* dummy read keeps the table warm */
-    (void)ext_w;
-    float v[16];
-    auto load = [&](int tl) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int t = tl * 64 + ty + 4 * k;
-            float x = 0.0f;
-            if (t < B) {
-                int pr = a.row0 + t;
-                if (pr >= R) pr -= R;
-                x = a.wave[((long)blk * R + pr) * AB_SLOT_BLOCK + tx];
-            }
-            v[k] = x;
-        }
-    };
-    if (tile_begin < tile_end) load(tile_begin);
-    int buf = 0;
     for (int tl = tile_begin; tl < tile_end; tl++) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) tile[buf][ty + 4 * k][tx] = v[k];
-        __syncthreads();
-        if (tl + 1 < tile_end) load(tl + 1);
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int r = ty + 4 * k;
-            const int slot = slot0 + r, t = tl * 64 + tx;
-            if (slot < a.n_slots && t < B) {
-                const int ext = a.slot_to_ext[slot];
-                if (ext >= 0) a.out_wave[(long)ext * B + t] = tile[buf][tx][r];
-            }
-        }
-        buf ^= 1; /* the other buffer is free: its readers passed the barrier above one iteration ago */
-    }
-    if (a.out_iq) {
-        for (int tl = tile_begin; tl < tile_end; tl++) {
-            for (int comp = 0; comp < 2; comp++) {
-                __syncthreads();
-                for (int r = ty; r < 64; r += 4) {
-                    const int t = tl * 64 + r;
-                    float x = 0.0f;
-                    if (t < B && slot0 + tx < a.n_slots) {
-                        const float2 q = a.iq_out[((long)blk * B + t) * AB_SLOT_BLOCK + tx];
-                        x = comp ? q.y : q.x;
-                    }
-                    tile[0][r][tx] = x;
+        for (int comp = 0; comp < 2; comp++) {
+            __syncthreads();
+            for (int r = ty; r < 64; r += 4) {
+                const int t = tl * 64 + r;
+                float x = 0.0f;
+                if (t < B && slot0 + tx < a.n_slots) {
+                    const float2 q = a.iq_out[((long)blockIdx.x * B + t) * AB_SLOT_BLOCK + tx];
+                    x = comp ? q.y : q.x;
                 }
-                __syncthreads();
-                for (int r = ty; r < 64; r += 4) {
-                    const int slot = slot0 + r, t = tl * 64 + tx;
-                    if (slot < a.n_slots && t < B) {
-                        const int ext = a.slot_to_ext[slot];
-                        if (ext >= 0) a.out_iq[((long)ext * B + t) * 2 + comp] = tile[0][tx][r];
-                    }
+                tile[r][tx] = x;
+            }
+            __syncthreads();
+            for (int r = ty; r < 64; r += 4) {
+                const int slot = slot0 + r, t = tl * 64 + tx;
+                if (slot < a.n_slots && t < B) {
+                    const int ext = a.slot_to_ext[slot];
+                    if (ext >= 0) a.out_iq[((long)ext * B + t) * 2 + comp] = tile[tx][r];
                 }
             }
-        }
-    }
-    if (blockIdx.y == 0 && threadIdx.x < 64) {
-        const int slot = slot0 + threadIdx.x;
-        if (slot < a.n_slots) {
-            const int ext = a.slot_to_ext[slot];
-            if (ext >= 0) a.out_axc[ext] = (uint8_t)a.cs[slot].axc;
         }
     }
 }
 
-void launch_emit(const EmitArgs& a, hipStream_t stream, int first_block, int n_blocks) {
-    const int blocks = n_blocks >= 0 ? n_blocks : (a.n_slots + 63) / 64;
-    if (blocks <= 0) return;
+/* axcindicate after AFC has had its say (afc.finalize() may turn '*' into '<' / '>', src/rtl_airband.cpp:626-630) */
+__global__ void axc_kernel(const ChanState* cs, const int* slot_to_ext, uint8_t* out_axc, int n_slots) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots) return;
+    const int ext = slot_to_ext[slot];
+    if (ext >= 0) out_axc[ext] = (uint8_t)cs[slot].axc;
+}
+
+void launch_emit_iq(const EmitArgs& a, hipStream_t stream) {
+    const int blocks = (a.n_slots + 63) / 64;
+    if (blocks <= 0 || !a.out_iq) return;
     const int n_tiles = (a.wave_batch + 63) / 64;
-    int ysplit = blocks >= 4096 ? 2 : (16384 / (blocks > 0 ? blocks : 1)); /* few slot blocks: split time instead, to fill the chip */
+    int ysplit = blocks >= 4096 ? 2 : (16384 / blocks);
     if (ysplit < 1) ysplit = 1;
     if (ysplit > n_tiles) ysplit = n_tiles;
-    hipLaunchKernelGGL(emit_kernel, dim3(blocks, ysplit), dim3(256), 0, stream, a, first_block);
+    hipLaunchKernelGGL(emit_iq_kernel, dim3(blocks, ysplit), dim3(256), 0, stream, a);
+}
+
+void launch_axc(const ChanState* cs, const int* slot_to_ext, uint8_t* out_axc, int n_slots, hipStream_t stream) {
+    hipLaunchKernelGGL(axc_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, cs, slot_to_ext, out_axc, n_slots);
 }
 
 /* ---- stats mirror (reference getters: src/output.cpp:617-761) ---------------------------------------------- */

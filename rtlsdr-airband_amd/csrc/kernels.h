@@ -60,7 +60,11 @@ struct DemodArgs {
     ChanState* cs;
     float* mag;
     const float2* iq;
-    float* wave;            /* [ring_rows][stride] */
+    float* out_wave;        /* [total_channels][wave_stride]: channel->waveout rows (tail + WAVE_BATCH), written directly */
+    uint8_t* out_axc;       /* [total_channels] */
+    const int* slot_to_ext;
+    int wave_stride;
+    int tail_copy;          /* 0 for the very first batch: nothing has been consumed yet */
     float2* iq_out;         /* [wave_batch][stride] */
     float* sqbuf;           /* [AB_SQ_BUF][stride] */
     const float* ct_coeff;  /* [n_ctcss][2 detectors][AB_MAX_TONES] */
@@ -76,19 +80,16 @@ struct DemodArgs {
     int n_slots, wave_batch, row0, ring_rows;
 };
 
-struct EmitArgs {
-    const float* wave;
+struct EmitArgs { /* raw I/Q outputs only: audio goes straight to its channel row */
     const float2* iq_out;
-    const ChanState* cs;
     const int* slot_to_ext;
-    float* out_wave;        /* [total_channels][wave_batch] */
     float* out_iq;          /* [total_channels][2*wave_batch] or null */
-    uint8_t* out_axc;       /* [total_channels] */
-    int n_slots, wave_batch, row0, ring_rows;
+    int n_slots, wave_batch;
 };
 
 struct MixArgs {
-    const float* out_wave;  /* [total_channels][wave_batch] */
+    const float* out_wave;  /* [total_channels][wave_stride] */
+    int wave_stride;
     const uint8_t* out_axc;
     const int* in_chan;     /* [n_inputs] external channel index, grouped by mixer */
     const float* in_ml;     /* ampfactor * ampl */
@@ -127,10 +128,9 @@ int dft_sub_tiles(int hop_bytes);
 int dft_nbuf(int hop_bytes);
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream);
 /* side: 3 extra streams, ev: 4 events (fork + 3 joins); both may be null -> everything on `stream` */
-/* `emit` != nullptr: every kind's slots are emitted on that kind's own stream as soon as its demod kernels are done */
-void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev, const EmitArgs* emit);
-/* slot blocks [first_block, first_block + n_blocks) (n_blocks < 0: all) */
-void launch_emit(const EmitArgs& a, hipStream_t stream, int first_block = 0, int n_blocks = -1);
+void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev);
+void launch_emit_iq(const EmitArgs& a, hipStream_t stream);
+void launch_axc(const ChanState* cs, const int* slot_to_ext, uint8_t* out_axc, int n_slots, hipStream_t stream);
 void launch_mix(const MixArgs& a, hipStream_t stream);
 void launch_stats(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, int n_slots, airband_hip_channel_stats* out, hipStream_t stream);
 void launch_siggen(const SiggenArgs& a, hipStream_t stream);

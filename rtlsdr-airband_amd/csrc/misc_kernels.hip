@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void mix_runs_kernel(MixArgs a) {
         if (a.out_axc[ch] == ' ') continue; /* has_signal == false: nothing is added (src/mixer.cpp:119-122,203) */
         any = true;
         if (t < a.wave_batch) {
-            const float w = a.out_wave[(long)ch * a.wave_batch + t];
+            const float w = a.out_wave[(long)ch * a.wave_stride + t];
             const float ml = a.in_ml[i], mr = a.in_mr[i];
             if (ml != 0.0f) l += w * ml;
             if (stereo && mr != 0.0f) r += w * mr;
