@@ -368,7 +368,7 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     h->B = p.wave_batch;
     /* ring rows, whole 16-row tiles: one batch plus its AGC_EXTRA carry -- or two batches deep when stage 1 of the next batch
      * is written while stage 2 still reads this one */
-    h->R = ((h->pipeline ? 2 : 1) * p.wave_batch + AB_AGC_EXTRA + AB_TILE_ROWS - 1) / AB_TILE_ROWS * AB_TILE_ROWS;
+    h->R = ((h->pipeline ? 2 : 1) * p.wave_batch + AB_AGC_EXTRA + 15) / 16 * 16; /* whole 16-hop MFMA tiles (a multiple of AB_TILE_ROWS too) */
     h->N = p.fft_size;
     /* demod slots: sort the channels by demod kind so that a 64-lane wavefront runs ONE code path (AM, NFM,
      * NFM+lowpass, NFM+CTCSS, everything else); kinds start on 64-slot block boundaries */

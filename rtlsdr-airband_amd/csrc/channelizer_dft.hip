@@ -71,6 +71,7 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
      * hops < 0 (first tile) and >= n_hops (last tile) are computed on whatever bytes are there and never stored */
     const int shift = (a.row0 + a.first_row) & 15;
     const int ring_tiles = a.ring_rows / AB_TILE_ROWS;
+    const int ring_tiles16 = a.ring_rows / TILE_HOPS; /* the ring length is a whole number of 16-hop MFMA tiles */
     const int ptile0 = (a.row0 + a.first_row) >> 4;
     const int tiles_total = (shift + a.n_hops + TILE_HOPS - 1) / TILE_HOPS;
     const int steps_total = (tiles_total + sub - 1) / sub;
@@ -194,8 +195,8 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
         if (!(col & 1) && ch_valid) {
 #endif
             int pt = ptile0 + t;
-            pt = pt >= ring_tiles ? pt - ring_tiles : pt;
-            const long off = slot_base + (long)pt * (AB_SLOT_BLOCK * AB_TILE_ROWS) + grp * 4;
+            pt = pt >= ring_tiles16 ? pt - ring_tiles16 : pt;
+            const long off = slot_base + ab_tile_off(pt * TILE_HOPS + grp * 4); /* the lane's 4 hops never straddle a ring tile (4, 8 or 16 rows) */
             const int hop_first = t * TILE_HOPS - shift + grp * 4;
             float m4[4];
 #pragma unroll
