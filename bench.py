@@ -158,7 +158,8 @@ def main():
 
     # the RCCL all-reduce is issued on torch's stream: that stream waits (on the GPU) for the batch's mixer sums, and the next
     # process call orders its overwrite of them behind the all-reduce -- no host synchronisation inside a step
-    consumer = torch.cuda.current_stream().cuda_stream if mix_t is not None else 0
+    cstream = torch.cuda.Stream() if mix_t is not None else None   # a real stream: torch's default one is the NULL handle
+    consumer = cstream.cuda_stream if cstream is not None else 0
 
     def step(i):
         if i == 0:
@@ -168,8 +169,9 @@ def main():
         hip.process_device(iq.data_ptr() + off, stride, consumer)
         if mix_t is not None:
             hip.stream_wait_results(consumer)
-            dist.all_reduce(mix_t, op=dist.ReduceOp.SUM)      # mixer sum over xGMI (src/mixer.cpp:133-140)
-            dist.all_reduce(sig_t, op=dist.ReduceOp.MAX)      # axcindicate of the mixer (src/mixer.cpp:209)
+            with torch.cuda.stream(cstream):
+                dist.all_reduce(mix_t, op=dist.ReduceOp.SUM)      # mixer sum over xGMI (src/mixer.cpp:133-140)
+                dist.all_reduce(sig_t, op=dist.ReduceOp.MAX)      # axcindicate of the mixer (src/mixer.cpp:209)
 
     def sync():
         hip.synchronize()
@@ -256,7 +258,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        # RCCL prints its version banner through C stdio, which a pipe buffers until exit: push it out first so that the JSON is the LAST line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
