@@ -21,10 +21,26 @@ def _tweak(d, ch):
         ch[6]["ampfactor"] = 2.5
 
 
+def _bursty(carriers):
+    """Transmitters that key in short, weak, irregular bursts: the squelch flaps, aborts on low signal, re-opens inside the
+    closing delay, fades out again and again -- the rare-event branches of the state machine and the AM fade-out path."""
+    sg = helpers.sg
+    out = []
+    for k, c in enumerate(carriers):
+        period, on = [(0.11, 0.045), (0.31, 0.02), (0.26, 0.19), (0.07, 0.05)][k % 4]
+        amp = [0.08, 0.03, 0.05, 0.012][(k // 2) % 4]
+        out.append(sg.make_carrier(sg.PLAN_OFFSETS_HZ[k], sg.SAMPLE_RATE, amplitude=amp, kind=c.kind, ctcss_hz=100.0 if c.step_ctcss else 0.0, key_slot=k,
+                                   key_period_s=period, key_on_s=on, key_slot_s=0.013))
+    return out
+
+
+@pytest.mark.parametrize("style", ["keyed", "bursty"])
 @pytest.mark.parametrize("mixed,wave_rate", [(False, 8000), (True, 16000)])
-def test_stage2_bit_exact_on_oracle_bins(pkg, built, mixed, wave_rate):
+def test_stage2_bit_exact_on_oracle_bins(pkg, built, mixed, wave_rate, style):
     """Feed the ORACLE's stage-1 output into GPU stage 2: everything must be bit-identical."""
     devices, carriers = helpers.plan_devices(3, mixed, _tweak if mixed else None)
+    if style == "bursty":
+        carriers = _bursty(carriers)
     n_batches = 10
     nbytes = helpers.stream_bytes(n_batches, wave_rate)
     src = pyoracle.Oracle(devices, wave_rate=wave_rate)
@@ -45,13 +61,19 @@ def test_stage2_bit_exact_on_oracle_bins(pkg, built, mixed, wave_rate):
             wi = np.concatenate([w["iq_out"] for w in want])
             assert np.array_equal(out["iq_out"].view(np.uint32), wi.view(np.uint32)), "batch %d: iq_out" % b
         k = 0
+        opens = flappy = 0
         for d in range(3):
             for j in range(8):
                 o, g = orc.stats(d, j), out["stats"][k]
                 for f in ("noise_level", "signal_level", "squelch_level", "agcavgfast", "open_count", "flappy_count", "ctcss_count", "no_ctcss_count",
                           "active_counter", "bin", "squelch_state"):
                     assert o[f] == g[f], (d, j, f, o[f], g[f])
+                opens += int(g["open_count"])
+                flappy += int(g["flappy_count"])
                 k += 1
+        assert opens > 0
+        if style == "bursty":
+            assert opens > 50 and flappy > 10, (opens, flappy)  # the signal did exercise re-opening and flap detection
 
 
 @pytest.mark.parametrize("force_fft", [False, True], ids=["dft_mfma", "fft_wave64"])
