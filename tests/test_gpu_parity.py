@@ -291,6 +291,71 @@ def test_mixers_match_reference_order_sum(pkg, built):
         assert seen
 
 
+def test_ragged_shapes_and_empty_inputs(pkg, built):
+    """Edge shapes: a dongle with ONE channel, one with the maximum of 64 (every feature combination, all five demod kinds,
+    mostly padding-free blocks), one with 8; zero-length submits, process() before enough data, collect() before any batch."""
+    sg = pkg.siggen
+    wave_rate, n_batches = 16000, 6
+    base = dict(modulation=0, afc=0, squelch_threshold_dbfs=0, squelch_snr_threshold_db=-1.0, notch_freq=0.0, notch_q=0.0, ctcss_freq=0.0, bandwidth_hz=0,
+                ampfactor=1.0, tau_us=-1, has_iq_outputs=0)
+    spacing = 35_000
+    many, carriers = [], []
+    for k in range(64):
+        off = (k - 32) * spacing + 5_000
+        c = dict(base, frequency=sg.CENTERFREQ + off)
+        c["modulation"] = 1 if k % 3 else 0
+        if k % 3 == 1:
+            c["ctcss_freq"] = 100.0 if k % 2 else 0.0
+            c["notch_freq"] = 100.0 if k % 4 == 1 else 0.0
+        if k % 5 == 0:
+            c["bandwidth_hz"] = 9000
+        if k % 7 == 0:
+            c["has_iq_outputs"] = 1
+        if k % 11 == 0:
+            c["squelch_threshold_dbfs"] = -42
+        if k % 13 == 0:
+            c["ampfactor"] = 3.0
+        many.append(c)
+        if k % 4 == 0:  # 16 transmitters; the other channels only ever see noise
+            carriers.append(sg.make_carrier(off, sg.SAMPLE_RATE, kind=c["modulation"], ctcss_hz=c["ctcss_freq"], key_slot=k, key_period_s=0.4, key_on_s=0.25, key_slot_s=0.03))
+    one = [dict(many[8])]
+    eight = [dict(many[k]) for k in range(0, 64, 8)]
+    devices = [dict(channels=one), dict(channels=many), dict(channels=eight)]
+    n_dev = len(devices)
+    nbytes = helpers.stream_bytes(n_batches, wave_rate)
+    iq = [sg.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)]
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate)
+    ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
+    with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=pkg.capi.FLAG_TRACE_SQUELCH) as hip:
+        assert hip.channelizer_name() == "fft_wave64"  # more than 8 channels on a dongle: not the matrix-core path
+        assert hip.total_channels == 73
+        with pytest.raises(pkg.AirbandError) as e:
+            hip.collect()
+        assert e.value.code == pkg.capi.EAGAIN
+        assert hip.process() is False                       # nothing queued at all
+        assert hip.submit(0, iq[0][:0]) == 0                # empty submit
+        assert hip.submit(1, iq[1][:1000]) == 1000          # far less than a batch
+        assert hip.process() is False
+        pos = [0, 1000, 0]
+        b = opened = 0
+        while b < n_batches:
+            for d in range(n_dev):
+                if pos[d] < nbytes:
+                    pos[d] += hip.submit(d, iq[d][pos[d]:pos[d] + 700_001])
+            while hip.process():
+                out = hip.collect(iq=True)
+                tr = hip.read_trace()
+                assert np.array_equal(out["axc"], np.concatenate([r["axc"][b] for r in ref])), "batch %d axc" % b
+                assert np.array_equal(tr, np.concatenate([r["trace"][b] for r in ref])), "batch %d squelch trace" % b
+                ww = np.concatenate([r["waveout"][b] for r in ref])
+                assert helpers.rms(out["waveout"] - ww) <= 1e-4
+                wi = np.concatenate([r["iq_out"][b] for r in ref])
+                assert helpers.rms(out["iq_out"] - wi) <= 1e-4 * max(1.0, helpers.rms(wi))
+                opened += int((out["axc"] == ord("*")).sum())
+                b += 1
+        assert opened > 0
+
+
 def _convert(iq_u8, sfmt, capi):
     """Re-express the synthetic u8 stream in the other sample formats the input drivers deliver (src/input-soapysdr.cpp:45-64)."""
     x = iq_u8.astype(np.float32) - 127.5
