@@ -79,11 +79,20 @@ struct OutRegs {
  * output thread's tail copy (src/output.cpp:920).  Samples leave in runs of RUN through the lane's LDS column (stride 64
  * floats): a lane stores whole 128-byte lines of its own row (rows are padded so that k = AGC_EXTRA is line-aligned). */
 constexpr int RUN = AB_OUT_RUN; /* 32 floats = one 128-byte cache line of the lane's row per flush (64-byte runs: 10.6 ms of stage 2, 32-byte runs: 11.5 ms, whole lines: 9.9 ms) */
+constexpr int OSTRIDE = 65; /* floats between two samples of the LDS staging area [RUN][OSTRIDE]: odd, so that both the per-lane writes and the
+                               transposed reads of the cooperative flush spread over the banks */
 struct WaveRow {
     float* row;
     float* staged; /* LDS, element i of the current run at staged[i * stride] */
     int stride;
     int j0;        /* first sample of the current run */
+    /* cooperative flush (blocks whose 64 lanes all own a channel): eight lanes store one channel's whole 128-byte line, so a
+     * store instruction is eight full lines instead of 64 sixteen-byte pieces of 64 different lines */
+    const float* stage_base; /* LDS [RUN][OSTRIDE] */
+    const int* ext_of;       /* LDS [64]: external channel index of the block's lanes */
+    float* out_wave;
+    int wave_stride;
+    bool coop;
 };
 
 __device__ __forceinline__ void wave_tail_copy(float* row, int B) {
@@ -97,6 +106,19 @@ __device__ __forceinline__ void wave_tail_copy(float* row, int B) {
 }
 
 __device__ __forceinline__ void wave_flush(const WaveRow& w, int n = RUN) { /* the finished run (n samples) -> row[j0 + AGC_EXTRA ...): 16-byte aligned by construction */
+    if (w.coop) { /* wave-uniform */
+        const int lane = threadIdx.x & 63, q = lane & 7;
+        if (4 * q < n) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int c = i * 8 + (lane >> 3);
+                const float* src = w.stage_base + (4 * q) * OSTRIDE + c;
+                float4* dst = reinterpret_cast<float4*>(w.out_wave + (long)w.ext_of[c] * w.wave_stride + AB_OUT_PAD + AB_AGC_EXTRA + w.j0 + 4 * q);
+                *dst = make_float4(src[0], src[OSTRIDE], src[2 * OSTRIDE], src[3 * OSTRIDE]);
+            }
+        }
+        return;
+    }
     float4* dst = reinterpret_cast<float4*>(w.row + AB_AGC_EXTRA + w.j0);
 #pragma unroll
     for (int q = 0; q < RUN / 4; q++)
@@ -162,7 +184,7 @@ struct LdsSlots {
 };
 
 template <int KIND, bool WAVE_HAS_CTCSS>
-__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, float* lds, const float2* lut, float* ostage) {
+__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, float* lds, const float2* lut, float* ostage, const int* ext_of, bool full_block) {
     constexpr int NS = LdsSlots<KIND>::value;
 #ifndef AB_DEMOD_UNROLL
 #define AB_DEMOD_UNROLL 2
@@ -217,12 +239,17 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     const int ext = a.slot_to_ext[slot];
     WaveRow wrow;
     wrow.row = a.out_wave + (long)ext * a.wave_stride + AB_OUT_PAD;
-    wrow.stride = 64;
+    wrow.stride = OSTRIDE;
     wrow.j0 = 0;
+    wrow.stage_base = ostage;
+    wrow.ext_of = ext_of;
+    wrow.out_wave = a.out_wave;
+    wrow.wave_stride = a.wave_stride;
+    wrow.coop = full_block;
     float2* iqout = a.iq_out + ab_ring_base(slot, B);
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
     float* my = lds + lane * NS;
-    wrow.staged = ostage + lane; /* [RUN][64] floats behind the input staging area (and the sincos table) */
+    wrow.staged = ostage + lane; /* [RUN][OSTRIDE] floats behind the input staging area (and the sincos table) */
     if (!WAVE_HAS_CTCSS && a.tail_copy) wave_tail_copy(wrow.row, B); /* src/output.cpp:920; the back kernel does it for the split kinds */ /* element (u, lane) at lds[(u * 64 + lane) * NS ...] */
     /* split kinds: (audio, flags) rows for the tone / back kernels, [ct block][sample][64 lanes] */
     /* split kinds: (audio, flags) for the tone / back kernels, channel-major [ct slot][sample] */
@@ -429,7 +456,11 @@ __global__ __launch_bounds__(64, AB_DEMOD_WAVES) void demod_kernel(DemodArgs a, 
         __syncthreads(); /* one wavefront per block: orders the table writes before any lane's reads */
     }
     float* ostage = reinterpret_cast<float*>(lut + (KIND == AB_KIND_AM ? 0 : 258));
-    demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lds_demod, lut, ostage);
+    int* ext_of = reinterpret_cast<int*>(ostage + RUN * OSTRIDE);
+    ext_of[threadIdx.x] = a.slot_to_ext[slot];
+    const bool full_block = __ballot((cc.flags & AB_F_VALID) != 0) == ~0ull; /* padding lanes leave early and cannot take part in a cooperative store */
+    __syncthreads();
+    demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lds_demod, lut, ostage, ext_of, full_block);
 }
 
 /* CTCSS tone detection (reference: src/ctcss.cpp, driven by Squelch::process_audio_sample src/squelch.cpp:278-295).
@@ -559,10 +590,14 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
 /* Back half of the split kinds: output gating (squelch open AND tone present), notch, ampfactor, clamp, AM fade-out
  * (reference: src/rtl_airband.cpp:532-547,589-620), one lane per channel, samples staged through LDS 25 at a time. */
 __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
-    __shared__ float staged[RUN][64];
+    __shared__ float staged[RUN][OSTRIDE];
+    __shared__ int ext_of[64];
     const int lane = threadIdx.x;
     const int slot = (a.ct_first_block + blockIdx.x) * 64 + lane;
     const ChanConst cc = a.cc[slot];
+    ext_of[lane] = a.slot_to_ext[slot];
+    const bool full_block = __ballot((cc.flags & AB_F_VALID) != 0) == ~0ull;
+    __syncthreads();
     if (!(cc.flags & AB_F_VALID)) return;
     ChanState* sp = a.cs + slot;
     const int B = a.wave_batch, NG = B / TONE_GROUP;
@@ -573,8 +608,13 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
     WaveRow w;
     w.row = a.out_wave + (long)ext * a.wave_stride + AB_OUT_PAD;
     w.staged = &staged[0][lane];
-    w.stride = 64;
+    w.stride = OSTRIDE;
     w.j0 = 0;
+    w.stage_base = &staged[0][0];
+    w.ext_of = ext_of;
+    w.out_wave = a.out_wave;
+    w.wave_stride = a.wave_stride;
+    w.coop = full_block;
     if (a.tail_copy) wave_tail_copy(w.row, B); /* src/output.cpp:920 */
     float2* iqout = a.iq_out + ab_ring_base(slot, B);
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
@@ -634,7 +674,7 @@ static size_t am_lds_pad() {
 
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev) {
     auto launch_kind = [&](int k, hipStream_t s) {
-        size_t lds = (size_t)CHUNK * 64 * sizeof(float) * (k == AB_KIND_AM ? 2 : 4) + (k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)RUN * 64 * sizeof(float);
+        size_t lds = (size_t)CHUNK * 64 * sizeof(float) * (k == AB_KIND_AM ? 2 : 4) + (k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)RUN * OSTRIDE * sizeof(float) + 64 * sizeof(int);
         if (k == AB_KIND_AM) lds += am_lds_pad();
         const int n = kind_n_blocks[k], f = kind_first_block[k];
         if (n <= 0) return;
