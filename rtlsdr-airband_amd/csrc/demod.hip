@@ -3,19 +3,20 @@
  * banks (src/ctcss.cpp), NotchFilter / LowpassFilter (src/filters.cpp), sincosf_lut (src/util.cpp:113-127) and
  * the FM helpers (src/rtl_airband.cpp:141-176).
  *
- * Mapping: one wavefront owns 64 consecutive channel slots, one lane per (dongle, channel).  Time is strictly
- * serial per channel (IIR / EMA / FSM state), so a lane walks the batch's WAVE_BATCH samples in order with all of
+ * Mapping: one wavefront owns 64 consecutive channel slots of ONE demod kind, one lane per (dongle, channel).  Time is
+ * strictly serial per channel (IIR / EMA / FSM state), so a lane walks the batch's WAVE_BATCH samples in order with all of
  * its state in registers.  The batch is cut into chunks of CHUNK samples:
  *   phase 0  the chunk's stage-1 rows (time-major, so one 256-byte row feeds all 64 lanes) are pulled from HBM
- *            with CHUNK independent loads per lane and parked in LDS -- memory latency is paid once per chunk,
+ *            with independent 16-byte loads per lane and parked in LDS -- memory latency is paid once per chunk,
  *            not once per sample;
- *   phase 1  squelch FSM + derotation/lowpass + AM AGC / FM discriminator per lane -> pre-notch audio + flags;
- *   phase 2  (only waves that own CTCSS channels) the wave turns 90 degrees: for each CTCSS channel the 64 lanes
- *            become the tone bank (lane t = tone t of the fast and the slow detector) and run the Goertzel
- *            recurrences over the chunk's audio, which is broadcast from LDS -- the reference's 104 multiply-adds
- *            per sample per channel stay in registers instead of becoming 104 round trips to memory;
- *   phase 3  output gating (squelch open AND tone present), notch, ampfactor, clamp, fade-out, writes.
- * Waves without CTCSS channels fuse phase 3 into phase 1.
+ *   phase 1  squelch state machine (squelch_fsm.h: lane masks in scalar registers) + derotation / lowpass + AM AGC or FM
+ *            discriminator, then -- fused kinds -- output gating, notch, ampfactor, clamp, AM fade-out.  Audio is parked in LDS
+ *            and leaves every 32 samples as whole 128-byte lines of the channel's channel->waveout-shaped result row.
+ * Kinds that can carry a CTCSS tone are split in three kernels instead: this file's demod_kernel<.., true> is the FRONT
+ * (squelch + discriminator -> pre-notch audio + flag word per sample, channel-major hand-off buffer), tone_kernel turns the
+ * problem 90 degrees (one wavefront per channel, lane t = tone t of the fast and the slow Goertzel bank: the reference's
+ * ~104 multiply-adds per audio sample are one 3-op recurrence per lane), back_kernel gates (squelch open AND tone present),
+ * notches and writes the result rows.
  *
  * This file MUST be compiled with -ffp-contract=off: squelch decisions have to be bit-identical to the
  * reference's scalar float code given the same stage-1 input, so no FMA contraction, IEEE divide and sqrt
@@ -23,8 +24,6 @@
  * index-order float sum of tone powers in the CTCSS decision).
  */
 #include <hip/hip_runtime.h>
-
-#include <cstdlib>
 
 #include "common.h"
 #include "kernels.h"
@@ -666,16 +665,9 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
  * lane-per-channel kernel holds at most 4 waves per SIMD and the NFM kinds have only half that many wavefronts at BASELINE
  * config #3.  So the split chain (front -> tone -> back, the longest) goes on the caller's stream and the fused kinds run
  * beside it on side streams, forked and joined with events (works the same under graph capture). */
-/* experiment knob: extra LDS per AM block caps how many of the (cheap, register-hungry in aggregate) AM waves a CU holds */
-static size_t am_lds_pad() {
-    static const size_t v = [] { const char* e = getenv("AIRBAND_AM_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
-    return v;
-}
-
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev) {
     auto launch_kind = [&](int k, hipStream_t s) {
         size_t lds = (size_t)CHUNK * 64 * sizeof(float) * (k == AB_KIND_AM ? 2 : 4) + (k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)RUN * OSTRIDE * sizeof(float) + 64 * sizeof(int);
-        if (k == AB_KIND_AM) lds += am_lds_pad();
         const int n = kind_n_blocks[k], f = kind_first_block[k];
         if (n <= 0) return;
         switch (k) {
