@@ -253,6 +253,30 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     /* split kinds: (audio, flags) rows for the tone / back kernels, [ct block][sample][64 lanes] */
     /* split kinds: (audio, flags) for the tone / back kernels, channel-major [ct slot][sample] */
     float2* ct_af = WAVE_HAS_CTCSS ? a.ct_af + (long)(slot - a.ct_first_block * 64) * B : nullptr;
+    /* the front kernel has no audio rows of its own, so the row staging area holds 16 samples of hand-off pairs instead:
+     * [HAND_RUN][OSTRIDE] float2, flushed like the audio rows (eight lanes store one channel's 128-byte line) */
+    constexpr int HAND_RUN = 16;
+    float2* hand_base = reinterpret_cast<float2*>(ostage);
+    float2* hand = hand_base + lane;
+    float2* ct_block = WAVE_HAS_CTCSS ? a.ct_af + (long)((slot & ~63) - a.ct_first_block * 64) * B : nullptr;
+    auto hand_flush = [&](int n, int jstart) { /* n samples starting at batch sample jstart */
+        if (full_block) { /* wave-uniform */
+            const int q = lane & 7; /* samples 2q, 2q + 1 */
+            if (2 * q < n) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int c = i * 8 + (lane >> 3);
+                    const float2 p0 = hand_base[(2 * q) * OSTRIDE + c], p1 = hand_base[(2 * q + 1) * OSTRIDE + c];
+                    *reinterpret_cast<float4*>(ct_block + (long)c * B + jstart + 2 * q) = make_float4(p0.x, p0.y, p1.x, p1.y);
+                }
+            }
+        } else {
+            for (int i = 0; i < n; i += 2) {
+                const float2 p0 = hand[i * OSTRIDE], p1 = hand[(i + 1) * OSTRIDE];
+                *reinterpret_cast<float4*>(ct_af + jstart + i) = make_float4(p0.x, p0.y, p1.x, p1.y);
+            }
+        }
+    };
 
     for (int j0 = 0; j0 < B; j0 += CHUNK) {
         /* ---- phase 0: the chunk's stage-1 values, 16 bytes (4 rows) per load, parked in LDS -------------------------
@@ -398,26 +422,20 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                     /* front half of a CTCSS-capable kind: hand (pre-notch audio, flags) to the tone and back kernels.  Raw I/Q of
                      * an open sample is written now; the back kernel zeroes it again if the tone gate turns out closed. */
                     const unsigned f = (audio ? FL_AUDIO : 0u) | (fade ? FL_FADE : 0u) | (ab_lane(went_closed) ? FL_RESET : 0u) | (a.trace ? (unsigned)sq_cur(s) << FL_STATE_SHIFT : 0u);
-                    /* parked in the (consumed) LDS slot of this sample; the chunk leaves as one 64-byte run per lane below */
-                    *reinterpret_cast<float2*>(my + u * 64 * NS) = make_float2(out, __uint_as_float(f));
+                    /* parked in LDS; 16 samples leave together as whole 128-byte lines of the channel-major hand-off rows */
+                    hand[((j & (HAND_RUN - 1)) * OSTRIDE)] = make_float2(out, __uint_as_float(f));
                     if ((cc.flags & AB_F_IQ_OUT) && audio) iqout[(long)j * S] = make_float2(re, im);
                 } else {
                     emit_sample(a, cc, o, wrow, iqout, trace, j, audio, fade, true, trace ? sq_cur(s) : 0, out, re, im, true);
                 }
             }
             if (!WAVE_HAS_CTCSS && ((j0 + CHUNK) % RUN) == 0) wave_flush(wrow);
-            if (WAVE_HAS_CTCSS) {
-                float4* dst = reinterpret_cast<float4*>(ct_af + j0); /* 16-byte aligned: wave_batch and the chunk start are even */
-#pragma unroll
-                for (int q = 0; q < CHUNK / 2; q++) {
-                    const float2 p0 = *reinterpret_cast<const float2*>(my + (2 * q) * 64 * NS), p1 = *reinterpret_cast<const float2*>(my + (2 * q + 1) * 64 * NS);
-                    dst[q] = make_float4(p0.x, p0.y, p1.x, p1.y);
-                }
-            }
+            if (WAVE_HAS_CTCSS && ((j0 + CHUNK) % HAND_RUN) == 0) hand_flush(HAND_RUN, j0 + CHUNK - HAND_RUN);
         }
     }
 
     if (!WAVE_HAS_CTCSS && (B % RUN) != 0) wave_flush(wrow, B % RUN); /* WAVE_BATCH = 1000: the last run is a short one */
+    if (WAVE_HAS_CTCSS && (B % HAND_RUN) != 0) hand_flush(B % HAND_RUN, B - B % HAND_RUN);
     if (!WAVE_HAS_CTCSS) { /* the back kernel owns these in the split kinds */
         if (o.axc != ' ') sp->active_counter++;
         sp->axc_prev = sp->axc;
