@@ -148,9 +148,9 @@ __device__ __forceinline__ void emit_sample(const DemodArgs& a, const ChanConst&
             out = o.ny2;
         }
         out *= cc.ampfactor;
-        if (out != out) out = 0.0f;
-        else if (out > 1.0f) out = 1.0f;
-        else if (out < -1.0f) out = -1.0f;
+        /* NaN -> 0, else clamp to [-1, 1] (src/rtl_airband.cpp:597-603): the median of (out, -1, 1) IS the clamp -- one of its
+         * inputs, unchanged -- in a single instruction */
+        out = (out != out) ? 0.0f : __builtin_amdgcn_fmed3f(out, -1.0f, 1.0f);
         o.axc = '*';
     } else {
         out = 0.0f;
