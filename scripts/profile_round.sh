@@ -1,3 +1,5 @@
+# Regenerates the round's measurements on a GPU box:  rm -rf gpurun_out/final; gpurun --timeout 1500 -- 'bash scripts/profile_round.sh'
+# (gpurun MERGES into the local gpurun_out/, so remove the old copy first), then copy what is wanted into profiles/.
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; rm -rf $O; mkdir -p $O
