@@ -89,7 +89,8 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("AIRBAND_BENCH_WORKLOAD", "cfg3"), choices=sorted(WORKLOADS))
     ap.add_argument("--dongles", type=int, default=0, help="override dongles per GPU")
     ap.add_argument("--ring", type=int, default=3, help="distinct I/Q batches kept in HBM and cycled through")
-    ap.add_argument("--mixers", type=int, default=-1, help="number of mixers (default: 64 when --gpus > 1, else 0)")
+    ap.add_argument("--mixers", type=int, default=0, help="number of mixers (BASELINE configs[4]: 64). Default 0 at every N, so that per-GPU work is the same "
+                    "from 1 to 8 GPUs (configs[1]-[3] have no exchange step); with mixers and N > 1 the per-rank sums are all-reduced over RCCL every step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-path", action="store_true", help="additionally time the host-buffer path (submit over PCIe) on a small slice; reported separately, never as value")
@@ -122,7 +123,7 @@ def main():
     wl = WORKLOADS[args.workload]
     D = args.dongles or wl["dongles"]
     mixed, wave_rate = wl["mixed"], wl["wave_rate"]
-    n_mixers = args.mixers if args.mixers >= 0 else (64 if use_dist else 0)
+    n_mixers = max(0, args.mixers)
 
     chans, carriers = pkg.siggen.baseline_plan(mixed=mixed)
     devices = [dict(channels=chans) for _ in range(D)]
