@@ -165,6 +165,11 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
  * src/mixer.cpp:57-94).  mixer_count mixers, n_inputs connections. */
 int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const airband_hip_mixer_input* inputs, int32_t n_inputs);
 
+/* Masks one mixer connection out (enabled = 0) or back in, by its index in the `inputs` array handed to airband_hip_set_mixers:
+ * a masked input adds nothing and does not raise the mixer's signal flag -- mixer_disable_input(), which the reference
+ * calls when a device fails (src/mixer.cpp:96-110, src/rtl_airband.cpp:377-391).  Takes effect from the next batch. */
+int airband_hip_mixer_enable_input(airband_hip_handle* h, int32_t input_index, int32_t enabled);
+
 /* Replaces: gpu_fft_release() on do_exit (reference: src/rtl_airband.cpp:360-365). */
 void airband_hip_release(airband_hip_handle* h);
 

@@ -28,7 +28,7 @@ EXPORTS = [
     "airband_hip_process", "airband_hip_process_device", "airband_hip_collect", "airband_hip_collect_mixers", "airband_hip_device_results",
     "airband_hip_synchronize", "airband_hip_process_bins", "airband_hip_read_bins", "airband_hip_read_trace", "airband_hip_channel_constants",
     "airband_hip_derive_constants", "airband_hip_last_timings", "airband_hip_channelizer_name", "airband_hip_set_signal_plan", "airband_hip_generate_iq",
-    "airband_hip_flush", "airband_hip_timing_totals", "airband_hip_stream_wait_results",
+    "airband_hip_flush", "airband_hip_timing_totals", "airband_hip_stream_wait_results", "airband_hip_mixer_enable_input",
 ]
 
 _lib = None
@@ -82,6 +82,7 @@ def load_library() -> C.CDLL:
     L.airband_hip_set_signal_plan.argtypes = [vp, vp, i32, i32, vp]
     L.airband_hip_generate_iq.argtypes = [vp, vp, sz, u64, sz, u64, i32, vp]
     L.airband_hip_flush.argtypes = [vp]
+    L.airband_hip_mixer_enable_input.argtypes = [vp, i32, i32]
     L.airband_hip_stream_wait_results.argtypes = [vp, vp]
     L.airband_hip_timing_totals.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     _lib = L
@@ -240,6 +241,9 @@ class AirbandHip:
         arr = (capi.MixerInput * len(inputs))(*[capi.MixerInput(int(a), int(b), int(c), float(d), float(e)) for a, b, c, d, e in inputs])
         self._check(self.L.airband_hip_set_mixers(self.h, n_mixers, arr, len(inputs)))
         self.n_mixers = n_mixers
+
+    def mixer_enable_input(self, input_index: int, enabled: bool):
+        self._check(self.L.airband_hip_mixer_enable_input(self.h, input_index, 1 if enabled else 0))
 
     def collect_mixers(self):
         left = np.empty((self.n_mixers, self.B), np.float32)

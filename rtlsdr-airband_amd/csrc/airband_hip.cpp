@@ -110,6 +110,8 @@ struct airband_hip_handle {
     int64_t stage_stride = 0;
 
     /* mixers */
+    std::vector<int> mix_pos;       /* connection index (order of airband_hip_set_mixers) -> position in the per-mixer grouped arrays */
+    std::vector<int> mix_chan_host; /* grouped external channel indices, for re-enabling an input */
     int n_mixers = 0;
     int n_mix_runs = 0;
     DevBuf<int> d_mix_chan, d_mix_first, d_mix_run_first, d_mix_run_mixer, d_mix_first_run;
@@ -535,8 +537,10 @@ int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const air
     }
     for (int m = 0; m < mixer_count; m++) first[m + 1] += first[m];
     std::vector<int> cur(first.begin(), first.end() - 1);
+    h->mix_pos.assign(n_in, 0);
     for (int i = 0; i < n_in; i++) { /* stable: connection order inside a mixer is kept (summation order) */
         const int k = cur[in[i].mixer]++;
+        h->mix_pos[i] = k;
         chan[k] = p.chan_base[in[i].device] + in[i].channel;
         ml[k] = in[i].ampfactor * fminf(1.0f, 1.0f - in[i].balance); /* src/mixer.cpp:82-83,203-208 */
         mr[k] = in[i].ampfactor * fminf(1.0f, 1.0f + in[i].balance);
@@ -570,7 +574,19 @@ int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const air
     HIP_TRY(h, h->d_mix_left.alloc((size_t)mixer_count * h->B), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, h->d_mix_right.alloc((size_t)mixer_count * h->B), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, h->d_mix_signal.alloc((size_t)mixer_count), AIRBAND_HIP_ENOMEM);
+    h->mix_chan_host = chan;
     h->n_mixers = mixer_count;
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_mixer_enable_input(airband_hip_handle* h, int32_t input_index, int32_t enabled) {
+    if (!h || h->n_mixers <= 0) return fail(h, AIRBAND_HIP_EINVAL, "no mixers configured");
+    if (input_index < 0 || input_index >= (int32_t)h->mix_pos.size()) return fail(h, AIRBAND_HIP_EINVAL, "mixer input index out of range");
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    const int k = h->mix_pos[input_index];
+    const int v = enabled ? h->mix_chan_host[k] : -1; /* a masked input is skipped like mixer->input_mask[i] == false (src/mixer.cpp:96-110,192) */
+    HIP_TRY(h, hipMemcpyAsync(h->d_mix_chan.p + k, &v, sizeof(int), hipMemcpyHostToDevice, h->stream), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipStreamSynchronize(h->stream), AIRBAND_HIP_ERUNTIME);
     return AIRBAND_HIP_OK;
 }
 

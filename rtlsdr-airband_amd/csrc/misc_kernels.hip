@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void mix_runs_kernel(MixArgs a) {
     bool any = false;
     for (int i = first; i < last; i++) {
         const int ch = a.in_chan[i];
+        if (ch < 0) continue;               /* input masked out (mixer_disable_input, src/mixer.cpp:96-110) */
         if (a.out_axc[ch] == ' ') continue; /* has_signal == false: nothing is added (src/mixer.cpp:119-122,203) */
         any = true;
         if (t < a.wave_batch) {

@@ -289,6 +289,27 @@ def test_mixers_match_reference_order_sum(pkg, built):
             assert not left[2].any() and not sig[2]
             seen |= bool(ws.any())
         assert seen
+        # mixer_disable_input (src/mixer.cpp:96-110): masked connections add nothing and raise no signal flag; order of the rest is kept
+        masked = [i for i, t in enumerate(inputs) if t[2] == 3 and t[0] % 3 == 0] + [i for i, t in enumerate(inputs) if t[2] == 0]
+        for i in masked:
+            hip.mixer_enable_input(i, False)
+        rest = [t for i, t in enumerate(inputs) if i not in set(masked)]
+        arr2 = (capi.MixerInput * len(rest))(*[capi.MixerInput(a, b, c, d, e) for a, b, c, d, e in rest])
+        for d in range(n_dev):
+            extra = pkg.siggen.generate_u8(d, nbytes // 2, hip.geometry.batch_bytes // 2, carriers)
+            assert hip.submit(d, extra) == extra.nbytes
+        assert hip.process()
+        out = hip.collect()
+        left, right, sig = hip.collect_mixers()
+        wl, wr, ws = np.zeros((n_mixers, B), np.float32), np.zeros((n_mixers, B), np.float32), np.zeros(n_mixers, np.uint8)
+        w = np.ascontiguousarray(out["waveout"])
+        a = np.ascontiguousarray(out["axc"])
+        L.orc_mix(arr2, len(rest), base.ctypes.data, w.ctypes.data, a.ctypes.data, B, n_mixers, wl.ctypes.data, wr.ctypes.data, ws.ctypes.data)
+        assert np.array_equal(sig, ws) and not sig[0] and not left[0].any() and not right[0].any()
+        assert np.array_equal(left[3].view(np.uint32), wl[3].view(np.uint32))
+        hip.mixer_enable_input(masked[0], True)  # and back in
+        with pytest.raises(pkg.AirbandError):
+            hip.mixer_enable_input(len(inputs), False)
 
 
 def test_ragged_shapes_and_empty_inputs(pkg, built):
