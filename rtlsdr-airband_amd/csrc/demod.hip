@@ -37,7 +37,7 @@ namespace {
 #define AB_DEMOD_CHUNK 8
 #endif
 constexpr int CHUNK = AB_DEMOD_CHUNK; /* multiple of 4 dividing WAVE_BATCH = 1000 and 2000; 64 lanes x 16 B x CHUNK of LDS per wave */
-static_assert(CHUNK == 8, "output runs (RUN) and the hand-off stores are sized for 8-sample chunks");
+static_assert(CHUNK == 4 || CHUNK == 8, "phase 0 works in groups of four rows; output runs and hand-off runs are whole multiples of the chunk");
 
 /* per-sample flag word parked in LDS between the phases */
 constexpr unsigned FL_AUDIO = 1u;   /* Squelch::should_process_audio()                        */
