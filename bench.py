@@ -64,10 +64,14 @@ def cpu_baseline(pkg, hip, devices, wave_rate, mixed, seconds):
         fast = os.path.exists(pyref.ref_lib_path(nfm, True))
         batches, el = pyref.reference_throughput(devices[:n_dev], [host[d] for d in range(n_dev)], seconds, threads, nfm=nfm, fast=fast)
         note = "oracle/_ref (%s build) " % ("-O3 -march=native -ffast-math" if fast else "-O2 strict")
+        # SURVEY 8d asks for T = 1 next to T = nproc: one demodulate() thread over one dongle, a few seconds
+        b1, e1 = pyref.reference_throughput(devices[:1], [host[0]], min(4.0, seconds), 1, nfm=nfm, fast=fast)
+        one_thread = round(b1 * SAMPLES_PER_BATCH / e1 / 1e6, 3)
     else:
         import pyoracle
 
         kind, threads = "port", 1
+        one_thread = None
         orc = pyoracle.Oracle(devices[:1], wave_rate=wave_rate)
         t0 = time.time()
         batches = 0
@@ -76,7 +80,9 @@ def cpu_baseline(pkg, hip, devices, wave_rate, mixed, seconds):
         el = time.time() - t0
         note = "oracle C restatement "
     value = batches * SAMPLES_PER_BATCH / el / 1e6
-    return dict(value=round(value, 3), unit="Msamples/s", cores=threads, kind=kind,
+    if one_thread is None:
+        one_thread = round(value, 3)
+    return dict(value=round(value, 3), unit="Msamples/s", cores=threads, kind=kind, value_1_thread=one_thread,
                 sample=note + "%d dongles x 8 ch of the same workload for %.1f s wall (%d batches); FFT behind fftwf_* is oracle_fft.c, FFTW3 is not installed" %
                 (n_dev, el, batches))
 
