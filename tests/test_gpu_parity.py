@@ -312,6 +312,36 @@ def test_mixers_match_reference_order_sum(pkg, built):
             hip.mixer_enable_input(len(inputs), False)
 
 
+def test_full_slot_blocks_of_every_kind(pkg, built):
+    """Enough dongles that every demod kind owns whole 64-slot blocks: those take the cooperative store paths (eight lanes per
+    channel write whole 128-byte lines of the audio rows and of the CTCSS hand-off rows), which small configurations never reach.
+    Stage 2 on the oracle's stage-1 output: bit-identical, blocks with padding lanes included (36 dongles -> 144 AM, 72 + 72 NFM)."""
+    mixed, wave_rate, n_dev, n_batches = True, 16000, 36, 4
+    devices, carriers = helpers.plan_devices(n_dev, mixed, _tweak)
+    carriers = _bursty(carriers)  # plenty of opens, fades and re-opens inside four batches
+    nbytes = helpers.stream_bytes(n_batches, wave_rate)
+    src = pyoracle.Oracle(devices, wave_rate=wave_rate)
+    raw = [src.run_device(d, pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers), n_batches) for d in range(n_dev)]
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate)
+    opened = 0
+    with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=pkg.capi.FLAG_TRACE_SQUELCH) as hip:
+        for b in range(n_batches):
+            wavein = np.concatenate([r["raw_wavein"][b] for r in raw])
+            iqin = np.concatenate([r["raw_iq"][b] for r in raw])
+            want = [orc.run_bins(d, raw[d]["raw_wavein"][b], raw[d]["raw_iq"][b]) for d in range(n_dev)]
+            hip.process_bins(wavein, iqin)
+            out = hip.collect(iq=True)
+            tr = hip.read_trace()
+            assert np.array_equal(tr, np.concatenate([w["trace"] for w in want])), "batch %d: squelch trace" % b
+            assert np.array_equal(out["axc"], np.concatenate([w["axc"] for w in want])), "batch %d: axc" % b
+            ww = np.concatenate([w["waveout"] for w in want])
+            assert np.array_equal(out["waveout"].view(np.uint32), ww.view(np.uint32)), "batch %d: waveout max diff %g" % (b, np.abs(out["waveout"] - ww).max())
+            wi = np.concatenate([w["iq_out"] for w in want])
+            assert np.array_equal(out["iq_out"].view(np.uint32), wi.view(np.uint32)), "batch %d: iq_out" % b
+            opened += int((out["axc"] == ord("*")).sum())
+    assert opened > 50
+
+
 def test_ragged_shapes_and_empty_inputs(pkg, built):
     """Edge shapes: a dongle with ONE channel, one with the maximum of 64 (every feature combination, all five demod kinds,
     mostly padding-free blocks), one with 8; zero-length submits, process() before enough data, collect() before any batch."""
