@@ -312,12 +312,14 @@ def test_mixers_match_reference_order_sum(pkg, built):
             hip.mixer_enable_input(len(inputs), False)
 
 
-def test_full_slot_blocks_of_every_kind(pkg, built):
+@pytest.mark.parametrize("mixed,wave_rate,n_dev", [(True, 16000, 36), (False, 8000, 20)], ids=["nfm_build", "am_build"])
+def test_full_slot_blocks_of_every_kind(pkg, built, mixed, wave_rate, n_dev):
     """Enough dongles that every demod kind owns whole 64-slot blocks: those take the cooperative store paths (eight lanes per
     channel write whole 128-byte lines of the audio rows and of the CTCSS hand-off rows), which small configurations never reach.
-    Stage 2 on the oracle's stage-1 output: bit-identical, blocks with padding lanes included (36 dongles -> 144 AM, 72 + 72 NFM)."""
-    mixed, wave_rate, n_dev, n_batches = True, 16000, 36, 4
-    devices, carriers = helpers.plan_devices(n_dev, mixed, _tweak)
+    Stage 2 on the oracle's stage-1 output: bit-identical, blocks with padding lanes included (36 mixed dongles -> 144 AM, 72 + 72 NFM
+    channels; 20 AM dongles -> 160 channels with WAVE_BATCH = 1000, whose last output run is a short one)."""
+    n_batches = 4
+    devices, carriers = helpers.plan_devices(n_dev, mixed, _tweak if mixed else None)
     carriers = _bursty(carriers)  # plenty of opens, fades and re-opens inside four batches
     nbytes = helpers.stream_bytes(n_batches, wave_rate)
     src = pyoracle.Oracle(devices, wave_rate=wave_rate)
