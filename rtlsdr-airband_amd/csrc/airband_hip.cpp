@@ -151,6 +151,10 @@ hipError_t upload(DevBuf<T>& b, const std::vector<T>& v) {
 void destroy(airband_hip_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->hip_device);
+    /* everything in flight must be done before its memory goes away: the front stream of a pipelined handle, the forked demod streams */
+    if (h->front) (void)hipStreamSynchronize(h->front);
+    for (auto& st : h->side)
+        if (st) (void)hipStreamSynchronize(st);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_dev.release(); h->d_cc.release(); h->d_cs.release(); h->d_slot_to_ext.release(); h->d_ext_to_slot.release(); h->d_block_kind.release();
     h->d_window.release(); h->d_sin.release(); h->d_cos.release();
