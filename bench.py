@@ -2,21 +2,36 @@
 """bench.py -- IQ Msamples/s channelized+demodulated (BASELINE.json metric) on N MI355X GPUs of one node.
 
 A "step" = one batch (WAVE_BATCH output samples per channel = 1/8 s of signal = 320 000 complex samples per dongle)
-of the whole hot path -- channelizer kernel, demod/squelch/filter kernel, emit (+ mixer sum) -- over every dongle of
-the rank, with the raw u8 I/Q already resident in HBM (generated on the GPU before the timed region).
+of the whole hot path -- channelizer kernel, demod/squelch/filter kernels, raw-I/Q emit (+ mixer sum) -- over every
+dongle of the rank, with the raw u8 I/Q already resident in HBM (generated on the GPU before the timed region).
 One process per GPU; dongles are independent, so ranks share nothing on the data path (weak scaling: per-GPU
-work is fixed).  With N > 1 and mixers enabled, the per-rank mixer sums are all-reduced over RCCL each step
+work is fixed).  With mixers enabled and N > 1 the per-rank mixer sums are all-reduced over RCCL each step
 (config #5 of BASELINE.json) -- the only exchange step the reference's data flow has (src/mixer.cpp:133-140).
+
+`python bench.py --gpus N` launches the N ranks ITSELF (re-exec under torch.distributed.run on a free port) when it is
+not already running under a launcher -- the analogue of the reference's one demodulate() pthread per device shard
+(src/rtl_airband.cpp:1110-1112) -- and refuses to report anything if the world size it ends up with is not N.
+
+After the timed region, outside it: `--verify K` (default 16) re-checks K sampled dongles of the very buffers that were
+benchmarked against the CPU oracle (oracle/pyverify.py); `--traffic` (default on at N = 1) re-runs a few steps under
+rocprofv3 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) to MEASURE the channelizer's HBM traffic in this run;
+the CPU baseline times the reference's own demodulate() on the host cores.
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import importlib
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -33,12 +48,26 @@ WORKLOADS = {
 }
 SAMPLES_PER_BATCH = 320_000  # complex samples per dongle per batch (2.56 MS/s / 8)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+METRIC = "IQ Msamples/sec channelized+demodulated per node; % HBM roofline"
+CHANNELIZER_KERNEL = {"dft_mfma_i8": "channelizer_dft_kernel", "fft_wave64": "channelizer_fft_kernel"}
 
 
-def cpu_baseline(pkg, hip, devices, wave_rate, mixed, seconds):
-    """The reference's own demodulate() (oracle/_ref, compiled in place) timed on this box's host cores, on a
-    bounded sample: min(nproc, 16) dongles of the same workload, one pthread per dongle shard."""
-    import numpy as np
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(pkg, devices, wave_rate, mixed, seconds):
+    """The reference's own demodulate() (oracle/_ref, compiled in place) timed on this box's host cores, on a bounded sample:
+    T = nproc dongles of the same workload, one pthread per dongle (the reference's multiple_demod_threads model,
+    src/rtl_airband.cpp:1052-1086), rings kept full by cursor rewind.  SURVEY 8d: T = 1 next to T = nproc.
+    FFTW3 is not installed in the image: the FFT behind fftwf_* is a float radix-4 Stockham (oracle_fft32.c) for `value`;
+    the same run behind the float64 radix-2 transform that defines the parity numbers is reported as value_f64_fft."""
     import torch
 
     try:
@@ -46,12 +75,12 @@ def cpu_baseline(pkg, hip, devices, wave_rate, mixed, seconds):
     except Exception as e:  # noqa: BLE001
         return dict(value=None, unit="Msamples/s", cores=0, kind="reference", sample="unavailable: %r" % (e,))
     nfm = wave_rate == 16000
-    threads = max(1, min(os.cpu_count() or 1, 16))
+    nproc = os.cpu_count() or 1
+    threads = nproc
     n_dev = threads
     rb = pyref.ring_bytes()
     buf = torch.zeros((n_dev, rb), dtype=torch.uint8, device="cuda")
-    # same generator, same plan; dongle indices 0..n_dev-1
-    sub = pkg.AirbandHip(devices[:n_dev], wave_rate=wave_rate)
+    sub = pkg.AirbandHip(devices[:n_dev], wave_rate=wave_rate)   # same generator, same plan; dongle indices 0..n_dev-1
     _, carriers = pkg.siggen.baseline_plan(mixed=mixed)
     sub.set_signal_plan(carriers)
     sub.generate_iq(buf.data_ptr(), buf.stride(0), 0, rb)
@@ -59,71 +88,190 @@ def cpu_baseline(pkg, hip, devices, wave_rate, mixed, seconds):
     host = buf.cpu().numpy()
     sub.close()
     del buf
-    kind = "reference"
-    if pyref.have_ref(nfm):
-        fast = os.path.exists(pyref.ref_lib_path(nfm, True))
-        batches, el = pyref.reference_throughput(devices[:n_dev], [host[d] for d in range(n_dev)], seconds, threads, nfm=nfm, fast=fast)
-        note = "oracle/_ref (%s build) " % ("-O3 -march=native -ffast-math" if fast else "-O2 strict")
-        # SURVEY 8d asks for T = 1 next to T = nproc: one demodulate() thread over one dongle, a few seconds
-        b1, e1 = pyref.reference_throughput(devices[:1], [host[0]], min(4.0, seconds), 1, nfm=nfm, fast=fast)
-        one_thread = round(b1 * SAMPLES_PER_BATCH / e1 / 1e6, 3)
-    else:
+    if not pyref.have_ref(nfm):
         import pyoracle
 
-        kind, threads = "port", 1
-        one_thread = None
         orc = pyoracle.Oracle(devices[:1], wave_rate=wave_rate)
         t0 = time.time()
         batches = 0
         while time.time() - t0 < seconds:
             batches += orc.run_device(0, host[0][:2 * 320000], 4)
         el = time.time() - t0
-        note = "oracle C restatement "
-    value = batches * SAMPLES_PER_BATCH / el / 1e6
-    if one_thread is None:
-        one_thread = round(value, 3)
-    return dict(value=round(value, 3), unit="Msamples/s", cores=threads, kind=kind, value_1_thread=one_thread,
-                sample=note + "%d dongles x 8 ch of the same workload for %.1f s wall (%d batches); FFT behind fftwf_* is oracle_fft.c, FFTW3 is not installed" %
-                (n_dev, el, batches))
+        v = round(batches * SAMPLES_PER_BATCH / el / 1e6, 3)
+        return dict(value=v, unit="Msamples/s", cores=1, nproc=nproc, cpu_model=cpu_model(), kind="port", value_1_thread=v, fft="f64 radix-2",
+                    sample="oracle C restatement, 1 dongle x 8 ch for %.1f s wall (%d batches)" % (el, batches))
+
+    def run(variant, n, secs):
+        b, e = pyref.reference_throughput(devices[:n], [host[d] for d in range(n)], secs, n, nfm=nfm, fast=variant)
+        return round(b * SAMPLES_PER_BATCH / e / 1e6, 3), b, e
+
+    have32 = os.path.exists(pyref.ref_lib_path(nfm, "fast32"))
+    have_fast = os.path.exists(pyref.ref_lib_path(nfm, "fast"))
+    main_variant = "fast32" if have32 else ("fast" if have_fast else False)
+    share = seconds / (2.0 if have32 and have_fast else 1.0)
+    value, batches, el = run(main_variant, threads, max(3.0, 0.7 * share))
+    one_thread, _, _ = run(main_variant, 1, max(2.0, 0.3 * share))
+    out = dict(value=value, unit="Msamples/s", cores=threads, nproc=nproc, cpu_model=cpu_model(), kind="reference", value_1_thread=one_thread,
+               fft="f32 radix-4 Stockham (oracle_fft32.c)" if have32 else "f64 radix-2 (oracle_fft.c)",
+               sample="oracle/_ref = the reference's demodulate() compiled in place (%s), %d dongles x 8 ch of the same workload, one pthread each, "
+                      "%.1f s wall (%d batches); FFTW3 is not installed: see `fft`" %
+                      ("-O3 -march=native -ffast-math" if main_variant else "-O2 strict", n_dev, el, batches))
+    if have32 and have_fast:
+        out["value_f64_fft"], _, _ = run("fast", threads, max(3.0, 0.7 * share))
+        out["value_f64_fft_1_thread"], _, _ = run("fast", 1, max(2.0, 0.3 * share))
+    return out
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int) -> int:
+    """Not under a launcher: become one.  N processes, one per GPU, rendezvous on 127.0.0.1 at a free port."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["AIRBAND_BENCH_SPAWNED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """Launcher / rendezvous check without a GPU (CPU test of the N-rank launch): gloo process group, the same barrier and
+    max-over-ranks reduction as the real run, JSON with the world size that was actually formed."""
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        got = dist.get_world_size()
+    else:
+        got = 1
+    if got != args.gpus:
+        raise SystemExit("bench.py: asked for %d ranks, formed %d" % (args.gpus, got))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(dict(metric=METRIC, value=None, unit="Msamples/s", n_gpus=got, steps=args.steps, warmup=args.warmup, dry_run=True, max_rank_seen=int(t.item()) - 1)),
+              flush=True)
+
+
+def measure_traffic(args, kernel_substr):
+    """HBM traffic of the dominant kernel, measured NOW: two short child runs of this very script under
+    `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and WRITE_SIZE cannot share a pass: TCC slots), first launch
+    dropped (it also produces the AGC_EXTRA lead-in).  Corrections per MI355X_MICROARCH.md "HBM": FETCH_SIZE [KB] x 1024 x 2
+    (gfx950 tallies a wide coalesced read at half its bytes), WRITE_SIZE [KB] x 1024 (calibrated 1.000 on siggen_kernel's
+    known byte count, profiles/r01_pmc_traffic.md).  Returns (bytes per launch | None, detail dict)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, dict(error="rocprofv3 not found")
+    detail = {}
+    per_kernel = {}
+    total = 0.0
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    for counter, mult in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
+        out_dir = tempfile.mkdtemp(prefix="airband_pmc_", dir="/tmp")
+        cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
+               "--child", "--workload", args.workload, "--steps", "3", "--warmup", "1", "--ring", "1"]
+        if args.dongles:
+            cmd += ["--dongles", str(args.dongles)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=args.traffic_timeout, check=False)
+            vals = []
+            others = {}
+            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    kname = row.get("Kernel_Name", "")
+                    if kernel_substr in kname:
+                        vals.append(float(row["Counter_Value"]))
+                    elif "airband::" in kname and "siggen" not in kname:
+                        short = kname.split("(")[0].replace("void ", "").replace("airband::", "").replace("(anonymous namespace)::", "")
+                        short = kname.replace("void ", "").replace("airband::", "").replace("(anonymous namespace)::", "").split("(")[0]
+                        others.setdefault(short, []).append(float(row["Counter_Value"]))
+            for short, v in others.items():  # every other kernel of a step (stage 2 ...): same corrections, all launches but the first
+                if len(v) >= 2:
+                    per_kernel.setdefault(short, {})[counter.lower() + "_bytes"] = sum(v[1:]) / (len(v) - 1) * mult
+            if len(vals) < 2:
+                return None, dict(error="%s: %d launches of %s seen" % (counter, len(vals), kernel_substr))
+            per = sum(vals[1:]) / (len(vals) - 1) * mult
+            detail[counter.lower() + "_bytes"] = per
+            total += per
+        except Exception as e:  # noqa: BLE001
+            return None, dict(error="%s pass failed: %r" % (counter, e))
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    detail["other_kernels"] = per_kernel
+    detail["method"] = "rocprofv3 --pmc FETCH_SIZE x1024x2 + WRITE_SIZE x1024 (separate passes, launches 2.. of a 4-step child run of this command)"
+    return total, detail
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=120, help="timed steps (default: >= 2 s of GPU work at configs[2])")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("AIRBAND_BENCH_WORKLOAD", "cfg3"), choices=sorted(WORKLOADS))
     ap.add_argument("--dongles", type=int, default=0, help="override dongles per GPU")
     ap.add_argument("--ring", type=int, default=3, help="distinct I/Q batches kept in HBM and cycled through")
     ap.add_argument("--mixers", type=int, default=0, help="number of mixers (BASELINE configs[4]: 64). Default 0 at every N, so that per-GPU work is the same "
                     "from 1 to 8 GPUs (configs[1]-[3] have no exchange step); with mixers and N > 1 the per-rank sums are all-reduced over RCCL every step")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", type=int, default=16, help="after the timed region, compare this many sampled dongles of the benchmarked handle with the CPU oracle (0 = off)")
+    ap.add_argument("--traffic", dest="traffic", action="store_true", default=None, help="measure the channelizer's HBM traffic with rocprofv3 PMC passes after the run (default at N = 1)")
+    ap.add_argument("--no-traffic", dest="traffic", action="store_false")
+    ap.add_argument("--traffic-timeout", type=float, default=240.0)
     ap.add_argument("--host-path", action="store_true", help="additionally time the host-buffer path (submit over PCIe) on a small slice; reported separately, never as value")
-    ap.add_argument("--pipelined", action="store_true", help="AIRBAND_HIP_FLAG_PIPELINE: stage 1 of batch k beside stage 2 of batch k-1 (results one batch late). "
-                    "Measured gain at configs[2]: ~3 %% -- both halves lean on the same HBM / vector-issue capacity -- and the channelizer's own launch time, "
-                    "which the roofline figure is built on, is then no longer that of the kernel alone; so the default is one batch at a time")
+    ap.add_argument("--pipelined", action="store_true", help="AIRBAND_HIP_FLAG_PIPELINE: stage 1 of batch k beside stage 2 of batch k-1 (results one batch late); the "
+                    "channelizer's launch time, which the roofline figure is built on, is then no longer that of the kernel alone, so the default is one batch at a time")
     ap.add_argument("--sequential", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--force-dist", action="store_true", help="initialise a process group even at world size 1 (plumbing check of the RCCL leg)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher check without GPUs: form the N-rank group over gloo, print the JSON skeleton")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # profiled child of measure_traffic(): steps only, no extras, no JSON
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if os.environ.get("AIRBAND_BENCH_SPAWNED"):
+            raise SystemExit("bench.py: spawned rank without WORLD_SIZE -- launcher failure")
+        sys.exit(spawn_ranks(args.gpus))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d -- refusing to report a number for a different job size" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libairband_hip has no CPU fallback")
+    if torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d GPUs visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(free_port())  # only reachable at world size 1 (--force-dist)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
     pkg = importlib.import_module("rtlsdr-airband_amd")
     wl = WORKLOADS[args.workload]
@@ -133,9 +281,7 @@ def main():
 
     chans, carriers = pkg.siggen.baseline_plan(mixed=mixed)
     devices = [dict(channels=chans) for _ in range(D)]
-    # --pipelined (AIRBAND_HIP_FLAG_PIPELINE): a step enqueues stage 1 of its batch beside stage 2 of the previous one -- every step
-    # still does one full stage 1 and one full stage 2, of consecutive batches.  AIRBAND_BENCH_FLAGS adds AIRBAND_HIP_FLAG_* bits for
-    # experiments (e.g. 8 = demod kinds one after the other, for per-kernel profiles).
+    # AIRBAND_BENCH_FLAGS adds AIRBAND_HIP_FLAG_* bits for experiments (e.g. 8 = demod kinds one after the other, for per-kernel profiles)
     flags = int(os.environ.get("AIRBAND_BENCH_FLAGS", "0"), 0) | (pkg.capi.FLAG_PIPELINE if args.pipelined else 0)
     hip = pkg.AirbandHip(devices, wave_rate=wave_rate, hip_device=local_rank, flags=flags)
     g = hip.geometry
@@ -168,12 +314,11 @@ def main():
     cstream = torch.cuda.Stream() if mix_t is not None else None   # a real stream: torch's default one is the NULL handle
     consumer = cstream.cuda_stream if cstream is not None else 0
 
+    def offset(i):
+        return 0 if i == 0 else g.first_batch_bytes + ((i - 1) % args.ring) * g.batch_bytes
+
     def step(i):
-        if i == 0:
-            off = 0
-        else:
-            off = g.first_batch_bytes + ((i - 1) % args.ring) * g.batch_bytes
-        hip.process_device(iq.data_ptr() + off, stride, consumer)
+        hip.process_device(iq.data_ptr() + offset(i), stride, consumer)
         if mix_t is not None:
             hip.stream_wait_results(consumer)
             with torch.cuda.stream(cstream):
@@ -195,75 +340,111 @@ def main():
         step(i)
     sync()
     elapsed = time.perf_counter() - t0
+    if args.child:  # profiled child: the kernels ran, that is all the parent wants
+        hip.close()
+        return
     # HIP events the library records around each kernel on the stream it runs on, read once after the timed region
     tt = hip.timing_totals()
     nb = max(1, tt["batches"])
-    chan_ms, demod_ms, emit_ms = [tt["channelizer_ms"] / nb], [tt["demod_ms"] / nb], [tt["emit_ms"] / nb]
+    ch_ms, demod_ms, emit_ms = tt["channelizer_ms"] / nb, tt["demod_ms"] / nb, tt["emit_ms"] / nb
     hip.flush()
     sync()
+    total_steps = args.warmup + args.steps
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
 
     total_samples = float(D) * world * SAMPLES_PER_BATCH * args.steps
     value = total_samples / elapsed / 1e6
     hop = g.batch_bytes // (2 * hip.B)
     alg_bytes_per_sample = 2.0 + 8 * 4.0 / hop          # u8 I/Q in, 8 channels of float audio out per hop
-    ch_ms = float(np.mean(chan_ms)) if chan_ms else None
-    roofline = None
-    if ch_ms:
-        achieved = alg_bytes_per_sample * D * SAMPLES_PER_BATCH / (ch_ms * 1e-3) / 1e9
-        traffic = None
-        cal = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(cal):
-            try:
-                traffic = json.load(open(cal)).get(args.workload, {}).get(hip.channelizer_name())
-            except Exception:  # noqa: BLE001
-                traffic = None
-        roofline = dict(bound="hbm", kernel=hip.channelizer_name(), achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                        traffic=traffic, avg_launch_ms=round(ch_ms, 4), algorithmic_bytes_per_launch=alg_bytes_per_sample * D * SAMPLES_PER_BATCH)
-    out = dict(metric="IQ Msamples/sec channelized+demodulated per node; % HBM roofline", value=round(value, 2), unit="Msamples/s", n_gpus=world, steps=args.steps,
-               warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
-               data="synthetic", config=dict(workload=wl["desc"], dongles_per_gpu=D, channels_per_dongle=8, fft_size=g.fft_size, wave_rate=wave_rate,
-                                               sample_format="u8", iq_resident="HBM", ring_batches=args.ring, mixers=n_mixers,
-                                               schedule="pipelined: stage 1 of batch k beside stage 2 of batch k-1" if args.pipelined else "one batch at a time",
-                                               parallelism="dongle-sharded x%d, %s" % (world, "RCCL all-reduce of mixer sums" if mix_t is not None else "no collective"),
-                                               channelizer=hip.channelizer_name()),
+    name = hip.channelizer_name()
+    build = hip.build_info()
+    achieved = alg_bytes_per_sample * D * SAMPLES_PER_BATCH / (ch_ms * 1e-3) / 1e9
+    read_only = 2.0 * D * SAMPLES_PER_BATCH / (ch_ms * 1e-3) / 1e9
+    roofline = dict(bound="hbm", kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    avg_launch_ms=round(ch_ms, 4), algorithmic_bytes_per_launch=alg_bytes_per_sample * D * SAMPLES_PER_BATCH,
+                    frac_read_only=round(read_only / HBM_PEAK_GBS, 4),
+                    read_only_note="input bytes only (2 B per I/Q sample) / launch time / peak: north_star words its target as READ bandwidth; `frac` uses SURVEY 8d's 2 B in + audio out")
+    out = dict(metric=METRIC, value=round(value, 2), unit="Msamples/s", n_gpus=world, steps=args.steps,
+               warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="i8x3->i32->f64->f32 (stage 1), f32 (stage 2)" if name == "dft_mfma_i8" else "f32", data="synthetic",
+               config=dict(workload=wl["desc"], dongles_per_gpu=D, channels_per_dongle=8, fft_size=g.fft_size, wave_rate=wave_rate,
+                           sample_format="u8", iq_resident="HBM", ring_batches=args.ring, mixers=n_mixers,
+                           schedule="pipelined: stage 1 of batch k beside stage 2 of batch k-1" if args.pipelined else "one batch at a time",
+                           parallelism="dongle-sharded x%d, %s" % (world, "RCCL all-reduce of mixer sums" if mix_t is not None else "no collective"),
+                           channelizer=name,
+                           arithmetic="stage 1: u8 x 24-bit window*twiddle as 3 int8 digits -> exact int32 MFMA sums -> f64 recombine -> f32 bins; stage 2: f32, reference operation order"
+                           if name == "dft_mfma_i8" else "stage 1: f32 radix-2 FFT; stage 2: f32, reference operation order",
+                           library=os.path.basename(pkg.LIB_PATH), build_defines=build),
                roofline=roofline,
-               stage_ms=dict(channelizer=ch_ms, demod=float(np.mean(demod_ms)) if demod_ms else None, mixers_and_iq_out=float(np.mean(emit_ms)) if emit_ms else None),
+               stage_ms=dict(channelizer=ch_ms, demod=demod_ms, mixers_and_iq_out=emit_ms),
                realtime_dongles=int(value / 2.56))
+
+    # ---- everything below is outside the timed region ------------------------------------------------------------------
+    if rank == 0 and args.verify > 0:
+        # spot check of the benchmarked buffers (oracle = test infrastructure, used here only as the checker)
+        try:
+            import pyverify
+
+            dongles = pyverify.sample_dongles(D, args.verify)
+            host = [iq[d].cpu().numpy() for d in dongles]
+            spot = pyverify.SpotCheck(lambda d: devices[d], dongles, wave_rate=wave_rate)
+            tv = time.perf_counter()
+            for i in range(total_steps):
+                spot.feed([h[offset(i):] for h in host], trace=False)
+            worst = spot.compare(hip, trace=False, what="bench")
+            spot.close()
+            out["verified_dongles"] = len(dongles)
+            out["verify"] = dict(dongles=dongles, batches=total_steps, checked="last batch: axcindicate, open/closed pattern, cumulative squelch/CTCSS counters and state "
+                                 "exact; audio RMS error <= 1e-4", worst_audio_rms=worst["audio_rms"], oracle_seconds=round(time.perf_counter() - tv, 1))
+        except AssertionError as e:
+            out["verified_dongles"] = 0
+            out["verify"] = dict(error=str(e)[:500])
+            out["value"] = None  # a number whose outputs are wrong is not a result
+        except Exception as e:  # noqa: BLE001
+            out["verified_dongles"] = 0
+            out["verify"] = dict(error="spot check could not run: %r" % (e,))
     if rank == 0 and world == 1 and args.host_path:
         # host-buffer path: the shim of INTEGRATION.md feeding pageable host memory through submit()/process()
         nd = min(D, 512)
         sub = pkg.AirbandHip(devices[:nd], wave_rate=wave_rate, hip_device=local_rank)
         gg = sub.geometry
+        nb_host = 6
         host = iq[:nd, :gg.first_batch_bytes + 3 * gg.batch_bytes + gg.lookahead_bytes].cpu().numpy()
         for d in range(nd):
             sub.submit(d, host[d, :gg.first_batch_bytes + gg.lookahead_bytes])
         sub.process(); sub.synchronize()
         t1 = time.perf_counter()
-        off = gg.first_batch_bytes + gg.lookahead_bytes
-        for k in range(3):
+        for k in range(nb_host):
+            off = gg.first_batch_bytes + gg.lookahead_bytes + (k % 3) * gg.batch_bytes
             for d in range(nd):
                 sub.submit(d, host[d, off:off + gg.batch_bytes])
             sub.process()
-            off += gg.batch_bytes
         sub.synchronize()
         el = time.perf_counter() - t1
-        out["host_path"] = dict(value=round(nd * SAMPLES_PER_BATCH * 3 / el / 1e6, 1), unit="Msamples/s", dongles=nd, note="pageable host buffers -> pinned staging -> PCIe; includes the H2D copy")
+        out["host_path"] = dict(value=round(nd * SAMPLES_PER_BATCH * nb_host / el / 1e6, 1), unit="Msamples/s", dongles=nd,
+                                note="pageable host buffers -> pinned staging -> PCIe; includes the H2D copy")
         sub.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(pkg, hip, devices, wave_rate, mixed, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(pkg, devices, wave_rate, mixed, args.cpu_seconds)
         except Exception as e:  # noqa: BLE001
             out["cpu_baseline"] = dict(value=None, unit="Msamples/s", cores=0, kind="reference", sample="failed: %r" % (e,))
     elif rank == 0:
         out["cpu_baseline"] = None
     hip.close()
+    del iq
+    torch.cuda.empty_cache()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    want_traffic = args.traffic if args.traffic is not None else (world == 1)
+    if rank == 0 and world == 1 and want_traffic:
+        traffic, detail = measure_traffic(args, CHANNELIZER_KERNEL.get(name, name))
+        out["roofline"]["traffic"] = traffic
+        out["roofline"]["traffic_detail"] = detail
     if rank == 0:
         # RCCL prints its version banner through C stdio, which a pipe buffers until exit: push it out first so that the JSON is the LAST line
         try:

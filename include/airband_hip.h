@@ -55,7 +55,8 @@ extern "C" {
 #define AIRBAND_HIP_FLAG_TRACE_SQUELCH 0x1u /* record per-sample squelch state (parity debugging;       \
                                                mirrors the reference's DEBUG_SQUELCH dump,               \
                                                src/squelch.cpp:593-633)                                 */
-#define AIRBAND_HIP_FLAG_KEEP_BINS 0x2u     /* keep stage-1 output (wavein/iq_in) readable after a batch */
+#define AIRBAND_HIP_FLAG_KEEP_BINS 0x2u     /* accepted for ABI compatibility, not needed: the stage-1 rings always hold \
+                                               the last batch (see airband_hip_read_bins)                                 */
 #define AIRBAND_HIP_FLAG_FORCE_FFT 0x4u     /* always use the full wavefront-FFT channelizer             */
 #define AIRBAND_HIP_FLAG_SERIAL_DEMOD 0x8u  /* run the per-kind demod kernels one after another instead   \
                                                of side by side on forked streams (profiling aid)          */
@@ -214,6 +215,13 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
  * Replaces: the hand-off at src/rtl_airband.cpp:649-662 (waveavail / Signal::send). */
 int airband_hip_collect(airband_hip_handle* h, float* waveout, float* iq_out, char* axcindicate, airband_hip_channel_stats* stats);
 
+/* The same four outputs for the channel range [first_channel, first_channel + n_channels) only (device-major numbering as
+ * above; arrays are sized for n_channels).  Does NOT mark the batch as collected, so it can be called any number of times
+ * between two process calls -- the reference's per-device consumer (process_outputs() walks one device_t at a time,
+ * src/output.cpp:905-935), and the spot checks of handles too large to copy whole (bench.py --verify). */
+int airband_hip_collect_channels(airband_hip_handle* h, int64_t first_channel, int64_t n_channels, float* waveout, float* iq_out, char* axcindicate,
+                                 airband_hip_channel_stats* stats);
+
 /* Mixer outputs of the batch last collected: left [mixer_count][wave_batch], right likewise (zeros for
  * mono mixers), has_signal [mixer_count] (reference: src/mixer.cpp:201-214). HOST pointers.
  * Multi-GPU callers all-reduce (sum / max) these across ranks. */
@@ -246,14 +254,19 @@ int airband_hip_synchronize(airband_hip_handle* h);
  * and demand bit-identical stage-2 results. */
 int airband_hip_process_bins(airband_hip_handle* h, const float* wavein, const float* iq_in);
 
-/* Stage-1 output of the last batch (needs AIRBAND_HIP_FLAG_KEEP_BINS): wavein [total_channels][wave_batch],
- * iq_in [total_channels][2*wave_batch].  HOST pointers. */
+/* Stage-1 output of the last batch, i.e. what the reference holds in channel->wavein[AGC_EXTRA..] / iq_in[2*AGC_EXTRA..] after
+ * its FFT loop (src/rtl_airband.cpp:483-489): wavein [total_channels][wave_batch], iq_in [total_channels][2*wave_batch] (zeros for
+ * channels that do not need raw I/Q).  HOST pointers.  NFM channels: stage 1 stores only the raw bin I/Q, |bin| is recomputed
+ * here as sqrtf(re^2 + im^2) exactly as stage 2 does.  AM channels with a lowpass filter / raw-I/Q output: stage 2 overwrites
+ * wavein[j] with the filtered magnitude in place, as the reference does (src/rtl_airband.cpp:524) -- that is what is returned. */
 int airband_hip_read_bins(airband_hip_handle* h, float* wavein, float* iq_in);
+int airband_hip_read_bins_channels(airband_hip_handle* h, int64_t first_channel, int64_t n_channels, float* wavein, float* iq_in);
 
 /* Per-sample squelch trace of the last batch (needs AIRBAND_HIP_FLAG_TRACE_SQUELCH):
  * state [total_channels][wave_batch] bytes: bits 0-2 Squelch::State after process_raw_sample,
  * bit 3 is_open(), bit 4 should_process_audio(), bit 5 CTCSS has_tone (slow if enough samples else fast). */
 int airband_hip_read_trace(airband_hip_handle* h, uint8_t* state);
+int airband_hip_read_trace_channels(airband_hip_handle* h, int64_t first_channel, int64_t n_channels, uint8_t* state);
 
 /* Derived per-channel constants (bin, dm_dphi, filter taps ...) as the library computed them; lets
  * tests compare against the reference's own derivation.  out_vals must hold 16 doubles:
@@ -273,6 +286,10 @@ int airband_hip_last_timings(airband_hip_handle* h, float* ms4);
 /* Sums of the same four figures over every batch that has FINISHED since the last reset, and how many batches that is.
  * Waits for the enqueued batches; callers that must not stall inside a run call it once, after airband_hip_synchronize(). */
 int airband_hip_timing_totals(airband_hip_handle* h, double* ms4_sum, int64_t* n_batches, int32_t reset);
+
+/* Extra preprocessor defines this library was compiled with ("" for the product build; kernel experiments are built under a
+ * different file name and say here what they changed, so that a measurement can always be traced to the code that produced it). */
+const char* airband_hip_build_info(void);
 
 /* Name of the channelizer variant the handle selected ("fft_wave64" / "dft_mfma_i8"). */
 const char* airband_hip_channelizer_name(const airband_hip_handle* h);

@@ -907,6 +907,25 @@ int orc_run_device(orc_t* o, int d, const void* iq, size_t nbytes, int max_batch
     return nb;
 }
 
+/* One batch straight from a caller-held span, the way airband_hip_process_device() is fed: hop h reads the fft_size samples at
+ * span + h * hop_bytes; the first call of a stream consumes WAVE_BATCH + AGC_EXTRA hops (waveend starts at 0,
+ * src/config.cpp:805), every later call WAVE_BATCH.  The span may come from anywhere (bench.py cycles through a few resident
+ * batches), so unlike orc_run_device nothing is buffered.  Returns 1 (one batch produced). */
+int orc_run_span(orc_t* o, int d, const void* span, float* waveout, float* iq_out, char* axc, uint8_t* trace, float* raw_wavein, float* raw_iq) {
+    odev_t* dev = o->dev + d;
+    const int B = o->wave_batch, C = dev->n_ch;
+    const unsigned char* p = (const unsigned char*)span;
+    while (dev->waveend < B + AGC_EXTRA) {
+        stage1_hop(o, dev, p);
+        p += dev->hop_bytes;
+    }
+    grab_raw(o, dev, raw_wavein, raw_iq);
+    for (int j = 0; j < C; j++) stage2_channel(o, dev, dev->ch + j, trace ? trace + (size_t)j * B : NULL);
+    dev->waveend -= B;
+    emit_batch(o, dev, waveout, iq_out, axc);
+    return 1;
+}
+
 int orc_run_bins(orc_t* o, int d, const float* wavein, const float* iq, float* waveout, float* iq_out, char* axc, uint8_t* trace) {
     odev_t* dev = o->dev + d;
     const int B = o->wave_batch;

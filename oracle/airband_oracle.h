@@ -28,6 +28,11 @@ int orc_total_channels(const orc_t* o);
 int orc_run_device(orc_t* o, int d, const void* iq, size_t nbytes, int max_batches, float* waveout, float* iq_out, char* axc, uint8_t* trace, float* raw_wavein,
                    float* raw_iq);
 
+/* One batch of device d from a caller-held span laid out as airband_hip_process_device() expects it (hop h at
+ * span + h * hop_bytes; WAVE_BATCH + AGC_EXTRA hops on the first call of a stream, WAVE_BATCH afterwards).  Outputs as one
+ * batch of orc_run_device ([C][B] ...), any pointer may be NULL. */
+int orc_run_span(orc_t* o, int d, const void* span, float* waveout, float* iq_out, char* axc, uint8_t* trace, float* raw_wavein, float* raw_iq);
+
 /* Stage-2 only for device d: consume B new hops of caller-provided stage-1 output (wavein [C][B], iq [C][2B])
  * and produce one batch. */
 int orc_run_bins(orc_t* o, int d, const float* wavein, const float* iq, float* waveout, float* iq_out, char* axc, uint8_t* trace);

@@ -26,6 +26,7 @@ def lib() -> C.CDLL:
         L.orc_wave_batch.argtypes = [C.c_void_p]
         L.orc_run_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 6
         L.orc_run_bins.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
+        L.orc_run_span.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
         L.orc_channel_stats.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(capi.ChannelStats)]
         L.orc_channel_constants.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.orc_window_coeff.restype = C.c_float
@@ -102,6 +103,18 @@ class Oracle:
         nb = self.L.orc_run_device(self.h, d, iq.ctypes.data, iq.nbytes, max_batches, wave.ctypes.data, iqo.ctypes.data, axc.ctypes.data, trace.ctypes.data,
                                    rw.ctypes.data, ri.ctypes.data)
         return dict(n_batches=nb, waveout=wave[:nb], iq_out=iqo[:nb], axc=axc[:nb], trace=trace[:nb], raw_wavein=rw[:nb], raw_iq=ri[:nb])
+
+    def run_span(self, d: int, span: np.ndarray, *, trace: bool = True):
+        """One batch from a span laid out like airband_hip_process_device's input (hop h at h * hop_bytes)."""
+        nch = len(self.devices[d]["channels"])
+        B = self.B
+        wave = np.zeros((nch, B), np.float32)
+        iqo = np.zeros((nch, 2 * B), np.float32)
+        axc = np.zeros((nch,), np.uint8)
+        tr = np.zeros((nch, B), np.uint8) if trace else None
+        span = np.ascontiguousarray(span)
+        self.L.orc_run_span(self.h, d, span.ctypes.data, wave.ctypes.data, iqo.ctypes.data, axc.ctypes.data, tr.ctypes.data if trace else None, None, None)
+        return dict(waveout=wave, iq_out=iqo, axc=axc, trace=tr)
 
     def run_bins(self, d: int, wavein: np.ndarray, iq: np.ndarray):
         nch = len(self.devices[d]["channels"])

@@ -14,15 +14,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 capi = importlib.import_module("rtlsdr-airband_amd.capi")
 
 
-def ref_lib_path(nfm: bool, fast: bool = False) -> str:
-    return os.path.join(HERE, "_ref", "libairband_ref_%s%s.so" % ("nfm" if nfm else "am", "_fast" if fast else ""))
+def ref_lib_path(nfm: bool, fast=False) -> str:
+    """fast: False = parity build (-O2, IEEE, float64 FFT behind fftwf_*); True / "fast" = the reference's own flags
+    (-O3 -march=native -ffast-math), same FFT; "fast32" = those flags with the float radix-4 FFT (oracle_fft32.c) -- timing only."""
+    suffix = "" if not fast else ("_" + fast if isinstance(fast, str) else "_fast")
+    return os.path.join(HERE, "_ref", "libairband_ref_%s%s.so" % ("nfm" if nfm else "am", suffix))
 
 
 def have_ref(nfm: bool = True) -> bool:
     return os.path.exists(ref_lib_path(nfm))
 
 
-def _load(nfm: bool, fast: bool = False) -> C.CDLL:
+def _load(nfm: bool, fast=False) -> C.CDLL:
     lib = C.CDLL(ref_lib_path(nfm, fast))
     lib.refh_init.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.refh_add_device.argtypes = [C.c_int, C.POINTER(capi.DeviceCfg)]
@@ -153,7 +156,7 @@ def ring_bytes(fft_size: int = 512, bytes_per_sample: int = 1) -> int:
     return 2560000 + 2 * bytes_per_sample * fft_size
 
 
-def reference_throughput(devices, iq_list, seconds: float, threads: int, *, nfm: bool, fast: bool = True, fft_log: int = 9):
+def reference_throughput(devices, iq_list, seconds: float, threads: int, *, nfm: bool, fast=True, fft_log: int = 9):
     """CPU baseline: the real reference demodulate() in `threads` pthreads over contiguous device shards, rings
     pre-filled and kept full by cursor rewind.  Returns (batches completed over all devices, elapsed seconds)."""
     ctx = mp.get_context("fork")

@@ -29,6 +29,7 @@ EXPORTS = [
     "airband_hip_synchronize", "airband_hip_process_bins", "airband_hip_read_bins", "airband_hip_read_trace", "airband_hip_channel_constants",
     "airband_hip_derive_constants", "airband_hip_last_timings", "airband_hip_channelizer_name", "airband_hip_set_signal_plan", "airband_hip_generate_iq",
     "airband_hip_flush", "airband_hip_timing_totals", "airband_hip_stream_wait_results", "airband_hip_mixer_enable_input",
+    "airband_hip_build_info", "airband_hip_collect_channels", "airband_hip_read_bins_channels", "airband_hip_read_trace_channels",
 ]
 
 _lib = None
@@ -68,6 +69,9 @@ def load_library() -> C.CDLL:
     L.airband_hip_process.argtypes = [vp]
     L.airband_hip_process_device.argtypes = [vp, vp, sz, vp]
     L.airband_hip_collect.argtypes = [vp, vp, vp, vp, vp]
+    L.airband_hip_collect_channels.argtypes = [vp, i64, i64, vp, vp, vp, vp]
+    L.airband_hip_read_bins_channels.argtypes = [vp, i64, i64, vp, vp]
+    L.airband_hip_read_trace_channels.argtypes = [vp, i64, i64, vp]
     L.airband_hip_collect_mixers.argtypes = [vp, vp, vp, vp]
     L.airband_hip_device_results.argtypes = [vp] + [C.POINTER(vp)] * 6
     L.airband_hip_synchronize.argtypes = [vp]
@@ -81,6 +85,8 @@ def load_library() -> C.CDLL:
     L.airband_hip_channelizer_name.restype = C.c_char_p
     L.airband_hip_set_signal_plan.argtypes = [vp, vp, i32, i32, vp]
     L.airband_hip_generate_iq.argtypes = [vp, vp, sz, u64, sz, u64, i32, vp]
+    L.airband_hip_build_info.argtypes = []
+    L.airband_hip_build_info.restype = C.c_char_p
     L.airband_hip_flush.argtypes = [vp]
     L.airband_hip_mixer_enable_input.argtypes = [vp, i32, i32]
     L.airband_hip_stream_wait_results.argtypes = [vp, vp]
@@ -171,14 +177,20 @@ class AirbandHip:
     def process_device(self, d_iq_ptr: int, stride_bytes: int, stream: int = 0):
         self._check(self.L.airband_hip_process_device(self.h, C.c_void_p(d_iq_ptr), stride_bytes, C.c_void_p(stream)))
 
-    def collect(self, *, iq: bool = False, stats: bool = False):
-        n, B = self.total_channels, self.B
+    def collect(self, *, iq: bool = False, stats: bool = False, first_channel: Optional[int] = None, n_channels: Optional[int] = None):
+        """Results of the last batch; with first_channel / n_channels only that channel range (airband_hip_collect_channels:
+        repeatable, does not mark the batch as collected)."""
+        ranged = first_channel is not None
+        n, B = (int(n_channels) if ranged else self.total_channels), self.B
         wave = np.empty((n, B), np.float32)
         axc = np.empty((n,), np.uint8)
         iqo = np.empty((n, 2 * B), np.float32) if iq else None
         st = (capi.ChannelStats * n)() if stats else None
-        self._check(self.L.airband_hip_collect(self.h, wave.ctypes.data, iqo.ctypes.data if iq else None, axc.ctypes.data,
-                                               C.cast(st, C.c_void_p) if stats else None))
+        args = (wave.ctypes.data, iqo.ctypes.data if iq else None, axc.ctypes.data, C.cast(st, C.c_void_p) if stats else None)
+        if ranged:
+            self._check(self.L.airband_hip_collect_channels(self.h, int(first_channel), n, *args))
+        else:
+            self._check(self.L.airband_hip_collect(self.h, *args))
         out = dict(waveout=wave, axc=axc)
         if iq:
             out["iq_out"] = iqo
@@ -203,16 +215,17 @@ class AirbandHip:
         assert wavein.shape == (self.total_channels, self.B) and iq_in.shape == (self.total_channels, 2 * self.B)
         self._check(self.L.airband_hip_process_bins(self.h, wavein.ctypes.data, iq_in.ctypes.data))
 
-    def read_bins(self):
-        n, B = self.total_channels, self.B
+    def read_bins(self, first_channel: int = 0, n_channels: Optional[int] = None):
+        n, B = (self.total_channels - first_channel if n_channels is None else int(n_channels)), self.B
         w = np.empty((n, B), np.float32)
         q = np.empty((n, 2 * B), np.float32)
-        self._check(self.L.airband_hip_read_bins(self.h, w.ctypes.data, q.ctypes.data))
+        self._check(self.L.airband_hip_read_bins_channels(self.h, int(first_channel), n, w.ctypes.data, q.ctypes.data))
         return w, q
 
-    def read_trace(self) -> np.ndarray:
-        t = np.empty((self.total_channels, self.B), np.uint8)
-        self._check(self.L.airband_hip_read_trace(self.h, t.ctypes.data))
+    def read_trace(self, first_channel: int = 0, n_channels: Optional[int] = None) -> np.ndarray:
+        n = self.total_channels - first_channel if n_channels is None else int(n_channels)
+        t = np.empty((n, self.B), np.uint8)
+        self._check(self.L.airband_hip_read_trace_channels(self.h, int(first_channel), n, t.ctypes.data))
         return t
 
     def constants(self, channel_index: int):
@@ -234,6 +247,9 @@ class AirbandHip:
 
     def channelizer_name(self) -> str:
         return self.L.airband_hip_channelizer_name(self.h).decode()
+
+    def build_info(self) -> str:
+        return self.L.airband_hip_build_info().decode()
 
     # ---- mixers ---------------------------------------------------------------------------------------
     def set_mixers(self, n_mixers: int, inputs: Sequence[tuple]):

@@ -10,11 +10,18 @@ import os
 import subprocess
 import sys
 
+import hashlib
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libairband_hip.so")
 ARCH = "gfx950"
+# Kernel experiments (AIRBAND_EXTRA_DEFINES="-DAB_..." [AIRBAND_BUILD_TAG=name]) never touch the product library: they get their own
+# object directory and their own file name (libairband_hip_exp_<tag>.so, loaded with AIRBAND_HIP_LIB=...), and every library reports
+# the defines it was compiled with through airband_hip_build_info() -- bench.py prints that string into its JSON line.
+EXTRA = os.environ.get("AIRBAND_EXTRA_DEFINES", "").split()
+TAG = os.environ.get("AIRBAND_BUILD_TAG") or (hashlib.sha1(" ".join(EXTRA).encode()).hexdigest()[:8] if EXTRA else "")
+OBJ = os.path.join(HERE, "build" + ("_exp_" + TAG if EXTRA else ""))
+LIB = os.path.join(HERE, "libairband_hip" + ("_exp_" + TAG if EXTRA else "") + ".so")
 
 HIP_SOURCES = {
     "channelizer_fft.hip": ["-O3"],
@@ -54,8 +61,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJ, name + ".o")
         objs.append(obj)
         if force or _newer(src, obj):
-            extra = os.environ.get("AIRBAND_EXTRA_DEFINES", "").split()  # experiments only (e.g. -DAB_SKIP_PHASE2)
-            cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + flags + extra + ["-c", src, "-o", obj]
+            info = ["-DAB_BUILD_DEFINES=\"%s\"" % " ".join(EXTRA)] if name == "airband_hip.cpp" else []
+            cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + flags + EXTRA + info + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             _run(cmd)

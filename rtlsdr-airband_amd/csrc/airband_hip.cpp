@@ -53,6 +53,9 @@ struct airband_hip_handle {
     hipStream_t front = nullptr;
     hipEvent_t ev_in = nullptr, ev_back = nullptr, ev_wait = nullptr, front_done[2] = {nullptr, nullptr};
     hipStream_t last_stream = nullptr; /* stream the last sequential batch ran on (the caller's or ours) */
+    hipEvent_t ev_last = nullptr;      /* recorded behind every batch that ran on a CALLER's stream: collect / read_* / synchronize / release
+                                          order themselves behind it (the caller's stream itself may be gone by then, our event is not) */
+    bool ev_last_pending = false;
     int row0_front = 0;            /* ring row of the batch stage 1 writes next (== row0 when not pipelined) */
     uint64_t front_batches = 0;    /* batches whose stage 1 has been enqueued */
     /* per-stage GPU time: a pool of event sets (one per process call) harvested lazily, so that nobody has to
@@ -152,6 +155,7 @@ void destroy(airband_hip_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->hip_device);
     /* everything in flight must be done before its memory goes away: the front stream of a pipelined handle, the forked demod streams */
+    if (h->ev_last && h->ev_last_pending) (void)hipEventSynchronize(h->ev_last); /* a batch enqueued on a caller's stream */
     if (h->front) (void)hipStreamSynchronize(h->front);
     for (auto& st : h->side)
         if (st) (void)hipStreamSynchronize(st);
@@ -176,6 +180,7 @@ void destroy(airband_hip_handle* h) {
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_back) (void)hipEventDestroy(h->ev_back);
     if (h->ev_wait) (void)hipEventDestroy(h->ev_wait);
+    if (h->ev_last) (void)hipEventDestroy(h->ev_last);
     for (auto& e : h->front_done)
         if (e) (void)hipEventDestroy(e);
     if (h->front) (void)hipStreamDestroy(h->front);
@@ -191,6 +196,12 @@ template <class T>
 hipError_t fill(T* p, size_t n, T value, hipStream_t s) {
     std::vector<T> v(n, value);
     return hipMemcpyAsync(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice, s);
+}
+
+/* Results of a batch that ran on a caller's stream: make the handle's own stream (on which collect / read_* / the stats kernel
+ * are issued) wait for it on the GPU. */
+void order_behind_last_batch(airband_hip_handle* h) {
+    if (h->ev_last && h->ev_last_pending) (void)hipStreamWaitEvent(h->stream, h->ev_last, 0);
 }
 
 /* Per-stage GPU times: every batch records into its own event set; finished sets are folded into running sums here. */
@@ -501,6 +512,14 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
             PREP_TRY(upload(h->d_bcorr, p.bcorr), AIRBAND_HIP_ENOMEM);
         }
     }
+    if (!h->use_dft) {
+        const size_t lds = fft_lds_bytes(p.fft_log, p.dev[0].hop_samples, p.dev[0].bytes_per_sample);
+        if (lds > 160 * 1024) { /* e.g. F32 at 20 MS/s: a 16-hop tile of raw samples does not fit a CU's LDS */
+            g_prepare_error = "sample_rate x bytes_per_sample too large for the FFT channelizer's LDS tile (" + std::to_string(lds) + " > 163840 bytes)";
+            destroy(h);
+            return AIRBAND_HIP_EBADSIZE;
+        }
+    }
     h->pending.resize(p.n_dev);
 #undef PREP_TRY
     *out = h;
@@ -674,7 +693,15 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
         hipStream_t s = stream ? (hipStream_t)stream : h->stream;
         h->last_stream = s;
         launch_front(h, d_iq, stride_bytes, s);
-        return run_back_half(h, s);
+        const int rc = run_back_half(h, s);
+        if (s != h->stream) { /* collect() and friends run on h->stream: give them something to wait for */
+            if (!h->ev_last) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
+            HIP_TRY(h, hipEventRecord(h->ev_last, s), AIRBAND_HIP_ERUNTIME);
+            h->ev_last_pending = true;
+        } else {
+            h->ev_last_pending = false;
+        }
+        return rc;
     }
     /* Pipelined: stage 1 of this batch (k) goes on the front stream and runs beside stage 2 of batch k-1, which is enqueued
      * right after it on the handle's stream.  Stage 1 (k) overwrites the ring rows stage 2 (k-2) read, and may use the
@@ -692,7 +719,9 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
     const uint64_t k = h->front_batches;
     launch_front(h, d_iq, stride_bytes, h->front);
     HIP_TRY(h, hipEventRecord(h->front_done[k & 1], h->front), AIRBAND_HIP_ERUNTIME);
-    if (k == 0) return AIRBAND_HIP_OK; /* nothing to demodulate yet: the first results appear with the second call (or flush) */
+    /* nothing to demodulate yet -- the very first call, or the first call after airband_hip_flush() drained the pipeline:
+     * the results of this batch appear with the next call (or flush) */
+    if (h->batches_done == k) return AIRBAND_HIP_OK;
     HIP_TRY(h, hipStreamWaitEvent(h->stream, h->front_done[(k - 1) & 1], 0), AIRBAND_HIP_ERUNTIME);
     return run_back_half(h, h->stream);
 }
@@ -758,8 +787,12 @@ int airband_hip_process_bins(airband_hip_handle* h, const float* wavein, const f
     if (h->pipeline) return fail(h, AIRBAND_HIP_EINVAL, "process_bins (stage 2 only) is not available on a pipelined handle");
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
     const size_t n = (size_t)h->plan.total_ch * h->B;
-    if (!h->d_tmp_wavein.p) {
+    if (h->d_tmp_wavein.n < n) {
+        h->d_tmp_wavein.release();
         HIP_TRY(h, h->d_tmp_wavein.alloc(n), AIRBAND_HIP_ENOMEM);
+    }
+    if (h->d_tmp_iqin.n < 2 * n) {
+        h->d_tmp_iqin.release();
         HIP_TRY(h, h->d_tmp_iqin.alloc(2 * n), AIRBAND_HIP_ENOMEM);
     }
     hipStream_t s = h->stream;
@@ -779,34 +812,50 @@ int airband_hip_synchronize(airband_hip_handle* h) {
     if (!h) return AIRBAND_HIP_EINVAL;
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
     if (h->front) HIP_TRY(h, hipStreamSynchronize(h->front), AIRBAND_HIP_ERUNTIME);
+    if (h->ev_last && h->ev_last_pending) HIP_TRY(h, hipEventSynchronize(h->ev_last), AIRBAND_HIP_ERUNTIME);
     HIP_TRY(h, hipStreamSynchronize(h->stream), AIRBAND_HIP_ERUNTIME);
+    return AIRBAND_HIP_OK;
+}
+
+/* results of channels [first, first + n) of the batch last completed; `consume` marks the batch as collected */
+static int collect_range(airband_hip_handle* h, int64_t first, int64_t n, float* waveout, float* iq_out, char* axc, airband_hip_channel_stats* stats, bool consume) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    if (first < 0 || n < 0 || first + n > h->plan.total_ch) return fail(h, AIRBAND_HIP_EINVAL, "channel range out of bounds");
+    if (!h->results_ready && consume) return AIRBAND_HIP_EAGAIN;
+    if (h->batches_done == 0) return AIRBAND_HIP_EAGAIN;
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    hipStream_t s = h->stream;
+    order_behind_last_batch(h);
+    const size_t nch = (size_t)n;
+    if (stats && nch) {
+        if (!h->d_stats.p) HIP_TRY(h, h->d_stats.alloc((size_t)h->plan.total_ch), AIRBAND_HIP_ENOMEM);
+        launch_stats(h->d_cc.p, h->d_cs.p, h->d_slot_to_ext.p, h->n_slots, h->d_stats.p, s);
+        HIP_TRY(h, hipMemcpyAsync(stats, h->d_stats.p + first, nch * sizeof(airband_hip_channel_stats), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
+    }
+    if (waveout && nch)
+        HIP_TRY(h, hipMemcpy2DAsync(waveout, h->B * sizeof(float), h->d_out_wave.p + (size_t)first * h->wave_stride + AB_OUT_PAD, (size_t)h->wave_stride * sizeof(float),
+                                    h->B * sizeof(float), nch, hipMemcpyDeviceToHost, s),
+                AIRBAND_HIP_ERUNTIME);
+    if (iq_out && nch) {
+        if (h->d_out_iq.p)
+            HIP_TRY(h, hipMemcpyAsync(iq_out, h->d_out_iq.p + (size_t)first * h->B * 2, nch * h->B * 2 * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
+        else
+            std::memset(iq_out, 0, nch * h->B * 2 * sizeof(float));
+    }
+    if (axc && nch) HIP_TRY(h, hipMemcpyAsync(axc, h->d_out_axc.p + first, nch, hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipStreamSynchronize(s), AIRBAND_HIP_ERUNTIME);
+    if (consume) h->results_ready = false;
     return AIRBAND_HIP_OK;
 }
 
 int airband_hip_collect(airband_hip_handle* h, float* waveout, float* iq_out, char* axc, airband_hip_channel_stats* stats) {
     if (!h) return AIRBAND_HIP_EINVAL;
-    if (!h->results_ready) return AIRBAND_HIP_EAGAIN;
-    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
-    hipStream_t s = h->stream;
-    const size_t nch = (size_t)h->plan.total_ch;
-    if (stats) {
-        if (!h->d_stats.p) HIP_TRY(h, h->d_stats.alloc(nch), AIRBAND_HIP_ENOMEM);
-        launch_stats(h->d_cc.p, h->d_cs.p, h->d_slot_to_ext.p, h->n_slots, h->d_stats.p, s);
-        HIP_TRY(h, hipMemcpyAsync(stats, h->d_stats.p, nch * sizeof(airband_hip_channel_stats), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
-    }
-    if (waveout)
-        HIP_TRY(h, hipMemcpy2DAsync(waveout, h->B * sizeof(float), h->d_out_wave.p + AB_OUT_PAD, (size_t)h->wave_stride * sizeof(float), h->B * sizeof(float), nch, hipMemcpyDeviceToHost, s),
-                AIRBAND_HIP_ERUNTIME);
-    if (iq_out) {
-        if (h->d_out_iq.p)
-            HIP_TRY(h, hipMemcpyAsync(iq_out, h->d_out_iq.p, nch * h->B * 2 * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
-        else
-            std::memset(iq_out, 0, nch * h->B * 2 * sizeof(float));
-    }
-    if (axc) HIP_TRY(h, hipMemcpyAsync(axc, h->d_out_axc.p, nch, hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
-    HIP_TRY(h, hipStreamSynchronize(s), AIRBAND_HIP_ERUNTIME);
-    h->results_ready = false;
-    return AIRBAND_HIP_OK;
+    return collect_range(h, 0, h->plan.total_ch, waveout, iq_out, axc, stats, true);
+}
+
+int airband_hip_collect_channels(airband_hip_handle* h, int64_t first_channel, int64_t n_channels, float* waveout, float* iq_out, char* axc,
+                                 airband_hip_channel_stats* stats) {
+    return collect_range(h, first_channel, n_channels, waveout, iq_out, axc, stats, false);
 }
 
 int airband_hip_collect_mixers(airband_hip_handle* h, float* left, float* right, uint8_t* has_signal) {
@@ -814,6 +863,7 @@ int airband_hip_collect_mixers(airband_hip_handle* h, float* left, float* right,
     if (h->n_mixers <= 0) return fail(h, AIRBAND_HIP_EINVAL, "no mixers configured");
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
     hipStream_t s = h->stream;
+    order_behind_last_batch(h);
     const size_t n = (size_t)h->n_mixers * h->B;
     if (left) HIP_TRY(h, hipMemcpyAsync(left, h->d_mix_left.p, n * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
     if (right) HIP_TRY(h, hipMemcpyAsync(right, h->d_mix_right.p, n * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
@@ -834,19 +884,29 @@ int airband_hip_device_results(airband_hip_handle* h, float** d_waveout, float**
     return AIRBAND_HIP_OK;
 }
 
-static int gather_last(airband_hip_handle* h, float* wavein, float* iq_in, uint8_t* trace) {
+static int gather_last(airband_hip_handle* h, int64_t first, int64_t nch, float* wavein, float* iq_in, uint8_t* trace) {
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    if (first < 0 || nch < 0 || first + nch > h->plan.total_ch) return fail(h, AIRBAND_HIP_EINVAL, "channel range out of bounds");
     if (h->batches_done == 0) return fail(h, AIRBAND_HIP_EAGAIN, "no batch processed yet");
-    const size_t n = (size_t)h->plan.total_ch * h->B;
-    if (!h->d_tmp_wavein.p) {
+    if (nch == 0) return AIRBAND_HIP_OK;
+    const size_t n = (size_t)nch * h->B;
+    if (wavein && h->d_tmp_wavein.n < n) {
+        h->d_tmp_wavein.release();
         HIP_TRY(h, h->d_tmp_wavein.alloc(n), AIRBAND_HIP_ENOMEM);
+    }
+    if (iq_in && h->d_tmp_iqin.n < 2 * n) {
+        h->d_tmp_iqin.release();
         HIP_TRY(h, h->d_tmp_iqin.alloc(2 * n), AIRBAND_HIP_ENOMEM);
     }
-    if (trace && !h->d_tmp_trace.p) HIP_TRY(h, h->d_tmp_trace.alloc(n), AIRBAND_HIP_ENOMEM);
+    if (trace && h->d_tmp_trace.n < n) {
+        h->d_tmp_trace.release();
+        HIP_TRY(h, h->d_tmp_trace.alloc(n), AIRBAND_HIP_ENOMEM);
+    }
     hipStream_t s = h->stream;
+    order_behind_last_batch(h);
     const int prev_row0 = (h->row0 + h->R - h->B) % h->R; /* row0 of the batch just finished */
-    launch_gather_bins(h->d_mag.p, h->d_iq.p, h->d_trace.p, h->d_slot_to_ext.p, wavein ? h->d_tmp_wavein.p : nullptr, iq_in ? h->d_tmp_iqin.p : nullptr,
-                       trace ? h->d_tmp_trace.p : nullptr, h->n_slots, h->B, prev_row0, h->R, s);
+    launch_gather_channels(h->d_mag.p, h->d_iq.p, h->d_trace.p, h->d_ext_to_slot.p, h->d_cc.p, (int)first, (int)nch, wavein ? h->d_tmp_wavein.p : nullptr,
+                           iq_in ? h->d_tmp_iqin.p : nullptr, trace ? h->d_tmp_trace.p : nullptr, h->B, prev_row0, h->R, s);
     if (wavein) HIP_TRY(h, hipMemcpyAsync(wavein, h->d_tmp_wavein.p, n * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
     if (iq_in) HIP_TRY(h, hipMemcpyAsync(iq_in, h->d_tmp_iqin.p, 2 * n * sizeof(float), hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
     if (trace) HIP_TRY(h, hipMemcpyAsync(trace, h->d_tmp_trace.p, n, hipMemcpyDeviceToHost, s), AIRBAND_HIP_ERUNTIME);
@@ -856,13 +916,24 @@ static int gather_last(airband_hip_handle* h, float* wavein, float* iq_in, uint8
 
 int airband_hip_read_bins(airband_hip_handle* h, float* wavein, float* iq_in) {
     if (!h) return AIRBAND_HIP_EINVAL;
-    return gather_last(h, wavein, iq_in, nullptr);
+    return gather_last(h, 0, h->plan.total_ch, wavein, iq_in, nullptr);
+}
+
+int airband_hip_read_bins_channels(airband_hip_handle* h, int64_t first_channel, int64_t n_channels, float* wavein, float* iq_in) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    return gather_last(h, first_channel, n_channels, wavein, iq_in, nullptr);
 }
 
 int airband_hip_read_trace(airband_hip_handle* h, uint8_t* state) {
     if (!h || !state) return AIRBAND_HIP_EINVAL;
     if (!(h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH)) return fail(h, AIRBAND_HIP_EINVAL, "handle was prepared without AIRBAND_HIP_FLAG_TRACE_SQUELCH");
-    return gather_last(h, nullptr, nullptr, state);
+    return gather_last(h, 0, h->plan.total_ch, nullptr, nullptr, state);
+}
+
+int airband_hip_read_trace_channels(airband_hip_handle* h, int64_t first_channel, int64_t n_channels, uint8_t* state) {
+    if (!h || !state) return AIRBAND_HIP_EINVAL;
+    if (!(h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH)) return fail(h, AIRBAND_HIP_EINVAL, "handle was prepared without AIRBAND_HIP_FLAG_TRACE_SQUELCH");
+    return gather_last(h, first_channel, n_channels, nullptr, nullptr, state);
 }
 
 int airband_hip_channel_constants(const airband_hip_handle* h, int32_t channel_index, double* out_vals) {
@@ -893,6 +964,11 @@ int airband_hip_timing_totals(airband_hip_handle* h, double* ms4_sum, int64_t* n
     }
     return AIRBAND_HIP_OK;
 }
+
+#ifndef AB_BUILD_DEFINES
+#define AB_BUILD_DEFINES ""
+#endif
+const char* airband_hip_build_info(void) { return AB_BUILD_DEFINES; }
 
 const char* airband_hip_channelizer_name(const airband_hip_handle* h) {
     return (h && h->use_dft) ? "dft_mfma_i8" : "fft_wave64";

@@ -55,16 +55,25 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
     const long mis = (long)((uintptr_t)src & 15);
     const uint8_t* src_al = src - mis;
     const long n16 = (span_bytes + mis + 15) >> 4;
+    /* 16-byte pieces that would start before the dongle's span or end past the bytes the API promises
+     * ((first_)batch_bytes + lookahead_bytes) are fetched byte by byte: nothing outside the documented span is touched */
+    const long avail_end = ((long)(a.n_hops - 1) * a.hop_samples + N) * bps2 - span_begin + mis; /* relative to src_al */
+    const long avail_begin = span_begin == 0 ? mis : 0;
     for (long i = threadIdx.x; i < n16; i += 256) {
-        const uint4 v = *reinterpret_cast<const uint4*>(src_al + (i << 4));
-        *reinterpret_cast<uint4*>(lds_raw + (i << 4)) = v;
+        const long o = i << 4;
+        if (o >= avail_begin && o + 16 <= avail_end) {
+            *reinterpret_cast<uint4*>(lds_raw + o) = *reinterpret_cast<const uint4*>(src_al + o);
+        } else {
+            for (int b = 0; b < 16; b++) lds_raw[o + b] = (o + b >= avail_begin && o + b < avail_end) ? src_al[o + b] : (uint8_t)0;
+        }
     }
 
     /* ---- per-lane constants ------------------------------------------------------------------------------ */
     /* window, pre-multiplied by the sample scale so conversion is one subtract/convert and one multiply:
      * u8 (b - 127.5)/127.5, s8 i/128 (src/rtl_airband.cpp:316-324), s16/f32 x/fullscale (:403,:421) */
     float win[P];
-    const float pre = a.sfmt == AIRBAND_SFMT_U8 ? (1.0f / 127.5f) : a.sfmt == AIRBAND_SFMT_S8 ? (1.0f / 128.0f) : a.scale;
+    /* S16 / F32: 1 / input->fullscale of THIS dongle (src/rtl_airband.cpp:403,421) -- two CS16 sources of one handle may differ */
+    const float pre = a.sfmt == AIRBAND_SFMT_U8 ? (1.0f / 127.5f) : a.sfmt == AIRBAND_SFMT_S8 ? (1.0f / 128.0f) : dev.scale;
 #pragma unroll
     for (int r = 0; r < P; r++) win[r] = a.window[r * 64 + lane] * pre;
     /* per-lane twiddles of the N = P x 64 decomposition, indexed by register (register rho holds k1 = bitrev(rho)) */
@@ -217,14 +226,20 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
 
 template <int LOGP>
 void launch_one(const ChannelizerArgs& a, hipStream_t stream) {
-    const int N = 64 << LOGP;
     const int tiles = (a.n_hops + HOPS_PER_TILE - 1) / HOPS_PER_TILE;
-    const size_t lds = (size_t)(((long)(HOPS_PER_TILE - 1) * a.hop_samples + N) * 2 * a.bytes_per_sample + 32);
+    const size_t lds = fft_lds_bytes(a.fft_log, a.hop_samples, a.bytes_per_sample);
     const long blocks = (long)tiles * a.n_dev;
+    /* wide formats at high sample rates: opt in to the CU's full 160 KiB (prepare() has checked the upper bound) */
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_fft_kernel<LOGP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(channelizer_fft_kernel<LOGP>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
 }
 
 }  // namespace
+
+/* dynamic LDS of one workgroup: the raw bytes of HOPS_PER_TILE consecutive hops (+ alignment slack) */
+size_t fft_lds_bytes(int fft_log, int hop_samples, int bytes_per_sample) {
+    return (size_t)(((long)(HOPS_PER_TILE - 1) * hop_samples + (1L << fft_log)) * 2 * bytes_per_sample + 32);
+}
 
 void launch_channelizer_fft(const ChannelizerArgs& a, hipStream_t stream) {
     switch (a.fft_log - 6) {

@@ -122,6 +122,7 @@ struct SiggenArgs {
 };
 
 void launch_channelizer_fft(const ChannelizerArgs& a, hipStream_t stream);
+size_t fft_lds_bytes(int fft_log, int hop_samples, int bytes_per_sample); /* dynamic LDS per workgroup; must stay <= 64 KiB */
 bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch);
 int dft_lds_per_buf(int hop_bytes);
 int dft_sub_tiles(int hop_bytes);
@@ -138,9 +139,10 @@ void launch_afc(const ChanConst* cc, ChanState* cs, const float* spectrum, int f
 /* scatter channel-major host-provided bins into the time-major rings (airband_hip_process_bins) */
 void launch_scatter_bins(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, int n_slots,
                          int wave_batch, int row0, int ring_rows, hipStream_t stream);
-/* gather the batch's new rows back into channel-major order (airband_hip_read_bins / read_trace) */
-void launch_gather_bins(const float* mag, const float2* iq, const uint8_t* trace, const int* slot_to_ext, float* wavein, float* iqin, uint8_t* trace_out,
-                        int n_slots, int wave_batch, int row0, int ring_rows, hipStream_t stream);
+/* the batch's new stage-1 rows (and squelch trace) of channels [first, first + n), channel-major (airband_hip_read_bins / read_trace);
+ * |bin| of NFM channels, which stage 1 does not store, is recomputed from the raw bin I/Q the way stage 2 does */
+void launch_gather_channels(const float* mag, const float2* iq, const uint8_t* trace, const int* ext_to_slot, const ChanConst* cc, int first, int n, float* wavein,
+                            float* iqin, uint8_t* trace_out, int wave_batch, int row0, int ring_rows, hipStream_t stream);
 
 }  // namespace airband
 #endif

@@ -234,29 +234,31 @@ void launch_scatter_bins(const float* wavein, const float* iqin, const int* slot
                        wave_batch, row0, ring_rows);
 }
 
-__global__ void gather_bins_kernel(const float* mag, const float2* iq, const uint8_t* trace, const int* slot_to_ext, float* wavein, float* iqin, uint8_t* trace_out,
-                                   int n_slots, int wave_batch, int row0, int ring_rows) {
-    const int slot = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (slot >= n_slots || t >= wave_batch) return;
-    const int ext = slot_to_ext[slot];
-    if (ext < 0) return;
+__global__ void gather_channels_kernel(const float* mag, const float2* iq, const uint8_t* trace, const int* ext_to_slot, const ChanConst* cc, int first, float* wavein,
+                                       float* iqin, uint8_t* trace_out, int wave_batch, int row0, int ring_rows) {
+    const int c = blockIdx.x; /* channel first + c */
+    const int t = blockIdx.y * 256 + threadIdx.x;
+    if (t >= wave_batch) return;
+    const int slot = ext_to_slot[first + c];
     int row = row0 + AB_AGC_EXTRA + t;
     if (row >= ring_rows) row -= ring_rows;
     const long off = ab_tile_base(slot, ring_rows / AB_TILE_ROWS) + ab_tile_off(row);
-    if (wavein) wavein[(long)ext * wave_batch + t] = mag[off];
+    const unsigned flags = cc[slot].flags;
+    const float2 q = (flags & AB_F_RAW_IQ) ? iq[off] : make_float2(0.0f, 0.0f);
+    if (wavein) /* NFM: wavein[j] = sqrtf(re^2 + im^2) (src/rtl_airband.cpp:484-487); stage 1 leaves it to stage 2, so does this */
+        wavein[(long)c * wave_batch + t] = (flags & AB_F_NFM) ? __fsqrt_rn(q.x * q.x + q.y * q.y) : mag[off];
     if (iqin) {
-        const float2 q = iq[off];
-        iqin[((long)ext * wave_batch + t) * 2] = q.x;
-        iqin[((long)ext * wave_batch + t) * 2 + 1] = q.y;
+        iqin[((long)c * wave_batch + t) * 2] = q.x;
+        iqin[((long)c * wave_batch + t) * 2 + 1] = q.y;
     }
-    if (trace_out && trace) trace_out[(long)ext * wave_batch + t] = trace[ab_ring_base(slot, wave_batch) + (long)t * AB_SLOT_BLOCK];
+    if (trace_out && trace) trace_out[(long)c * wave_batch + t] = trace[ab_ring_base(slot, wave_batch) + (long)t * AB_SLOT_BLOCK];
 }
 
-void launch_gather_bins(const float* mag, const float2* iq, const uint8_t* trace, const int* slot_to_ext, float* wavein, float* iqin, uint8_t* trace_out,
-                        int n_slots, int wave_batch, int row0, int ring_rows, hipStream_t stream) {
-    hipLaunchKernelGGL(gather_bins_kernel, dim3((n_slots + 63) / 64, (wave_batch + 3) / 4), dim3(256), 0, stream, mag, iq, trace, slot_to_ext, wavein, iqin, trace_out,
-                       n_slots, wave_batch, row0, ring_rows);
+void launch_gather_channels(const float* mag, const float2* iq, const uint8_t* trace, const int* ext_to_slot, const ChanConst* cc, int first, int n, float* wavein,
+                            float* iqin, uint8_t* trace_out, int wave_batch, int row0, int ring_rows, hipStream_t stream) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(gather_channels_kernel, dim3(n, (wave_batch + 255) / 256), dim3(256), 0, stream, mag, iq, trace, ext_to_slot, cc, first, wavein, iqin, trace_out,
+                       wave_batch, row0, ring_rows);
 }
 
 }  // namespace airband

@@ -1,0 +1,41 @@
+"""bench.py's own N-rank launch (no GPU needed): `python bench.py --gpus N` must form an N-rank job by itself -- the analogue
+of the reference starting one demodulate() thread per device shard (src/rtl_airband.cpp:1110-1112) -- report that N, and
+refuse to report anything for a different world size."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def _json(stdout):
+    lines = [ln for ln in stdout.strip().splitlines() if ln.startswith("{")]
+    assert lines, stdout
+    return json.loads(lines[-1])
+
+
+def test_gpus_2_spawns_two_ranks():
+    r = _run(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json(r.stdout)
+    assert out["n_gpus"] == 2 and out["max_rank_seen"] == 1 and out["dry_run"] is True
+    assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1, "only rank 0 prints"
+
+
+def test_gpus_1_stays_single_process():
+    r = _run(["--gpus", "1", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _json(r.stdout)["n_gpus"] == 1
+
+
+def test_world_size_mismatch_is_refused():
+    r = _run(["--gpus", "2", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

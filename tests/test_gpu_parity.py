@@ -110,9 +110,11 @@ def test_end_to_end_stream(pkg, built, mixed, wave_rate, force_fft):
                 assert helpers.rms(out["waveout"] - ww) <= 1e-4, "batch %d audio rms %g" % (b, helpers.rms(out["waveout"] - ww))
                 wi = np.concatenate([r["iq_out"][b] for r in ref])
                 assert helpers.rms(out["iq_out"] - wi) <= 1e-4 * max(1.0, helpers.rms(wi))
-                # stage-1 bins: magnitudes of raw-I/Q channels are rewritten in place by stage 2 (as in the reference,
-                # src/rtl_airband.cpp:524), so compare |bin| on the untouched channels and re/im on all of them
-                plain = np.array([not (c["modulation"] or c["bandwidth_hz"] or c["has_iq_outputs"]) for dev in devices for c in dev["channels"]])
+                # stage-1 bins: magnitudes of AM channels that need raw I/Q are rewritten in place by stage 2 (as in the reference,
+                # src/rtl_airband.cpp:524), so compare |bin| on every other channel -- NFM ones included, which read_bins
+                # recomputes from the raw bin I/Q -- and re/im on all of them
+                plain = np.array([bool(c["modulation"]) or not (c["bandwidth_hz"] or c["has_iq_outputs"]) for dev in devices for c in dev["channels"]])
+                assert plain.sum() > len(plain) // 2
                 assert helpers.rel_rms(w[plain], np.concatenate([r["raw_wavein"][b] for r in ref])[plain]) <= 1e-5
                 assert helpers.rel_rms(q, np.concatenate([r["raw_iq"][b] for r in ref])) <= 1e-5
                 opened += int((out["axc"] == ord("*")).sum())
@@ -161,15 +163,55 @@ def test_zero_copy_device_path_matches_host_ring_path(pkg, built):
             off += g.first_batch_bytes if k == 0 else g.batch_bytes
 
 
+def test_collect_waits_for_a_batch_enqueued_on_the_callers_stream(pkg, built):
+    """process_device(..., stream=S) runs the whole batch on S; collect / collect_channels / read_trace / collect_mixers issue
+    their copies on the handle's own stream and must order themselves behind S on the GPU.  S is kept busy with a long
+    independent kernel queue first, so a missing dependency shows up as stale results."""
+    torch = pytest.importorskip("torch")
+    n_dev, n_batches, wave_rate = 24, 4, 16000
+    devices, carriers = helpers.plan_devices(n_dev, True)
+    nbytes = helpers.stream_bytes(n_batches, wave_rate)
+    iq = np.stack([pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)])
+    mix = [(d, c, (d + c) % 2, 1.0, 0.0) for d in range(n_dev) for c in range(8)]
+    T = pkg.capi.FLAG_TRACE_SQUELCH
+    with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=T) as a, pkg.AirbandHip(devices, wave_rate=wave_rate, flags=T) as b:
+        a.set_mixers(2, mix)
+        b.set_mixers(2, mix)
+        g = a.geometry
+        dbuf = torch.from_numpy(iq).cuda()
+        side = torch.cuda.Stream()
+        junk = torch.zeros((4096, 4096), device="cuda")
+        off = 0
+        for k in range(n_batches):
+            a.process_device(dbuf.data_ptr() + off, dbuf.stride(0))
+            ra = a.collect(stats=True)
+            ta, ma = a.read_trace(), a.collect_mixers()
+            with torch.cuda.stream(side):
+                for _ in range(40):  # ~tens of ms of queued work in front of the batch
+                    junk = junk @ junk * 1e-4
+            b.process_device(dbuf.data_ptr() + off, dbuf.stride(0), side.cuda_stream)
+            part = b.collect(first_channel=8, n_channels=16, stats=True)   # ranged, repeatable
+            rb = b.collect(stats=True)
+            tb, mb = b.read_trace(), b.collect_mixers()
+            assert np.array_equal(ra["waveout"].view(np.uint32), rb["waveout"].view(np.uint32)), "batch %d" % k
+            assert np.array_equal(ra["axc"], rb["axc"]) and np.array_equal(ta, tb)
+            assert np.array_equal(part["waveout"].view(np.uint32), ra["waveout"][8:24].view(np.uint32)) and np.array_equal(part["axc"], ra["axc"][8:24])
+            assert part["stats"] == ra["stats"][8:24] and ra["stats"] == rb["stats"]
+            for x, y in zip(ma, mb):
+                assert np.array_equal(np.asarray(x).view(np.uint8), np.asarray(y).view(np.uint8))
+            off += g.first_batch_bytes if k == 0 else g.batch_bytes
+        b.synchronize()  # waits for the caller's stream too
+
+
 @pytest.mark.parametrize("mixed,wave_rate", [(False, 8000), (True, 16000)])
 def test_pipelined_mode_is_the_sequential_mode_one_batch_late(pkg, built, mixed, wave_rate):
     """AIRBAND_HIP_FLAG_PIPELINE (stage 1 of batch k beside stage 2 of batch k-1, two-batch-deep rings, two streams):
     every output is bit-identical to the sequential handle's, one process call later; flush() drains the last batch.
     Both entry points are covered: the zero-copy device path and the host-ring path."""
     torch = pytest.importorskip("torch")
-    n_dev, n_batches = 5, 9
+    n_dev, n_batches, n_more = 5, 9, 3
     devices, carriers = helpers.plan_devices(n_dev, mixed, _tweak if mixed else None)
-    nbytes = helpers.stream_bytes(n_batches, wave_rate)
+    nbytes = helpers.stream_bytes(n_batches + n_more, wave_rate)
     iq = np.stack([pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)])
     mix = [(d, c, (d * 8 + c) % 3, 1.0 + 0.1 * c, 0.0) for d in range(n_dev) for c in range(8)]
     P = pkg.capi.FLAG_PIPELINE | pkg.capi.FLAG_TRACE_SQUELCH
@@ -183,7 +225,7 @@ def test_pipelined_mode_is_the_sequential_mode_one_batch_late(pkg, built, mixed,
         want = []
         off = 0
         opened = 0
-        for k in range(n_batches):
+        for k in range(n_batches + n_more):
             seq.process_device(dbuf.data_ptr() + off, dbuf.stride(0))
             r = seq.collect(iq=True, stats=True)
             r["trace"] = seq.read_trace()
@@ -226,6 +268,18 @@ def test_pipelined_mode_is_the_sequential_mode_one_batch_late(pkg, built, mixed,
         pip.flush()
         check(grab(pip), n_batches - 1, "device path (flush)")
         pip.flush()  # idempotent
+        # a drained pipeline starts again: the call after flush() only runs stage 1 (no results, nothing raced), then business as usual
+        for k in range(n_batches, n_batches + n_more):
+            pip.process_device(dbuf.data_ptr() + off, dbuf.stride(0))
+            if k == n_batches:
+                with pytest.raises(pkg.AirbandError) as e:
+                    pip.collect()
+                assert e.value.code == pkg.capi.EAGAIN
+            else:
+                check(grab(pip), k - 1, "device path after flush")
+            off += g.batch_bytes
+        pip.flush()
+        check(grab(pip), n_batches + n_more - 1, "device path (second flush)")
         # host-ring path, fed in ragged pieces
         pos = [0] * n_dev
         done = started = 0
@@ -241,7 +295,7 @@ def test_pipelined_mode_is_the_sequential_mode_one_batch_late(pkg, built, mixed,
         pip_host.flush()
         check(grab(pip_host), done, "host path (flush)")
         t = pip.timing_totals()
-        assert t["batches"] == n_batches and t["channelizer_ms"] > 0 and t["demod_ms"] > 0
+        assert t["batches"] == n_batches + n_more and t["channelizer_ms"] > 0 and t["demod_ms"] > 0
 
 
 def test_mixers_match_reference_order_sum(pkg, built):
@@ -409,7 +463,7 @@ def test_ragged_shapes_and_empty_inputs(pkg, built):
         assert opened > 0
 
 
-def _convert(iq_u8, sfmt, capi):
+def _convert(iq_u8, sfmt, capi, s16_gain=200.0):
     """Re-express the synthetic u8 stream in the other sample formats the input drivers deliver (src/input-soapysdr.cpp:45-64)."""
     x = iq_u8.astype(np.float32) - 127.5
     if sfmt == capi.SFMT_U8:
@@ -417,7 +471,7 @@ def _convert(iq_u8, sfmt, capi):
     if sfmt == capi.SFMT_S8:
         return np.clip(np.round(x), -127, 127).astype(np.int8)  # -128 indexes a table entry the reference never initialises
     if sfmt == capi.SFMT_S16:
-        return np.round(x * 200.0).astype(np.int16)
+        return np.round(x * s16_gain).astype(np.int16)
     return (x / 127.5).astype(np.float32)
 
 
@@ -446,11 +500,14 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
         off = (b if b < n_fft // 2 else b - n_fft) * sample_rate / n_fft
         kind = c["modulation"]
         carriers.append(pkg.siggen.make_carrier(off, sample_rate, kind=kind, ctcss_hz=c["ctcss_freq"], key_slot=k, key_period_s=0.5, key_on_s=0.3, key_slot_s=0.04))
-    fullscale = 0.0 if sfmt != capi.SFMT_S16 else 127.5 * 200.0
-    devices = [dict(channels=[dict(c) for c in chans], sample_rate=sample_rate, sfmt=sfmt, fullscale=fullscale) for _ in range(n_dev)]
+    # two CS16 sources of one handle need not share a full scale (a 12-bit and a 16-bit SoapySDR device): the second dongle
+    # delivers the same signal at a quarter of the amplitude and says so in input->fullscale (src/rtl_airband.cpp:403)
+    gains = [200.0, 50.0] if sfmt == capi.SFMT_S16 else [1.0, 1.0]
+    devices = [dict(channels=[dict(c) for c in chans], sample_rate=sample_rate, sfmt=sfmt, fullscale=0.0 if sfmt != capi.SFMT_S16 else 127.5 * gains[d])
+               for d in range(n_dev)]
     hop = round(sample_rate / wave_rate)
     n_samples = (n_batches * (wave_rate // 8) + 100) * hop + (1 << fft_log)
-    iq = [_convert(pkg.siggen.generate_u8(d, 0, n_samples, carriers), sfmt, capi) for d in range(n_dev)]
+    iq = [_convert(pkg.siggen.generate_u8(d, 0, n_samples, carriers), sfmt, capi, gains[d]) for d in range(n_dev)]
     orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fft_log=fft_log)
     ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
     assert all(r["n_batches"] == n_batches for r in ref)

@@ -1,0 +1,105 @@
+"""Parity at BASELINE scale: handles with 1 024 ... 65 536 dongles (BASELINE.json configs[1] and configs[2] at their stated
+sizes) against the CPU oracle on a SAMPLE of dongles.
+
+Every device_t of the reference is independent and any partition of them over demodulate() threads is correct
+(src/rtl_airband.cpp:1052-1056,1070-1076), so a big handle is checked dongle by dongle on a sample: the indices around
+the channelizer's 16 / 128-dongle XCD placement groups and the 64-slot demod blocks, first and last, plus pseudo-random
+ones.  The big handles take branches small ones never reach: whole 128-dongle groups are XCD-permuted and the ragged
+last group is not (200, 1 000 dongles), a dongle's tiles are split over several wavefronts or not (splits > 1 below
+8 192 dongles, == 1 above), and at 65 536 dongles the stage-1 rings and the result rows are indexed beyond 2^31 elements.
+
+Input is generated ON the GPU into an HBM-resident span per dongle and cycled through the way bench.py does it (first
+batch with its AGC_EXTRA lead-in, then a ring of resident batches); the oracle twins get exactly those bytes, copied back.
+"""
+import numpy as np
+import pytest
+
+import helpers
+import pyverify
+
+pytestmark = pytest.mark.gpu
+
+RING = 3
+
+
+def _tweak(d, ch):
+    if d % 2 == 1:
+        ch[0]["bandwidth_hz"] = 8000
+        ch[2]["squelch_threshold_dbfs"] = -40
+        ch[4]["squelch_snr_threshold_db"] = 6.0
+        ch[6]["ampfactor"] = 2.5
+
+
+CASES = [
+    # n_dev, mixed, wave_rate, sampled dongles, pipelined, tweak
+    pytest.param(1024, False, 8000, 40, False, False, id="configs1_1024_am"),
+    pytest.param(200, True, 16000, 24, False, True, id="200_mixed_partial_group"),
+    pytest.param(1000, True, 16000, 32, False, False, id="1000_mixed_partial_group"),
+    pytest.param(4096, True, 16000, 40, False, True, id="4096_mixed_splits2"),
+    pytest.param(4096, True, 16000, 24, True, False, id="4096_mixed_pipelined"),
+    pytest.param(65536, True, 16000, 48, False, False, id="configs2_65536_mixed"),
+    pytest.param(65536, False, 8000, 32, False, False, id="65536_am"),
+]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n_dev,mixed,wave_rate,k,pipelined,tweak", CASES)
+def test_sampled_dongles_of_large_handles(pkg, built, n_dev, mixed, wave_rate, k, pipelined, tweak):
+    torch = pytest.importorskip("torch")
+    n_batches = 7
+    chans, carriers = pkg.siggen.baseline_plan(mixed=mixed)
+
+    def device(d):
+        ch = [dict(c) for c in chans]
+        if tweak:
+            _tweak(d, ch)
+        return dict(channels=ch)
+
+    devices = [device(d) for d in range(n_dev)]
+    flags = pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_PIPELINE if pipelined else 0)
+    dongles = pyverify.sample_dongles(n_dev, k)
+    with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=flags) as hip:
+        assert hip.channelizer_name() == "dft_mfma_i8"
+        g = hip.geometry
+        lead = g.first_batch_bytes - g.batch_bytes
+        span = lead + (RING + 1) * g.batch_bytes + g.lookahead_bytes
+        stride = (span + 255) // 256 * 256
+        iq = torch.empty((n_dev, stride), dtype=torch.uint8, device="cuda")
+        hip.set_signal_plan(carriers)
+        hip.generate_iq(iq.data_ptr(), stride, 0, span, seed=0x5EED)
+        hip.synchronize()
+        host = {d: iq[d].cpu().numpy() for d in dongles}
+        # the on-device generator is the host generator, also at the far end of the handle
+        last = dongles[-1]
+        assert last == n_dev - 1
+        assert np.array_equal(host[last][:65536], pkg.siggen.generate_u8(last, 0, 32768, carriers))
+
+        spot = pyverify.SpotCheck(device, dongles, wave_rate=wave_rate)
+        try:
+            def offset(i):
+                return 0 if i == 0 else g.first_batch_bytes + ((i - 1) % RING) * g.batch_bytes
+
+            opened = 0
+            worst = 0.0
+            for i in range(n_batches):
+                hip.process_device(iq.data_ptr() + offset(i), stride)
+                j = i - 1 if pipelined else i  # batch whose results the handle holds now
+                if j < 0:
+                    continue
+                spot.feed([host[d][offset(j):] for d in dongles])
+                w = spot.compare(hip, trace=True, what="%d dongles" % n_dev)
+                worst = max(worst, w["audio_rms"])
+                opened += sum(int((r["axc"] == ord("*")).sum()) for r in spot.last)
+            if pipelined:
+                hip.flush()
+                spot.feed([host[d][offset(n_batches - 1):] for d in dongles])
+                spot.compare(hip, trace=True, what="%d dongles (flush)" % n_dev)
+            assert opened > 0, "no sampled channel ever opened its squelch: not a meaningful parity run"
+            # channels outside the sample: every one of them must at least have produced the right KIND of output
+            # (finite audio, a legal axcindicate) -- catches a block of dongles that was never written at all
+            for d in (n_dev // 3, (2 * n_dev) // 3):
+                r = hip.collect(first_channel=8 * d, n_channels=8)
+                assert np.isfinite(r["waveout"]).all() and set(np.unique(r["axc"])) <= {ord(" "), ord("*")}
+        finally:
+            spot.close()
+    print("%d dongles, %d sampled: worst audio RMS error %.3g" % (n_dev, len(dongles), worst))
