@@ -98,7 +98,8 @@ class SpotCheck:
                 for f in STAT_EXACT:
                     assert o[f] == g[f], "%s channel %d: %s %r vs oracle %r" % (tag, j, f, g[f], o[f])
                 for f in STAT_CLOSE:
-                    rel = abs(o[f] - g[f]) / max(abs(o[f]), 1e-12)
+                    # relative, with a floor: an NFM channel's agcavgfast is the DC estimate of the discriminator output, i.e. noise around 0
+                    rel = abs(o[f] - g[f]) / max(abs(o[f]), 1e-2)
                     assert rel <= 1e-4, "%s channel %d: %s %r vs oracle %r" % (tag, j, f, g[f], o[f])
                     worst["level_rel"] = max(worst["level_rel"], rel)
         return worst

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
             if (hop_first >= 0 && hop_first + 3 < a.n_hops) {
 #ifdef AB_DFT_NT_STORE
                 typedef float v4f __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store((v4f){m4[0], m4[1], m4[2], m4[3]}, reinterpret_cast<v4f*>(a.mag + off));
+                if (want_mag) __builtin_nontemporal_store((v4f){m4[0], m4[1], m4[2], m4[3]}, reinterpret_cast<v4f*>(a.mag + off));
                 if (want_iq) {
                     v4f* q = reinterpret_cast<v4f*>(a.iq_bins + off);
                     __builtin_nontemporal_store((v4f){val[0], im4[0], val[1], im4[1]}, q);

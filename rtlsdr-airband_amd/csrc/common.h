@@ -111,7 +111,7 @@ static inline AB_HD long ab_ring_base(int slot, int rows) { return ((long)(slot 
  * stores 16 contiguous bytes and the four lanes of a column complete a 64-byte segment -- full-width HBM writes instead
  * of 4-byte scatters; the demod kernels fetch the same tiles back 16 bytes (4 rows) per lane. */
 #ifndef AB_TILE_ROWS
-#define AB_TILE_ROWS 16 /* 4, 8 or 16 */
+#define AB_TILE_ROWS 8 /* 4, 8 or 16 */
 #endif
 static inline AB_HD long ab_tile_base(int slot, int tiles) { return (((long)(slot >> 6) * tiles) * AB_SLOT_BLOCK + (slot & 63)) * AB_TILE_ROWS; }
 static inline AB_HD long ab_tile_off(int row) { return ((long)(row / AB_TILE_ROWS) * AB_SLOT_BLOCK * AB_TILE_ROWS) + (row % AB_TILE_ROWS); }

@@ -5,11 +5,10 @@
  *
  * Mapping: one wavefront owns 64 consecutive channel slots of ONE demod kind, one lane per (dongle, channel).  Time is
  * strictly serial per channel (IIR / EMA / FSM state), so a lane walks the batch's WAVE_BATCH samples in order with all of
- * its state in registers.  The batch is cut into chunks of CHUNK samples:
- *   phase 0  the chunk's stage-1 rows (time-major, so one 256-byte row feeds all 64 lanes) are pulled from HBM
- *            with independent 16-byte loads per lane and parked in LDS -- memory latency is paid once per chunk,
- *            not once per sample;
- *   phase 1  squelch state machine (squelch_fsm.h: lane masks in scalar registers) + derotation / lowpass + AM AGC or FM
+ * its state in registers.  The batch is walked four samples (a "quad") at a time:
+ *   input    a quad's stage-1 values are one or two 16-byte loads per stream out of the lane's own 16-row ring tile; two
+ *            register sets alternate, the loads of quad k+1 are in flight while the per-sample code works through quad k;
+ *   step     squelch state machine (squelch_fsm.h: lane masks in scalar registers) + derotation / lowpass + AM AGC or FM
  *            discriminator, then -- fused kinds -- output gating, notch, ampfactor, clamp, AM fade-out.  Audio is parked in LDS
  *            and leaves every 32 samples as whole 128-byte lines of the channel's channel->waveout-shaped result row.
  * Kinds that can carry a CTCSS tone are split in three kernels instead: this file's demod_kernel<.., true> is the FRONT
@@ -32,12 +31,6 @@
 namespace airband {
 
 namespace {
-
-#ifndef AB_DEMOD_CHUNK
-#define AB_DEMOD_CHUNK 8
-#endif
-constexpr int CHUNK = AB_DEMOD_CHUNK; /* multiple of 4 dividing WAVE_BATCH = 1000 and 2000; 64 lanes x 16 B x CHUNK of LDS per wave */
-static_assert(CHUNK == 4 || CHUNK == 8, "phase 0 works in groups of four rows; output runs and hand-off runs are whole multiples of the chunk");
 
 /* per-sample flag word parked in LDS between the phases */
 constexpr unsigned FL_AUDIO = 1u;   /* Squelch::should_process_audio()                        */
@@ -176,22 +169,8 @@ struct KindBits {
                                                                     : 0u;
 };
 
-/* floats parked in LDS per (sample, lane): AM needs only the current and the delayed magnitude */
-template <int KIND>
-struct LdsSlots {
-    static constexpr int value = KIND == AB_KIND_AM ? 2 : 4;
-};
-
 template <int KIND, bool WAVE_HAS_CTCSS>
-__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, float* lds, const float2* lut, float* ostage, const int* ext_of, bool full_block) {
-    constexpr int NS = LdsSlots<KIND>::value;
-#ifndef AB_DEMOD_UNROLL
-#define AB_DEMOD_UNROLL 2
-#endif
-#ifndef AB_DEMOD_UNROLL_AM
-#define AB_DEMOD_UNROLL_AM CHUNK
-#endif
-    constexpr int UNROLL = KIND == AB_KIND_AM ? AB_DEMOD_UNROLL_AM : AB_DEMOD_UNROLL; /* per-sample loop: how many samples share one loop body */
+__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, const float2* lut, float* ostage, const int* ext_of, bool full_block) {
     const int lane = threadIdx.x & 63;
     constexpr long S = AB_SLOT_BLOCK;
     const int R = a.ring_rows, B = a.wave_batch;
@@ -219,6 +198,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     L.prefetched_delay = (KIND == AB_KIND_NFM_LOWPASS);
     /* only channels with a lowpass filter ever touch the delay line: the other kinds move head/tail once per batch */
     L.track_delay_line = (KIND == AB_KIND_NFM_LOWPASS || KIND == AB_KIND_GENERIC);
+    L.may_post_filter = (KIND == AB_KIND_NFM_LOWPASS || KIND == AB_KIND_GENERIC);
 
     SqRegs s;
     sq_load(s, L, sp, true);
@@ -247,10 +227,8 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     wrow.coop = full_block;
     float2* iqout = a.iq_out + ab_ring_base(slot, B);
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
-    float* my = lds + lane * NS;
-    wrow.staged = ostage + lane; /* [RUN][OSTRIDE] floats behind the input staging area (and the sincos table) */
-    if (!WAVE_HAS_CTCSS && a.tail_copy) wave_tail_copy(wrow.row, B); /* src/output.cpp:920; the back kernel does it for the split kinds */ /* element (u, lane) at lds[(u * 64 + lane) * NS ...] */
-    /* split kinds: (audio, flags) rows for the tone / back kernels, [ct block][sample][64 lanes] */
+    wrow.staged = ostage + lane; /* [RUN][OSTRIDE] floats behind the sincos table */
+    if (!WAVE_HAS_CTCSS && a.tail_copy) wave_tail_copy(wrow.row, B); /* src/output.cpp:920; the back kernel does it for the split kinds */
     /* split kinds: (audio, flags) for the tone / back kernels, channel-major [ct slot][sample] */
     float2* ct_af = WAVE_HAS_CTCSS ? a.ct_af + (long)(slot - a.ct_first_block * 64) * B : nullptr;
     /* the front kernel has no audio rows of its own, so the row staging area holds 16 samples of hand-off pairs instead:
@@ -278,159 +256,196 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         }
     };
 
-    for (int j0 = 0; j0 < B; j0 += CHUNK) {
-        /* ---- phase 0: the chunk's stage-1 values, 16 bytes (4 rows) per load, parked in LDS -------------------------
-         * row0, AGC_EXTRA, WAVE_BATCH and the chunk start are multiples of 4 and the ring length is a multiple of 16, so
-         * a group of 4 rows is always 16-byte aligned inside one tile and never straddles the ring wrap */
-        {
+    /* ---- input: register ping-pong, a GROUP of 4 (NFM kinds) or 8 (AM) samples at a time ---------------------------------------
+     * Four samples of a channel are 16 contiguous bytes of its 16-row tile (|bin|) or 32 (raw bin I/Q): one or two 16-byte loads
+     * per stream.  Two register sets alternate: the loads of group k+1 are issued as soon as group k's registers have ARRIVED
+     * (touch(): the compiler's own wait lands there), and fly while the per-sample code works through group k -- a wave no longer
+     * sits out a memory round trip per group -- and nothing is staged through LDS on the way in (round 1 parked 8-sample chunks
+     * in LDS, 4-8 KiB per wave, and consumed the loads right where it issued them).
+     * row0, AGC_EXTRA and WAVE_BATCH are multiples of 4 and the ring length is a multiple of 16, so four samples are always 16-byte
+     * aligned inside one tile and never straddle the ring wrap.  Stage 2 may rewrite a magnitude (AM lanes that need raw I/Q, :524)
+     * that is read back AGC_EXTRA = 100 samples later: far outside the 16 samples a prefetch runs ahead. */
+#ifndef AB_AM_GROUP
+#define AB_AM_GROUP 8
+#endif
+    constexpr int GS = KIND == AB_KIND_AM ? AB_AM_GROUP : 4; /* samples per group; divides WAVE_BATCH = 1000 / 2000 */
+    constexpr int GQ = GS / 4;
+    struct Group {
+        float4 mc[GQ], md[GQ], c01[GQ], c23[GQ], q01[GQ], q23[GQ];
+        float dv[GS];
+    };
+    auto fetch = [&](Group& q, int j0, int tail0) { /* tail0 = squelch delay-line tail at the start of the group (lowpass kind) */
 #pragma unroll
-            for (int g = 0; g < CHUNK / 4; g++) {
-                const int rc = ring_row(a.row0 + AB_AGC_EXTRA + j0 + 4 * g, R); /* current hops */
-                const int rd = ring_row(a.row0 + j0 + 4 * g, R);                /* hops AGC_EXTRA earlier */
-                float4 mc, md = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q01 = md, q23 = md;
-                if (!nfm) {
-                    mc = *reinterpret_cast<const float4*>(mag + ab_tile_off(rc));
-                } else { /* NFM: wavein[j] = sqrtf(re^2 + im^2) of the current hop's raw bin (src/rtl_airband.cpp:484-487), recomputed here */
-                    const float4* cp = reinterpret_cast<const float4*>(iqin + ab_tile_off(rc));
-                    const float4 c01 = cp[0], c23 = cp[1];
-                    mc = make_float4(sqrtf(c01.x * c01.x + c01.y * c01.y), sqrtf(c01.z * c01.z + c01.w * c01.w), sqrtf(c23.x * c23.x + c23.y * c23.y),
-                                     sqrtf(c23.z * c23.z + c23.w * c23.w));
-                }
-                if (!nfm) md = *reinterpret_cast<const float4*>(mag + ab_tile_off(rd));
-                if (raw_iq) {
-                    const float4* qp = reinterpret_cast<const float4*>(iqin + ab_tile_off(rd));
-                    q01 = qp[0];
-                    q23 = qp[1];
-                }
-                if (KIND == AB_KIND_NFM_LOWPASS) { /* delay-line entries the 4 samples will see after their tail increment */
-                    float dv[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        int e = s.tail + 1 + 4 * g + r;
-                        e = e >= AB_SQ_BUF ? e - AB_SQ_BUF : e;
-                        dv[r] = L.sqbuf[(long)e * S];
-                    }
-                    md = make_float4(dv[0], dv[1], dv[2], dv[3]);
-                }
-                const float mcs[4] = {mc.x, mc.y, mc.z, mc.w}, mds[4] = {md.x, md.y, md.z, md.w};
-                const float qr[4] = {q01.x, q01.z, q23.x, q23.z}, qi[4] = {q01.y, q01.w, q23.y, q23.w};
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float* dst = my + (4 * g + r) * 64 * NS;
-                    if (NS == 2)
-                        *reinterpret_cast<float2*>(dst) = make_float2(mcs[r], mds[r]);
-                    else
-                        *reinterpret_cast<float4*>(dst) = make_float4(mcs[r], mds[r], qr[r], qi[r]);
-                }
+        for (int g = 0; g < GQ; g++) {
+            const int rc = ring_row(a.row0 + AB_AGC_EXTRA + j0 + 4 * g, R); /* current hops */
+            const int rd = ring_row(a.row0 + j0 + 4 * g, R);                /* hops AGC_EXTRA earlier */
+            if (!nfm) {
+                q.mc[g] = *reinterpret_cast<const float4*>(mag + ab_tile_off(rc));
+                q.md[g] = *reinterpret_cast<const float4*>(mag + ab_tile_off(rd));
+            } else { /* NFM: wavein[j] = sqrtf(re^2 + im^2) of the current hop's raw bin (src/rtl_airband.cpp:484-487), recomputed when used */
+                const float4* cp = reinterpret_cast<const float4*>(iqin + ab_tile_off(rc));
+                q.c01[g] = cp[0];
+                q.c23[g] = cp[1];
+            }
+            if (raw_iq) {
+                const float4* qp = reinterpret_cast<const float4*>(iqin + ab_tile_off(rd));
+                q.q01[g] = qp[0];
+                q.q23[g] = qp[1];
             }
         }
-        if ((j0 % RUN) == 0) wrow.j0 = j0;
-        /* ---- phase 1 (+3 when fused): the sequential per-sample loop ---------------------------------------------- */
-        {
-#pragma unroll UNROLL
-            for (int u = 0; u < CHUNK; u++) {
-                const int j = j0 + u;
-                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (NS == 2) {
-                    const float2 t2 = *reinterpret_cast<const float2*>(my + u * 64 * NS);
-                    v.x = t2.x;
-                    v.y = t2.y;
-                } else {
-                    v = *reinterpret_cast<const float4*>(my + u * 64 * NS);
-                }
-                float cur_mag = v.x, re = v.z, im = v.w;
-                /* stage 2 may have rewritten the delayed magnitude (lowpass channels) less than a chunk ago: those
-                 * samples are AGC_EXTRA = 100 > CHUNK steps old, so the value parked in phase 0 is always current */
-                const float delayed_mag = v.y;
+        if (KIND == AB_KIND_NFM_LOWPASS) { /* delay-line entries the samples will see after their tail increment (written >= 101 samples ago) */
+#pragma unroll
+            for (int r = 0; r < GS; r++) {
+                int e = tail0 + 1 + r;
+                e = e >= AB_SQ_BUF ? e - AB_SQ_BUF : e;
+                q.dv[r] = L.sqbuf[(long)e * S];
+            }
+        }
+    };
+    /* "these registers are needed now": the compiler puts its wait for the group's loads here, BEFORE the next group's loads are issued */
+    auto touch = [&](const Group& q) {
+#pragma unroll
+        for (int g = 0; g < GQ; g++) {
+            if (!nfm) asm volatile("" ::"v"(q.mc[g].x), "v"(q.mc[g].y), "v"(q.mc[g].z), "v"(q.mc[g].w), "v"(q.md[g].x), "v"(q.md[g].y), "v"(q.md[g].z), "v"(q.md[g].w));
+            else asm volatile("" ::"v"(q.c01[g].x), "v"(q.c01[g].y), "v"(q.c01[g].z), "v"(q.c01[g].w), "v"(q.c23[g].x), "v"(q.c23[g].y), "v"(q.c23[g].z), "v"(q.c23[g].w));
+            if (raw_iq) asm volatile("" ::"v"(q.q01[g].x), "v"(q.q01[g].y), "v"(q.q01[g].z), "v"(q.q01[g].w), "v"(q.q23[g].x), "v"(q.q23[g].y), "v"(q.q23[g].z), "v"(q.q23[g].w));
+        }
+        if (KIND == AB_KIND_NFM_LOWPASS) asm volatile("" ::"v"(q.dv[0]), "v"(q.dv[1]), "v"(q.dv[2]), "v"(q.dv[3]));
+    };
+    auto tail_in = [&](int n) { /* the delay-line tail advances once per sample (sq_advance) */
+        int t = s.tail + n;
+        return t >= AB_SQ_BUF ? t - AB_SQ_BUF : t;
+    };
 
-                const lmask went_closed = sq_raw(s, L, cur_mag, delayed_mag /* = prefetched delay-line entry for the lowpass kind */);
+    /* ---- the sequential per-sample step ------------------------------------------------------------------------------------ */
+    auto sample = [&](const int j, float cur_mag, const float delayed_mag /* lowpass kind: the prefetched delay-line entry */, float re, float im) {
+        const lmask went_closed = sq_raw(s, L, cur_mag, delayed_mag /* = prefetched delay-line entry for the lowpass kind */);
 
-                if (ab_any(m_raw_iq)) { /* src/rtl_airband.cpp:510-530 */
-                    const lmask filt = sq_should_filter(s) & m_raw_iq;
-                    if (ab_lane(filt)) { /* per-lane float work only: lane masks are not touched inside divergent code */
-                        const unsigned idx = dm_phi >> 16; /* sincosf_lut (src/util.cpp:113-127) */
-                        const float fract = (float)(dm_phi & 0xffffu) / 65536.0f;
-                        const float2 e0 = lut[idx], e1 = lut[idx + 1];
-                        const float s0 = e0.x, s1 = e1.x, c0 = e0.y, c1 = e1.y;
-                        const float swf = s0 + (s1 - s0) * fract;
-                        const float cwf = c0 + (c1 - c0) * fract;
-                        const float nswf = -swf;
-                        float tr = re * cwf - im * nswf; /* multiply(real, imag, cwf, -swf) */
-                        float ti = im * cwf + re * nswf;
-                        dm_phi = (dm_phi + cc.dm_dphi) & 0xffffffu;
-                        if (lowpass) { /* LowpassFilter::apply (src/filters.cpp:146-163) */
-                            lxr0 = lxr1; lxi0 = lxi1;
-                            lxr1 = lxr2; lxi1 = lxi2;
-                            lxr2 = tr / cc.lp_gain; lxi2 = ti / cc.lp_gain;
-                            lyr0 = lyr1; lyi0 = lyi1;
-                            lyr1 = lyr2; lyi1 = lyi2;
-                            lyr2 = (lxr0 + lxr2) + (2.0f * lxr1) + (cc.lp_yc0 * lyr0) + (cc.lp_yc1 * lyr1);
-                            lyi2 = (lxi0 + lxi2) + (2.0f * lxi1) + (cc.lp_yc0 * lyi0) + (cc.lp_yc1 * lyi1);
-                            tr = lyr2;
-                            ti = lyi2;
-                        }
-                        re = tr;
-                        im = ti;
-                        cur_mag = sqrtf(re * re + im * im); /* double sqrt rounded to float == correctly rounded sqrtf */
-                        /* the reference overwrites wavein[j] here (src/rtl_airband.cpp:524); only AM reads it back later */
-                        if (!nfm) mag[ab_tile_off(ring_row(a.row0 + AB_AGC_EXTRA + j, R))] = cur_mag;
-                    }
-                    sq_filtered(s, L, filt, cur_mag); /* process_filtered_sample for the lanes with a lowpass filter */
+        if (ab_any(m_raw_iq)) { /* src/rtl_airband.cpp:510-530 */
+            const lmask filt = sq_should_filter(s) & m_raw_iq;
+            if (ab_lane(filt)) { /* per-lane float work only: lane masks are not touched inside divergent code */
+                const unsigned idx = dm_phi >> 16; /* sincosf_lut (src/util.cpp:113-127) */
+                const float fract = (float)(dm_phi & 0xffffu) / 65536.0f;
+                const float2 e0 = lut[idx], e1 = lut[idx + 1];
+                const float s0 = e0.x, s1 = e1.x, c0 = e0.y, c1 = e1.y;
+                const float swf = s0 + (s1 - s0) * fract;
+                const float cwf = c0 + (c1 - c0) * fract;
+                const float nswf = -swf;
+                float tr = re * cwf - im * nswf; /* multiply(real, imag, cwf, -swf) */
+                float ti = im * cwf + re * nswf;
+                dm_phi = (dm_phi + cc.dm_dphi) & 0xffffffu;
+                if (lowpass) { /* LowpassFilter::apply (src/filters.cpp:146-163) */
+                    lxr0 = lxr1; lxi0 = lxi1;
+                    lxr1 = lxr2; lxi1 = lxi2;
+                    lxr2 = tr / cc.lp_gain; lxi2 = ti / cc.lp_gain;
+                    lyr0 = lyr1; lyi0 = lyi1;
+                    lyr1 = lyr2; lyi1 = lyi2;
+                    lyr2 = (lxr0 + lxr2) + (2.0f * lxr1) + (cc.lp_yc0 * lyr0) + (cc.lp_yc1 * lyr1);
+                    lyi2 = (lxi0 + lxi2) + (2.0f * lxi1) + (cc.lp_yc0 * lyi0) + (cc.lp_yc1 * lyi1);
+                    tr = lyr2;
+                    ti = lyi2;
                 }
+                re = tr;
+                im = ti;
+                cur_mag = sqrtf(re * re + im * im); /* double sqrt rounded to float == correctly rounded sqrtf */
+                /* the reference overwrites wavein[j] here (src/rtl_airband.cpp:524); only AM reads it back later */
+                if (!nfm) mag[ab_tile_off(ring_row(a.row0 + AB_AGC_EXTRA + j, R))] = cur_mag;
+            }
+            sq_filtered(s, L, filt, cur_mag); /* process_filtered_sample for the lanes with a lowpass filter */
+        }
 
-                lmask fade_m = 0;
-                if (ab_any(m_am)) { /* src/rtl_airband.cpp:532-547 */
-                    if (ab_lane(sq_first_open(s) & m_am)) {
-                        const float lvl = sq_level(s);
-                        for (int k = j; k < j + AB_AGC_EXTRA; k++) { /* the AGC_EXTRA magnitudes before the current one */
-                            const float w = mag[ab_tile_off(ring_row(a.row0 + k, R))];
-                            if (w >= lvl) agc = agc * 0.9f + w * 0.1f;
-                        }
-                    }
-                    fade_m = sq_last_open(s) & m_am;
-                }
-                const bool fade = ab_lane(fade_m);
-
-                float out = 0.0f;
-                const bool audio = ab_lane(sq_should_audio(s));
-                if (audio) {
-                    if (!nfm) { /* AM: src/rtl_airband.cpp:553-563 */
-                        if (cur_mag > sq_level(s)) agc = agc * 0.995f + cur_mag * 0.005f;
-                        out = (delayed_mag - agc) / (agc * 1.5f);
-                        if (fabsf(out) > 0.8f) {
-                            out *= 0.85f;
-                            agc *= 1.15f;
-                        }
-                    } else { /* NFM: src/rtl_airband.cpp:565-582 */
-                        if (!(cc.flags & AB_F_QUADRI)) {
-                            const float nbj = -pj;
-                            const float cr = re * pr - im * nbj;
-                            const float cj = im * pr + re * nbj;
-                            out = (float)((double)fast_atan2_dev(cj, cr) * 0.31830988618379067154);
-                        } else {
-                            out = (float)((double)((pr * im - re * pj) / (re * re + im * im + 1.0f)) * 0.31830988618379067154);
-                        }
-                        pr = re;
-                        pj = im;
-                        agc = agc * 0.995f + out * 0.005f;
-                        out -= agc;
-                        out = out * one_minus_alpha + prev_out * cc.alpha;
-                        prev_out = out;
-                    }
-                }
-                if (WAVE_HAS_CTCSS) {
-                    /* front half of a CTCSS-capable kind: hand (pre-notch audio, flags) to the tone and back kernels.  Raw I/Q of
-                     * an open sample is written now; the back kernel zeroes it again if the tone gate turns out closed. */
-                    const unsigned f = (audio ? FL_AUDIO : 0u) | (fade ? FL_FADE : 0u) | (ab_lane(went_closed) ? FL_RESET : 0u) | (a.trace ? (unsigned)sq_cur(s) << FL_STATE_SHIFT : 0u);
-                    /* parked in LDS; 16 samples leave together as whole 128-byte lines of the channel-major hand-off rows */
-                    hand[((j & (HAND_RUN - 1)) * OSTRIDE)] = make_float2(out, __uint_as_float(f));
-                    if ((cc.flags & AB_F_IQ_OUT) && audio) iqout[(long)j * S] = make_float2(re, im);
-                } else {
-                    emit_sample(a, cc, o, wrow, iqout, trace, j, audio, fade, true, trace ? sq_cur(s) : 0, out, re, im, true);
+        lmask fade_m = 0;
+        if (ab_any(m_am)) { /* src/rtl_airband.cpp:532-547 */
+            if (ab_lane(sq_first_open(s) & m_am)) {
+                const float lvl = sq_level(s);
+                for (int k = j; k < j + AB_AGC_EXTRA; k++) { /* the AGC_EXTRA magnitudes before the current one */
+                    const float w = mag[ab_tile_off(ring_row(a.row0 + k, R))];
+                    if (w >= lvl) agc = agc * 0.9f + w * 0.1f;
                 }
             }
-            if (!WAVE_HAS_CTCSS && ((j0 + CHUNK) % RUN) == 0) wave_flush(wrow);
-            if (WAVE_HAS_CTCSS && ((j0 + CHUNK) % HAND_RUN) == 0) hand_flush(HAND_RUN, j0 + CHUNK - HAND_RUN);
+            fade_m = sq_last_open(s) & m_am;
+        }
+        const bool fade = ab_lane(fade_m);
+
+        float out = 0.0f;
+        const bool audio = ab_lane(sq_should_audio(s));
+        if (audio) {
+            if (!nfm) { /* AM: src/rtl_airband.cpp:553-563 */
+                if (cur_mag > sq_level(s)) agc = agc * 0.995f + cur_mag * 0.005f;
+                out = (delayed_mag - agc) / (agc * 1.5f);
+                if (fabsf(out) > 0.8f) {
+                    out *= 0.85f;
+                    agc *= 1.15f;
+                }
+            } else { /* NFM: src/rtl_airband.cpp:565-582 */
+                if (!(cc.flags & AB_F_QUADRI)) {
+                    const float nbj = -pj;
+                    const float cr = re * pr - im * nbj;
+                    const float cj = im * pr + re * nbj;
+                    out = (float)((double)fast_atan2_dev(cj, cr) * 0.31830988618379067154);
+                } else {
+                    out = (float)((double)((pr * im - re * pj) / (re * re + im * im + 1.0f)) * 0.31830988618379067154);
+                }
+                pr = re;
+                pj = im;
+                agc = agc * 0.995f + out * 0.005f;
+                out -= agc;
+                out = out * one_minus_alpha + prev_out * cc.alpha;
+                prev_out = out;
+            }
+        }
+        if (WAVE_HAS_CTCSS) {
+            /* front half of a CTCSS-capable kind: hand (pre-notch audio, flags) to the tone and back kernels.  Raw I/Q of
+             * an open sample is written now; the back kernel zeroes it again if the tone gate turns out closed. */
+            const unsigned f = (audio ? FL_AUDIO : 0u) | (fade ? FL_FADE : 0u) | (ab_lane(went_closed) ? FL_RESET : 0u) | (a.trace ? (unsigned)sq_cur(s) << FL_STATE_SHIFT : 0u);
+            /* parked in LDS; 16 samples leave together as whole 128-byte lines of the channel-major hand-off rows */
+            hand[((j & (HAND_RUN - 1)) * OSTRIDE)] = make_float2(out, __uint_as_float(f));
+            if ((cc.flags & AB_F_IQ_OUT) && audio) iqout[(long)j * S] = make_float2(re, im);
+        } else {
+            emit_sample(a, cc, o, wrow, iqout, trace, j, audio, fade, true, trace ? sq_cur(s) : 0, out, re, im, true);
+        }
+    };
+    auto group = [&](const Group& q, int j0) {
+#pragma unroll
+        for (int g = 0; g < GQ; g++) {
+            float mcs[4], mds[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qr[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qi[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (!nfm) {
+                mcs[0] = q.mc[g].x; mcs[1] = q.mc[g].y; mcs[2] = q.mc[g].z; mcs[3] = q.mc[g].w;
+                mds[0] = q.md[g].x; mds[1] = q.md[g].y; mds[2] = q.md[g].z; mds[3] = q.md[g].w;
+            } else {
+                mcs[0] = sqrtf(q.c01[g].x * q.c01[g].x + q.c01[g].y * q.c01[g].y);
+                mcs[1] = sqrtf(q.c01[g].z * q.c01[g].z + q.c01[g].w * q.c01[g].w);
+                mcs[2] = sqrtf(q.c23[g].x * q.c23[g].x + q.c23[g].y * q.c23[g].y);
+                mcs[3] = sqrtf(q.c23[g].z * q.c23[g].z + q.c23[g].w * q.c23[g].w);
+            }
+            if (raw_iq) {
+                qr[0] = q.q01[g].x; qi[0] = q.q01[g].y; qr[1] = q.q01[g].z; qi[1] = q.q01[g].w;
+                qr[2] = q.q23[g].x; qi[2] = q.q23[g].y; qr[3] = q.q23[g].z; qi[3] = q.q23[g].w;
+            }
+            if (KIND == AB_KIND_NFM_LOWPASS) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) mds[r] = q.dv[4 * g + r];
+            }
+            const int jq = j0 + 4 * g;
+            if ((jq % RUN) == 0) wrow.j0 = jq;
+#pragma unroll
+            for (int r = 0; r < 4; r++) sample(jq + r, mcs[r], mds[r], qr[r], qi[r]);
+            if (!WAVE_HAS_CTCSS && ((jq + 4) % RUN) == 0) wave_flush(wrow);
+            if (WAVE_HAS_CTCSS && ((jq + 4) % HAND_RUN) == 0) hand_flush(HAND_RUN, jq + 4 - HAND_RUN);
+        }
+    };
+
+    Group qa, qb;
+    fetch(qa, 0, s.tail);
+    for (int j0 = 0; j0 < B; j0 += 2 * GS) { /* WAVE_BATCH = 1000 is 125 groups of 8: the last pair is half a pair */
+        const bool second = j0 + GS < B;
+        touch(qa);
+        if (second) fetch(qb, j0 + GS, tail_in(GS));
+        group(qa, j0);
+        if (second) {
+            touch(qb);
+            if (j0 + 2 * GS < B) fetch(qa, j0 + 2 * GS, tail_in(GS));
+            group(qb, j0 + GS);
         }
     }
 
@@ -458,16 +473,18 @@ constexpr int TONE_GROUP = 50; /* samples per tone-kernel step; divides WAVE_BAT
  * CTCSS-capable kinds are split in three: this "front" (squelch + discriminator -> audio, flags), the tone kernel
  * (Goertzel banks, one wavefront per channel) and the back kernel (gate, notch, output). */
 #ifndef AB_DEMOD_WAVES
-#define AB_DEMOD_WAVES 4
+#define AB_DEMOD_WAVES 3
+#endif
+#ifndef AB_AM_WAVES
+#define AB_AM_WAVES AB_DEMOD_WAVES
 #endif
 template <int KIND, bool WAVE_HAS_CTCSS>
-__global__ __launch_bounds__(64, AB_DEMOD_WAVES) void demod_kernel(DemodArgs a, int first_block) {
-    extern __shared__ __attribute__((aligned(16))) float lds_demod[];
-    const int slot = (first_block + blockIdx.x) * 64 + threadIdx.x; /* padding slots carry flags == 0 */
+__device__ __forceinline__ void demod_block(const DemodArgs& a, int block, float* lds_demod) {
+    const int slot = block * 64 + threadIdx.x; /* padding slots carry flags == 0 */
     const ChanConst cc = a.cc[slot];
-    /* behind the sample staging area: the (sin, cos) table of sincosf_lut (src/util.cpp:105-127), 257 float2 -- a sample's
+    /* the (sin, cos) table of sincosf_lut (src/util.cpp:105-127), 257 float2 -- a sample's
      * derotation then costs one LDS read instead of four dependent trips to L2 on the serial path */
-    float2* lut = reinterpret_cast<float2*>(lds_demod + CHUNK * 64 * LdsSlots<KIND>::value);
+    float2* lut = reinterpret_cast<float2*>(lds_demod);
     if (KIND != AB_KIND_AM) {
         for (int i = threadIdx.x; i < 257; i += 64) lut[i] = make_float2(a.sin_lut[i], a.cos_lut[i]);
         __syncthreads(); /* one wavefront per block: orders the table writes before any lane's reads */
@@ -477,7 +494,28 @@ __global__ __launch_bounds__(64, AB_DEMOD_WAVES) void demod_kernel(DemodArgs a, 
     ext_of[threadIdx.x] = a.slot_to_ext[slot];
     const bool full_block = __ballot((cc.flags & AB_F_VALID) != 0) == ~0ull; /* padding lanes leave early and cannot take part in a cooperative store */
     __syncthreads();
-    demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lds_demod, lut, ostage, ext_of, full_block);
+    demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lut, ostage, ext_of, full_block);
+}
+
+template <int KIND, bool WAVE_HAS_CTCSS>
+__global__ __launch_bounds__(64, KIND == AB_KIND_AM ? AB_AM_WAVES : AB_DEMOD_WAVES) void demod_kernel(DemodArgs a, int first_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds_demod[];
+    demod_block<KIND, WAVE_HAS_CTCSS>(a, first_block + blockIdx.x, lds_demod);
+}
+
+/* The fused kinds (AM, NFM, NFM + lowpass: squelch, demodulation and output in one pass) in ONE launch.  Each of them alone leaves
+ * issue slots idle -- a lane-per-channel wavefront is a long dependent chain -- and as separate kernels on forked streams they
+ * mostly ran one after another (the first one's waves fill the CUs, the next kernel's get what drains).  Here the host interleaves
+ * the blocks of all kinds in proportion (demod_order: block b of the grid is block demod_order[b] of the slot space), so every
+ * CU holds a mix from the first wave to the last and the kinds finish together. */
+__global__ __launch_bounds__(64, AB_DEMOD_WAVES) void demod_multi_kernel(DemodArgs a, const int* order, const uint8_t* block_kind) {
+    extern __shared__ __attribute__((aligned(16))) float lds_demod[];
+    const int block = order[blockIdx.x];
+    switch (block_kind[block]) { /* wave-uniform */
+        case AB_KIND_AM: demod_block<AB_KIND_AM, false>(a, block, lds_demod); break;
+        case AB_KIND_NFM: demod_block<AB_KIND_NFM, false>(a, block, lds_demod); break;
+        default: demod_block<AB_KIND_NFM_LOWPASS, false>(a, block, lds_demod); break;
+    }
 }
 
 /* CTCSS tone detection (reference: src/ctcss.cpp, driven by Squelch::process_audio_sample src/squelch.cpp:278-295).
@@ -683,9 +721,13 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
  * lane-per-channel kernel holds at most 4 waves per SIMD and the NFM kinds have only half that many wavefronts at BASELINE
  * config #3.  So the split chain (front -> tone -> back, the longest) goes on the caller's stream and the fused kinds run
  * beside it on side streams, forked and joined with events (works the same under graph capture). */
-void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev) {
+void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, const int* d_order, int n_order, const uint8_t* d_block_kind, hipStream_t stream,
+                  hipStream_t* side, hipEvent_t* ev) {
+    auto lds_of = [](int k) { /* sincos table, output-line staging, ext_of */
+        return (size_t)(k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)RUN * OSTRIDE * sizeof(float) + 64 * sizeof(int);
+    };
     auto launch_kind = [&](int k, hipStream_t s) {
-        size_t lds = (size_t)CHUNK * 64 * sizeof(float) * (k == AB_KIND_AM ? 2 : 4) + (k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)RUN * OSTRIDE * sizeof(float) + 64 * sizeof(int);
+        const size_t lds = lds_of(k);
         const int n = kind_n_blocks[k], f = kind_first_block[k];
         if (n <= 0) return;
         switch (k) {
@@ -699,15 +741,25 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
     const bool fork = side != nullptr && ev != nullptr;
     const int fused[3] = {AB_KIND_NFM_LOWPASS, AB_KIND_NFM, AB_KIND_AM};
     if (fork) (void)hipEventRecord(ev[0], stream); /* stage 1 is done at this point of the caller's stream */
-    /* the split chain is the longest dependent sequence of stage 2: it is enqueued first (and its stream has the higher
-     * priority), the fused kinds fill in beside it -- heaviest first, the cheap AM kernel last */
+    /* the split chain (front -> tone -> back) is the longest dependent sequence of stage 2: it is enqueued first (and its stream has
+     * the higher priority), the fused kinds fill in beside it */
     launch_kind(AB_KIND_NFM_CTCSS, stream);
     launch_kind(AB_KIND_GENERIC, stream);
     if (a.ct_n_blocks > 0) {
         hipLaunchKernelGGL(tone_kernel, dim3((a.ct_n_blocks * 64 * 64 + 255) / 256), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(back_kernel, dim3(a.ct_n_blocks), dim3(64), 0, stream, a);
     }
-    for (int i = 0; i < 3; i++) {
+#ifndef AB_NO_FUSED_LAUNCH
+    if (fork && d_order && n_order > 0) { /* one launch for all fused kinds, blocks interleaved by the host */
+        hipStream_t s = side[0];
+        (void)hipStreamWaitEvent(s, ev[0], 0);
+        hipLaunchKernelGGL(demod_multi_kernel, dim3(n_order), dim3(64), lds_of(AB_KIND_NFM_LOWPASS), s, a, d_order, d_block_kind);
+        (void)hipEventRecord(ev[1], s);
+        (void)hipStreamWaitEvent(stream, ev[1], 0);
+        return;
+    }
+#endif
+    for (int i = 0; i < 3; i++) { /* AIRBAND_HIP_FLAG_SERIAL_DEMOD (profiling): every kind as its own kernel, one after the other */
         if (kind_n_blocks[fused[i]] <= 0) continue;
         hipStream_t s = fork ? side[i] : stream;
         if (fork) (void)hipStreamWaitEvent(s, ev[0], 0);
@@ -718,9 +770,6 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
         }
     }
 }
-
-namespace {
-}  // namespace
 
 /* ---- raw I/Q outputs: time-major device rows -> the channel-major layout the output thread consumes (reference:
  * src/output.cpp:521,535 read channel->iq_out).  Only handles with has_iq_outputs channels run this; audio needs no

@@ -58,6 +58,7 @@ struct SqRegs { /* Squelch members that change per sample */
 struct Lane { /* per-lane constants */
     bool prefetched_delay; /* SqRegs::dly is maintained by the caller instead of reading sqbuf from memory (compile-time per kind) */
     bool track_delay_line; /* head/tail advance per sample (only kinds that touch the delay line need them inside a batch) */
+    bool may_post_filter;  /* some lane of this kind may have a lowpass filter, i.e. using_post_filter_ can ever be set (compile-time per kind) */
     lmask m_lowpass, m_manual, m_flappy_lower;
     float manual_level, normal_ratio, flappy_ratio;
     float* sqbuf; /* this lane's column of the 102-deep pre-filter delay line, stride S */
@@ -95,7 +96,7 @@ AB_FSM_FN lmask sq_has_pre(const SqRegs& s) { return ab_ballot(s.pre_capped >= s
 AB_FSM_FN lmask sq_has_signal(const SqRegs& s, const Lane& L) { /* src/squelch.cpp:462-475 */
     lmask sig = sq_has_pre(s);
     /* using_post_filter_ can only ever be set on channels with a lowpass filter */
-    if (ab_any(s.using_post)) sig &= ~s.using_post | ab_ballot(s.post_capped >= sq_delayed(s, L));
+    if (L.may_post_filter && ab_any(s.using_post)) sig &= ~s.using_post | ab_ballot(s.post_capped >= sq_delayed(s, L));
     return sig;
 }
 
@@ -182,7 +183,7 @@ AB_FSM_FN lmask sq_raw(SqRegs& s, const Lane& L, float x, float dly_new) {
         s.lvl = sq_level_compute(s, L);
     }
     sq_avg(s.cap, s.pre_full, s.pre_capped, x);
-    if (ab_any(L.m_lowpass)) {
+    if (L.may_post_filter && ab_any(L.m_lowpass)) {
         if (ab_lane(L.m_lowpass)) L.sqbuf[(long)s.head * L.S] = s.pre_capped * 0.9f; /* only ever read on the post-filter path */
     }
     const lmask sig = sq_has_signal(s, L);

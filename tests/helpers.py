@@ -55,3 +55,20 @@ def afc_case(n_dev: int = 1):
         off = sg.PLAN_OFFSETS_HZ[k] + shifts[k] * bin_hz
         out.append(sg.make_carrier(off, sg.SAMPLE_RATE, kind=0, key_slot=k, key_period_s=0.75, key_on_s=0.4, key_slot_s=0.05))
     return [dict(channels=[dict(c) for c in chans]) for _ in range(n_dev)], out
+
+
+def wait_for_gpu_memory(nbytes: int, timeout_s: float = 60.0) -> None:
+    """The driver hands back a freed allocation of >100 GiB (the previous case's resident I/Q) with a delay: wait until that
+    much device memory is actually free before asking for it again."""
+    import time
+
+    import torch
+
+    t0 = time.time()
+    while time.time() - t0 < timeout_s:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info()
+        if free >= nbytes:
+            return
+        time.sleep(0.5)

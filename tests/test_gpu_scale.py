@@ -20,6 +20,21 @@ import pyverify
 pytestmark = pytest.mark.gpu
 
 RING = 3
+_IQ_POOL = {"buf": None}
+
+
+def _resident_iq(torch, nbytes):
+    """One device buffer for the resident I/Q of every case, grown when a bigger case comes along (the cases run smallest
+    first).  Under pytest a tensor freed at the end of a case is not handed back to the driver before the next case starts
+    (a stand-alone script with the same sequence gets it back at once), and two 160 GiB buffers do not fit one GPU."""
+    buf = _IQ_POOL["buf"]
+    if buf is None or buf.numel() < nbytes:
+        _IQ_POOL["buf"] = None
+        del buf
+        torch.cuda.empty_cache()
+        helpers.wait_for_gpu_memory(nbytes + (1 << 30), timeout_s=5.0)
+        _IQ_POOL["buf"] = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
+    return _IQ_POOL["buf"]
 
 
 def _tweak(d, ch):
@@ -58,13 +73,15 @@ def test_sampled_dongles_of_large_handles(pkg, built, n_dev, mixed, wave_rate, k
     devices = [device(d) for d in range(n_dev)]
     flags = pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_PIPELINE if pipelined else 0)
     dongles = pyverify.sample_dongles(n_dev, k)
-    with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=flags) as hip:
+    hip = pkg.AirbandHip(devices, wave_rate=wave_rate, flags=flags)
+    iq = spot = None
+    try:
         assert hip.channelizer_name() == "dft_mfma_i8"
         g = hip.geometry
         lead = g.first_batch_bytes - g.batch_bytes
         span = lead + (RING + 1) * g.batch_bytes + g.lookahead_bytes
         stride = (span + 255) // 256 * 256
-        iq = torch.empty((n_dev, stride), dtype=torch.uint8, device="cuda")
+        iq = _resident_iq(torch, n_dev * stride)[:n_dev * stride].view(n_dev, stride)
         hip.set_signal_plan(carriers)
         hip.generate_iq(iq.data_ptr(), stride, 0, span, seed=0x5EED)
         hip.synchronize()
@@ -75,31 +92,34 @@ def test_sampled_dongles_of_large_handles(pkg, built, n_dev, mixed, wave_rate, k
         assert np.array_equal(host[last][:65536], pkg.siggen.generate_u8(last, 0, 32768, carriers))
 
         spot = pyverify.SpotCheck(device, dongles, wave_rate=wave_rate)
-        try:
-            def offset(i):
-                return 0 if i == 0 else g.first_batch_bytes + ((i - 1) % RING) * g.batch_bytes
 
-            opened = 0
-            worst = 0.0
-            for i in range(n_batches):
-                hip.process_device(iq.data_ptr() + offset(i), stride)
-                j = i - 1 if pipelined else i  # batch whose results the handle holds now
-                if j < 0:
-                    continue
-                spot.feed([host[d][offset(j):] for d in dongles])
-                w = spot.compare(hip, trace=True, what="%d dongles" % n_dev)
-                worst = max(worst, w["audio_rms"])
-                opened += sum(int((r["axc"] == ord("*")).sum()) for r in spot.last)
-            if pipelined:
-                hip.flush()
-                spot.feed([host[d][offset(n_batches - 1):] for d in dongles])
-                spot.compare(hip, trace=True, what="%d dongles (flush)" % n_dev)
-            assert opened > 0, "no sampled channel ever opened its squelch: not a meaningful parity run"
-            # channels outside the sample: every one of them must at least have produced the right KIND of output
-            # (finite audio, a legal axcindicate) -- catches a block of dongles that was never written at all
-            for d in (n_dev // 3, (2 * n_dev) // 3):
-                r = hip.collect(first_channel=8 * d, n_channels=8)
-                assert np.isfinite(r["waveout"]).all() and set(np.unique(r["axc"])) <= {ord(" "), ord("*")}
-        finally:
+        def offset(i):
+            return 0 if i == 0 else g.first_batch_bytes + ((i - 1) % RING) * g.batch_bytes
+
+        opened = 0
+        worst = 0.0
+        for i in range(n_batches):
+            hip.process_device(iq.data_ptr() + offset(i), stride)
+            j = i - 1 if pipelined else i  # batch whose results the handle holds now
+            if j < 0:
+                continue
+            spot.feed([host[d][offset(j):] for d in dongles])
+            w = spot.compare(hip, trace=True, what="%d dongles" % n_dev)
+            worst = max(worst, w["audio_rms"])
+            opened += sum(int((r["axc"] == ord("*")).sum()) for r in spot.last)
+        if pipelined:
+            hip.flush()
+            spot.feed([host[d][offset(n_batches - 1):] for d in dongles])
+            spot.compare(hip, trace=True, what="%d dongles (flush)" % n_dev)
+        assert opened > 0, "no sampled channel ever opened its squelch: not a meaningful parity run"
+        # channels outside the sample: every one of them must at least have produced the right KIND of output
+        # (finite audio, a legal axcindicate) -- catches a block of dongles that was never written at all
+        for d in (n_dev // 3, (2 * n_dev) // 3):
+            r = hip.collect(first_channel=8 * d, n_channels=8)
+            assert np.isfinite(r["waveout"]).all() and set(np.unique(r["axc"])) <= {ord(" "), ord("*")}
+    finally:
+        if spot is not None:
             spot.close()
+        hip.close()
+        del iq
     print("%d dongles, %d sampled: worst audio RMS error %.3g" % (n_dev, len(dongles), worst))
