@@ -28,6 +28,9 @@ def _resident_iq(torch, nbytes):
     first).  Under pytest a tensor freed at the end of a case is not handed back to the driver before the next case starts
     (a stand-alone script with the same sequence gets it back at once), and two 160 GiB buffers do not fit one GPU."""
     buf = _IQ_POOL["buf"]
+    biggest = 65536 * 2_624_512  # the 65 536-dongle AM case (hop 640 B): ask for that much as soon as a 65 536-dongle case shows up
+    if nbytes > biggest // 2:
+        nbytes = max(nbytes, biggest)
     if buf is None or buf.numel() < nbytes:
         _IQ_POOL["buf"] = None
         del buf
