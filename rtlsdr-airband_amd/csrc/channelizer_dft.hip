@@ -37,10 +37,27 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int TILE_HOPS = 16;
 
+/* staging geometry as a function of the hop size (host and device, usable in constant expressions):
+ * a staging step feeds `sub` consecutive 16-hop MFMA tiles; whole 1 KiB DMA pieces, so the last piece of a step may run past the
+ * bytes the step needs, never past its buffer */
+constexpr __host__ __device__ int c_sub_tiles(int hop_bytes) {
+    const int sub = 640 / hop_bytes;
+    return sub < 1 ? 1 : (sub > 4 ? 4 : sub);
+}
+constexpr __host__ __device__ int c_lds_for(int hop_bytes, int sub) { return ((TILE_HOPS * sub - 1) * hop_bytes + 1024 + 1023) / 1024 * 1024; }
+/* three small buffers (two steps in flight) when eight waves of them fit a CU's 160 KiB, else two larger ones */
+constexpr __host__ __device__ int c_nbuf(int hop_bytes) { return 3 * c_lds_for(hop_bytes, 1) * 8 <= 160 * 1024 ? 3 : 2; }
+constexpr __host__ __device__ int c_lds_per_buf(int hop_bytes) { return c_nbuf(hop_bytes) == 3 ? c_lds_for(hop_bytes, 1) : c_lds_for(hop_bytes, c_sub_tiles(hop_bytes)); }
+constexpr __host__ __device__ int c_sub(int hop_bytes) { return c_nbuf(hop_bytes) == 3 ? 1 : c_sub_tiles(hop_bytes); }
+
 /* EDGE_HI_ZERO: the most significant coefficient digit is zero for every k-step in which the window is below 2^-8
  * (steps 0,1,14,15 of the 7-term cosine window at N = 512 -- checked on the host, see build_dft_tables): those four
  * MFMAs and their 16 VGPRs are dropped. */
-template <int FFT_N, bool EDGE_HI_ZERO>
+/* HOPB: bytes per hop as a compile-time constant (320: 2.56 MS/s at WAVE_RATE 16000, 640: at 8000 -- the BASELINE configurations), or
+ * 0 = run-time value.  With the hop known, the staging geometry (pieces per step, buffers, tiles per step) is constant: the DMA loops
+ * unroll, the wait-count switch disappears and the scalar bookkeeping around every tile shrinks by about two thirds -- the kernel
+ * issues one instruction per SIMD every four cycles whatever its type, so scalar instructions are not free. */
+template <int FFT_N, bool EDGE_HI_ZERO, int HOPB>
 __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     constexpr int WIN_BYTES = 2 * FFT_N;          /* bytes per window (u8/s8 I/Q)      */
     constexpr int KSTEPS = WIN_BYTES / 64;        /* MFMA k-steps per window           */
@@ -59,10 +76,11 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     const int d = ((a.n_dev_pad - g128) >= 128) ? g128 + (in128 & 7) * 16 + (in128 >> 3) : d_lin;
     const int split = wave_global / a.n_dev_pad;
     if (d >= a.n_dev || split >= a.splits) return;
-    const int hop_bytes = a.hop_bytes;
+    const int hop_bytes = HOPB ? HOPB : a.hop_bytes;
     /* a staging step feeds `sub` consecutive 16-hop MFMA tiles: ~10 KiB of stream per step whatever the hop size, so
      * the bytes a wave keeps in flight (one step ahead) do not shrink when the hop does */
-    const int sub = a.sub;
+    const int sub = HOPB ? c_sub(HOPB ? HOPB : 64) : a.sub;
+    const int lds_per_buf = HOPB ? c_lds_per_buf(HOPB ? HOPB : 64) : a.lds_per_buf;
     const int step_hops = TILE_HOPS * sub;
     const int buf_bytes = (step_hops - 1) * hop_bytes + WIN_BYTES;
     uint8_t* lds = lds_all;                               /* two buffers of lds_per_buf bytes */
@@ -125,14 +143,14 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
         }
     };
     /* staging ring of nbuf buffers: step st lives in buffer (st - st_begin) % nbuf; nbuf - 1 steps are in flight */
-    const int nbuf = a.nbuf;
+    const int nbuf = HOPB ? c_nbuf(HOPB ? HOPB : 64) : a.nbuf;
     stage(st_begin, lds);
-    if (nbuf == 3 && st_begin + 1 < st_end) stage(st_begin + 1, lds + a.lds_per_buf);
+    if (nbuf == 3 && st_begin + 1 < st_end) stage(st_begin + 1, lds + lds_per_buf);
     int cur = 0;
 
     const int row_l = lane & 15, grp = lane >> 4;
     for (int st = st_begin; st < st_end; st++) {
-        uint8_t* buf = lds + cur * a.lds_per_buf;
+        uint8_t* buf = lds + cur * lds_per_buf;
         if (nbuf == 3) {
             /* Loads complete in issue order, so once at most n_dma vector-memory operations are outstanding none of them
              * can belong to step st: the step-(st+1) transfer alone has n_dma pieces, all younger.  (Stores issued in
@@ -147,10 +165,10 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
             if (st + 1 >= st_end) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* last step: nothing younger to hide behind */
             int nb = cur + 2;
             nb = nb >= 3 ? nb - 3 : nb;
-            if (st + 2 < st_end) stage(st + 2, lds + nb * a.lds_per_buf); /* two steps ahead: the buffer step st-1 just left */
+            if (st + 2 < st_end) stage(st + 2, lds + nb * lds_per_buf); /* two steps ahead: the buffer step st-1 just left */
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this step's bytes have landed in LDS */
-            if (st + 1 < st_end) stage(st + 1, lds + (cur ^ 1) * a.lds_per_buf); /* next step streams in under this step's MFMAs */
+            if (st + 1 < st_end) stage(st + 1, lds + (cur ^ 1) * lds_per_buf); /* next step streams in under this step's MFMAs */
         }
       for (int sb = 0; sb < sub; sb++) {
         const int t = st * sub + sb;
@@ -198,10 +216,11 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
             pt = pt >= ring_tiles16 ? pt - ring_tiles16 : pt;
             const long off = slot_base + ab_tile_off(pt * TILE_HOPS + grp * 4); /* the lane's 4 hops never straddle a ring tile (4, 8 or 16 rows) */
             const int hop_first = t * TILE_HOPS - shift + grp * 4;
+            const bool whole_tile = t * TILE_HOPS - shift >= 0 && t * TILE_HOPS - shift + TILE_HOPS <= a.n_hops; /* wave-uniform: all 16 hops of the tile are stored */
             float m4[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) m4[r] = __builtin_amdgcn_sqrtf(val[r] * val[r] + im4[r] * im4[r]); /* v_sqrt_f32, 1 ulp: stage 1 is tolerance-bound anyway */
-            if (hop_first >= 0 && hop_first + 3 < a.n_hops) {
+            if (whole_tile || (hop_first >= 0 && hop_first + 3 < a.n_hops)) {
 #ifdef AB_DFT_NT_STORE
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 if (want_mag) __builtin_nontemporal_store((v4f){m4[0], m4[1], m4[2], m4[3]}, reinterpret_cast<v4f*>(a.mag + off));
@@ -240,23 +259,27 @@ bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch) {
     return fft_size == 512 && sfmt == AIRBAND_SFMT_U8 && max_ch <= 8 && (hop_bytes % 16) == 0 && hop_bytes <= 640 && hop_bytes >= 64;
 }
 
-/* whole 1 KiB DMA pieces: the last piece of a tile may run past the bytes the tile needs, never past its buffer */
-int dft_sub_tiles(int hop_bytes) {
-    int sub = 640 / hop_bytes;
-    return sub < 1 ? 1 : (sub > 4 ? 4 : sub);
-}
-static int lds_for(int hop_bytes, int sub) { return ((TILE_HOPS * sub - 1) * hop_bytes + 1024 + 1023) / 1024 * 1024; }
-/* three small buffers (two steps in flight) when eight waves of them fit a CU's 160 KiB, else two larger ones */
-int dft_nbuf(int hop_bytes) { return 3 * lds_for(hop_bytes, 1) * 8 <= 160 * 1024 ? 3 : 2; }
-int dft_lds_per_buf(int hop_bytes) { return dft_nbuf(hop_bytes) == 3 ? lds_for(hop_bytes, 1) : lds_for(hop_bytes, dft_sub_tiles(hop_bytes)); }
+int dft_sub_tiles(int hop_bytes) { return c_sub_tiles(hop_bytes); }
+int dft_nbuf(int hop_bytes) { return c_nbuf(hop_bytes); }
+int dft_lds_per_buf(int hop_bytes) { return c_lds_per_buf(hop_bytes); }
 
-void launch_channelizer_dft(const DftArgs& a, hipStream_t stream) {
+template <int HOPB>
+static void launch_hop(const DftArgs& a, hipStream_t stream) {
     const long waves = (long)a.n_dev_pad * a.splits;
     const size_t lds = (size_t)a.nbuf * a.lds_per_buf;
     if (a.edge_hi_zero)
-        hipLaunchKernelGGL((channelizer_dft_kernel<512, true>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((channelizer_dft_kernel<512, true, HOPB>), dim3((unsigned)waves), dim3(64), lds, stream, a);
     else
-        hipLaunchKernelGGL((channelizer_dft_kernel<512, false>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((channelizer_dft_kernel<512, false, HOPB>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+}
+
+void launch_channelizer_dft(const DftArgs& a, hipStream_t stream) {
+#ifndef AB_DFT_GENERIC_ONLY
+    /* the host derives nbuf / sub / lds_per_buf with the same functions the specialised kernels fold in at compile time */
+    if (a.hop_bytes == 320 && a.nbuf == c_nbuf(320) && a.sub == c_sub(320) && a.lds_per_buf == c_lds_per_buf(320)) return launch_hop<320>(a, stream);
+    if (a.hop_bytes == 640 && a.nbuf == c_nbuf(640) && a.sub == c_sub(640) && a.lds_per_buf == c_lds_per_buf(640)) return launch_hop<640>(a, stream);
+#endif
+    launch_hop<0>(a, stream);
 }
 
 }  // namespace airband
