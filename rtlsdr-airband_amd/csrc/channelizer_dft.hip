@@ -135,6 +135,19 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     const int n_dma = (buf_bytes + 1023) >> 10;
     auto stage = [&](int step, uint8_t* buf) {
         const long base = ((long)step * step_hops - shift) * hop_bytes;
+        if (HOPB && base >= 0 && base + (long)n_dma * 1024 <= span_end) {
+            /* interior step (wave-uniform test): every piece lies inside the batch span, so no lane needs its address clamped -- one
+             * 64-bit add per step, the pieces differ only in the instruction's immediate offset, which moves the global source and
+             * the LDS destination alike.  The offset field holds 12 bits: a second base covers the pieces past 4 KiB. */
+            const uint8_t* p = src + base + lane * 16;
+#define AB_PIECE(K, BASE, OFF) \
+    if (n_dma > (K)) __builtin_amdgcn_global_load_lds((gptr_t)(p + (BASE)), (lptr_t)(uintptr_t)(buf + (BASE)), 16, (OFF), 0)
+            AB_PIECE(0, 0, 0); AB_PIECE(1, 0, 1024); AB_PIECE(2, 0, 2048); AB_PIECE(3, 0, 3072);
+            AB_PIECE(4, 4096, 0); AB_PIECE(5, 4096, 1024); AB_PIECE(6, 4096, 2048); AB_PIECE(7, 4096, 3072);
+            AB_PIECE(8, 8192, 0); AB_PIECE(9, 8192, 1024); AB_PIECE(10, 8192, 2048); AB_PIECE(11, 8192, 3072);
+#undef AB_PIECE
+            return;
+        }
         for (int i = 0; i < n_dma; i++) {
             long so = base + i * 1024 + lane * 16;
             if (so + 16 > span_end) so = span_end - 16;
