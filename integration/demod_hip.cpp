@@ -1,42 +1,3 @@
-# INTEGRATION — wiring `libairband_hip.so` into RTLSDR-Airband
-
-The reference has no run-time plugin API for its DSP; its one GPU precedent is the compile-time VideoCore FFT backend
-(`#ifdef WITH_BCM_VC` inside `demodulate()`, `src/rtl_airband.cpp:293-310,404-481,626-631`; C API `src/hello_fft/gpu_fft.h:66-74`).
-The MI355X backend follows that precedent one level up: instead of replacing only the FFT call it replaces the whole body of
-`demodulate()` for the devices a demod thread owns. Everything around it — `main()`, config parser, input drivers and their
-ring buffers, output/mixer threads, stats file — stays as it is.
-
-## 1. What the maintainer adds
-
-Two files, both in this repository and both compiled by its test build (`make -C oracle ref` → `oracle/_ref/libairband_ref_*_patched.so`):
-
-* **`integration/airband_hip.patch`** — 66 added lines against the reference's `src/`, everything under `#ifdef WITH_AIRBAND_HIP`:
-  * `CMakeLists.txt`, `config.h.in`: option `AIRBAND_HIP` → `WITH_AIRBAND_HIP`, adds `demod_hip.cpp` and `-lairband_hip`;
-  * `rtl_airband.cpp:1110-1112`: `pthread_create(..., &demodulate_hip, ...)` instead of `&demodulate` — the only change to that file;
-  * `rtl_airband.h`: `channel_t` keeps the seven config-level numbers of its channel (`cfg_squelch_threshold`, `cfg_squelch_snr`, `cfg_notch`,
-    `cfg_notch_q`, `cfg_ctcss`, `cfg_bandwidth`, `cfg_tau`), `device_t` keeps `cfg_tau`; two prototypes;
-  * `config.cpp`: one call per channel (`demod_hip_keep_channel_cfg(chans[j], channel)`) and one line per device that store those numbers —
-    `parse_channels()` otherwise turns them straight into `Squelch` / `NotchFilter` / `LowpassFilter` objects whose members are private;
-  * `squelch.h/.cpp`: `Squelch::mirror(...)`, a setter for the seven statistics the stats file and the TUI read through the existing getters
-    (`src/output.cpp:617-761`, `src/rtl_airband.cpp:633-640`) — with the GPU backend the `Squelch` object itself processes no samples.
-  The input drivers, `input-common/-helpers`, `output.cpp`, `mixer.cpp` and the body of `demodulate()` are untouched.
-* **`integration/demod_hip.cpp`** — the new translation unit, shown in full below. It only reads/writes the fields `demodulate()` itself
-  touches (SURVEY §8b) plus the ones the patch adds.
-
-How this is tested, not only documented: `oracle/Makefile` copies the reference's `src/` into a scratch directory (`oracle/_ref/patched_src`,
-git-ignored), applies the patch with `patch -p1`, compiles the patched `config.cpp` (proof that the patch compiles; the parser itself needs
-libconfig++ to *run*, which this image lacks, so the test harness fills `device_t/channel_t` by hand exactly as `parse_channels()` does,
-including the new `cfg_*` fields), compiles `integration/demod_hip.cpp` **verbatim** against the patched headers and links both with the
-reference's own `squelch/ctcss/filters/util/input-*` objects. `tests/test_dropin_shim.py` then runs the reference's `device_t/channel_t/input_t`
-plumbing twice on the GPU box — `circbuffer_append()` on the producer side, the `waveavail` / tail-copy protocol on the consumer side — once
-with `demodulate()`, once with `demodulate_hip()`: identical `axcindicate`, counters read back through `Squelch::open_count()` & co. identical,
-levels within 1e-4, audio within 1e-4 RMS. `tests/test_integration_patch.py` checks (CPU) that the patch applies cleanly to the reference tree
-and that the code block below is byte for byte `integration/demod_hip.cpp` (`scripts/sync_integration_md.py` regenerates it).
-
-## 2. The binding (C++, against the reference's own headers)
-
-<!-- demod_hip.cpp:begin -->
-```cpp
 // demod_hip.cpp -- RTLSDR-Airband side of the MI355X backend: demodulate() for a shard of devices, done by
 // libairband_hip.so (C ABI: airband_hip.h).  Added to the reference tree by integration/airband_hip.patch together with
 // the few fields / one setter it uses; everything else -- main(), the config parser, the input drivers and their ring
@@ -211,46 +172,3 @@ void* demodulate_hip(void* params) {
     airband_hip_release(h);  // like gpu_fft_release on do_exit (rtl_airband.cpp:360-365)
     return NULL;
 }
-```
-<!-- demod_hip.cpp:end -->
-
-Notes for the maintainer
-
-* `output_thread` keeps doing `memcpy(channel->waveout, channel->waveout + WAVE_BATCH, AGC_EXTRA*4)` (`src/output.cpp:920`); with this backend
-  that copy moves stale floats and is harmless — or guard it with `#ifndef WITH_AIRBAND_HIP`.
-* The shim holds a batch back while the output thread has not drained the previous one (`waveavail` still set) instead of overwriting it and
-  counting an overrun (`src/rtl_airband.cpp:649-654`): the library's staging ring absorbs the wait, nothing is lost.
-* Device failure handling stays on the host (`src/rtl_airband.cpp:377-391`); its one effect on this path, `mixer_disable_input()`, is
-  `airband_hip_mixer_enable_input(h, input_index, 0)` when the mixers run on the GPU.
-* Mixers need no change: `process_outputs()` still calls `mixer_put_samples()` with the `waveout` the shim filled. For *GPU-side* mixing
-  (config #5: hundreds of thousands of inputs) call `airband_hip_set_mixers()` once and read `airband_hip_collect_mixers()`; across GPUs
-  all-reduce `airband_hip_device_results().mix_left/right` with RCCL (SUM) and `mix_signal` (MAX) — `bench.py` does exactly that.
-* GPU-resident producers (SDR front-ends that DMA straight into HBM, or the synthetic generator) skip `submit`: `airband_hip_process_device(h, d_iq, stride, stream)`
-  takes a device pointer laid out like the reference's tail-replicated ring (`lookahead_bytes` readable past each batch).
-* GPU-resident consumers read `airband_hip_device_results()`: `d_waveout` has the reference's own shape — channel `c`'s `WAVE_BATCH` samples start at
-  `d_waveout + c * geometry.wave_stride`, the `AGC_EXTRA` floats behind them are the carry into the next batch (`channel->waveout`, `src/rtl_airband.h:230`).
-  `airband_hip_stream_wait_results(h, consumer_stream)` orders the consumer behind the batch on the GPU; handing the same stream to the next
-  `process_device()` orders the overwrite behind the consumer. No host synchronisation is needed in a steady-state loop.
-* Throughput mode: `AIRBAND_HIP_FLAG_PIPELINE` in `cfg.flags` lets a process call run stage 1 of its batch beside stage 2 of the previous one. The loop
-  above stays as it is except that the first `airband_hip_collect()` returns `AIRBAND_HIP_EAGAIN` (results lag one batch = 125 ms) and
-  `airband_hip_flush(h)` before `airband_hip_release(h)` drains the last batch. Values are bit-identical to the default mode. Worth ~5 % on an MI355X
-  (DESIGN.md §4.3); handles with AFC channels ignore the flag.
-* One handle per `demodulate` thread; all dongles of a handle share sample format and hop (`sample_rate/WAVE_RATE`); mixed fleets use one
-  handle per class, exactly like `multiple_demod_threads` shards devices today (`src/rtl_airband.cpp:1052-1086`).
-
-## 3. Other languages
-
-The ABI is plain C (`extern "C"`, pointers and sizes). The repository's own binding is the ctypes layer in
-`rtlsdr-airband_amd/__init__.py` (`AirbandHip`), used by the tests and `bench.py`:
-
-```python
-pkg = importlib.import_module("rtlsdr-airband_amd")
-hip = pkg.AirbandHip([dict(channels=[dict(frequency=119_500_000), dict(frequency=120_225_000, modulation=1, ctcss_freq=100.0)])], wave_rate=16000)
-hip.submit(0, iq_bytes); hip.process(); out = hip.collect(stats=True)     # out["waveout"][channel][WAVE_BATCH]
-```
-
-## 4. Build
-
-`python -c "import __graft_entry__ as g; g.build()"` — hipcc `--offload-arch=gfx950` for `csrc/*.hip` + `airband_hip.cpp`, g++ for the
-host-only parameter derivation, output `rtlsdr-airband_amd/libairband_hip.so` (in-tree). The oracle (`make -C oracle`) is test infrastructure
-and is never linked into the library.

@@ -172,7 +172,7 @@ def reference_throughput(devices, iq_list, seconds: float, threads: int, *, nfm:
 
 def _all_worker(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib):
     try:
-        lib = _load(nfm)
+        lib = _load(nfm, "patched" if hip_lib else False)
         lib.refh_run_all.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
         lib.refh_start_hip.argtypes = [C.c_char_p]
         lib.refh_hip_channel_stats.argtypes = [C.c_int, C.c_int, C.POINTER(capi.ChannelStats)]
@@ -208,8 +208,9 @@ def _all_worker(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib)
 
 def run_reference_all(devices, iq_list, n_batches, *, nfm: bool, fft_log: int = 9, fm_demod: int = 0, hip_lib: str | None = None):
     """All devices fed concurrently through the reference's own rings.  hip_lib=None: the reference's demodulate();
-    hip_lib=path to libairband_hip.so: the SAME harness with demodulate() swapped for the drop-in shim (oracle/ref_harness.cpp
-    demodulate_hip, the code INTEGRATION.md shows)."""
+    hip_lib=path to libairband_hip.so: the harness built from the PATCHED reference (integration/airband_hip.patch applied to a
+    scratch copy, integration/demod_hip.cpp compiled verbatim): demodulate_hip() instead of demodulate(), statistics read back
+    through the reference's own Squelch getters."""
     ctx = mp.get_context("spawn" if hip_lib else "fork")
     q = ctx.Queue()
     p = ctx.Process(target=_all_worker, args=(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib))

@@ -58,10 +58,6 @@ static demod_params_t g_demod_params[REFH_MAX_THREADS];
 static Signal g_signal;
 static size_t* g_hops_fed_bytes = NULL;  /* total bytes fed per device */
 static char g_trace_dir[512] = "";
-/* config-level values per device, kept next to the objects built from them (what a maintainer's shim would keep) */
-static std::vector<airband_hip_device_cfg> g_dev_cfg;
-static std::vector<std::vector<airband_hip_channel_cfg> > g_ch_cfg;
-static int g_fm_demod_algo = 0;
 
 extern "C" {
 
@@ -86,9 +82,6 @@ int refh_init(int n_devices, int fft_log, int fm_demod_algo, int global_tau_us) 
     device_count = n_devices;
     devices = (device_t*)XCALLOC(n_devices, sizeof(device_t));
     g_hops_fed_bytes = (size_t*)XCALLOC(n_devices, sizeof(size_t));
-    g_dev_cfg.assign(n_devices, airband_hip_device_cfg());
-    g_ch_cfg.assign(n_devices, std::vector<airband_hip_channel_cfg>());
-    g_fm_demod_algo = fm_demod_algo;
     mixer_count = 0;
     do_exit = 0;
 #ifdef NFM
@@ -106,9 +99,9 @@ int refh_init(int n_devices, int fft_log, int fm_demod_algo, int global_tau_us) 
 
 int refh_add_device(int d, const airband_hip_device_cfg* cfg) {
     device_t* dev = devices + d;
-    g_ch_cfg[d].assign(cfg->channels, cfg->channels + cfg->channel_count);
-    g_dev_cfg[d] = *cfg;
-    g_dev_cfg[d].channels = g_ch_cfg[d].data();
+#ifdef WITH_AIRBAND_HIP
+    dev->cfg_tau = cfg->tau_us; /* what the patched parse_devices() keeps (integration/airband_hip.patch, src/config.cpp:776) */
+#endif
     input_t* input = (input_t*)XCALLOC(1, sizeof(input_t));
     input->state = INPUT_RUNNING;
     input->sfmt = (sample_format_t)cfg->sfmt;
@@ -213,6 +206,17 @@ int refh_add_device(int d, const airband_hip_device_cfg* cfg) {
 #ifdef NFM
         if (cc->tau_us >= 0) channel->alpha = (cc->tau_us == 0 ? 0.0f : exp(-1.0f / (WAVE_RATE * 1e-6 * cc->tau_us)));
 #endif
+#ifdef WITH_AIRBAND_HIP
+        /* what the patched parse_channels() keeps through demod_hip_keep_channel_cfg() (integration/demod_hip.cpp): the numbers
+         * as they stand in the config file */
+        channel->cfg_squelch_threshold = cc->squelch_threshold_dbfs;
+        channel->cfg_squelch_snr = cc->squelch_snr_threshold_db;
+        channel->cfg_notch = cc->notch_freq;
+        channel->cfg_notch_q = cc->notch_q;
+        channel->cfg_ctcss = cc->ctcss_freq;
+        channel->cfg_bandwidth = cc->bandwidth_hz;
+        channel->cfg_tau = cc->tau_us;
+#endif
         /* raw-I/Q output: parse_outputs() sets both flags for a rawfile output (src/config.cpp:34-263) */
         if (cc->has_iq_outputs) {
             channel->has_iq_outputs = 1;
@@ -248,9 +252,11 @@ int refh_add_device(int d, const airband_hip_device_cfg* cfg) {
     return 0;
 }
 
-/* ---- the reference-side shim of INTEGRATION.md, for real: demodulate()'s replacement driving libairband_hip.so through
- * its C ABI from the reference's own device_t / channel_t / input_t objects.  The library is dlopen()ed so that the oracle
- * build never links against the product. ------------------------------------------------------------------------------ */
+/* ---- the drop-in, for real (REFH_PATCHED builds only): this file is then compiled against a scratch copy of the reference with
+ * integration/airband_hip.patch applied (-DWITH_AIRBAND_HIP), next to integration/demod_hip.cpp compiled VERBATIM -- the translation
+ * unit the patch adds to the reference.  demod_hip.cpp calls the airband_hip_* C ABI directly; so that the oracle build never links
+ * against the product, the symbols it needs are provided here as trampolines into a dlopen()ed libairband_hip.so. --------------- */
+#ifdef REFH_PATCHED
 struct HipApi {
     void* dl;
     int (*prepare)(const airband_hip_config*, airband_hip_handle**);
@@ -262,91 +268,37 @@ struct HipApi {
     int (*collect)(airband_hip_handle*, float*, float*, char*, airband_hip_channel_stats*);
 };
 static HipApi g_hip;
-static std::vector<airband_hip_channel_stats> g_hip_stats; /* last batch's statistics mirror, device-major */
 
-static void* demodulate_hip(void* params) {
-    demod_params_t* dp = (demod_params_t*)params;
-    const int n = dp->device_end - dp->device_start;
-    airband_hip_config cfg;
-    memset(&cfg, 0, sizeof(cfg));
-    cfg.abi_version = AIRBAND_HIP_ABI_VERSION;
-    cfg.fft_size_log = (int32_t)fft_size_log;
-    cfg.wave_rate = WAVE_RATE;
-    cfg.fm_demod = g_fm_demod_algo ? AIRBAND_FM_QUADRI_DEMOD : AIRBAND_FM_FAST_ATAN2;
-    cfg.hip_device = 0;
-    cfg.device_count = n;
-    cfg.devices = g_dev_cfg.data() + dp->device_start;
-    airband_hip_handle* h = NULL;
-    int rc = g_hip.prepare(&cfg, &h);
-    if (rc != 0) { /* same reaction as to gpu_fft_prepare() failures, src/rtl_airband.cpp:297-310 */
-        fprintf(stderr, "demodulate_hip: airband_hip_prepare failed (%d): %s\n", rc, g_hip.last_error(NULL));
-        do_exit = 1;
-        return NULL;
-    }
-    airband_hip_geometry g;
-    g_hip.get_geometry(h, &g);
-    std::vector<float> wave((size_t)g.total_channels * g.wave_batch), iq((size_t)g.total_channels * g.wave_batch * 2);
-    std::vector<char> axc(g.total_channels);
-    g_hip_stats.assign(g.total_channels, airband_hip_channel_stats());
-    while (!do_exit) {
-        /* hand over what the rx side appended (circbuffer_append); same cursor discipline as src/rtl_airband.cpp:370-375,:669 */
-        for (int i = 0; i < n; i++) {
-            input_t* in = devices[dp->device_start + i].input;
-            pthread_mutex_lock(&in->buffer_lock);
-            const size_t bufe = in->bufe;
-            pthread_mutex_unlock(&in->buffer_lock);
-            while (in->bufs != bufe) {
-                const size_t run = (bufe > in->bufs ? bufe : in->buf_size) - in->bufs;
-                const int64_t took = g_hip.submit(h, i, in->buffer + in->bufs, run);
-                if (took <= 0) break;
-                in->bufs = (in->bufs + (size_t)took) % in->buf_size;
-            }
-        }
-        bool busy = false;
-        for (int i = 0; i < n; i++) busy |= devices[dp->device_start + i].waveavail != 0;
-        if (busy) { /* the consumer has not drained the previous batch yet: do not overwrite it */
-            sched_yield();
-            continue;
-        }
-        rc = g_hip.process(h);
-        if (rc == AIRBAND_HIP_EAGAIN) {
-            SLEEP(1);
-            continue;
-        }
-        if (rc < 0) {
-            fprintf(stderr, "demodulate_hip: %s\n", g_hip.last_error(h));
-            do_exit = 1;
-            break;
-        }
-        g_hip.collect(h, wave.data(), iq.data(), axc.data(), g_hip_stats.data());
-        size_t k = 0;
-        for (int i = 0; i < n; i++) { /* publish what the per-channel loop publishes (src/rtl_airband.cpp:549-619,:645-655) */
-            device_t* dev = devices + dp->device_start + i;
-            for (int j = 0; j < dev->channel_count; j++, k++) {
-                channel_t* c = dev->channels + j;
-                memcpy(c->waveout, &wave[k * g.wave_batch], sizeof(float) * g.wave_batch);
-                if (c->has_iq_outputs) memcpy(c->iq_out, &iq[k * g.wave_batch * 2], sizeof(float) * 2 * g.wave_batch);
-                c->axcindicate = (status)axc[k];
-                c->freqlist->active_counter = g_hip_stats[k].active_counter;
-            }
-            dev->waveavail = 1;
-        }
-        dp->mp3_signal->send();
-    }
-    g_hip.release(h);
-    return NULL;
+extern "C" {
+int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out) { return g_hip.prepare(cfg, out); }
+void airband_hip_release(airband_hip_handle* h) { g_hip.release(h); }
+int airband_hip_get_geometry(const airband_hip_handle* h, airband_hip_geometry* g) { return g_hip.get_geometry(h, g); }
+const char* airband_hip_last_error(const airband_hip_handle* h) { return g_hip.last_error(h); }
+int64_t airband_hip_submit(airband_hip_handle* h, int32_t dev, const void* iq, size_t n) { return g_hip.submit(h, dev, iq, n); }
+int airband_hip_process(airband_hip_handle* h) { return g_hip.process(h); }
+int airband_hip_collect(airband_hip_handle* h, float* w, float* q, char* a, airband_hip_channel_stats* st) { return g_hip.collect(h, w, q, a, st); }
 }
 
-/* statistics as the stats file would see them with the HIP backend (mirror of Squelch getters, src/output.cpp:617-761) */
+/* statistics exactly as the stats file / TUI would read them with the HIP backend: through the reference's own Squelch getters
+ * (src/output.cpp:617-761), which the shim feeds through the patch's Squelch::mirror() */
 int refh_hip_channel_stats(int d, int j, airband_hip_channel_stats* out) {
-    size_t k = 0;
-    for (int i = 0; i < d; i++) k += devices[i].channel_count;
-    if (k + j >= g_hip_stats.size()) return -1;
-    *out = g_hip_stats[k + j];
+    if (d < 0 || d >= device_count || j < 0 || j >= devices[d].channel_count) return -1;
+    freq_t* f = devices[d].channels[j].freqlist;
+    memset(out, 0, sizeof(*out));
+    out->noise_level = f->squelch.noise_level();
+    out->signal_level = f->squelch.signal_level();
+    out->squelch_level = f->squelch.squelch_level();
+    out->agcavgfast = f->agcavgfast;
+    out->open_count = f->squelch.open_count();
+    out->flappy_count = f->squelch.flappy_count();
+    out->ctcss_count = f->squelch.ctcss_count();
+    out->no_ctcss_count = f->squelch.no_ctcss_count();
+    out->active_counter = f->active_counter;
+    out->bin = (int32_t)devices[d].bins[j];
     return 0;
 }
 
-/* Starts ONE demodulate_hip thread over all devices (instead of demodulate()). */
+/* Starts ONE demodulate_hip() thread (integration/demod_hip.cpp) over all devices, instead of demodulate(). */
 int refh_start_hip(const char* lib_path) {
     g_hip.dl = dlopen(lib_path, RTLD_NOW | RTLD_LOCAL);
     if (!g_hip.dl) {
@@ -367,6 +319,10 @@ int refh_start_hip(const char* lib_path) {
     g_threads_running = 1;
     return 0;
 }
+#else
+int refh_hip_channel_stats(int, int, airband_hip_channel_stats*) { return -1; }
+int refh_start_hip(const char*) { return -3; } /* only the *_patched builds carry the HIP backend */
+#endif /* REFH_PATCHED */
 
 /* n_threads demodulate() instances over contiguous device shards: the reference's own
  * multiple_demod_threads model (src/rtl_airband.cpp:1052-1086,1110-1112), 1 = its default. */

@@ -30,6 +30,11 @@ class Setting {
     int getLength() const { std::abort(); }
     Type getType() const { std::abort(); }
     const char* getName() const { std::abort(); }
+    const char* c_str() const { std::abort(); }
+    const char* getPath() const { std::abort(); }
+    bool isNumber() const { std::abort(); }
+    bool isRoot() const { std::abort(); }
+    unsigned int getSourceLine() const { std::abort(); }
     Setting& operator[](const char*) const { std::abort(); }
     Setting& operator[](const std::string&) const { std::abort(); }
     Setting& operator[](int) const { std::abort(); }
