@@ -104,7 +104,7 @@ struct airband_hip_handle {
     int ct_stride = 0;
     /* matrix-core channelizer */
     bool use_dft = false;
-    DevBuf<int> d_dev_bset;
+    DevBuf<int> d_item_dev, d_item_group, d_item_bset;
     DevBuf<int8_t> d_bfrag;
     DevBuf<double> d_bcorr;
 
@@ -168,7 +168,7 @@ void destroy(airband_hip_handle* h) {
     h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release(); h->d_ct_af.release(); h->d_ct_mask.release();
     h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
     h->d_tmp_wavein.release(); h->d_tmp_iqin.release(); h->d_tmp_trace.release(); h->d_spectrum.release();
-    h->d_dev_bset.release(); h->d_bfrag.release(); h->d_bcorr.release();
+    h->d_item_dev.release(); h->d_item_group.release(); h->d_item_bset.release(); h->d_bfrag.release(); h->d_bcorr.release();
     h->d_stage.release();
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     h->d_mix_chan.release(); h->d_mix_first.release(); h->d_mix_ml.release(); h->d_mix_mr.release();
@@ -534,7 +534,9 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
         if (p.n_bsets > 4096) {
             h->use_dft = false; /* table would not stay cache resident; fall back */
         } else {
-            PREP_TRY(upload(h->d_dev_bset, p.dev_bset), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(upload(h->d_item_dev, p.item_dev), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(upload(h->d_item_group, p.item_group), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(upload(h->d_item_bset, p.item_bset), AIRBAND_HIP_ENOMEM);
             PREP_TRY(upload(h->d_bfrag, p.bfrag), AIRBAND_HIP_ENOMEM);
             PREP_TRY(upload(h->d_bcorr, p.bcorr), AIRBAND_HIP_ENOMEM);
         }
@@ -652,7 +654,9 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         a.dev = h->d_dev.p;
         a.cc = h->d_cc.p;
         a.ext_to_slot = h->d_ext_to_slot.p;
-        a.dev_bset = h->d_dev_bset.p;
+        a.item_dev = h->d_item_dev.p;
+        a.item_group = h->d_item_group.p;
+        a.item_bset = h->d_item_bset.p;
         a.bfrag = h->d_bfrag.p;
         a.corr = h->d_bcorr.p;
         a.unscale = p.b_unscale;
@@ -660,18 +664,19 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         a.mag = h->d_mag.p;
         a.iq_bins = h->d_iq.p;
         a.n_dev = p.n_dev;
-        a.n_dev_pad = p.n_dev;
+        a.n_items = (int)p.item_dev.size();
+        a.fft_size = p.fft_size;
         a.hop_bytes = (int)h->hop_bytes;
-        a.lds_per_buf = dft_lds_per_buf((int)h->hop_bytes);
-        a.nbuf = dft_nbuf((int)h->hop_bytes);
-        a.sub = a.nbuf == 3 ? 1 : dft_sub_tiles((int)h->hop_bytes);
+        a.lds_per_buf = dft_lds_per_buf((int)h->hop_bytes, p.fft_size);
+        a.nbuf = dft_nbuf((int)h->hop_bytes, p.fft_size);
+        a.sub = dft_sub((int)h->hop_bytes, p.fft_size);
         a.row0 = h->row0_front;
         a.ring_rows = h->R;
         a.first_row = first ? 0 : AB_AGC_EXTRA;
         a.n_hops = first ? h->B + AB_AGC_EXTRA : h->B;
         /* enough waves to fill 256 CUs x 8 waves even with few dongles: split each dongle's tiles */
         const int steps = ((a.n_hops + 15) / 16 + 1 + a.sub - 1) / a.sub;
-        int splits = (8192 + a.n_dev_pad - 1) / a.n_dev_pad;
+        int splits = (8192 + a.n_items - 1) / a.n_items;
         if (splits > steps / 4) splits = steps / 4;
         if (splits < 1) splits = 1;
         a.splits = splits;

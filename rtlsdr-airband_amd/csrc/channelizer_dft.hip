@@ -14,8 +14,9 @@
  * LUT is restored with a per-column constant.  Result = the exact DFT with coefficients rounded at 2^-24 of full
  * scale -- the same class of error as a float FFT (~1e-7 relative), no accumulation round-off at all.
  *
- * Only u8 takes this path (s8's LUT has an uninitialised entry, s16/f32 are not bytes); everything else -- other
- * FFT sizes, > 8 channels per dongle, odd hop sizes -- uses channelizer_fft.hip.
+ * Only u8 takes this path (s8's LUT has an uninitialised entry, s16/f32 are not bytes), at fft_size 256 or 512; dongles with
+ * more than 8 channels are processed in groups of 8 (one wavefront per group); everything else -- other FFT sizes, odd hop
+ * sizes -- uses channelizer_fft.hip.
  *
  * Mapping (wave64, CDNA4): one wavefront owns one dongle and a range of 16-hop tiles.
  *   A (16 hops x 64 bytes per MFMA): lane l reads the 16 consecutive stream bytes at hop (l&15), k-chunk (l>>4)
@@ -44,11 +45,13 @@ constexpr __host__ __device__ int c_sub_tiles(int hop_bytes) {
     const int sub = 640 / hop_bytes;
     return sub < 1 ? 1 : (sub > 4 ? 4 : sub);
 }
-constexpr __host__ __device__ int c_lds_for(int hop_bytes, int sub) { return ((TILE_HOPS * sub - 1) * hop_bytes + 1024 + 1023) / 1024 * 1024; }
+constexpr __host__ __device__ int c_lds_for(int hop_bytes, int sub, int win_bytes) { return ((TILE_HOPS * sub - 1) * hop_bytes + win_bytes + 1023) / 1024 * 1024; }
 /* three small buffers (two steps in flight) when eight waves of them fit a CU's 160 KiB, else two larger ones */
-constexpr __host__ __device__ int c_nbuf(int hop_bytes) { return 3 * c_lds_for(hop_bytes, 1) * 8 <= 160 * 1024 ? 3 : 2; }
-constexpr __host__ __device__ int c_lds_per_buf(int hop_bytes) { return c_nbuf(hop_bytes) == 3 ? c_lds_for(hop_bytes, 1) : c_lds_for(hop_bytes, c_sub_tiles(hop_bytes)); }
-constexpr __host__ __device__ int c_sub(int hop_bytes) { return c_nbuf(hop_bytes) == 3 ? 1 : c_sub_tiles(hop_bytes); }
+constexpr __host__ __device__ int c_nbuf(int hop_bytes, int win_bytes = 1024) { return 3 * c_lds_for(hop_bytes, 1, win_bytes) * 8 <= 160 * 1024 ? 3 : 2; }
+constexpr __host__ __device__ int c_lds_per_buf(int hop_bytes, int win_bytes = 1024) {
+    return c_nbuf(hop_bytes, win_bytes) == 3 ? c_lds_for(hop_bytes, 1, win_bytes) : c_lds_for(hop_bytes, c_sub_tiles(hop_bytes), win_bytes);
+}
+constexpr __host__ __device__ int c_sub(int hop_bytes, int win_bytes = 1024) { return c_nbuf(hop_bytes, win_bytes) == 3 ? 1 : c_sub_tiles(hop_bytes); }
 
 /* EDGE_HI_ZERO: the most significant coefficient digit is zero for every k-step in which the window is below 2^-8
  * (steps 0,1,14,15 of the 7-term cosine window at N = 512 -- checked on the host, see build_dft_tables): those four
@@ -61,7 +64,9 @@ template <int FFT_N, bool EDGE_HI_ZERO, int HOPB>
 __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     constexpr int WIN_BYTES = 2 * FFT_N;          /* bytes per window (u8/s8 I/Q)      */
     constexpr int KSTEPS = WIN_BYTES / 64;        /* MFMA k-steps per window           */
-    static_assert(KSTEPS == 16, "B-fragment register budget is sized for fft_size 512");
+    static_assert(KSTEPS == 16 || KSTEPS == 8, "B fragments (3 digits x KSTEPS x 4 VGPRs) must fit beside everything else: fft_size 256 or 512");
+    static_assert(HOPB == 0 || FFT_N == 512, "the hop-specialised variants are built for fft_size 512");
+    constexpr int EDGE = KSTEPS / 8; /* k-steps at either end of the window whose most significant coefficient digit may be all zero */
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
 
     /* one wavefront per workgroup: waves share nothing, and a 64-thread block lets the LDS budget (two staging
@@ -71,11 +76,14 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
      * dongles write neighbouring slots of the same 128-byte lines, so they are given to the SAME XCD and meet in
      * one L2: inside every group of 128 dongles, workgroup i*8 + x takes dongle x*16 + i. */
     const int wave_global = blockIdx.x;
-    const int d_lin = wave_global % a.n_dev_pad;
-    const int g128 = d_lin & ~127, in128 = d_lin & 127;
-    const int d = ((a.n_dev_pad - g128) >= 128) ? g128 + (in128 & 7) * 16 + (in128 >> 3) : d_lin;
-    const int split = wave_global / a.n_dev_pad;
-    if (d >= a.n_dev || split >= a.splits) return;
+    /* a work item = (dongle, group of 8 channels): dongles with more than 8 channels appear once per group, side by side, so the
+     * groups of a dongle stream the same bytes at the same time through the same L2 */
+    const int i_lin = wave_global % a.n_items;
+    const int g128 = i_lin & ~127, in128 = i_lin & 127;
+    const int item = ((a.n_items - g128) >= 128) ? g128 + (in128 & 7) * 16 + (in128 >> 3) : i_lin;
+    const int split = wave_global / a.n_items;
+    if (split >= a.splits) return;
+    const int d = a.item_dev[item], ch0 = a.item_group[item] * 8;
     const int hop_bytes = HOPB ? HOPB : a.hop_bytes;
     /* a staging step feeds `sub` consecutive 16-hop MFMA tiles: ~10 KiB of stream per step whatever the hop size, so
      * the bytes a wave keeps in flight (one step ahead) do not shrink when the hop does */
@@ -102,19 +110,19 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     const long span_end = (long)(a.n_hops - 1) * hop_bytes + WIN_BYTES; /* bytes of the batch span that may be read */
 
     /* ---- B fragments: 3 digits x 16 k-steps, resident for the whole wave ---------------------------------- */
-    const int bset = a.dev_bset[d];
+    const int bset = a.item_bset[item];
     const v4i* btab = reinterpret_cast<const v4i*>(a.bfrag) + (long)bset * 3 * KSTEPS * 64 + lane;
     v4i b0[KSTEPS], b1[KSTEPS], b2[KSTEPS];
 #pragma unroll
     for (int s = 0; s < KSTEPS; s++) {
         b0[s] = btab[(0 * KSTEPS + s) * 64];
         b1[s] = btab[(1 * KSTEPS + s) * 64];
-        if (!(EDGE_HI_ZERO && (s < 2 || s >= KSTEPS - 2))) b2[s] = btab[(2 * KSTEPS + s) * 64];
+        if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) b2[s] = btab[(2 * KSTEPS + s) * 64];
     }
     const int col = lane & 15;
     const double corr = a.corr[bset * 16 + col];
     const double unscale = a.unscale;
-    const int ch = col >> 1;
+    const int ch = ch0 + (col >> 1);
     const DevConst dev = a.dev[d];
     const bool ch_valid = ch < dev.n_ch;
     const int slot = a.ext_to_slot[dev.chan_base + (ch_valid ? ch : 0)];
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
             x.x ^= 0x80808080; x.y ^= 0x80808080; x.z ^= 0x80808080; x.w ^= 0x80808080; /* u8 -> b - 128 as int8 */
             acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b0[s], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b1[s], acc1, 0, 0, 0);
-            if (!(EDGE_HI_ZERO && (s < 2 || s >= KSTEPS - 2))) acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b2[s], acc2, 0, 0, 0);
+            if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b2[s], acc2, 0, 0, 0);
             if (s & 1) __builtin_amdgcn_sched_barrier(0); /* keep the prefetch distance the source order spells out */
         }
         /* recombine the digits exactly, restore the -127.5 offset of the reference's LUT, undo the fixed-point scale */
@@ -269,30 +277,32 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
 }  // namespace
 
 bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch) {
-    return fft_size == 512 && sfmt == AIRBAND_SFMT_U8 && max_ch <= 8 && (hop_bytes % 16) == 0 && hop_bytes <= 640 && hop_bytes >= 64;
+    (void)max_ch; /* any channel count: dongles with more than 8 channels are split into groups of 8 */
+    return (fft_size == 512 || fft_size == 256) && sfmt == AIRBAND_SFMT_U8 && (hop_bytes % 16) == 0 && hop_bytes <= 640 && hop_bytes >= 64;
 }
 
-int dft_sub_tiles(int hop_bytes) { return c_sub_tiles(hop_bytes); }
-int dft_nbuf(int hop_bytes) { return c_nbuf(hop_bytes); }
-int dft_lds_per_buf(int hop_bytes) { return c_lds_per_buf(hop_bytes); }
+int dft_sub(int hop_bytes, int fft_size) { return c_sub(hop_bytes, 2 * fft_size); }
+int dft_nbuf(int hop_bytes, int fft_size) { return c_nbuf(hop_bytes, 2 * fft_size); }
+int dft_lds_per_buf(int hop_bytes, int fft_size) { return c_lds_per_buf(hop_bytes, 2 * fft_size); }
 
-template <int HOPB>
+template <int FFT_N, int HOPB>
 static void launch_hop(const DftArgs& a, hipStream_t stream) {
-    const long waves = (long)a.n_dev_pad * a.splits;
+    const long waves = (long)a.n_items * a.splits;
     const size_t lds = (size_t)a.nbuf * a.lds_per_buf;
     if (a.edge_hi_zero)
-        hipLaunchKernelGGL((channelizer_dft_kernel<512, true, HOPB>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, true, HOPB>), dim3((unsigned)waves), dim3(64), lds, stream, a);
     else
-        hipLaunchKernelGGL((channelizer_dft_kernel<512, false, HOPB>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, false, HOPB>), dim3((unsigned)waves), dim3(64), lds, stream, a);
 }
 
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream) {
+    if (a.fft_size == 256) return launch_hop<256, 0>(a, stream);
 #ifndef AB_DFT_GENERIC_ONLY
     /* the host derives nbuf / sub / lds_per_buf with the same functions the specialised kernels fold in at compile time */
-    if (a.hop_bytes == 320 && a.nbuf == c_nbuf(320) && a.sub == c_sub(320) && a.lds_per_buf == c_lds_per_buf(320)) return launch_hop<320>(a, stream);
-    if (a.hop_bytes == 640 && a.nbuf == c_nbuf(640) && a.sub == c_sub(640) && a.lds_per_buf == c_lds_per_buf(640)) return launch_hop<640>(a, stream);
+    if (a.hop_bytes == 320 && a.nbuf == c_nbuf(320) && a.sub == c_sub(320) && a.lds_per_buf == c_lds_per_buf(320)) return launch_hop<512, 320>(a, stream);
+    if (a.hop_bytes == 640 && a.nbuf == c_nbuf(640) && a.sub == c_sub(640) && a.lds_per_buf == c_lds_per_buf(640)) return launch_hop<512, 640>(a, stream);
 #endif
-    launch_hop<0>(a, stream);
+    launch_hop<512, 0>(a, stream);
 }
 
 }  // namespace airband

@@ -294,64 +294,71 @@ void build_dft_tables(Plan& p) {
     const int N = p.fft_size, K = 2 * N, KS = K / 64;
     const double S = 8355000.0; /* max |coefficient| < 1  ->  |value| <= 127*65536 + 127*256 + 127 */
     p.b_unscale = 1.0 / (S * 127.5);
-    p.dev_bset.assign(p.n_dev, 0);
+    p.item_dev.clear();
+    p.item_group.clear();
+    p.item_bset.clear();
     p.bfrag.clear();
     p.bcorr.clear();
     std::vector<std::vector<int>> keys;
     for (int d = 0; d < p.n_dev; d++) {
-        std::vector<int> key;
-        for (int j = 0; j < p.dev[d].n_ch; j++) key.push_back(p.cc[p.chan_base[d] + j].base_bin);
-        int found = -1;
-        for (size_t i = 0; i < keys.size(); i++)
-            if (keys[i] == key) {
-                found = (int)i;
-                break;
-            }
-        if (found < 0) {
-            found = (int)keys.size();
-            keys.push_back(key);
-            std::vector<int> q((size_t)K * 16, 0);
-            for (int c = 0; c < (int)key.size() && c < 8; c++) {
-                for (int n = 0; n < N; n++) {
-                    /* the phase is reduced exactly in integers before it meets a double */
-                    const double th = 2.0 * M_PI * (double)(((long long)key[c] * n) % N) / (double)N;
-                    const double wc = (double)p.window[n] * std::cos(th), ws = (double)p.window[n] * std::sin(th);
-                    q[(size_t)(2 * n) * 16 + 2 * c] = (int)std::llround(wc * S);       /* I -> re */
-                    q[(size_t)(2 * n + 1) * 16 + 2 * c] = (int)std::llround(ws * S);   /* Q -> re */
-                    q[(size_t)(2 * n) * 16 + 2 * c + 1] = (int)std::llround(-ws * S);  /* I -> im */
-                    q[(size_t)(2 * n + 1) * 16 + 2 * c + 1] = (int)std::llround(wc * S); /* Q -> im */
-                }
-            }
-            const size_t base = p.bfrag.size();
-            p.bfrag.resize(base + (size_t)3 * KS * 64 * 16, 0);
-            for (int col = 0; col < 16; col++) {
-                double sum = 0.0;
-                for (int k = 0; k < K; k++) {
-                    const int v = q[(size_t)k * 16 + col];
-                    sum += v;
-                    int dgt[3];
-                    int rest = v;
-                    for (int t = 0; t < 3; t++) {
-                        int lo = ((rest + 128) & 255) - 128; /* balanced digit */
-                        dgt[t] = lo;
-                        rest = (rest - lo) / 256;
+        for (int g = 0; g * 8 < p.dev[d].n_ch; g++) { /* one work item per group of 8 channels */
+            std::vector<int> key;
+            for (int j = g * 8; j < p.dev[d].n_ch && j < g * 8 + 8; j++) key.push_back(p.cc[p.chan_base[d] + j].base_bin);
+            int found = -1;
+            if (!keys.empty() && keys.back() == key) found = (int)keys.size() - 1; /* fleets of identical dongles: the common case */
+            for (size_t i = 0; found < 0 && i < keys.size(); i++)
+                if (keys[i] == key) found = (int)i;
+            if (found < 0) {
+                found = (int)keys.size();
+                keys.push_back(key);
+                std::vector<int> q((size_t)K * 16, 0);
+                for (int c = 0; c < (int)key.size(); c++) {
+                    for (int n = 0; n < N; n++) {
+                        /* the phase is reduced exactly in integers before it meets a double */
+                        const double th = 2.0 * M_PI * (double)(((long long)key[c] * n) % N) / (double)N;
+                        const double wc = (double)p.window[n] * std::cos(th), ws = (double)p.window[n] * std::sin(th);
+                        q[(size_t)(2 * n) * 16 + 2 * c] = (int)std::llround(wc * S);       /* I -> re */
+                        q[(size_t)(2 * n + 1) * 16 + 2 * c] = (int)std::llround(ws * S);   /* Q -> re */
+                        q[(size_t)(2 * n) * 16 + 2 * c + 1] = (int)std::llround(-ws * S);  /* I -> im */
+                        q[(size_t)(2 * n + 1) * 16 + 2 * c + 1] = (int)std::llround(wc * S); /* Q -> im */
                     }
-                    const int s = k / 64, g = (k % 64) / 16, jj = k % 16;
-                    const int lane = g * 16 + col;
-                    for (int t = 0; t < 3; t++) p.bfrag[base + (((size_t)t * KS + s) * 64 + lane) * 16 + jj] = (int8_t)dgt[t];
                 }
-                p.bcorr.push_back(0.5 * sum); /* (b - 127.5) = (b - 128) + 0.5 */
+                const size_t base = p.bfrag.size();
+                p.bfrag.resize(base + (size_t)3 * KS * 64 * 16, 0);
+                for (int col = 0; col < 16; col++) {
+                    double sum = 0.0;
+                    for (int k = 0; k < K; k++) {
+                        const int v = q[(size_t)k * 16 + col];
+                        sum += v;
+                        int dgt[3];
+                        int rest = v;
+                        for (int t = 0; t < 3; t++) {
+                            int lo = ((rest + 128) & 255) - 128; /* balanced digit */
+                            dgt[t] = lo;
+                            rest = (rest - lo) / 256;
+                        }
+                        const int s = k / 64, gg = (k % 64) / 16, jj = k % 16;
+                        const int lane = gg * 16 + col;
+                        for (int t = 0; t < 3; t++) p.bfrag[base + (((size_t)t * KS + s) * 64 + lane) * 16 + jj] = (int8_t)dgt[t];
+                    }
+                    p.bcorr.push_back(0.5 * sum); /* (b - 127.5) = (b - 128) + 0.5 */
+                }
             }
+            p.item_dev.push_back(d);
+            p.item_group.push_back(g);
+            p.item_bset.push_back(found);
         }
-        p.dev_bset[d] = found;
     }
     p.n_bsets = (int)keys.size();
     /* the window is below 2^-8 of full scale in the outer k-steps, so the top digit vanishes there: verify, don't assume */
     p.b_edge_hi_zero = true;
+    const int edge = KS / 8;
     for (int b = 0; b < p.n_bsets && p.b_edge_hi_zero; b++)
-        for (int s : {0, 1, KS - 2, KS - 1})
+        for (int s = 0; s < KS; s++) {
+            if (s >= edge && s < KS - edge) continue;
             for (int i = 0; i < 64 * 16; i++)
                 if (p.bfrag[(size_t)b * 3 * KS * 64 * 16 + ((size_t)2 * KS + s) * 64 * 16 + i] != 0) p.b_edge_hi_zero = false;
+        }
 }
 
 void channel_constants(const Plan& p, int i, double* v) {

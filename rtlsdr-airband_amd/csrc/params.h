@@ -30,11 +30,11 @@ struct Plan {
     std::vector<float> sin_lut, cos_lut; /* 257 entries each (src/util.cpp:105-110) */
     float lev_u8[256], lev_s8[256];    /* src/rtl_airband.cpp:316-324 */
     /* matrix-core channelizer tables (channelizer_dft.hip); empty unless the configuration qualifies */
-    std::vector<int> dev_bset;         /* [n_dev] coefficient-table index */
-    std::vector<int8_t> bfrag;         /* [n_bsets][3][16][64][16] */
+    std::vector<int> item_dev, item_group, item_bset; /* channelizer work items: (dongle, group of 8 channels, coefficient-table index) */
+    std::vector<int8_t> bfrag;         /* [n_bsets][3][fft_size / 32][64][16] */
     std::vector<double> bcorr;         /* [n_bsets][16] */
     double b_unscale = 0.0;
-    bool b_edge_hi_zero = false;       /* digit 2 is zero in k-steps 0,1,14,15 of every table */
+    bool b_edge_hi_zero = false;       /* digit 2 is zero in the outer k-steps (fft_size / 256 at either end) of every table */
     int n_bsets = 0;
     int64_t hop_bytes_max = 0;
     bool uniform_hop = true;           /* every dongle has the same sfmt / hop (needed by the batched launch) */

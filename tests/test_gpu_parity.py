@@ -434,7 +434,7 @@ def test_ragged_shapes_and_empty_inputs(pkg, built):
     orc = pyoracle.Oracle(devices, wave_rate=wave_rate)
     ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
     with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=pkg.capi.FLAG_TRACE_SQUELCH) as hip:
-        assert hip.channelizer_name() == "fft_wave64"  # more than 8 channels on a dongle: not the matrix-core path
+        assert hip.channelizer_name() == "dft_mfma_i8"  # the 64-channel dongle runs as eight groups of 8 on the matrix-core path
         assert hip.total_channels == 73
         with pytest.raises(pkg.AirbandError) as e:
             hip.collect()
@@ -480,8 +480,8 @@ def _convert(iq_u8, sfmt, capi, s16_gain=200.0):
     ("SFMT_U8", 8, 2_560_000, 16000), ("SFMT_U8", 10, 2_560_000, 8000), ("SFMT_U8", 11, 2_560_000, 16000), ("SFMT_S16", 13, 2_560_000, 8000),
     ("SFMT_U8", 9, 2_400_000, 16000), ("SFMT_U8", 9, 1_024_000, 8000)])
 def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sample_rate, wave_rate):
-    """Everything the matrix-core path does not take (s8/s16/f32, fft sizes 256..8192, hops that are not a multiple of 16 bytes)
-    runs on the wavefront-FFT channelizer: same parity bars."""
+    """Sample formats s8/s16/f32, fft sizes 256..8192, sample rates whose hop is not a multiple of 16 bytes: the matrix-core path
+    takes u8 at fft 256 / 512, everything else runs on the wavefront-FFT channelizer -- same parity bars either way."""
     capi = pkg.capi
     sfmt = getattr(capi, sfmt_name)
     mixed = wave_rate == 16000
@@ -513,7 +513,7 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
     assert all(r["n_batches"] == n_batches for r in ref)
     opened = 0
     with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=capi.FLAG_TRACE_SQUELCH) as hip:
-        expect_dft = sfmt == capi.SFMT_U8 and fft_log == 9 and (2 * hop) % 16 == 0 and 64 <= 2 * hop <= 640
+        expect_dft = sfmt == capi.SFMT_U8 and fft_log in (8, 9) and (2 * hop) % 16 == 0 and 64 <= 2 * hop <= 640
         assert hip.channelizer_name() == ("dft_mfma_i8" if expect_dft else "fft_wave64")
         pos = [0] * n_dev
         for b in range(n_batches):
