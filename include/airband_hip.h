@@ -181,12 +181,14 @@ const char* airband_hip_last_error(const airband_hip_handle* h);
 
 /* ---- data path ------------------------------------------------------------------------------ */
 
-/* Host-ring path.  Appends `nbytes` of raw interleaved I/Q of device `dev` to the library's
- * staging ring (pinned host -> HBM, asynchronous on the handle's stream).
- * Replaces: the consumer side of input->buffer (reference: src/rtl_airband.cpp:370-375,:669); the
- * reference-side shim calls it with the span [bufs, bufe) the rx thread produced
- * (circbuffer_append, src/input-helpers.cpp:37-63) and then advances bufs.
- * Returns number of bytes accepted (may be < nbytes when the staging ring is full) or <0. */
+/* Host-ring path.  Appends `nbytes` of raw interleaved I/Q of device `dev` to the library's pinned staging ring of that device
+ * (one CPU copy; the batch later leaves the ring by DMA, asynchronously, on a copy stream).
+ * Replaces: the consumer side of input->buffer (reference: src/rtl_airband.cpp:370-375,:669); the reference-side shim calls it with
+ * the span [bufs, bufe) the rx thread produced (circbuffer_append, src/input-helpers.cpp:37-63) and then advances bufs.
+ * Returns the number of bytes accepted -- fewer than nbytes when the ring is full (it holds the first batch with its lead-in plus
+ * three more batches, about the reference's own 2 560 000-byte ring) -- or <0.
+ * Thread-compatibility: calls for DIFFERENT devices may run concurrently (one rx / feeder thread per dongle, like the reference's
+ * input threads); calls for one device, and airband_hip_process(), must not overlap each other. */
 int64_t airband_hip_submit(airband_hip_handle* h, int32_t dev, const void* iq, size_t nbytes);
 
 /* Runs ONE batch (WAVE_BATCH output samples for every channel of every device) if every device has

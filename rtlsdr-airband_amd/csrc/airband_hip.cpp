@@ -7,8 +7,11 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -108,11 +111,21 @@ struct airband_hip_handle {
     DevBuf<int8_t> d_bfrag;
     DevBuf<double> d_bcorr;
 
-    /* host-ring path */
-    std::vector<std::vector<uint8_t>> pending; /* per dongle: stream bytes not yet consumed */
-    DevBuf<uint8_t> d_stage;
-    uint8_t* h_stage = nullptr;                /* pinned */
+    /* host-ring path: one PINNED circular buffer per dongle (row d of h_ring, ring_cap bytes).  submit() copies the caller's bytes
+     * straight into it -- the only CPU copy on the way -- and may be called for DIFFERENT dongles from several threads at once;
+     * process() ships a batch with (at most two, where the span wraps) strided DMA transfers on a copy stream into one of two
+     * device staging buffers while the kernels of the previous batch still read the other. */
+    uint8_t* h_ring = nullptr;
+    int64_t ring_cap = 0;                                  /* bytes per dongle */
+    std::unique_ptr<std::atomic<uint64_t>[]> ring_wr;      /* per dongle: stream bytes accepted so far */
+    uint64_t ring_rd = 0;                                  /* stream position of the next batch (common to all dongles: they advance in lockstep) */
+    std::atomic<uint64_t> ring_free{0};                    /* stream position up to which the ring may be overwritten (lags ring_rd by the batch in flight) */
+    DevBuf<uint8_t> d_stage2[2];
     int64_t stage_stride = 0;
+    hipStream_t h2d = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_stage_read[2] = {nullptr, nullptr};
+    uint64_t host_batches = 0;
+    std::mutex host_init_lock;
 
     /* mixers */
     std::vector<int> mix_pos;       /* connection index (order of airband_hip_set_mixers) -> position in the per-mixer grouped arrays */
@@ -169,8 +182,14 @@ void destroy(airband_hip_handle* h) {
     h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
     h->d_tmp_wavein.release(); h->d_tmp_iqin.release(); h->d_tmp_trace.release(); h->d_spectrum.release();
     h->d_item_dev.release(); h->d_item_group.release(); h->d_item_bset.release(); h->d_bfrag.release(); h->d_bcorr.release();
-    h->d_stage.release();
-    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h2d) (void)hipStreamSynchronize(h->h2d);
+    h->d_stage2[0].release(); h->d_stage2[1].release();
+    if (h->h_ring) (void)hipHostFree(h->h_ring);
+    for (auto& e : h->ev_h2d)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : h->ev_stage_read)
+        if (e) (void)hipEventDestroy(e);
+    if (h->h2d) (void)hipStreamDestroy(h->h2d);
     h->d_mix_chan.release(); h->d_mix_first.release(); h->d_mix_ml.release(); h->d_mix_mr.release();
     h->d_mix_left.release(); h->d_mix_right.release(); h->d_mix_stereo.release(); h->d_mix_signal.release();
     h->d_mix_run_first.release(); h->d_mix_run_mixer.release(); h->d_mix_first_run.release();
@@ -549,7 +568,8 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
             return AIRBAND_HIP_EBADSIZE;
         }
     }
-    h->pending.resize(p.n_dev);
+    h->ring_wr.reset(new std::atomic<uint64_t>[p.n_dev]);
+    for (int d = 0; d < p.n_dev; d++) h->ring_wr[d].store(0);
 #undef PREP_TRY
     *out = h;
     return AIRBAND_HIP_OK;
@@ -777,41 +797,85 @@ int airband_hip_flush(airband_hip_handle* h) {
     return run_back_half(h, h->stream);
 }
 
+/* first use of the host-ring path: pinned rings, device staging, copy stream */
+static int host_path_init(airband_hip_handle* h) {
+    std::lock_guard<std::mutex> guard(h->host_init_lock);
+    if (h->h_ring) return AIRBAND_HIP_OK;
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    /* bounded like the reference's ring (MIN_BUF_SIZE = 2 560 000 bytes ~ 4 batches, src/rtl_airband.h:64): the first batch with its
+     * lead-in, the batch in flight, one more being filled, and the look-ahead */
+    h->ring_cap = (h->first_batch_bytes + 3 * h->batch_bytes + h->lookahead_bytes + 4095) / 4096 * 4096;
+    h->stage_stride = (h->first_batch_bytes + h->lookahead_bytes + 255) / 256 * 256;
+    for (auto& b : h->d_stage2)
+        if (!b.p) HIP_TRY(h, b.alloc((size_t)h->stage_stride * h->plan.n_dev), AIRBAND_HIP_ENOMEM);
+    if (!h->h2d) HIP_TRY(h, hipStreamCreateWithFlags(&h->h2d, hipStreamNonBlocking), AIRBAND_HIP_ENODEV);
+    for (auto& e : h->ev_h2d)
+        if (!e) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
+    for (auto& e : h->ev_stage_read)
+        if (!e) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
+    uint8_t* ring = nullptr;
+    HIP_TRY(h, hipHostMalloc((void**)&ring, (size_t)h->ring_cap * h->plan.n_dev, hipHostMallocDefault), AIRBAND_HIP_ENOMEM);
+    h->h_ring = ring; /* published last: submit() / process() test this pointer without the lock */
+    return AIRBAND_HIP_OK;
+}
+
 int64_t airband_hip_submit(airband_hip_handle* h, int32_t dev, const void* iq, size_t nbytes) {
     if (!h || !iq) return fail(h, AIRBAND_HIP_EINVAL, "NULL argument");
     if (dev < 0 || dev >= h->plan.n_dev) return fail(h, AIRBAND_HIP_EINVAL, "device index out of range");
-    /* bounded like the reference's ring (MIN_BUF_SIZE = 2 560 000 bytes ~ 4 batches, src/rtl_airband.h:64): at most
-     * first batch + 4 batches may be queued */
-    const size_t cap = (size_t)(h->first_batch_bytes + 4 * h->batch_bytes + h->lookahead_bytes);
-    std::vector<uint8_t>& q = h->pending[dev];
+    if (!h->h_ring) { /* the first submit of a handle sets the path up (callers that submit from several threads start with one) */
+        const int rc = host_path_init(h);
+        if (rc != AIRBAND_HIP_OK) return rc;
+    }
+    const uint64_t wr = h->ring_wr[dev].load(std::memory_order_relaxed);
+    const uint64_t used = wr - h->ring_free.load(std::memory_order_acquire);
     size_t take = nbytes;
-    if (q.size() + take > cap) take = cap > q.size() ? cap - q.size() : 0;
-    q.insert(q.end(), (const uint8_t*)iq, (const uint8_t*)iq + take);
+    if (used + take > (uint64_t)h->ring_cap) take = (uint64_t)h->ring_cap > used ? (size_t)((uint64_t)h->ring_cap - used) : 0;
+    uint8_t* row = h->h_ring + (size_t)dev * h->ring_cap;
+    const size_t pos = (size_t)(wr % (uint64_t)h->ring_cap);
+    const size_t first = take < (size_t)h->ring_cap - pos ? take : (size_t)h->ring_cap - pos;
+    std::memcpy(row + pos, iq, first);
+    if (take > first) std::memcpy(row, (const uint8_t*)iq + first, take - first);
+    h->ring_wr[dev].store(wr + take, std::memory_order_release);
     return (int64_t)take;
 }
 
 int airband_hip_process(airband_hip_handle* h) {
     if (!h) return AIRBAND_HIP_EINVAL;
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    if (!h->h_ring) {
+        const int rc = host_path_init(h);
+        if (rc != AIRBAND_HIP_OK) return rc;
+    }
     const bool first = h->front_batches == 0;
     const int64_t consume = first ? h->first_batch_bytes : h->batch_bytes;
     const int64_t need = consume + h->lookahead_bytes; /* availability rule (src/rtl_airband.cpp:394-400) applied to a whole batch */
-    for (auto& q : h->pending)
-        if ((int64_t)q.size() < need) return AIRBAND_HIP_EAGAIN;
-    if (!h->d_stage.p) {
-        h->stage_stride = (h->first_batch_bytes + h->lookahead_bytes + 255) / 256 * 256;
-        HIP_TRY(h, h->d_stage.alloc((size_t)h->stage_stride * h->plan.n_dev), AIRBAND_HIP_ENOMEM);
-        HIP_TRY(h, hipHostMalloc((void**)&h->h_stage, (size_t)h->stage_stride * h->plan.n_dev, hipHostMallocDefault), AIRBAND_HIP_ENOMEM);
+    for (int d = 0; d < h->plan.n_dev; d++)
+        if ((int64_t)(h->ring_wr[d].load(std::memory_order_acquire) - h->ring_rd) < need) return AIRBAND_HIP_EAGAIN;
+    const int b = (int)(h->host_batches & 1);
+    /* the DMA of the previous batch has left the ring: its bytes (up to the look-ahead the next batch re-reads) may be overwritten */
+    if (h->host_batches > 0) {
+        HIP_TRY(h, hipEventSynchronize(h->ev_h2d[b ^ 1]), AIRBAND_HIP_ERUNTIME);
+        h->ring_free.store(h->ring_rd, std::memory_order_release);
     }
-    HIP_TRY(h, hipStreamSynchronize(h->stream), AIRBAND_HIP_ERUNTIME); /* previous batch may still read the staging buffer */
-    if (h->pipeline) HIP_TRY(h, hipStreamSynchronize(h->front), AIRBAND_HIP_ERUNTIME);
-    for (int d = 0; d < h->plan.n_dev; d++) {
-        std::vector<uint8_t>& q = h->pending[d];
-        std::memcpy(h->h_stage + (size_t)d * h->stage_stride, q.data(), (size_t)need);
-        q.erase(q.begin(), q.begin() + consume);
-    }
-    HIP_TRY(h, hipMemcpyAsync(h->d_stage.p, h->h_stage, (size_t)h->stage_stride * h->plan.n_dev, hipMemcpyHostToDevice, h->stream), AIRBAND_HIP_ERUNTIME);
-    return airband_hip_process_device(h, h->d_stage.p, (size_t)h->stage_stride, nullptr);
+    /* staging buffer b was last read by the kernels of batch (k - 2) */
+    if (h->host_batches >= 2) HIP_TRY(h, hipStreamWaitEvent(h->h2d, h->ev_stage_read[b], 0), AIRBAND_HIP_ERUNTIME);
+    const size_t pos = (size_t)(h->ring_rd % (uint64_t)h->ring_cap);
+    const size_t run = (size_t)need < (size_t)h->ring_cap - pos ? (size_t)need : (size_t)h->ring_cap - pos;
+    HIP_TRY(h, hipMemcpy2DAsync(h->d_stage2[b].p, (size_t)h->stage_stride, h->h_ring + pos, (size_t)h->ring_cap, run, (size_t)h->plan.n_dev, hipMemcpyHostToDevice, h->h2d),
+            AIRBAND_HIP_ERUNTIME);
+    if (run < (size_t)need) /* the span wraps around the end of the rings */
+        HIP_TRY(h, hipMemcpy2DAsync(h->d_stage2[b].p + run, (size_t)h->stage_stride, h->h_ring, (size_t)h->ring_cap, (size_t)need - run, (size_t)h->plan.n_dev,
+                                    hipMemcpyHostToDevice, h->h2d),
+                AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipEventRecord(h->ev_h2d[b], h->h2d), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_h2d[b], 0), AIRBAND_HIP_ERUNTIME);
+    if (h->pipeline) HIP_TRY(h, hipStreamWaitEvent(h->front, h->ev_h2d[b], 0), AIRBAND_HIP_ERUNTIME);
+    h->ring_rd += (uint64_t)consume;
+    h->host_batches++;
+    const int rc = airband_hip_process_device(h, h->d_stage2[b].p, (size_t)h->stage_stride, nullptr);
+    /* stage 1 of this batch (the only reader of the staging buffer) is enqueued: mark the point after which the buffer is free again */
+    (void)hipEventRecord(h->ev_stage_read[b], h->pipeline ? h->front : h->stream);
+    return rc;
 }
 
 int airband_hip_process_bins(airband_hip_handle* h, const float* wavein, const float* iq_in) {
