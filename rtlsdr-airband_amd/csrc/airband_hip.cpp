@@ -679,7 +679,8 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         a.item_bset = h->d_item_bset.p;
         a.bfrag = h->d_bfrag.p;
         a.corr = h->d_bcorr.p;
-        a.unscale = p.b_unscale;
+        a.unscale = p.dev[0].sfmt == AIRBAND_SFMT_S16 ? p.b_unscale * 127.5 : p.b_unscale;
+        a.sfmt = p.dev[0].sfmt;
         a.edge_hi_zero = p.b_edge_hi_zero ? 1 : 0;
         a.mag = h->d_mag.p;
         a.iq_bins = h->d_iq.p;
@@ -687,9 +688,10 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         a.n_items = (int)p.item_dev.size();
         a.fft_size = p.fft_size;
         a.hop_bytes = (int)h->hop_bytes;
-        a.lds_per_buf = dft_lds_per_buf((int)h->hop_bytes, p.fft_size);
-        a.nbuf = dft_nbuf((int)h->hop_bytes, p.fft_size);
-        a.sub = dft_sub((int)h->hop_bytes, p.fft_size);
+        const int win_bytes = 2 * p.fft_size * p.dev[0].bytes_per_sample;
+        a.lds_per_buf = dft_lds_per_buf((int)h->hop_bytes, win_bytes);
+        a.nbuf = dft_nbuf((int)h->hop_bytes, win_bytes);
+        a.sub = dft_sub((int)h->hop_bytes, win_bytes);
         a.row0 = h->row0_front;
         a.ring_rows = h->R;
         a.first_row = first ? 0 : AB_AGC_EXTRA;

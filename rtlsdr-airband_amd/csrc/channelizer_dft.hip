@@ -14,7 +14,7 @@
  * LUT is restored with a per-column constant.  Result = the exact DFT with coefficients rounded at 2^-24 of full
  * scale -- the same class of error as a float FFT (~1e-7 relative), no accumulation round-off at all.
  *
- * Only u8 takes this path (s8's LUT has an uninitialised entry, s16/f32 are not bytes), at fft_size 256 or 512; dongles with
+ * u8 and CS16 take this path (s8's LUT has an uninitialised entry, f32 is not bytes), at fft_size 256 or 512; dongles with
  * more than 8 channels are processed in groups of 8 (one wavefront per group); everything else -- other FFT sizes, odd hop
  * sizes -- uses channelizer_fft.hip.
  *
@@ -60,12 +60,17 @@ constexpr __host__ __device__ int c_sub(int hop_bytes, int win_bytes = 1024) { r
  * 0 = run-time value.  With the hop known, the staging geometry (pieces per step, buffers, tiles per step) is constant: the DMA loops
  * unroll, the wait-count switch disappears and the scalar bookkeeping around every tile shrinks by about two thirds -- the kernel
  * issues one instruction per SIMD every four cycles whatever its type, so scalar instructions are not free. */
-template <int FFT_N, bool EDGE_HI_ZERO, int HOPB>
+/* S16: the dongle delivers CS16 (SoapySDR, src/input-soapysdr.cpp:45-64): a sample component is lo + 256 * hi with lo the unsigned low byte
+ * and hi the signed high byte, so   sum_n s_n c_n  =  sum_n lo_n c_n  +  256 * sum_n hi_n c_n  -- TWO byte planes against the SAME
+ * coefficient table.  The planes are pulled apart with v_perm_b32 on the way from LDS to the MFMA (the raw stream interleaves them),
+ * the B fragments are the ones of the u8 case, the number of MFMAs per sample doubles and so does the number of bytes per sample. */
+template <int FFT_N, bool EDGE_HI_ZERO, int HOPB, bool S16>
 __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
-    constexpr int WIN_BYTES = 2 * FFT_N;          /* bytes per window (u8/s8 I/Q)      */
-    constexpr int KSTEPS = WIN_BYTES / 64;        /* MFMA k-steps per window           */
+    constexpr int BPS = S16 ? 2 : 1;              /* bytes per sample component        */
+    constexpr int WIN_BYTES = 2 * FFT_N * BPS;    /* bytes per window                  */
+    constexpr int KSTEPS = 2 * FFT_N / 64;        /* MFMA k-steps per window and plane */
     static_assert(KSTEPS == 16 || KSTEPS == 8, "B fragments (3 digits x KSTEPS x 4 VGPRs) must fit beside everything else: fft_size 256 or 512");
-    static_assert(HOPB == 0 || FFT_N == 512, "the hop-specialised variants are built for fft_size 512");
+    static_assert(HOPB == 0 || (FFT_N == 512 && !S16), "the hop-specialised variants are built for u8 at fft_size 512");
     constexpr int EDGE = KSTEPS / 8; /* k-steps at either end of the window whose most significant coefficient digit may be all zero */
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
 
@@ -120,10 +125,11 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
         if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) b2[s] = btab[(2 * KSTEPS + s) * 64];
     }
     const int col = lane & 15;
-    const double corr = a.corr[bset * 16 + col];
-    const double unscale = a.unscale;
+    const double corr = S16 ? a.corr[bset * 16 + col] * 256.0 : a.corr[bset * 16 + col]; /* table holds 0.5 * sum c (u8: b - 127.5 = (b - 128) + 0.5); CS16 needs 128 * sum c */
     const int ch = ch0 + (col >> 1);
     const DevConst dev = a.dev[d];
+    /* u8: a.unscale = 1 / (table scale * 127.5); CS16: 1 / (table scale * this dongle's input->fullscale) (src/rtl_airband.cpp:403) */
+    const double unscale = S16 ? a.unscale * (double)dev.scale : a.unscale;
     const bool ch_valid = ch < dev.n_ch;
     const int slot = a.ext_to_slot[dev.chan_base + (ch_valid ? ch : 0)];
     const unsigned ch_flags = a.cc[slot].flags;
@@ -196,6 +202,8 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
         if (t >= tiles_total) break;
 
         v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+        float val[4];
+        if (!S16) {
         const uint8_t* arow = buf + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 16;
         /* A fragments are fetched two k-steps ahead of the MFMAs that consume them, so the LDS latency (and the 2-way
          * bank conflict of the strided rows) hides behind six MFMAs instead of stalling in front of them */
@@ -218,11 +226,48 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
             if (s & 1) __builtin_amdgcn_sched_barrier(0); /* keep the prefetch distance the source order spells out */
         }
         /* recombine the digits exactly, restore the -127.5 offset of the reference's LUT, undo the fixed-point scale */
-        float val[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const double y = ((double)acc2[r] * 65536.0 + (double)acc1[r] * 256.0 + (double)acc0[r] + corr) * unscale;
             val[r] = (float)y;
+        }
+        } else {
+        /* CS16: plane k-step s of the lane = 16 plane bytes = 8 samples x (I, Q) = 32 raw bytes [Ilo Ihi Qlo Qhi] x 8 */
+        v4i hc0 = {0, 0, 0, 0}, hc1 = {0, 0, 0, 0}, hc2 = {0, 0, 0, 0}; /* high-byte plane */
+        const uint8_t* arow = buf + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 32;
+        v4i ra[2], rb[2]; /* raw 32 bytes of k-step s in (ra, rb)[s & 1]; the next k-step is fetched under this one's MFMAs */
+        ra[0] = *reinterpret_cast<const v4i*>(arow);
+        rb[0] = *reinterpret_cast<const v4i*>(arow + 16);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; s++) {
+            if (s + 1 < KSTEPS) {
+                ra[(s + 1) & 1] = *reinterpret_cast<const v4i*>(arow + (s + 1) * 128);
+                rb[(s + 1) & 1] = *reinterpret_cast<const v4i*>(arow + (s + 1) * 128 + 16);
+            }
+            const v4i p = ra[s & 1], q = rb[s & 1];
+            v4i lo, hi; /* v_perm_b32(hi dword, lo dword, selector): selector bytes 0-3 index the second operand, 4-7 the first */
+            lo.x = (int)__builtin_amdgcn_perm((unsigned)p.y, (unsigned)p.x, 0x06040200u); hi.x = (int)__builtin_amdgcn_perm((unsigned)p.y, (unsigned)p.x, 0x07050301u);
+            lo.y = (int)__builtin_amdgcn_perm((unsigned)p.w, (unsigned)p.z, 0x06040200u); hi.y = (int)__builtin_amdgcn_perm((unsigned)p.w, (unsigned)p.z, 0x07050301u);
+            lo.z = (int)__builtin_amdgcn_perm((unsigned)q.y, (unsigned)q.x, 0x06040200u); hi.z = (int)__builtin_amdgcn_perm((unsigned)q.y, (unsigned)q.x, 0x07050301u);
+            lo.w = (int)__builtin_amdgcn_perm((unsigned)q.w, (unsigned)q.z, 0x06040200u); hi.w = (int)__builtin_amdgcn_perm((unsigned)q.w, (unsigned)q.z, 0x07050301u);
+            lo.x ^= 0x80808080; lo.y ^= 0x80808080; lo.z ^= 0x80808080; lo.w ^= 0x80808080; /* unsigned low byte -> lo - 128 as int8 */
+            acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, b0[s], acc0, 0, 0, 0);
+            hc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, b0[s], hc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, b1[s], acc1, 0, 0, 0);
+            hc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, b1[s], hc1, 0, 0, 0);
+            if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) {
+                acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, b2[s], acc2, 0, 0, 0);
+                hc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, b2[s], hc2, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        /* value = sum lo c + 256 sum hi c, with lo = (lo - 128) + 128: corr = 128 * sum c (table units); all exact in float64 (< 2^50) */
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double l = (double)acc2[r] * 65536.0 + (double)acc1[r] * 256.0 + (double)acc0[r];
+            const double h = (double)hc2[r] * 65536.0 + (double)hc1[r] * 256.0 + (double)hc0[r];
+            val[r] = (float)((h * 256.0 + l + corr) * unscale);
+        }
         }
         /* lane pairs (2ch, 2ch+1) hold (re, im) of the same hop; even lanes write 4 consecutive rows of their slot */
         float im4[4];
@@ -278,31 +323,44 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
 
 bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch) {
     (void)max_ch; /* any channel count: dongles with more than 8 channels are split into groups of 8 */
-    return (fft_size == 512 || fft_size == 256) && sfmt == AIRBAND_SFMT_U8 && (hop_bytes % 16) == 0 && hop_bytes <= 640 && hop_bytes >= 64;
+    if (fft_size != 512 && fft_size != 256) return false;
+    if (sfmt == AIRBAND_SFMT_U8) return (hop_bytes % 16) == 0 && hop_bytes <= 640 && hop_bytes >= 64;
+    if (sfmt == AIRBAND_SFMT_S16) /* two staging buffers of 16 hops + one window must leave room for 3+ waves per CU */
+        return (hop_bytes % 16) == 0 && hop_bytes <= 1280 && hop_bytes >= 128;
+    return false;
 }
 
-int dft_sub(int hop_bytes, int fft_size) { return c_sub(hop_bytes, 2 * fft_size); }
-int dft_nbuf(int hop_bytes, int fft_size) { return c_nbuf(hop_bytes, 2 * fft_size); }
-int dft_lds_per_buf(int hop_bytes, int fft_size) { return c_lds_per_buf(hop_bytes, 2 * fft_size); }
+/* win_bytes = 2 * fft_size * bytes per sample component */
+int dft_sub(int hop_bytes, int win_bytes) { return c_sub(hop_bytes, win_bytes); }
+int dft_nbuf(int hop_bytes, int win_bytes) { return c_nbuf(hop_bytes, win_bytes); }
+int dft_lds_per_buf(int hop_bytes, int win_bytes) { return c_lds_per_buf(hop_bytes, win_bytes); }
 
-template <int FFT_N, int HOPB>
+template <int FFT_N, int HOPB, bool S16>
 static void launch_hop(const DftArgs& a, hipStream_t stream) {
     const long waves = (long)a.n_items * a.splits;
     const size_t lds = (size_t)a.nbuf * a.lds_per_buf;
+    if (lds > 64 * 1024) { /* CS16 at hop 1280: two 21 KiB buffers... stays below 64 KiB; kept for safety */
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_dft_kernel<FFT_N, true, HOPB, S16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_dft_kernel<FFT_N, false, HOPB, S16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     if (a.edge_hi_zero)
-        hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, true, HOPB>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, true, HOPB, S16>), dim3((unsigned)waves), dim3(64), lds, stream, a);
     else
-        hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, false, HOPB>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, false, HOPB, S16>), dim3((unsigned)waves), dim3(64), lds, stream, a);
 }
 
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream) {
-    if (a.fft_size == 256) return launch_hop<256, 0>(a, stream);
+    if (a.sfmt == AIRBAND_SFMT_S16) {
+        if (a.fft_size == 256) return launch_hop<256, 0, true>(a, stream);
+        return launch_hop<512, 0, true>(a, stream);
+    }
+    if (a.fft_size == 256) return launch_hop<256, 0, false>(a, stream);
 #ifndef AB_DFT_GENERIC_ONLY
     /* the host derives nbuf / sub / lds_per_buf with the same functions the specialised kernels fold in at compile time */
-    if (a.hop_bytes == 320 && a.nbuf == c_nbuf(320) && a.sub == c_sub(320) && a.lds_per_buf == c_lds_per_buf(320)) return launch_hop<512, 320>(a, stream);
-    if (a.hop_bytes == 640 && a.nbuf == c_nbuf(640) && a.sub == c_sub(640) && a.lds_per_buf == c_lds_per_buf(640)) return launch_hop<512, 640>(a, stream);
+    if (a.hop_bytes == 320 && a.nbuf == c_nbuf(320) && a.sub == c_sub(320) && a.lds_per_buf == c_lds_per_buf(320)) return launch_hop<512, 320, false>(a, stream);
+    if (a.hop_bytes == 640 && a.nbuf == c_nbuf(640) && a.sub == c_sub(640) && a.lds_per_buf == c_lds_per_buf(640)) return launch_hop<512, 640, false>(a, stream);
 #endif
-    launch_hop<512, 0>(a, stream);
+    launch_hop<512, 0, false>(a, stream);
 }
 
 }  // namespace airband

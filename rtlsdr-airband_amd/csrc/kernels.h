@@ -48,10 +48,10 @@ struct DftArgs {
     const int* item_bset;
     const int8_t* bfrag;    /* [n_bsets][3 digits][fft_size / 32 k-steps][64 lanes][16 bytes] MFMA B fragments */
     const double* corr;     /* [n_bsets][16] offset restoring (b - 127.5) from (b - 128), in table units */
-    double unscale;         /* 1 / (table scale * 127.5) */
+    double unscale;         /* u8: 1 / (table scale * 127.5); CS16: 1 / table scale (the kernel multiplies by the dongle's 1 / fullscale) */
     float* mag;
     float2* iq_bins;
-    int n_dev, n_items, splits, fft_size;
+    int n_dev, n_items, splits, fft_size, sfmt;
     int edge_hi_zero;                /* most significant digit is zero in k-steps 0,1,14,15 for every coefficient table */
     int hop_bytes, lds_per_buf, sub, nbuf; /* sub = 16-hop MFMA tiles per staging step; nbuf staging buffers */
     int row0, ring_rows, first_row, n_hops;
@@ -126,9 +126,9 @@ struct SiggenArgs {
 void launch_channelizer_fft(const ChannelizerArgs& a, hipStream_t stream);
 size_t fft_lds_bytes(int fft_log, int hop_samples, int bytes_per_sample); /* dynamic LDS per workgroup; must stay <= 64 KiB */
 bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch);
-int dft_lds_per_buf(int hop_bytes, int fft_size);
-int dft_sub(int hop_bytes, int fft_size);
-int dft_nbuf(int hop_bytes, int fft_size);
+int dft_lds_per_buf(int hop_bytes, int win_bytes);
+int dft_sub(int hop_bytes, int win_bytes);
+int dft_nbuf(int hop_bytes, int win_bytes);
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream);
 /* side: 3 extra streams, ev: 4 events (fork + 3 joins); both may be null -> everything on `stream`, every kind its own kernel.
  * d_order [n_order]: the fused kinds' blocks (AM, NFM, NFM + lowpass), interleaved by the host, for the single fused launch;
