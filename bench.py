@@ -183,6 +183,8 @@ def measure_traffic(args, kernel_substr):
                "--child", "--workload", args.workload, "--steps", "3", "--warmup", "1", "--ring", "1"]
         if args.dongles:
             cmd += ["--dongles", str(args.dongles)]
+        if args.sample_format != "u8":
+            cmd += ["--sample-format", args.sample_format]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=args.traffic_timeout, check=False)
             vals = []
@@ -222,6 +224,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("AIRBAND_BENCH_WORKLOAD", "cfg3"), choices=sorted(WORKLOADS))
     ap.add_argument("--dongles", type=int, default=0, help="override dongles per GPU")
+    ap.add_argument("--sample-format", default="u8", choices=["u8", "s16"], help="u8 = RTL-SDR bytes (BASELINE configs); s16 = CS16 as SoapySDR devices deliver it "
+                    "(the same synthetic signal re-expressed at 16 bits, full scale 25 500)")
     ap.add_argument("--ring", type=int, default=3, help="distinct I/Q batches kept in HBM and cycled through")
     ap.add_argument("--mixers", type=int, default=0, help="number of mixers (BASELINE configs[4]: 64). Default 0 at every N, so that per-GPU work is the same "
                     "from 1 to 8 GPUs (configs[1]-[3] have no exchange step); with mixers and N > 1 the per-rank sums are all-reduced over RCCL every step")
@@ -282,7 +286,8 @@ def main():
     n_mixers = max(0, args.mixers)
 
     chans, carriers = pkg.siggen.baseline_plan(mixed=mixed)
-    devices = [dict(channels=chans) for _ in range(D)]
+    s16 = args.sample_format == "s16"
+    devices = [dict(channels=chans, sfmt=pkg.capi.SFMT_S16, fullscale=25500.0) if s16 else dict(channels=chans) for _ in range(D)]
     # AIRBAND_BENCH_FLAGS adds AIRBAND_HIP_FLAG_* bits for experiments (e.g. 8 = demod kinds one after the other, for per-kernel profiles)
     flags = int(os.environ.get("AIRBAND_BENCH_FLAGS", "0"), 0) | (pkg.capi.FLAG_PIPELINE if args.pipelined else 0)
     hip = pkg.AirbandHip(devices, wave_rate=wave_rate, hip_device=local_rank, flags=flags)
@@ -297,7 +302,22 @@ def main():
     span = lead + (args.ring + 1) * g.batch_bytes + g.lookahead_bytes
     stride = (span + 255) // 256 * 256
     iq = torch.empty((D, stride), dtype=torch.uint8, device="cuda")
-    hip.generate_iq(iq.data_ptr(), stride, 0, span, seed=0x5EED, device_index_offset=rank * D)
+    if not s16:
+        hip.generate_iq(iq.data_ptr(), stride, 0, span, seed=0x5EED, device_index_offset=rank * D)
+    else:
+        # the generator emits u8; CS16 dongles get the same signal as (b - 127.5) * 200, converted slab by slab
+        slab = min(D, 2048)
+        gen = pkg.AirbandHip([dict(channels=chans) for _ in range(slab)], wave_rate=wave_rate, hip_device=local_rank)
+        gen.set_signal_plan(carriers)
+        tmp = torch.empty((slab, span // 2), dtype=torch.uint8, device="cuda")
+        iq16 = iq.view(torch.int16)
+        for d0 in range(0, D, slab):
+            n = min(slab, D - d0)
+            gen.generate_iq(tmp.data_ptr(), span // 2, 0, span // 2, seed=0x5EED, device_index_offset=rank * D + d0)
+            gen.synchronize()
+            iq16[d0:d0 + n, :span // 2] = tmp[:n].to(torch.int16) * 200 - 25500
+        gen.close()
+        del tmp
     hip.synchronize()
     torch.cuda.synchronize()
 
@@ -359,12 +379,12 @@ def main():
 
     total_samples = float(D) * world * SAMPLES_PER_BATCH * args.steps
     value = total_samples / elapsed / 1e6
-    hop = g.batch_bytes // (2 * hip.B)
-    alg_bytes_per_sample = 2.0 + 8 * 4.0 / hop          # u8 I/Q in, 8 channels of float audio out per hop
+    hop = g.batch_bytes // ((4 if s16 else 2) * hip.B)
+    alg_bytes_per_sample = (4.0 if s16 else 2.0) + 8 * 4.0 / hop   # u8 (cs16) I/Q in, 8 channels of float audio out per hop
     name = hip.channelizer_name()
     build = hip.build_info()
     achieved = alg_bytes_per_sample * D * SAMPLES_PER_BATCH / (ch_ms * 1e-3) / 1e9
-    read_only = 2.0 * D * SAMPLES_PER_BATCH / (ch_ms * 1e-3) / 1e9
+    read_only = (4.0 if s16 else 2.0) * D * SAMPLES_PER_BATCH / (ch_ms * 1e-3) / 1e9
     roofline = dict(bound="hbm", kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                     avg_launch_ms=round(ch_ms, 4), algorithmic_bytes_per_launch=alg_bytes_per_sample * D * SAMPLES_PER_BATCH,
                     frac_read_only=round(read_only / HBM_PEAK_GBS, 4),
@@ -373,7 +393,7 @@ def main():
                warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="i8x3->i32->f64->f32 (stage 1), f32 (stage 2)" if name == "dft_mfma_i8" else "f32", data="synthetic",
                config=dict(workload=wl["desc"], dongles_per_gpu=D, channels_per_dongle=8, fft_size=g.fft_size, wave_rate=wave_rate,
-                           sample_format="u8", iq_resident="HBM", ring_batches=args.ring, mixers=n_mixers,
+                           sample_format=args.sample_format, iq_resident="HBM", ring_batches=args.ring, mixers=n_mixers,
                            schedule="pipelined: stage 1 of batch k beside stage 2 of batch k-1" if args.pipelined else "one batch at a time",
                            parallelism="dongle-sharded x%d, %s" % (world, "RCCL all-reduce of mixer sums" if mix_t is not None else "no collective"),
                            channelizer=name,
@@ -444,7 +464,7 @@ def main():
         out["host_path"] = dict(value=round(gs, 1), unit="Msamples/s", gbytes_per_s=round(gs * 2e6 / 1e9, 1), dongles=nd, feeder_threads=feeders,
                                 note="pageable host buffers -> submit() (one CPU copy into pinned rings, %d feeder threads) -> strided DMA -> kernels; includes PCIe" % feeders)
         sub.close()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not s16:
         try:
             out["cpu_baseline"] = cpu_baseline(pkg, devices, wave_rate, mixed, args.cpu_seconds)
         except Exception as e:  # noqa: BLE001
