@@ -355,7 +355,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         }
 
         lmask fade_m = 0;
-        if (ab_any(m_am)) { /* src/rtl_airband.cpp:532-547 */
+        if (!s.quiet && ab_any(m_am)) { /* src/rtl_airband.cpp:532-547; first / last open samples only exist while a transition is pending */
             if (ab_lane(sq_first_open(s) & m_am)) {
                 const float lvl = sq_level(s);
                 for (int k = j; k < j + AB_AGC_EXTRA; k++) { /* the AGC_EXTRA magnitudes before the current one */

@@ -53,6 +53,10 @@ struct SqRegs { /* Squelch members that change per sample */
     int delay, low_count, head, tail;
     unsigned sample_count, open_count, flappy_count, recent_open, closed_count;
     float dly; /* buffer_[buffer_tail_] for the current tail, when the kind prefetches the delay line (else unused) */
+    /* QUIET (wave-uniform): every lane's next_state_ equals its current_state_, and that state is CLOSED or OPEN -- no timer runs,
+     * nothing is being entered, nothing can expire.  Keyed transmissions spend >= 85 % of their samples like this, and then the
+     * transition algebra of update_current_state() is a no-op: sq_raw() skips it and only watches for the next request. */
+    bool quiet;
 };
 
 struct Lane { /* per-lane constants */
@@ -98,6 +102,11 @@ AB_FSM_FN lmask sq_has_signal(const SqRegs& s, const Lane& L) { /* src/squelch.c
     /* using_post_filter_ can only ever be set on channels with a lowpass filter */
     if (L.may_post_filter && ab_any(s.using_post)) sig &= ~s.using_post | ab_ballot(s.post_capped >= sq_delayed(s, L));
     return sig;
+}
+
+AB_FSM_FN bool sq_is_quiet(const SqRegs& s) {
+    const lmask busy = (s.nC ^ s.cC) | (s.nO ^ s.cO) | s.cOg | s.cCg | s.cA | s.nOg | s.nCg | s.nA;
+    return !ab_any(busy & s.active);
 }
 
 /* Squelch::update_current_state (src/squelch.cpp:363-460).  Returns the lanes whose squelch just went CLOSED (the reference
@@ -168,7 +177,23 @@ AB_FSM_FN void sq_avg(float cap, float& full, float& capped, float x) {
 
 /* Squelch::process_raw_sample (src/squelch.cpp:195-246) */
 AB_FSM_FN lmask sq_raw(SqRegs& s, const Lane& L, float x, float dly_new) {
-    const lmask went_closed = sq_advance(s, L); /* evaluates the post-filter gate against buffer_[tail] BEFORE the tail moves */
+    lmask went_closed = 0;
+    if (s.quiet) {
+        /* update_current_state() when nothing is pending (:363-460): only the CLOSED lanes' closed-sample counter and the delay line move */
+        const lmask below = ab_ballot(s.closed_count < 1000u);
+        const lmask forget = s.cC & ~below & ab_ballot(s.recent_open != 0u);
+        s.closed_count += ab_lane(s.cC & below) ? 1u : 0u;
+        if (ab_any(forget)) {
+            s.recent_open = ab_lane(forget) ? 0u : s.recent_open;
+            s.lvl = sq_level_compute(s, L);
+        }
+        if (L.track_delay_line) {
+            s.tail = s.tail + 1 == AB_SQ_BUF ? 0 : s.tail + 1;
+            s.head = s.head + 1 == AB_SQ_BUF ? 0 : s.head + 1;
+        }
+    } else {
+        went_closed = sq_advance(s, L); /* evaluates the post-filter gate against buffer_[tail] BEFORE the tail moves */
+    }
     s.dly = dly_new;                            /* ... everything after it sees the entry under the advanced tail */
     s.sample_count++;
     const lmask sweep = ab_ballot((s.sample_count & 15u) == 0u); /* calculate_noise_floor every 16th sample, :477-490 */
@@ -187,6 +212,24 @@ AB_FSM_FN lmask sq_raw(SqRegs& s, const Lane& L, float x, float dly_new) {
         if (ab_lane(L.m_lowpass)) L.sqbuf[(long)s.head * L.S] = s.pre_capped * 0.9f; /* only ever read on the post-filter path */
     }
     const lmask sig = sq_has_signal(s, L);
+    if (s.quiet) {
+        /* the requests a steady lane can raise: OPEN -> CLOSING (signal gone) or LOW_SIGNAL_ABORT (:233-245), CLOSED -> OPENING */
+        const lmask to_closing = s.cO & ~sig;
+        const lmask to_opening = s.cC & sig;
+        const lmask low = s.cO & ab_ballot(!(x >= s.lvl));
+        s.low_count = ab_lane(low) ? s.low_count + 1 : (ab_lane(s.cO) ? 0 : s.low_count);
+        const lmask abort_now = low & ab_ballot(s.low_count >= 88); /* low_signal_abort_ */
+        const lmask any_req = to_closing | to_opening | abort_now;
+        if (ab_any(any_req)) {
+            s.nA = abort_now;
+            s.nCg = to_closing & ~abort_now;
+            s.nOg = to_opening;
+            s.nO &= ~any_req;
+            s.nC &= ~any_req;
+            s.quiet = false;
+        }
+        return went_closed;
+    }
     /* set_state() requests (:297-361), already clamped: OPEN -> CLOSING, CLOSED -> OPENING are legal as asked */
     const lmask to_closing = s.cO & ~sig;
     const lmask to_opening = s.cC & sig;
@@ -203,6 +246,7 @@ AB_FSM_FN lmask sq_raw(SqRegs& s, const Lane& L, float x, float dly_new) {
         s.nOg = (s.nOg & ~any_req) | (to_opening & ~abort_now);
         s.nO &= ~any_req;
     }
+    s.quiet = sq_is_quiet(s);
     return went_closed;
 }
 
@@ -232,6 +276,7 @@ AB_FSM_FN void sq_filtered(SqRegs& s, const Lane& L, lmask filt, float x) {
         s.nOg &= ~close;
         s.nA &= ~close;
         s.nO &= ~close;
+        s.quiet = false; /* re-derived by the next sq_raw() */
     }
 }
 
@@ -248,6 +293,7 @@ AB_FSM_FN void sq_load(SqRegs& s, const Lane& L, const ChanState* sp, bool valid
     s.flappy_count = sp->flappy_count; s.recent_open = sp->recent_open; s.closed_count = sp->closed_count;
     s.lvl = sq_level_compute(s, L);
     s.dly = 0.0f;
+    s.quiet = sq_is_quiet(s);
 }
 
 /* `samples` = how many process_raw_sample calls ran since sq_load (head/tail advance once per call, :453-456) */
