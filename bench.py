@@ -236,7 +236,7 @@ def main():
     ap.add_argument("--no-traffic", dest="traffic", action="store_false")
     ap.add_argument("--traffic-timeout", type=float, default=240.0)
     ap.add_argument("--host-dongles", type=int, default=2048, help="dongles of the --host-path measurement")
-    ap.add_argument("--host-threads", type=int, default=16, help="feeder threads of the --host-path measurement (submit() of different dongles may run concurrently)")
+    ap.add_argument("--host-threads", type=int, default=32, help="feeder threads of the --host-path measurement (submit() of different dongles may run concurrently)")
     ap.add_argument("--host-path", action="store_true", help="additionally time the host-buffer path (submit over PCIe) on a small slice; reported separately, never as value")
     ap.add_argument("--pipelined", action="store_true", help="AIRBAND_HIP_FLAG_PIPELINE: stage 1 of batch k beside stage 2 of batch k-1 (results one batch late); the "
                     "channelizer's launch time, which the roofline figure is built on, is then no longer that of the kernel alone, so the default is one batch at a time")

@@ -105,11 +105,14 @@ enum { AB_KIND_AM = 0, AB_KIND_NFM = 1, AB_KIND_NFM_LOWPASS = 2, AB_KIND_NFM_CTC
 #endif
 static inline AB_HD long ab_ring_base(int slot, int rows) { return ((long)(slot >> 6) * rows) * AB_SLOT_BLOCK + (slot & 63); }
 
-/* The two stage-1 -> stage-2 rings (|bin| and raw bin I/Q) are additionally transposed inside 16-row tiles:
- * element (row, slot) lives at ((slot/64 * tiles + row/16) * 64 + slot%64) * 16 + row%16, tiles = ring_rows / 16.
+/* The two stage-1 -> stage-2 rings (|bin| and raw bin I/Q) are additionally transposed inside tiles of AB_TILE_ROWS rows:
+ * element (row, slot) lives at ((slot/64 * tiles + row/T) * 64 + slot%64) * T + row%T, tiles = ring_rows / T.
  * The matrix-core channelizer produces 16 hops x 16 columns per MFMA tile with 4 consecutive hops per lane, so a lane
- * stores 16 contiguous bytes and the four lanes of a column complete a 64-byte segment -- full-width HBM writes instead
- * of 4-byte scatters; the demod kernels fetch the same tiles back 16 bytes (4 rows) per lane. */
+ * stores 16 contiguous bytes and the lanes of a column complete a contiguous run per slot; the demod kernels fetch the same
+ * tiles back 16 bytes (4 rows) per lane.  T = 8: a slot's tile is 32 bytes of |bin| / 64 bytes of raw I/Q, the four AM (two
+ * NFM) channels of a dongle are adjacent slots, so the channelizer still completes whole 128-byte lines per dongle, and a demod
+ * wavefront consumes every line it touches within one 8-sample group (T = 16 left half of each line for a later group: by then
+ * it had left the caches, and stage 2 fetched 33 GB per batch instead of 17). */
 #ifndef AB_TILE_ROWS
 #define AB_TILE_ROWS 8 /* 4, 8 or 16 */
 #endif
