@@ -90,8 +90,6 @@ struct airband_hip_handle {
     DevBuf<ChanState> d_cs;
     DevBuf<int> d_slot_to_ext, d_ext_to_slot;
     DevBuf<uint8_t> d_block_kind;
-    DevBuf<int> d_demod_order; /* blocks of the fused demod kinds, interleaved in proportion (one launch for all of them) */
-    int n_demod_order = 0;
     DevBuf<float> d_window, d_sin, d_cos;
     DevBuf<float> d_mag, d_sqbuf, d_ct_coeff, d_ct_q;
     DevBuf<float2> d_iq, d_iq_out, d_ct_af;
@@ -175,7 +173,7 @@ void destroy(airband_hip_handle* h) {
     for (auto& st : h->side)
         if (st) (void)hipStreamSynchronize(st);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->d_dev.release(); h->d_cc.release(); h->d_cs.release(); h->d_slot_to_ext.release(); h->d_ext_to_slot.release(); h->d_block_kind.release(); h->d_demod_order.release();
+    h->d_dev.release(); h->d_cc.release(); h->d_cs.release(); h->d_slot_to_ext.release(); h->d_ext_to_slot.release(); h->d_block_kind.release();
     h->d_window.release(); h->d_sin.release(); h->d_cos.release();
     h->d_mag.release(); h->d_sqbuf.release(); h->d_ct_coeff.release(); h->d_ct_q.release();
     h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release(); h->d_ct_af.release(); h->d_ct_mask.release();
@@ -286,8 +284,7 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.wave_batch = h->B;
     da.row0 = h->row0;
     da.ring_rows = h->R;
-    launch_demod(da, h->kind_first_block, h->kind_n_blocks, h->d_demod_order.p, h->n_demod_order, h->d_block_kind.p, s,
-                 (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
+    launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
     if (h->any_afc && h->afc_spectrum_valid) { /* afc.finalize(), src/rtl_airband.cpp:626-630: may turn '*' into '<' / '>' */
         launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, s);
         launch_axc(h->d_cs.p, h->d_slot_to_ext.p, h->d_out_axc.p, h->n_slots, s);
@@ -464,30 +461,6 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     PREP_TRY(upload(h->d_slot_to_ext, h->slot_to_ext), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_ext_to_slot, h->ext_to_slot), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_block_kind, block_kind), AIRBAND_HIP_ENOMEM);
-    {
-        /* launch order of the fused kinds' blocks: block i of a kind with n blocks sits at position (i + 0.5) / n of the launch, so
-         * the kinds progress in proportion and finish together; at equal position the kind with the longer wavefronts goes first */
-        const int fused[3] = {AB_KIND_NFM_LOWPASS, AB_KIND_NFM, AB_KIND_AM};
-        int idx[3] = {0, 0, 0};
-        std::vector<int> order;
-        for (;;) {
-            int best = -1;
-            double best_pos = 2.0;
-            for (int f = 0; f < 3; f++) {
-                const int n = h->kind_n_blocks[fused[f]];
-                if (idx[f] >= n) continue;
-                const double pos = (idx[f] + 0.5) / n;
-                if (pos < best_pos) {
-                    best_pos = pos;
-                    best = f;
-                }
-            }
-            if (best < 0) break;
-            order.push_back(h->kind_first_block[fused[best]] + idx[best]++);
-        }
-        h->n_demod_order = (int)order.size();
-        PREP_TRY(upload(h->d_demod_order, order), AIRBAND_HIP_ENOMEM);
-    }
     PREP_TRY(upload(h->d_window, p.window), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_sin, p.sin_lut), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_cos, p.cos_lut), AIRBAND_HIP_ENOMEM);

@@ -266,7 +266,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
      * aligned inside one tile and never straddle the ring wrap.  Stage 2 may rewrite a magnitude (AM lanes that need raw I/Q, :524)
      * that is read back AGC_EXTRA = 100 samples later: far outside the 16 samples a prefetch runs ahead. */
 #ifndef AB_AM_GROUP
-#define AB_AM_GROUP 8
+#define AB_AM_GROUP 4
 #endif
     constexpr int GS = KIND == AB_KIND_AM ? AB_AM_GROUP : 4; /* samples per group; divides WAVE_BATCH = 1000 / 2000 */
     constexpr int GQ = GS / 4;
@@ -476,7 +476,10 @@ constexpr int TONE_GROUP = 50; /* samples per tone-kernel step; divides WAVE_BAT
 #define AB_DEMOD_WAVES 3
 #endif
 #ifndef AB_AM_WAVES
-#define AB_AM_WAVES AB_DEMOD_WAVES
+#define AB_AM_WAVES 4
+#endif
+#ifndef AB_FRONT_WAVES
+#define AB_FRONT_WAVES 4
 #endif
 template <int KIND, bool WAVE_HAS_CTCSS>
 __device__ __forceinline__ void demod_block(const DemodArgs& a, int block, float* lds_demod) {
@@ -498,24 +501,12 @@ __device__ __forceinline__ void demod_block(const DemodArgs& a, int block, float
 }
 
 template <int KIND, bool WAVE_HAS_CTCSS>
-__global__ __launch_bounds__(64, KIND == AB_KIND_AM ? AB_AM_WAVES : AB_DEMOD_WAVES) void demod_kernel(DemodArgs a, int first_block) {
+/* wavefronts per SIMD the register allocation is held to.  A lane-per-channel wavefront advances at about one instruction per
+ * eight cycles whatever shares its SIMD (VALU -> SGPR -> SALU -> VALU hops of the lane-mask state machine), so throughput
+ * rises with residency until the vector pipe saturates: the AM kind, light on registers, is built for four (2.12 -> 1.63 ms alone). */
+__global__ __launch_bounds__(64, KIND == AB_KIND_AM ? AB_AM_WAVES : KIND == AB_KIND_NFM_CTCSS ? AB_FRONT_WAVES : AB_DEMOD_WAVES) void demod_kernel(DemodArgs a, int first_block) {
     extern __shared__ __attribute__((aligned(16))) float lds_demod[];
     demod_block<KIND, WAVE_HAS_CTCSS>(a, first_block + blockIdx.x, lds_demod);
-}
-
-/* The fused kinds (AM, NFM, NFM + lowpass: squelch, demodulation and output in one pass) in ONE launch.  Each of them alone leaves
- * issue slots idle -- a lane-per-channel wavefront is a long dependent chain -- and as separate kernels on forked streams they
- * mostly ran one after another (the first one's waves fill the CUs, the next kernel's get what drains).  Here the host interleaves
- * the blocks of all kinds in proportion (demod_order: block b of the grid is block demod_order[b] of the slot space), so every
- * CU holds a mix from the first wave to the last and the kinds finish together. */
-__global__ __launch_bounds__(64, AB_DEMOD_WAVES) void demod_multi_kernel(DemodArgs a, const int* order, const uint8_t* block_kind) {
-    extern __shared__ __attribute__((aligned(16))) float lds_demod[];
-    const int block = order[blockIdx.x];
-    switch (block_kind[block]) { /* wave-uniform */
-        case AB_KIND_AM: demod_block<AB_KIND_AM, false>(a, block, lds_demod); break;
-        case AB_KIND_NFM: demod_block<AB_KIND_NFM, false>(a, block, lds_demod); break;
-        default: demod_block<AB_KIND_NFM_LOWPASS, false>(a, block, lds_demod); break;
-    }
 }
 
 /* CTCSS tone detection (reference: src/ctcss.cpp, driven by Squelch::process_audio_sample src/squelch.cpp:278-295).
@@ -721,8 +712,7 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
  * lane-per-channel kernel holds at most 4 waves per SIMD and the NFM kinds have only half that many wavefronts at BASELINE
  * config #3.  So the split chain (front -> tone -> back, the longest) goes on the caller's stream and the fused kinds run
  * beside it on side streams, forked and joined with events (works the same under graph capture). */
-void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, const int* d_order, int n_order, const uint8_t* d_block_kind, hipStream_t stream,
-                  hipStream_t* side, hipEvent_t* ev) {
+void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev) {
     auto lds_of = [](int k) { /* sincos table, output-line staging, ext_of */
         return (size_t)(k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)RUN * OSTRIDE * sizeof(float) + 64 * sizeof(int);
     };
@@ -749,17 +739,10 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
         hipLaunchKernelGGL(tone_kernel, dim3((a.ct_n_blocks * 64 * 64 + 255) / 256), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(back_kernel, dim3(a.ct_n_blocks), dim3(64), 0, stream, a);
     }
-#ifndef AB_NO_FUSED_LAUNCH
-    if (fork && d_order && n_order > 0) { /* one launch for all fused kinds, blocks interleaved by the host */
-        hipStream_t s = side[0];
-        (void)hipStreamWaitEvent(s, ev[0], 0);
-        hipLaunchKernelGGL(demod_multi_kernel, dim3(n_order), dim3(64), lds_of(AB_KIND_NFM_LOWPASS), s, a, d_order, d_block_kind);
-        (void)hipEventRecord(ev[1], s);
-        (void)hipStreamWaitEvent(stream, ev[1], 0);
-        return;
-    }
-#endif
-    for (int i = 0; i < 3; i++) { /* AIRBAND_HIP_FLAG_SERIAL_DEMOD (profiling): every kind as its own kernel, one after the other */
+    /* the fused kinds as forked launches (one kernel per kind keeps each kind's own register budget: the AM kind runs four waves per
+     * SIMD, the heavier ones three; a single launch with host-interleaved blocks was measured equal at best, 7.8 vs 7.7 ms);
+     * without side streams (AIRBAND_HIP_FLAG_SERIAL_DEMOD, profiling) one after the other */
+    for (int i = 0; i < 3; i++) {
         if (kind_n_blocks[fused[i]] <= 0) continue;
         hipStream_t s = fork ? side[i] : stream;
         if (fork) (void)hipStreamWaitEvent(s, ev[0], 0);

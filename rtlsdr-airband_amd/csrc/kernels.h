@@ -130,11 +130,8 @@ int dft_lds_per_buf(int hop_bytes, int win_bytes);
 int dft_sub(int hop_bytes, int win_bytes);
 int dft_nbuf(int hop_bytes, int win_bytes);
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream);
-/* side: 3 extra streams, ev: 4 events (fork + 3 joins); both may be null -> everything on `stream`, every kind its own kernel.
- * d_order [n_order]: the fused kinds' blocks (AM, NFM, NFM + lowpass), interleaved by the host, for the single fused launch;
- * d_block_kind [n_slots / 64]: demod kind of every 64-slot block */
-void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, const int* d_order, int n_order, const uint8_t* d_block_kind, hipStream_t stream,
-                  hipStream_t* side, hipEvent_t* ev);
+/* side: 3 extra streams, ev: 4 events (fork + 3 joins); both may be null -> everything on `stream`, one kind after the other */
+void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev);
 void launch_emit_iq(const EmitArgs& a, hipStream_t stream);
 void launch_axc(const ChanState* cs, const int* slot_to_ext, uint8_t* out_axc, int n_slots, hipStream_t stream);
 void launch_mix(const MixArgs& a, hipStream_t stream);
