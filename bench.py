@@ -185,6 +185,8 @@ def measure_traffic(args, kernel_substr):
             cmd += ["--dongles", str(args.dongles)]
         if args.sample_format != "u8":
             cmd += ["--sample-format", args.sample_format]
+        if args.sample_rate != 2_560_000:
+            cmd += ["--sample-rate", str(args.sample_rate)]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=args.traffic_timeout, check=False)
             vals = []
@@ -226,6 +228,8 @@ def main():
     ap.add_argument("--dongles", type=int, default=0, help="override dongles per GPU")
     ap.add_argument("--sample-format", default="u8", choices=["u8", "s16"], help="u8 = RTL-SDR bytes (BASELINE configs); s16 = CS16 as SoapySDR devices deliver it "
                     "(the same synthetic signal re-expressed at 16 bits, full scale 25 500)")
+    ap.add_argument("--sample-rate", type=int, default=2_560_000, help="dongle sample rate (BASELINE: 2 560 000; 2 400 000 is the other common RTL-SDR rate: hops of "
+                    "300 / 600 bytes, not multiples of 16)")
     ap.add_argument("--ring", type=int, default=3, help="distinct I/Q batches kept in HBM and cycled through")
     ap.add_argument("--mixers", type=int, default=0, help="number of mixers (BASELINE configs[4]: 64). Default 0 at every N, so that per-GPU work is the same "
                     "from 1 to 8 GPUs (configs[1]-[3] have no exchange step); with mixers and N > 1 the per-rank sums are all-reduced over RCCL every step")
@@ -287,7 +291,9 @@ def main():
 
     chans, carriers = pkg.siggen.baseline_plan(mixed=mixed)
     s16 = args.sample_format == "s16"
-    devices = [dict(channels=chans, sfmt=pkg.capi.SFMT_S16, fullscale=25500.0) if s16 else dict(channels=chans) for _ in range(D)]
+    sr = args.sample_rate
+    samples_per_batch = sr // 8
+    devices = [dict(channels=chans, sample_rate=sr, sfmt=pkg.capi.SFMT_S16, fullscale=25500.0) if s16 else dict(channels=chans, sample_rate=sr) for _ in range(D)]
     # AIRBAND_BENCH_FLAGS adds AIRBAND_HIP_FLAG_* bits for experiments (e.g. 8 = demod kinds one after the other, for per-kernel profiles)
     flags = int(os.environ.get("AIRBAND_BENCH_FLAGS", "0"), 0) | (pkg.capi.FLAG_PIPELINE if args.pipelined else 0)
     hip = pkg.AirbandHip(devices, wave_rate=wave_rate, hip_device=local_rank, flags=flags)
@@ -307,7 +313,7 @@ def main():
     else:
         # the generator emits u8; CS16 dongles get the same signal as (b - 127.5) * 200, converted slab by slab
         slab = min(D, 2048)
-        gen = pkg.AirbandHip([dict(channels=chans) for _ in range(slab)], wave_rate=wave_rate, hip_device=local_rank)
+        gen = pkg.AirbandHip([dict(channels=chans, sample_rate=sr) for _ in range(slab)], wave_rate=wave_rate, hip_device=local_rank)
         gen.set_signal_plan(carriers)
         tmp = torch.empty((slab, span // 2), dtype=torch.uint8, device="cuda")
         iq16 = iq.view(torch.int16)
@@ -377,22 +383,22 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    total_samples = float(D) * world * SAMPLES_PER_BATCH * args.steps
+    total_samples = float(D) * world * samples_per_batch * args.steps
     value = total_samples / elapsed / 1e6
     hop = g.batch_bytes // ((4 if s16 else 2) * hip.B)
     alg_bytes_per_sample = (4.0 if s16 else 2.0) + 8 * 4.0 / hop   # u8 (cs16) I/Q in, 8 channels of float audio out per hop
     name = hip.channelizer_name()
     build = hip.build_info()
-    achieved = alg_bytes_per_sample * D * SAMPLES_PER_BATCH / (ch_ms * 1e-3) / 1e9
-    read_only = (4.0 if s16 else 2.0) * D * SAMPLES_PER_BATCH / (ch_ms * 1e-3) / 1e9
+    achieved = alg_bytes_per_sample * D * samples_per_batch / (ch_ms * 1e-3) / 1e9
+    read_only = (4.0 if s16 else 2.0) * D * samples_per_batch / (ch_ms * 1e-3) / 1e9
     roofline = dict(bound="hbm", kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
-                    avg_launch_ms=round(ch_ms, 4), algorithmic_bytes_per_launch=alg_bytes_per_sample * D * SAMPLES_PER_BATCH,
+                    avg_launch_ms=round(ch_ms, 4), algorithmic_bytes_per_launch=alg_bytes_per_sample * D * samples_per_batch,
                     frac_read_only=round(read_only / HBM_PEAK_GBS, 4),
                     read_only_note="input bytes only (2 B per I/Q sample) / launch time / peak: north_star words its target as READ bandwidth; `frac` uses SURVEY 8d's 2 B in + audio out")
     out = dict(metric=METRIC, value=round(value, 2), unit="Msamples/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="i8x3->i32->f64->f32 (stage 1), f32 (stage 2)" if name == "dft_mfma_i8" else "f32", data="synthetic",
-               config=dict(workload=wl["desc"], dongles_per_gpu=D, channels_per_dongle=8, fft_size=g.fft_size, wave_rate=wave_rate,
+               config=dict(workload=wl["desc"], dongles_per_gpu=D, channels_per_dongle=8, fft_size=g.fft_size, wave_rate=wave_rate, sample_rate=sr,
                            sample_format=args.sample_format, iq_resident="HBM", ring_batches=args.ring, mixers=n_mixers,
                            schedule="pipelined: stage 1 of batch k beside stage 2 of batch k-1" if args.pipelined else "one batch at a time",
                            parallelism="dongle-sharded x%d, %s" % (world, "RCCL all-reduce of mixer sums" if mix_t is not None else "no collective"),
@@ -402,7 +408,7 @@ def main():
                            library=os.path.basename(pkg.LIB_PATH), build_defines=build),
                roofline=roofline,
                stage_ms=dict(channelizer=ch_ms, demod=demod_ms, mixers_and_iq_out=emit_ms),
-               realtime_dongles=int(value / 2.56))
+               realtime_dongles=int(value / (sr / 1e6)))
 
     # ---- everything below is outside the timed region ------------------------------------------------------------------
     if rank == 0 and args.verify > 0:
@@ -464,7 +470,7 @@ def main():
         out["host_path"] = dict(value=round(gs, 1), unit="Msamples/s", gbytes_per_s=round(gs * 2e6 / 1e9, 1), dongles=nd, feeder_threads=feeders,
                                 note="pageable host buffers -> submit() (one CPU copy into pinned rings, %d feeder threads) -> strided DMA -> kernels; includes PCIe" % feeders)
         sub.close()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not s16:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not s16 and sr == 2_560_000:
         try:
             out["cpu_baseline"] = cpu_baseline(pkg, devices, wave_rate, mixed, args.cpu_seconds)
         except Exception as e:  # noqa: BLE001

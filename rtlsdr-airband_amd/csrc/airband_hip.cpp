@@ -453,6 +453,9 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     h->batch_bytes = h->hop_bytes * h->B;
     h->lookahead_bytes = 2LL * p.dev[0].bytes_per_sample * p.fft_size - h->hop_bytes;
     if (h->lookahead_bytes < 0) h->lookahead_bytes = 0;
+    /* hops that are not multiples of 16 bytes (2.4 MS/s): the channelizer stages whole 16-byte pieces, the piece holding the span's last
+     * byte included -- make batch + look-ahead a whole number of pieces so that callers size (and fill) their spans accordingly */
+    h->lookahead_bytes += (16 - (h->batch_bytes + h->lookahead_bytes) % 16) % 16;
 
     /* constants */
     PREP_TRY(upload(h->d_dev, p.dev), AIRBAND_HIP_ENOMEM);

@@ -45,7 +45,9 @@ constexpr __host__ __device__ int c_sub_tiles(int hop_bytes) {
     const int sub = 640 / hop_bytes;
     return sub < 1 ? 1 : (sub > 4 ? 4 : sub);
 }
-constexpr __host__ __device__ int c_lds_for(int hop_bytes, int sub, int win_bytes) { return ((TILE_HOPS * sub - 1) * hop_bytes + win_bytes + 1023) / 1024 * 1024; }
+constexpr __host__ __device__ int c_lds_for(int hop_bytes, int sub, int win_bytes) {
+    return ((TILE_HOPS * sub - 1) * hop_bytes + win_bytes + ((hop_bytes & 15) ? 16 : 0) + 1023) / 1024 * 1024; /* + the up-to-15 bytes in front of an unaligned step */
+}
 /* three small buffers (two steps in flight) when eight waves of them fit a CU's 160 KiB, else two larger ones */
 constexpr __host__ __device__ int c_nbuf(int hop_bytes, int win_bytes = 1024) { return 3 * c_lds_for(hop_bytes, 1, win_bytes) * 8 <= 160 * 1024 ? 3 : 2; }
 constexpr __host__ __device__ int c_lds_per_buf(int hop_bytes, int win_bytes = 1024) {
@@ -64,13 +66,28 @@ constexpr __host__ __device__ int c_sub(int hop_bytes, int win_bytes = 1024) { r
  * and hi the signed high byte, so   sum_n s_n c_n  =  sum_n lo_n c_n  +  256 * sum_n hi_n c_n  -- TWO byte planes against the SAME
  * coefficient table.  The planes are pulled apart with v_perm_b32 on the way from LDS to the MFMA (the raw stream interleaves them),
  * the B fragments are the ones of the u8 case, the number of MFMAs per sample doubles and so does the number of bytes per sample. */
-template <int FFT_N, bool EDGE_HI_ZERO, int HOPB, bool S16>
+/* AL: alignment every hop start is known to have inside the dongle's span (16, 8 or 4 bytes).  2.4 MS/s, the other common RTL-SDR
+ * rate, hops 300 (WAVE_RATE 16000) or 600 bytes (8000): the stream is still staged in aligned 16-byte pieces -- the LDS image simply
+ * starts up to 15 bytes before the first hop -- and the A fragments are assembled from 8- or 4-byte LDS reads. */
+template <int AL>
+__device__ __forceinline__ v4i lds_read16(const uint8_t* p) {
+    if (AL >= 16) return *reinterpret_cast<const v4i*>(p);
+    if (AL == 8) {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const v2i lo = *reinterpret_cast<const v2i*>(p), hi = *reinterpret_cast<const v2i*>(p + 8);
+        return (v4i){lo.x, lo.y, hi.x, hi.y};
+    }
+    const int* q = reinterpret_cast<const int*>(p);
+    return (v4i){q[0], q[1], q[2], q[3]};
+}
+
+template <int FFT_N, bool EDGE_HI_ZERO, int HOPB, bool S16, int AL>
 __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     constexpr int BPS = S16 ? 2 : 1;              /* bytes per sample component        */
     constexpr int WIN_BYTES = 2 * FFT_N * BPS;    /* bytes per window                  */
     constexpr int KSTEPS = 2 * FFT_N / 64;        /* MFMA k-steps per window and plane */
     static_assert(KSTEPS == 16 || KSTEPS == 8, "B fragments (3 digits x KSTEPS x 4 VGPRs) must fit beside everything else: fft_size 256 or 512");
-    static_assert(HOPB == 0 || (FFT_N == 512 && !S16), "the hop-specialised variants are built for u8 at fft_size 512");
+    static_assert(HOPB == 0 || (FFT_N == 512 && !S16 && AL == 16), "the hop-specialised variants are built for u8 at fft_size 512, 16-byte aligned hops");
     constexpr int EDGE = KSTEPS / 8; /* k-steps at either end of the window whose most significant coefficient digit may be all zero */
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
 
@@ -95,12 +112,15 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     const int sub = HOPB ? c_sub(HOPB ? HOPB : 64) : a.sub;
     const int lds_per_buf = HOPB ? c_lds_per_buf(HOPB ? HOPB : 64) : a.lds_per_buf;
     const int step_hops = TILE_HOPS * sub;
-    const int buf_bytes = (step_hops - 1) * hop_bytes + WIN_BYTES;
+    const int buf_bytes = (step_hops - 1) * hop_bytes + WIN_BYTES + (AL >= 16 ? 0 : 16);
     uint8_t* lds = lds_all;                               /* two buffers of lds_per_buf bytes */
 
     /* MFMA tiles are aligned to the 16-row tiles of the output rings: tile t covers hops [16 t - shift, 16 t - shift + 16);
      * hops < 0 (first tile) and >= n_hops (last tile) are computed on whatever bytes are there and never stored */
     const int shift = (a.row0 + a.first_row) & 15;
+    /* hops that are not multiples of 16 bytes: a step's first byte sits `delta` bytes into its (16-byte aligned) LDS image; a step
+     * advances by 16 hops, so delta is the same for every step of the wave */
+    const int delta = AL >= 16 ? 0 : (int)((-(long)shift * (HOPB ? HOPB : a.hop_bytes)) & 15);
     const int ring_tiles = a.ring_rows / AB_TILE_ROWS;
     const int ring_tiles16 = a.ring_rows / TILE_HOPS; /* the ring length is a whole number of 16-hop MFMA tiles */
     const int ptile0 = (a.row0 + a.first_row) >> 4;
@@ -112,7 +132,8 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     if (st_begin >= st_end) return;
 
     const uint8_t* src = a.iq + (long)d * a.iq_stride;    /* first byte of this batch's first hop */
-    const long span_end = (long)(a.n_hops - 1) * hop_bytes + WIN_BYTES; /* bytes of the batch span that may be read */
+    /* bytes of the batch span that may be read, rounded up to whole 16-byte pieces (geometry.lookahead_bytes includes the round-up) */
+    const long span_end = ((long)(a.n_hops - 1) * hop_bytes + WIN_BYTES + 15) & ~15L;
 
     /* ---- B fragments: 3 digits x 16 k-steps, resident for the whole wave ---------------------------------- */
     const int bset = a.item_bset[item];
@@ -162,8 +183,9 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
 #undef AB_PIECE
             return;
         }
+        const long base_al = AL >= 16 ? base : ((base >> 4) << 4); /* floor to 16 bytes, also below zero */
         for (int i = 0; i < n_dma; i++) {
-            long so = base + i * 1024 + lane * 16;
+            long so = base_al + i * 1024 + lane * 16;
             if (so + 16 > span_end) so = span_end - 16;
             if (so < 0) so = 0;
             __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(uintptr_t)(buf + i * 1024), 16, 0, 0);
@@ -204,19 +226,19 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
         v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
         float val[4];
         if (!S16) {
-        const uint8_t* arow = buf + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 16;
+        const uint8_t* arow = buf + delta + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 16;
         /* A fragments are fetched two k-steps ahead of the MFMAs that consume them, so the LDS latency (and the 2-way
          * bank conflict of the strided rows) hides behind six MFMAs instead of stalling in front of them */
         v4i av[KSTEPS];
-        av[0] = *reinterpret_cast<const v4i*>(arow);
-        av[1] = *reinterpret_cast<const v4i*>(arow + 64);
-        av[2] = *reinterpret_cast<const v4i*>(arow + 128);
-        av[3] = *reinterpret_cast<const v4i*>(arow + 192);
+        av[0] = lds_read16<AL>(arow);
+        av[1] = lds_read16<AL>(arow + 64);
+        av[2] = lds_read16<AL>(arow + 128);
+        av[3] = lds_read16<AL>(arow + 192);
 #pragma unroll
         for (int s = 0; s < KSTEPS; s++) {
             if ((s & 1) == 0 && s + 4 < KSTEPS) {
-                av[s + 4] = *reinterpret_cast<const v4i*>(arow + (s + 4) * 64);
-                av[s + 5] = *reinterpret_cast<const v4i*>(arow + (s + 5) * 64);
+                av[s + 4] = lds_read16<AL>(arow + (s + 4) * 64);
+                av[s + 5] = lds_read16<AL>(arow + (s + 5) * 64);
             }
             v4i x = av[s];
             x.x ^= 0x80808080; x.y ^= 0x80808080; x.z ^= 0x80808080; x.w ^= 0x80808080; /* u8 -> b - 128 as int8 */
@@ -234,15 +256,15 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
         } else {
         /* CS16: plane k-step s of the lane = 16 plane bytes = 8 samples x (I, Q) = 32 raw bytes [Ilo Ihi Qlo Qhi] x 8 */
         v4i hc0 = {0, 0, 0, 0}, hc1 = {0, 0, 0, 0}, hc2 = {0, 0, 0, 0}; /* high-byte plane */
-        const uint8_t* arow = buf + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 32;
+        const uint8_t* arow = buf + delta + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 32;
         v4i ra[2], rb[2]; /* raw 32 bytes of k-step s in (ra, rb)[s & 1]; the next k-step is fetched under this one's MFMAs */
-        ra[0] = *reinterpret_cast<const v4i*>(arow);
-        rb[0] = *reinterpret_cast<const v4i*>(arow + 16);
+        ra[0] = lds_read16<AL>(arow);
+        rb[0] = lds_read16<AL>(arow + 16);
 #pragma unroll
         for (int s = 0; s < KSTEPS; s++) {
             if (s + 1 < KSTEPS) {
-                ra[(s + 1) & 1] = *reinterpret_cast<const v4i*>(arow + (s + 1) * 128);
-                rb[(s + 1) & 1] = *reinterpret_cast<const v4i*>(arow + (s + 1) * 128 + 16);
+                ra[(s + 1) & 1] = lds_read16<AL>(arow + (s + 1) * 128);
+                rb[(s + 1) & 1] = lds_read16<AL>(arow + (s + 1) * 128 + 16);
             }
             const v4i p = ra[s & 1], q = rb[s & 1];
             v4i lo, hi; /* v_perm_b32(hi dword, lo dword, selector): selector bytes 0-3 index the second operand, 4-7 the first */
@@ -324,9 +346,10 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
 bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch) {
     (void)max_ch; /* any channel count: dongles with more than 8 channels are split into groups of 8 */
     if (fft_size != 512 && fft_size != 256) return false;
-    if (sfmt == AIRBAND_SFMT_U8) return (hop_bytes % 16) == 0 && hop_bytes <= 640 && hop_bytes >= 64;
-    if (sfmt == AIRBAND_SFMT_S16) /* two staging buffers of 16 hops + one window must leave room for 3+ waves per CU */
-        return (hop_bytes % 16) == 0 && hop_bytes <= 1280 && hop_bytes >= 128;
+    /* hops must start on 4-byte boundaries (even hop_samples for u8: 2.4 MS/s -> 300 / 600 bytes); two staging buffers of 16 hops +
+     * one window must leave room for 3+ waves per CU */
+    if (sfmt == AIRBAND_SFMT_U8) return (hop_bytes % 4) == 0 && hop_bytes <= 1024 && hop_bytes >= 64;
+    if (sfmt == AIRBAND_SFMT_S16) return (hop_bytes % 4) == 0 && hop_bytes <= 1280 && hop_bytes >= 128;
     return false;
 }
 
@@ -335,32 +358,35 @@ int dft_sub(int hop_bytes, int win_bytes) { return c_sub(hop_bytes, win_bytes); 
 int dft_nbuf(int hop_bytes, int win_bytes) { return c_nbuf(hop_bytes, win_bytes); }
 int dft_lds_per_buf(int hop_bytes, int win_bytes) { return c_lds_per_buf(hop_bytes, win_bytes); }
 
-template <int FFT_N, int HOPB, bool S16>
-static void launch_hop(const DftArgs& a, hipStream_t stream) {
+template <int FFT_N, int HOPB, bool S16, int AL>
+static void launch_al(const DftArgs& a, hipStream_t stream) {
     const long waves = (long)a.n_items * a.splits;
     const size_t lds = (size_t)a.nbuf * a.lds_per_buf;
-    if (lds > 64 * 1024) { /* CS16 at hop 1280: two 21 KiB buffers... stays below 64 KiB; kept for safety */
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_dft_kernel<FFT_N, true, HOPB, S16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_dft_kernel<FFT_N, false, HOPB, S16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
     if (a.edge_hi_zero)
-        hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, true, HOPB, S16>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, true, HOPB, S16, AL>), dim3((unsigned)waves), dim3(64), lds, stream, a);
     else
-        hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, false, HOPB, S16>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, false, HOPB, S16, AL>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+}
+
+template <int FFT_N, bool S16>
+static void launch_generic(const DftArgs& a, hipStream_t stream) {
+    if ((a.hop_bytes & 15) == 0) return launch_al<FFT_N, 0, S16, 16>(a, stream);
+    if ((a.hop_bytes & 7) == 0) return launch_al<FFT_N, 0, S16, 8>(a, stream);
+    launch_al<FFT_N, 0, S16, 4>(a, stream);
 }
 
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream) {
     if (a.sfmt == AIRBAND_SFMT_S16) {
-        if (a.fft_size == 256) return launch_hop<256, 0, true>(a, stream);
-        return launch_hop<512, 0, true>(a, stream);
+        if (a.fft_size == 256) return launch_generic<256, true>(a, stream);
+        return launch_generic<512, true>(a, stream);
     }
-    if (a.fft_size == 256) return launch_hop<256, 0, false>(a, stream);
+    if (a.fft_size == 256) return launch_generic<256, false>(a, stream);
 #ifndef AB_DFT_GENERIC_ONLY
     /* the host derives nbuf / sub / lds_per_buf with the same functions the specialised kernels fold in at compile time */
-    if (a.hop_bytes == 320 && a.nbuf == c_nbuf(320) && a.sub == c_sub(320) && a.lds_per_buf == c_lds_per_buf(320)) return launch_hop<512, 320, false>(a, stream);
-    if (a.hop_bytes == 640 && a.nbuf == c_nbuf(640) && a.sub == c_sub(640) && a.lds_per_buf == c_lds_per_buf(640)) return launch_hop<512, 640, false>(a, stream);
+    if (a.hop_bytes == 320 && a.nbuf == c_nbuf(320) && a.sub == c_sub(320) && a.lds_per_buf == c_lds_per_buf(320)) return launch_al<512, 320, false, 16>(a, stream);
+    if (a.hop_bytes == 640 && a.nbuf == c_nbuf(640) && a.sub == c_sub(640) && a.lds_per_buf == c_lds_per_buf(640)) return launch_al<512, 640, false, 16>(a, stream);
 #endif
-    launch_hop<512, 0, false>(a, stream);
+    launch_generic<512, false>(a, stream);
 }
 
 }  // namespace airband

@@ -478,7 +478,8 @@ def _convert(iq_u8, sfmt, capi, s16_gain=200.0):
 @pytest.mark.parametrize("sfmt_name,fft_log,sample_rate,wave_rate", [
     ("SFMT_S8", 9, 2_560_000, 8000), ("SFMT_S16", 9, 2_560_000, 16000), ("SFMT_F32", 9, 2_560_000, 16000),
     ("SFMT_U8", 8, 2_560_000, 16000), ("SFMT_U8", 10, 2_560_000, 8000), ("SFMT_U8", 11, 2_560_000, 16000), ("SFMT_S16", 13, 2_560_000, 8000),
-    ("SFMT_U8", 9, 2_400_000, 16000), ("SFMT_U8", 9, 1_024_000, 8000), ("SFMT_S16", 9, 2_560_000, 8000), ("SFMT_S16", 8, 2_048_000, 16000)])
+    ("SFMT_U8", 9, 2_400_000, 16000), ("SFMT_U8", 9, 2_400_000, 8000), ("SFMT_U8", 9, 1_024_000, 8000), ("SFMT_S16", 9, 2_560_000, 8000), ("SFMT_S16", 8, 2_048_000, 16000),
+    ("SFMT_S16", 9, 2_400_000, 16000), ("SFMT_U8", 9, 3_200_000, 8000)])
 def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sample_rate, wave_rate):
     """Sample formats s8/s16/f32, fft sizes 256..8192, sample rates whose hop is not a multiple of 16 bytes: the matrix-core path
     takes u8 at fft 256 / 512, everything else runs on the wavefront-FFT channelizer -- same parity bars either way."""
@@ -506,7 +507,7 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
     devices = [dict(channels=[dict(c) for c in chans], sample_rate=sample_rate, sfmt=sfmt, fullscale=0.0 if sfmt != capi.SFMT_S16 else 127.5 * gains[d])
                for d in range(n_dev)]
     hop = round(sample_rate / wave_rate)
-    n_samples = (n_batches * (wave_rate // 8) + 100) * hop + (1 << fft_log)
+    n_samples = (n_batches * (wave_rate // 8) + 100) * hop + (1 << fft_log) + 8  # + 8: hops of 300 / 600 bytes are staged in whole 16-byte pieces
     iq = [_convert(pkg.siggen.generate_u8(d, 0, n_samples, carriers), sfmt, capi, gains[d]) for d in range(n_dev)]
     orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fft_log=fft_log)
     ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
@@ -514,7 +515,7 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
     opened = 0
     with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=capi.FLAG_TRACE_SQUELCH) as hip:
         hop_bytes = 2 * hop * capi.BYTES_PER_SAMPLE[sfmt]
-        expect_dft = fft_log in (8, 9) and hop_bytes % 16 == 0 and ((sfmt == capi.SFMT_U8 and 64 <= hop_bytes <= 640) or (sfmt == capi.SFMT_S16 and 128 <= hop_bytes <= 1280))
+        expect_dft = fft_log in (8, 9) and hop_bytes % 4 == 0 and ((sfmt == capi.SFMT_U8 and 64 <= hop_bytes <= 1024) or (sfmt == capi.SFMT_S16 and 128 <= hop_bytes <= 1280))
         assert hip.channelizer_name() == ("dft_mfma_i8" if expect_dft else "fft_wave64")
         pos = [0] * n_dev
         for b in range(n_batches):
