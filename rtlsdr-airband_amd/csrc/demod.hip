@@ -275,6 +275,9 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         float dv[GS];
     };
     auto fetch = [&](Group& q, int j0, int tail0) { /* tail0 = squelch delay-line tail at the start of the group (lowpass kind) */
+#ifdef AB_DEMOD_FAKE_FETCH /* experiment (wrong results): every group re-reads the batch's first rows -- cache hits, i.e. what perfectly hidden memory latency would buy */
+        j0 &= 15;
+#endif
 #pragma unroll
         for (int g = 0; g < GQ; g++) {
             const int rc = ring_row(a.row0 + AB_AGC_EXTRA + j0 + 4 * g, R); /* current hops */
@@ -430,22 +433,35 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             if ((jq % RUN) == 0) wrow.j0 = jq;
 #pragma unroll
             for (int r = 0; r < 4; r++) sample(jq + r, mcs[r], mds[r], qr[r], qi[r]);
-            if (!WAVE_HAS_CTCSS && ((jq + 4) % RUN) == 0) wave_flush(wrow);
-            if (WAVE_HAS_CTCSS && ((jq + 4) % HAND_RUN) == 0) hand_flush(HAND_RUN, jq + 4 - HAND_RUN);
         }
+    };
+    /* finished output runs leave AFTER the next group's loads have been waited for: the compiler's wait is `s_waitcnt vmcnt(0)`, which
+     * also waits for every store still in flight -- issued the other way round, each run's 128-byte-line stores were waited out in
+     * full (write acknowledgements take microseconds) before the next group could start.  GS is 4 or 8 and the runs are 32 (audio)
+     * or 16 (hand-off) samples long, so a run can only end with a group. */
+    auto flush = [&](int j0) {
+#ifdef AB_DEMOD_NO_FLUSH /* experiment (no results leave the kernel): what the output path costs */
+        return;
+#endif
+        if (!WAVE_HAS_CTCSS && ((j0 + GS) % RUN) == 0) wave_flush(wrow);
+        if (WAVE_HAS_CTCSS && ((j0 + GS) % HAND_RUN) == 0) hand_flush(HAND_RUN, j0 + GS - HAND_RUN);
     };
 
     Group qa, qb;
     fetch(qa, 0, s.tail);
+    touch(qa);
     for (int j0 = 0; j0 < B; j0 += 2 * GS) { /* WAVE_BATCH = 1000 is 125 groups of 8: the last pair is half a pair */
         const bool second = j0 + GS < B;
-        touch(qa);
-        if (second) fetch(qb, j0 + GS, tail_in(GS));
+        if (second) fetch(qb, j0 + GS, tail_in(GS)); /* flies under this group's samples */
         group(qa, j0);
+        if (second) touch(qb);
+        flush(j0);
         if (second) {
-            touch(qb);
-            if (j0 + 2 * GS < B) fetch(qa, j0 + 2 * GS, tail_in(GS));
+            const bool more = j0 + 2 * GS < B;
+            if (more) fetch(qa, j0 + 2 * GS, tail_in(GS));
             group(qb, j0 + GS);
+            if (more) touch(qa);
+            flush(j0 + GS);
         }
     }
 
