@@ -117,6 +117,11 @@ static inline AB_HD long ab_ring_base(int slot, int rows) { return ((long)(slot 
 #define AB_TILE_ROWS 8 /* 4, 8 or 16 */
 #endif
 static inline AB_HD long ab_tile_base(int slot, int tiles) { return (((long)(slot >> 6) * tiles) * AB_SLOT_BLOCK + (slot & 63)) * AB_TILE_ROWS; }
-static inline AB_HD long ab_tile_off(int row) { return ((long)(row / AB_TILE_ROWS) * AB_SLOT_BLOCK * AB_TILE_ROWS) + (row % AB_TILE_ROWS); }
+/* row >= 0 and the offset stays far below 2^31 elements (ring_rows * 64): unsigned shifts and masks, no signed-division fix-ups and no
+ * 64-bit scalar arithmetic -- the demod kernels compute four of these per group of four samples */
+static inline AB_HD int ab_tile_off(int row) {
+    const unsigned r = (unsigned)row;
+    return (int)((r / (unsigned)AB_TILE_ROWS) * (unsigned)(AB_SLOT_BLOCK * AB_TILE_ROWS) + (r % (unsigned)AB_TILE_ROWS));
+}
 
 #endif

@@ -30,6 +30,20 @@
 
 namespace airband {
 
+#ifdef AB_DEMOD_TIMING /* experiment: shader-clock time per phase of a lane-per-channel wavefront, summed per demod kind */
+__device__ unsigned long long g_demod_cycles[AB_KIND_COUNT][8];
+#define AB_T0() unsigned long long t_prev_ = __builtin_readcyclecounter()
+#define AB_TICK(slot)                                                        \
+    do {                                                                      \
+        const unsigned long long t_now_ = __builtin_readcyclecounter();      \
+        t_acc_[slot] += t_now_ - t_prev_;                                     \
+        t_prev_ = t_now_;                                                     \
+    } while (0)
+#else
+#define AB_T0()
+#define AB_TICK(slot)
+#endif
+
 namespace {
 
 /* per-sample flag word parked in LDS between the phases */
@@ -179,6 +193,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     if (KIND != AB_KIND_GENERIC) cc.flags = (cc.flags & ~KIND_MASK) | KindBits<KIND>::value;
 
     if (!valid) return; /* padding slots of the last block: lanes share nothing (no barriers, per-lane LDS columns) */
+    AB_T0();
 
     const bool nfm = cc.flags & AB_F_NFM, raw_iq = cc.flags & AB_F_RAW_IQ, lowpass = cc.flags & AB_F_LOWPASS;
     /* feature bits as lane masks (compile-time all-or-nothing inside a specialised kind) */
@@ -448,20 +463,33 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     };
 
     Group qa, qb;
+#ifdef AB_DEMOD_TIMING
+    unsigned long long t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    AB_TICK(0); /* prologue: state load, tail copy */
     fetch(qa, 0, s.tail);
     touch(qa);
+    AB_TICK(2);
     for (int j0 = 0; j0 < B; j0 += 2 * GS) { /* WAVE_BATCH = 1000 is 125 groups of 8: the last pair is half a pair */
         const bool second = j0 + GS < B;
         if (second) fetch(qb, j0 + GS, tail_in(GS)); /* flies under this group's samples */
+        AB_TICK(1);
         group(qa, j0);
+        AB_TICK(3);
         if (second) touch(qb);
+        AB_TICK(2);
         flush(j0);
+        AB_TICK(4);
         if (second) {
             const bool more = j0 + 2 * GS < B;
             if (more) fetch(qa, j0 + 2 * GS, tail_in(GS));
+            AB_TICK(1);
             group(qb, j0 + GS);
+            AB_TICK(3);
             if (more) touch(qa);
+            AB_TICK(2);
             flush(j0 + GS);
+            AB_TICK(4);
         }
     }
 
@@ -478,6 +506,12 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     sq_store(s, L, sp, B);
     sp->lxr[0] = lxr0; sp->lxr[1] = lxr1; sp->lxr[2] = lxr2; sp->lxi[0] = lxi0; sp->lxi[1] = lxi1; sp->lxi[2] = lxi2;
     sp->lyr[0] = lyr0; sp->lyr[1] = lyr1; sp->lyr[2] = lyr2; sp->lyi[0] = lyi0; sp->lyi[1] = lyi1; sp->lyi[2] = lyi2;
+#ifdef AB_DEMOD_TIMING
+    AB_TICK(5); /* epilogue */
+    if (lane == 0)
+        for (int k = 0; k < 6; k++) atomicAdd(&g_demod_cycles[KIND][k], t_acc_[k]);
+    if (lane == 0) atomicAdd(&g_demod_cycles[KIND][7], 1ull);
+#endif
 }
 
 constexpr int TONE_GROUP = 50; /* samples per tone-kernel step; divides WAVE_BATCH = 1000 and 2000, fits one wavefront's lanes */
@@ -728,6 +762,17 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
  * lane-per-channel kernel holds at most 4 waves per SIMD and the NFM kinds have only half that many wavefronts at BASELINE
  * config #3.  So the split chain (front -> tone -> back, the longest) goes on the caller's stream and the fused kinds run
  * beside it on side streams, forked and joined with events (works the same under graph capture). */
+#ifdef AB_DEMOD_TIMING
+extern "C" int airband_hip_debug_demod_cycles(unsigned long long* out40, int reset) {
+    if (hipMemcpyFromSymbol(out40, HIP_SYMBOL(g_demod_cycles), sizeof(unsigned long long) * AB_KIND_COUNT * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[AB_KIND_COUNT * 8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_demod_cycles), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
+
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev) {
     auto lds_of = [](int k) { /* sincos table, output-line staging, ext_of */
         return (size_t)(k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)RUN * OSTRIDE * sizeof(float) + 64 * sizeof(int);
