@@ -136,7 +136,9 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     const long span_end = ((long)(a.n_hops - 1) * hop_bytes + WIN_BYTES + 15) & ~15L;
 
     /* ---- B fragments: 3 digits x 16 k-steps, resident for the whole wave ---------------------------------- */
-    const int bset = a.item_bset[item];
+    /* fft_size > 512: the window is cut into n_pass pieces of 512 samples, one launch per piece (see launch_channelizer_dft);
+     * each piece has its own coefficient table */
+    const int bset = a.item_bset[item] * a.n_pass + a.pass;
     const v4i* btab = reinterpret_cast<const v4i*>(a.bfrag) + (long)bset * 3 * KSTEPS * 64 + lane;
     v4i b0[KSTEPS], b1[KSTEPS], b2[KSTEPS];
 #pragma unroll
@@ -291,6 +293,19 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
             val[r] = (float)((h * 256.0 + l + corr) * unscale);
         }
         }
+        if (a.n_pass > 1) { /* wave-uniform.  Partial sums of the window pieces travel through the raw-I/Q ring (every slot has a row there) */
+            int ptp = ptile0 + t;
+            ptp = ptp >= ring_tiles16 ? ptp - ring_tiles16 : ptp;
+            float* part = reinterpret_cast<float*>(a.iq_bins + slot_base + ab_tile_off(ptp * TILE_HOPS + grp * 4)) + (col & 1);
+            const int hf = t * TILE_HOPS - shift + grp * 4;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const bool live = ch_valid && hf + r >= 0 && hf + r < a.n_hops;
+                if (a.pass > 0 && live) val[r] += part[2 * r];
+                if (a.pass + 1 < a.n_pass && live) part[2 * r] = val[r];
+            }
+            if (a.pass + 1 < a.n_pass) continue; /* only the last piece produces |bin| / raw I/Q */
+        }
         /* lane pairs (2ch, 2ch+1) hold (re, im) of the same hop; even lanes write 4 consecutive rows of their slot */
         float im4[4];
 #pragma unroll
@@ -345,6 +360,8 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
 
 bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch) {
     (void)max_ch; /* any channel count: dongles with more than 8 channels are split into groups of 8 */
+    if (fft_size == 1024 || fft_size == 2048) /* window pieces of 512 samples, one launch per piece: u8 only for now */
+        return sfmt == AIRBAND_SFMT_U8 && (hop_bytes % 4) == 0 && hop_bytes <= 1024 && hop_bytes >= 64;
     if (fft_size != 512 && fft_size != 256) return false;
     /* hops must start on 4-byte boundaries (even hop_samples for u8: 2.4 MS/s -> 300 / 600 bytes); two staging buffers of 16 hops +
      * one window must leave room for 3+ waves per CU */
@@ -375,7 +392,30 @@ static void launch_generic(const DftArgs& a, hipStream_t stream) {
     launch_al<FFT_N, 0, S16, 4>(a, stream);
 }
 
-void launch_channelizer_dft(const DftArgs& a, hipStream_t stream) {
+static void launch_one_piece(const DftArgs& a, hipStream_t stream);
+
+void launch_channelizer_dft(const DftArgs& a0, hipStream_t stream) {
+    if (a0.fft_size > 512) {
+        /* fft_size 1024 / 2048: X[bin] = sum over window pieces p of  sum_{n in piece p} x[n] w[n] e^{-2 pi i bin n / N}: every piece is a
+         * 512-sample contraction of the same kind (own coefficient table, input 1024 bytes further on), run as its own launch; the partial
+         * sums travel through the raw-I/Q ring as floats (1e-7 relative: stage 1 is tolerance-bound).  The stream is read once per piece. */
+        DftArgs a = a0;
+        a.n_pass = a0.fft_size / 512;
+        a.fft_size = 512;
+        for (int p = 0; p < a.n_pass; p++) {
+            a.pass = p;
+            a.iq = a0.iq + (long)p * 1024;
+            launch_one_piece(a, stream);
+        }
+        return;
+    }
+    DftArgs a = a0;
+    a.n_pass = 1;
+    a.pass = 0;
+    launch_one_piece(a, stream);
+}
+
+static void launch_one_piece(const DftArgs& a, hipStream_t stream) {
     if (a.sfmt == AIRBAND_SFMT_S16) {
         if (a.fft_size == 256) return launch_generic<256, true>(a, stream);
         return launch_generic<512, true>(a, stream);

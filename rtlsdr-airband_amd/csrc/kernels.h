@@ -46,12 +46,13 @@ struct DftArgs {
     const int* item_dev;    /* [n_items] work items: (dongle, group of 8 channels, coefficient-table index) */
     const int* item_group;
     const int* item_bset;
-    const int8_t* bfrag;    /* [n_bsets][3 digits][fft_size / 32 k-steps][64 lanes][16 bytes] MFMA B fragments */
+    const int8_t* bfrag;    /* [n_bsets][window pieces][3 digits][k-steps][64 lanes][16 bytes] MFMA B fragments (k-steps = min(fft_size, 512) / 32) */
     const double* corr;     /* [n_bsets][16] offset restoring (b - 127.5) from (b - 128), in table units */
     double unscale;         /* u8: 1 / (table scale * 127.5); CS16: 1 / table scale (the kernel multiplies by the dongle's 1 / fullscale) */
     float* mag;
     float2* iq_bins;
     int n_dev, n_items, splits, fft_size, sfmt;
+    int pass, n_pass;                /* fft_size > 512: window piece of this launch / number of pieces (set by launch_channelizer_dft) */
     int edge_hi_zero;                /* most significant digit is zero in k-steps 0,1,14,15 for every coefficient table */
     int hop_bytes, lds_per_buf, sub, nbuf; /* sub = 16-hop MFMA tiles per staging step; nbuf staging buffers */
     int row0, ring_rows, first_row, n_hops;

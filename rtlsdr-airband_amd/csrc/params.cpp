@@ -291,7 +291,8 @@ int build_plan(const airband_hip_config* cfg, Plan& p) {
  * (same transform as src/rtl_airband.cpp:451-460 + :483-489 evaluated for one bin).  Values are scaled to 24-bit
  * integers and split into balanced base-256 digits d0 + 256 d1 + 65536 d2, each in [-128, 127]. */
 void build_dft_tables(Plan& p) {
-    const int N = p.fft_size, K = 2 * N, KS = K / 64;
+    /* fft_size > 512: one table per window piece of 512 samples (NP pieces); a table then covers K = 1024 bytes of the window */
+    const int N = p.fft_size, NP = N > 512 ? N / 512 : 1, NS = N / NP, K = 2 * NS, KS = K / 64;
     const double S = 8355000.0; /* max |coefficient| < 1  ->  |value| <= 127*65536 + 127*256 + 127 */
     p.b_unscale = 1.0 / (S * 127.5);
     p.item_dev.clear();
@@ -311,16 +312,18 @@ void build_dft_tables(Plan& p) {
             if (found < 0) {
                 found = (int)keys.size();
                 keys.push_back(key);
+              for (int piece = 0; piece < NP; piece++) {
                 std::vector<int> q((size_t)K * 16, 0);
                 for (int c = 0; c < (int)key.size(); c++) {
-                    for (int n = 0; n < N; n++) {
+                    for (int i = 0; i < NS; i++) {
+                        const int n = piece * NS + i;
                         /* the phase is reduced exactly in integers before it meets a double */
                         const double th = 2.0 * M_PI * (double)(((long long)key[c] * n) % N) / (double)N;
                         const double wc = (double)p.window[n] * std::cos(th), ws = (double)p.window[n] * std::sin(th);
-                        q[(size_t)(2 * n) * 16 + 2 * c] = (int)std::llround(wc * S);       /* I -> re */
-                        q[(size_t)(2 * n + 1) * 16 + 2 * c] = (int)std::llround(ws * S);   /* Q -> re */
-                        q[(size_t)(2 * n) * 16 + 2 * c + 1] = (int)std::llround(-ws * S);  /* I -> im */
-                        q[(size_t)(2 * n + 1) * 16 + 2 * c + 1] = (int)std::llround(wc * S); /* Q -> im */
+                        q[(size_t)(2 * i) * 16 + 2 * c] = (int)std::llround(wc * S);       /* I -> re */
+                        q[(size_t)(2 * i + 1) * 16 + 2 * c] = (int)std::llround(ws * S);   /* Q -> re */
+                        q[(size_t)(2 * i) * 16 + 2 * c + 1] = (int)std::llround(-ws * S);  /* I -> im */
+                        q[(size_t)(2 * i + 1) * 16 + 2 * c + 1] = (int)std::llround(wc * S); /* Q -> im */
                     }
                 }
                 const size_t base = p.bfrag.size();
@@ -343,6 +346,7 @@ void build_dft_tables(Plan& p) {
                     }
                     p.bcorr.push_back(0.5 * sum); /* (b - 127.5) = (b - 128) + 0.5 */
                 }
+              }
             }
             p.item_dev.push_back(d);
             p.item_group.push_back(g);
@@ -351,7 +355,7 @@ void build_dft_tables(Plan& p) {
     }
     p.n_bsets = (int)keys.size();
     /* the window is below 2^-8 of full scale in the outer k-steps, so the top digit vanishes there: verify, don't assume */
-    p.b_edge_hi_zero = true;
+    p.b_edge_hi_zero = NP == 1; /* window pieces have their small coefficients at one end only */
     const int edge = KS / 8;
     for (int b = 0; b < p.n_bsets && p.b_edge_hi_zero; b++)
         for (int s = 0; s < KS; s++) {

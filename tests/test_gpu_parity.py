@@ -515,7 +515,8 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
     opened = 0
     with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=capi.FLAG_TRACE_SQUELCH) as hip:
         hop_bytes = 2 * hop * capi.BYTES_PER_SAMPLE[sfmt]
-        expect_dft = fft_log in (8, 9) and hop_bytes % 4 == 0 and ((sfmt == capi.SFMT_U8 and 64 <= hop_bytes <= 1024) or (sfmt == capi.SFMT_S16 and 128 <= hop_bytes <= 1280))
+        expect_dft = hop_bytes % 4 == 0 and ((sfmt == capi.SFMT_U8 and fft_log in (8, 9, 10, 11) and 64 <= hop_bytes <= 1024) or
+                                             (sfmt == capi.SFMT_S16 and fft_log in (8, 9) and 128 <= hop_bytes <= 1280))
         assert hip.channelizer_name() == ("dft_mfma_i8" if expect_dft else "fft_wave64")
         pos = [0] * n_dev
         for b in range(n_batches):
