@@ -187,6 +187,8 @@ def measure_traffic(args, kernel_substr):
             cmd += ["--sample-format", args.sample_format]
         if args.sample_rate != 2_560_000:
             cmd += ["--sample-rate", str(args.sample_rate)]
+        if args.fft_log != 9:
+            cmd += ["--fft-log", str(args.fft_log)]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=args.traffic_timeout, check=False)
             vals = []
@@ -230,6 +232,7 @@ def main():
                     "(the same synthetic signal re-expressed at 16 bits, full scale 25 500)")
     ap.add_argument("--sample-rate", type=int, default=2_560_000, help="dongle sample rate (BASELINE: 2 560 000; 2 400 000 is the other common RTL-SDR rate: hops of "
                     "300 / 600 bytes, not multiples of 16)")
+    ap.add_argument("--fft-log", type=int, default=9, help="fft_size_log (BASELINE: 9 = 512 points)")
     ap.add_argument("--ring", type=int, default=3, help="distinct I/Q batches kept in HBM and cycled through")
     ap.add_argument("--mixers", type=int, default=0, help="number of mixers (BASELINE configs[4]: 64). Default 0 at every N, so that per-GPU work is the same "
                     "from 1 to 8 GPUs (configs[1]-[3] have no exchange step); with mixers and N > 1 the per-rank sums are all-reduced over RCCL every step")
@@ -296,7 +299,7 @@ def main():
     devices = [dict(channels=chans, sample_rate=sr, sfmt=pkg.capi.SFMT_S16, fullscale=25500.0) if s16 else dict(channels=chans, sample_rate=sr) for _ in range(D)]
     # AIRBAND_BENCH_FLAGS adds AIRBAND_HIP_FLAG_* bits for experiments (e.g. 8 = demod kinds one after the other, for per-kernel profiles)
     flags = int(os.environ.get("AIRBAND_BENCH_FLAGS", "0"), 0) | (pkg.capi.FLAG_PIPELINE if args.pipelined else 0)
-    hip = pkg.AirbandHip(devices, wave_rate=wave_rate, hip_device=local_rank, flags=flags)
+    hip = pkg.AirbandHip(devices, wave_rate=wave_rate, hip_device=local_rank, flags=flags, fft_log=args.fft_log)
     g = hip.geometry
     if n_mixers:
         base = rank * D
@@ -418,7 +421,7 @@ def main():
 
             dongles = pyverify.sample_dongles(D, args.verify)
             host = [iq[d].cpu().numpy() for d in dongles]
-            spot = pyverify.SpotCheck(lambda d: devices[d], dongles, wave_rate=wave_rate)
+            spot = pyverify.SpotCheck(lambda d: devices[d], dongles, wave_rate=wave_rate, fft_log=args.fft_log)
             tv = time.perf_counter()
             for i in range(total_steps):
                 spot.feed([h[offset(i):] for h in host], trace=False)
@@ -470,7 +473,7 @@ def main():
         out["host_path"] = dict(value=round(gs, 1), unit="Msamples/s", gbytes_per_s=round(gs * 2e6 / 1e9, 1), dongles=nd, feeder_threads=feeders,
                                 note="pageable host buffers -> submit() (one CPU copy into pinned rings, %d feeder threads) -> strided DMA -> kernels; includes PCIe" % feeders)
         sub.close()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not s16 and sr == 2_560_000:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not s16 and sr == 2_560_000 and args.fft_log == 9:
         try:
             out["cpu_baseline"] = cpu_baseline(pkg, devices, wave_rate, mixed, args.cpu_seconds)
         except Exception as e:  # noqa: BLE001
