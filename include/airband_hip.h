@@ -280,6 +280,12 @@ int airband_hip_channel_constants(const airband_hip_handle* h, int32_t channel_i
 /* Same slots, computed without any GPU (pure host arithmetic): lets CPU-only tests pin the derivations. */
 int airband_hip_derive_constants(const airband_hip_config* cfg, int32_t channel_index, double* out_vals);
 
+/* Host-only check of the matrix-core channelizer's coefficient tables for `cfg` (needs no GPU): the value the kernel's integer digit
+ * sums recombine to, on `windows` pseudo-random raw windows per (dongle, group of 8 channels), against the defining sum
+ * X[bin] = sum_n lev[b_n] w[n] exp(-2 pi i bin n / N) (reference: src/rtl_airband.cpp:316-351,402-489) evaluated in double.
+ * *max_rel_err = largest error / RMS of the exact values.  AIRBAND_HIP_EBADSIZE when `cfg` would run on the wavefront-FFT channelizer. */
+int airband_hip_dft_selftest(const airband_hip_config* cfg, int32_t windows, double* max_rel_err);
+
 /* Milliseconds the GPU spent on the last finished batch (HIP events on the streams the kernels run on):
  * [0] channelizer kernel, [1] demod kernels (+ per-kind emit), [2] joint emit / mixers, [3] their sum.  Waits for the
  * enqueued batches. */

@@ -29,7 +29,7 @@ EXPORTS = [
     "airband_hip_synchronize", "airband_hip_process_bins", "airband_hip_read_bins", "airband_hip_read_trace", "airband_hip_channel_constants",
     "airband_hip_derive_constants", "airband_hip_last_timings", "airband_hip_channelizer_name", "airband_hip_set_signal_plan", "airband_hip_generate_iq",
     "airband_hip_flush", "airband_hip_timing_totals", "airband_hip_stream_wait_results", "airband_hip_mixer_enable_input",
-    "airband_hip_build_info", "airband_hip_collect_channels", "airband_hip_read_bins_channels", "airband_hip_read_trace_channels",
+    "airband_hip_build_info", "airband_hip_dft_selftest", "airband_hip_collect_channels", "airband_hip_read_bins_channels", "airband_hip_read_trace_channels",
 ]
 
 _lib = None
@@ -85,6 +85,7 @@ def load_library() -> C.CDLL:
     L.airband_hip_channelizer_name.restype = C.c_char_p
     L.airband_hip_set_signal_plan.argtypes = [vp, vp, i32, i32, vp]
     L.airband_hip_generate_iq.argtypes = [vp, vp, sz, u64, sz, u64, i32, vp]
+    L.airband_hip_dft_selftest.argtypes = [C.POINTER(capi.Config), i32, C.POINTER(C.c_double)]
     L.airband_hip_build_info.argtypes = []
     L.airband_hip_build_info.restype = C.c_char_p
     L.airband_hip_flush.argtypes = [vp]
@@ -117,6 +118,17 @@ def derive_constants(devices: Sequence[dict], channel_index: int, *, wave_rate: 
     if rc != 0:
         raise AirbandError(rc, (L.airband_hip_last_error(None) or b"").decode())
     return list(v)
+
+
+def dft_selftest(devices: Sequence[dict], *, wave_rate: int, fft_log: int = 9, windows: int = 2) -> float:
+    """Largest relative error of the matrix-core channelizer's coefficient tables for this configuration (host arithmetic, no GPU)."""
+    L = load_library()
+    cfg, keep = make_config(devices, wave_rate=wave_rate, fft_log=fft_log)
+    err = C.c_double(0.0)
+    rc = L.airband_hip_dft_selftest(C.byref(cfg), windows, C.byref(err))
+    if rc != 0:
+        raise AirbandError(rc, (L.airband_hip_last_error(None) or b"").decode())
+    return float(err.value)
 
 
 class AirbandHip:

@@ -349,6 +349,19 @@ int airband_hip_derive_constants(const airband_hip_config* cfg, int32_t channel_
     return AIRBAND_HIP_OK;
 }
 
+int airband_hip_dft_selftest(const airband_hip_config* cfg, int32_t windows, double* max_rel_err) {
+    if (!cfg || !max_rel_err) return fail(nullptr, AIRBAND_HIP_EINVAL, "NULL argument");
+    Plan plan;
+    const int rc = build_plan(cfg, plan);
+    if (rc != AIRBAND_HIP_OK) return fail(nullptr, rc, plan.error);
+    const int hop_bytes = 2 * plan.dev[0].bytes_per_sample * plan.dev[0].hop_samples;
+    if (!plan.uniform_hop || !dft_supported(plan.fft_size, hop_bytes, plan.dev[0].sfmt, plan.max_ch))
+        return fail(nullptr, AIRBAND_HIP_EBADSIZE, "configuration does not take the matrix-core channelizer");
+    build_dft_tables(plan);
+    *max_rel_err = dft_table_selftest(plan, windows < 1 ? 1 : windows);
+    return AIRBAND_HIP_OK;
+}
+
 int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out) {
     if (!out) return fail(nullptr, AIRBAND_HIP_EINVAL, "out is NULL");
     *out = nullptr;

@@ -7,6 +7,7 @@
  */
 #include "params.h"
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <complex>
@@ -363,6 +364,66 @@ void build_dft_tables(Plan& p) {
             for (int i = 0; i < 64 * 16; i++)
                 if (p.bfrag[(size_t)b * 3 * KS * 64 * 16 + ((size_t)2 * KS + s) * 64 * 16 + i] != 0) p.b_edge_hi_zero = false;
         }
+}
+
+/* Host-only check of the coefficient tables: for pseudo-random raw windows, the value the matrix-core channelizer would produce -- the
+ * integer sums of (byte - 128) x balanced base-256 digits over every window piece, recombined, offset-corrected and scaled exactly as
+ * the kernel does -- against the definition  X[bin] = sum_n lev[b_n] w[n] exp(-2 pi i bin n / N)  (src/rtl_airband.cpp:316-351,402-489)
+ * evaluated directly in double.  Returns the largest error relative to the RMS of the exact values over all work items. */
+double dft_table_selftest(const Plan& p, int windows) {
+    const int N = p.fft_size, NP = N > 512 ? N / 512 : 1, NS = N / NP, K = 2 * NS, KS = K / 64;
+    const bool s16 = p.dev[0].sfmt == AIRBAND_SFMT_S16;
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() {
+        rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+        return rng;
+    };
+    double worst = 0.0, sumsq = 0.0;
+    long count = 0;
+    std::vector<double> errs;
+    for (size_t item = 0; item < p.item_dev.size(); item++) {
+        const int d = p.item_dev[item], g = p.item_group[item], set = p.item_bset[item];
+        const int nch = std::min(8, p.dev[d].n_ch - 8 * g);
+        for (int w = 0; w < windows; w++) {
+            std::vector<int> raw(2 * N); /* u8: 0..255; CS16: -32768..32767 */
+            for (int k = 0; k < 2 * N; k++) raw[k] = s16 ? (int)(int16_t)(next() >> 17) : (int)((next() >> 23) & 255);
+            for (int c = 0; c < nch; c++) {
+                const int bin = p.cc[p.chan_base[d] + 8 * g + c].base_bin;
+                for (int comp = 0; comp < 2; comp++) {
+                    const int col = 2 * c + comp;
+                    double table_units = 0.0; /* what the int32 accumulators + f64 recombination hold, all pieces */
+                    for (int piece = 0; piece < NP; piece++) {
+                        const size_t base = ((size_t)set * NP + piece) * 3 * KS * 64 * 16;
+                        long long acc = 0;
+                        for (int k = 0; k < K; k++) {
+                            const int s_ = k / 64, gg = (k % 64) / 16, jj = k % 16, lane = gg * 16 + col;
+                            long long coef = 0;
+                            for (int t = 2; t >= 0; t--) coef = coef * 256 + p.bfrag[base + (((size_t)t * KS + s_) * 64 + lane) * 16 + jj];
+                            const int v = raw[piece * K + k];
+                            /* u8: (b - 128) + the 0.5 of the correction term; CS16: (lo - 128) + 256 hi + 128 = the sample itself */
+                            acc += (long long)(s16 ? v : v - 128) * coef;
+                        }
+                        table_units += (double)acc + (s16 ? 0.0 : p.bcorr[((size_t)set * NP + piece) * 16 + col]);
+                    }
+                    const double got = table_units * (s16 ? p.b_unscale * 127.5 * (double)p.dev[d].scale : p.b_unscale);
+                    double want = 0.0;
+                    for (int n = 0; n < N; n++) {
+                        const double th = 2.0 * M_PI * (double)(((long long)bin * n) % N) / (double)N;
+                        const double xi = s16 ? (double)p.dev[d].scale * raw[2 * n] : (double)p.lev_u8[raw[2 * n]];
+                        const double xq = s16 ? (double)p.dev[d].scale * raw[2 * n + 1] : (double)p.lev_u8[raw[2 * n + 1]];
+                        const double wn = (double)p.window[n];
+                        want += comp == 0 ? wn * (xi * std::cos(th) + xq * std::sin(th)) : wn * (xq * std::cos(th) - xi * std::sin(th));
+                    }
+                    errs.push_back(std::fabs(got - want));
+                    sumsq += want * want;
+                    count++;
+                }
+            }
+        }
+    }
+    const double rms = count ? std::sqrt(sumsq / (double)count) : 1.0;
+    for (double e : errs) worst = std::max(worst, e / (rms > 0 ? rms : 1.0));
+    return worst;
 }
 
 void channel_constants(const Plan& p, int i, double* v) {

@@ -49,6 +49,8 @@ void build_dft_tables(Plan& plan);
 
 /* The 16 "derived constants" slots documented at airband_hip_channel_constants(). */
 void channel_constants(const Plan& plan, int ext_index, double* out16);
+/* host-only: largest error (relative to the RMS of the exact values) of the matrix-core coefficient tables on `windows` pseudo-random windows per work item */
+double dft_table_selftest(const Plan& plan, int windows);
 
 }  // namespace airband
 #endif
