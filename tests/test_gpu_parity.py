@@ -563,3 +563,39 @@ def test_afc(pkg, built):
                 assert out["stats"][k]["bin"] == orc.stats(d, j)["bin"], (d, j)
                 k += 1
     assert moved > 0
+
+
+def test_fft_channelizer_lds_budget(pkg, built):
+    """The wavefront-FFT channelizer stages 16 hops of raw samples in LDS: a wide format at a high sample rate needs more than the default
+    64 KiB (CS16 at 10 MS/s: 77 KiB -- the kernel opts in to the CU's full 160 KiB and runs), and one that cannot fit at all is refused by
+    prepare() with the 'unsupported size' code instead of failing every batch at launch."""
+    capi = pkg.capi
+    chans, _ = pkg.siggen.baseline_plan(mixed=False)
+    sr = 10_000_000
+    for c in chans:
+        c["frequency"] = 120_000_000 + int((c["frequency"] - 120_000_000) * 3.0)
+    dev = [dict(channels=[dict(c) for c in chans], sample_rate=sr, sfmt=capi.SFMT_S16, fullscale=25500.0)]
+    hop, B, n_batches = sr // 8000, 1000, 2
+    rng = np.random.RandomState(7)
+    n = (n_batches * B + 100) * hop + 512
+    t = np.arange(n)
+    sig = 3000.0 * np.exp(2j * np.pi * (chans[1]["frequency"] - 120_000_000) / sr * t) + rng.normal(0, 300, n) + 1j * rng.normal(0, 300, n)
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2] = np.round(sig.real)
+    iq[1::2] = np.round(sig.imag)
+    orc = pyoracle.Oracle(dev, wave_rate=8000)
+    ref = orc.run_device(0, iq, n_batches)
+    with pkg.AirbandHip(dev, wave_rate=8000, flags=capi.FLAG_TRACE_SQUELCH) as hip:
+        assert hip.channelizer_name() == "fft_wave64"  # hops of 5 000 bytes: beyond the matrix-core path's staging
+        raw = iq.view(np.uint8)
+        pos = 0
+        for b in range(n_batches):
+            pos += hip.submit(0, raw[pos:])
+            assert hip.process()
+            out = hip.collect()
+            assert np.array_equal(out["axc"], ref["axc"][b]) and np.array_equal(hip.read_trace(), ref["trace"][b])
+            assert helpers.rms(out["waveout"] - ref["waveout"][b]) <= 1e-4
+    too_wide = [dict(channels=[dict(c) for c in chans], sample_rate=20_000_000, sfmt=capi.SFMT_F32)]
+    with pytest.raises(pkg.AirbandError) as e:
+        pkg.AirbandHip(too_wide, wave_rate=8000)
+    assert e.value.code == capi.EBADSIZE
