@@ -24,6 +24,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 #include "squelch_fsm.h"
@@ -135,8 +137,9 @@ __device__ __forceinline__ void wave_flush(const WaveRow& w, int n = RUN) { /* t
 __device__ __forceinline__ void emit_sample(const DemodArgs& a, const ChanConst& cc, OutRegs& o, const WaveRow& w, float2* iqout, uint8_t* trace, int j, bool audio, bool fade,
                                             bool tone, int state, float out, float re, float im, bool write_iq_always) {
     constexpr long S = AB_SLOT_BLOCK;
-    if (fade) { /* AM, squelch just closing: waveout[k] = waveout[k-1] * 0.94 over the previous AGC_EXTRA-1 samples */
+    if (AB_UNLIKELY(fade)) { /* AM, squelch just closing: waveout[k] = waveout[k-1] * 0.94 over the previous AGC_EXTRA-1 samples */
         float prev = w.row[j]; /* = output of sample j - AGC_EXTRA: left its run long ago */
+#pragma nounroll
         for (int k = j + 1; k < j + AB_AGC_EXTRA; k++) {
             prev = prev * 0.94f;
             const int i = k - AB_AGC_EXTRA - w.j0; /* position in the run still parked in LDS, if it is that recent */
@@ -271,7 +274,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         }
     };
 
-    /* ---- input: register ping-pong, a GROUP of 4 (NFM kinds) or 8 (AM) samples at a time ---------------------------------------
+    /* ---- input: register ping-pong, a GROUP of 4 samples at a time ----------------------------------------------------------
      * Four samples of a channel are 16 contiguous bytes of its 16-row tile (|bin|) or 32 (raw bin I/Q): one or two 16-byte loads
      * per stream.  Two register sets alternate: the loads of group k+1 are issued as soon as group k's registers have ARRIVED
      * (touch(): the compiler's own wait lands there), and fly while the per-sample code works through group k -- a wave no longer
@@ -280,10 +283,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
      * row0, AGC_EXTRA and WAVE_BATCH are multiples of 4 and the ring length is a multiple of 16, so four samples are always 16-byte
      * aligned inside one tile and never straddle the ring wrap.  Stage 2 may rewrite a magnitude (AM lanes that need raw I/Q, :524)
      * that is read back AGC_EXTRA = 100 samples later: far outside the 16 samples a prefetch runs ahead. */
-#ifndef AB_AM_GROUP
-#define AB_AM_GROUP 4
-#endif
-    constexpr int GS = KIND == AB_KIND_AM ? AB_AM_GROUP : 4; /* samples per group; divides WAVE_BATCH = 1000 / 2000 */
+    constexpr int GS = 4; /* samples per group; 2 * GS divides WAVE_BATCH = 1000 / 2000 */
     constexpr int GQ = GS / 4;
     struct Group {
         float4 mc[GQ], md[GQ], c01[GQ], c23[GQ], q01[GQ], q23[GQ];
@@ -335,10 +335,16 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         return t >= AB_SQ_BUF ? t - AB_SQ_BUF : t;
     };
 
-    /* ---- the sequential per-sample step ------------------------------------------------------------------------------------ */
-    auto sample = [&](const int j, float cur_mag, const float delayed_mag /* lowpass kind: the prefetched delay-line entry */, float re, float im) {
-        const lmask went_closed = sq_raw(s, L, cur_mag, delayed_mag /* = prefetched delay-line entry for the lowpass kind */);
-
+    /* ---- the sequential per-sample step ------------------------------------------------------------------------------------
+     * Two versions of everything behind process_raw_sample(): the general one, and the one a QUIET wavefront takes (squelch_fsm.h:
+     * every lane CLOSED or OPEN, nothing pending) -- there no sample is a first or last open one, audio is wanted by exactly the
+     * OPEN lanes, and the code is one straight run with a few seldom-taken exits. */
+#ifndef AB_SPLIT_REST_KINDS
+#define AB_SPLIT_REST_KINDS 0x09 /* bit k: kind k gets the second version (it doubles the per-sample code: the register-hungry kinds lose more to spills than they gain) */
+#endif
+    constexpr bool SPLIT_REST = ((AB_SPLIT_REST_KINDS >> KIND) & 1) != 0;
+    auto rest = [&](auto quiet_tag, const int j, float cur_mag, const float delayed_mag, float re, float im, const lmask went_closed) {
+        constexpr bool Q = decltype(quiet_tag)::value;
         if (ab_any(m_raw_iq)) { /* src/rtl_airband.cpp:510-530 */
             const lmask filt = sq_should_filter(s) & m_raw_iq;
             if (ab_lane(filt)) { /* per-lane float work only: lane masks are not touched inside divergent code */
@@ -373,9 +379,10 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         }
 
         lmask fade_m = 0;
-        if (!s.quiet && ab_any(m_am)) { /* src/rtl_airband.cpp:532-547; first / last open samples only exist while a transition is pending */
-            if (ab_lane(sq_first_open(s) & m_am)) {
+        if (!Q && ab_any(m_am)) { /* src/rtl_airband.cpp:532-547; first / last open samples only exist while a transition is pending */
+            if (AB_UNLIKELY(ab_lane(sq_first_open(s) & m_am))) {
                 const float lvl = sq_level(s);
+#pragma nounroll
                 for (int k = j; k < j + AB_AGC_EXTRA; k++) { /* the AGC_EXTRA magnitudes before the current one */
                     const float w = mag[ab_tile_off(ring_row(a.row0 + k, R))];
                     if (w >= lvl) agc = agc * 0.9f + w * 0.1f;
@@ -383,10 +390,10 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             }
             fade_m = sq_last_open(s) & m_am;
         }
-        const bool fade = ab_lane(fade_m);
+        const bool fade = Q ? false : ab_lane(fade_m);
 
         float out = 0.0f;
-        const bool audio = ab_lane(sq_should_audio(s));
+        const bool audio = ab_lane(Q ? s.cO : sq_should_audio(s));
         if (audio) {
             if (!nfm) { /* AM: src/rtl_airband.cpp:553-563 */
                 if (cur_mag > sq_level(s)) agc = agc * 0.995f + cur_mag * 0.005f;
@@ -412,16 +419,25 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                 prev_out = out;
             }
         }
+        const int state = !a.trace ? 0 : Q ? (ab_lane(s.cO) ? AB_ST_OPEN : AB_ST_CLOSED) : sq_cur(s);
         if (WAVE_HAS_CTCSS) {
             /* front half of a CTCSS-capable kind: hand (pre-notch audio, flags) to the tone and back kernels.  Raw I/Q of
              * an open sample is written now; the back kernel zeroes it again if the tone gate turns out closed. */
-            const unsigned f = (audio ? FL_AUDIO : 0u) | (fade ? FL_FADE : 0u) | (ab_lane(went_closed) ? FL_RESET : 0u) | (a.trace ? (unsigned)sq_cur(s) << FL_STATE_SHIFT : 0u);
+            const unsigned f = (audio ? FL_AUDIO : 0u) | (fade ? FL_FADE : 0u) | (ab_lane(went_closed) ? FL_RESET : 0u) | ((unsigned)state << FL_STATE_SHIFT);
             /* parked in LDS; 16 samples leave together as whole 128-byte lines of the channel-major hand-off rows */
             hand[((j & (HAND_RUN - 1)) * OSTRIDE)] = make_float2(out, __uint_as_float(f));
             if ((cc.flags & AB_F_IQ_OUT) && audio) iqout[(long)j * S] = make_float2(re, im);
         } else {
-            emit_sample(a, cc, o, wrow, iqout, trace, j, audio, fade, true, trace ? sq_cur(s) : 0, out, re, im, true);
+            emit_sample(a, cc, o, wrow, iqout, trace, j, audio, fade, true, state, out, re, im, true);
         }
+    };
+    auto sample = [&](const int j, const float cur_mag, const float delayed_mag /* lowpass kind: the prefetched delay-line entry */, const float re, const float im) {
+        lmask went_closed = 0;
+        if (AB_LIKELY(s.quiet)) sq_raw_quiet(s, L, cur_mag, delayed_mag);
+        else went_closed = sq_raw_full(s, L, cur_mag, delayed_mag);
+        /* a request raised by this very sample ends the quiet spell at once: its last-open handling is in the general version */
+        if (SPLIT_REST && AB_LIKELY(s.quiet)) rest(std::true_type{}, j, cur_mag, delayed_mag, re, im, went_closed); /* the sample that settles the last lane still reports who just closed */
+        else rest(std::false_type{}, j, cur_mag, delayed_mag, re, im, went_closed);
     };
     auto group = [&](const Group& q, int j0) {
 #pragma unroll
@@ -452,7 +468,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     };
     /* finished output runs leave AFTER the next group's loads have been waited for: the compiler's wait is `s_waitcnt vmcnt(0)`, which
      * also waits for every store still in flight -- issued the other way round, each run's 128-byte-line stores were waited out in
-     * full (write acknowledgements take microseconds) before the next group could start.  GS is 4 or 8 and the runs are 32 (audio)
+     * full (write acknowledgements take microseconds) before the next group could start.  GS is 4 and the runs are 32 (audio)
      * or 16 (hand-off) samples long, so a run can only end with a group. */
     auto flush = [&](int j0) {
 #ifdef AB_DEMOD_NO_FLUSH /* experiment (no results leave the kernel): what the output path costs */
@@ -470,27 +486,27 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     fetch(qa, 0, s.tail);
     touch(qa);
     AB_TICK(2);
-    for (int j0 = 0; j0 < B; j0 += 2 * GS) { /* WAVE_BATCH = 1000 is 125 groups of 8: the last pair is half a pair */
-        const bool second = j0 + GS < B;
-        if (second) fetch(qb, j0 + GS, tail_in(GS)); /* flies under this group's samples */
+    /* WAVE_BATCH is 1000 or 2000 (params.cpp): a whole number of group PAIRS.  Every fetch and every touch below is unconditional --
+     * behind an `if` the compiler can no longer pair a wait with its loads and falls back to waiting for everything in flight at the
+     * first use of a group, which is right after the NEXT group's loads were issued.  The pair after the last one re-reads the
+     * batch's last group instead (never used). */
+    for (int j0 = 0; j0 < B; j0 += 2 * GS) {
+        fetch(qb, j0 + GS, tail_in(GS)); /* flies under this group's samples */
         AB_TICK(1);
         group(qa, j0);
         AB_TICK(3);
-        if (second) touch(qb);
+        touch(qb);
         AB_TICK(2);
         flush(j0);
         AB_TICK(4);
-        if (second) {
-            const bool more = j0 + 2 * GS < B;
-            if (more) fetch(qa, j0 + 2 * GS, tail_in(GS));
-            AB_TICK(1);
-            group(qb, j0 + GS);
-            AB_TICK(3);
-            if (more) touch(qa);
-            AB_TICK(2);
-            flush(j0 + GS);
-            AB_TICK(4);
-        }
+        fetch(qa, j0 + 2 * GS < B ? j0 + 2 * GS : B - GS, tail_in(GS));
+        AB_TICK(1);
+        group(qb, j0 + GS);
+        AB_TICK(3);
+        touch(qa);
+        AB_TICK(2);
+        flush(j0 + GS);
+        AB_TICK(4);
     }
 
     if (!WAVE_HAS_CTCSS && (B % RUN) != 0) wave_flush(wrow, B % RUN); /* WAVE_BATCH = 1000: the last run is a short one */

@@ -36,11 +36,24 @@ typedef unsigned long long lmask;
 AB_FSM_FN lmask ab_ballot(bool b) { return __ballot(b); }                                   /* per-lane bool -> lane mask (one v_cmp) */
 AB_FSM_FN bool ab_lane(lmask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }          /* lane mask -> this lane's bool        */
 AB_FSM_FN bool ab_any(lmask m) { return m != 0ull; }
+AB_FSM_FN unsigned ab_uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); } /* a value every lane holds alike: keep it in a scalar register */
+#ifdef AB_NO_BRANCH_HINTS /* experiment: the layout the compiler picks on its own */
+#define AB_LIKELY(x) (x)
+#define AB_UNLIKELY(x) (x)
+#else
+#define AB_LIKELY(x) __builtin_expect(!!(x), 1)
+#define AB_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#endif
+AB_FSM_FN bool ab_rare(lmask m) { return AB_UNLIKELY(m != 0ull); } /* ab_any() of an event that is seldom there: its code goes out of line */
 #else
 #define AB_FSM_FN static inline
 AB_FSM_FN lmask ab_ballot(bool b) { return b ? 1ull : 0ull; }
 AB_FSM_FN bool ab_lane(lmask m) { return (m & 1ull) != 0ull; }
 AB_FSM_FN bool ab_any(lmask m) { return (m & 1ull) != 0ull; }
+AB_FSM_FN unsigned ab_uniform(unsigned v) { return v; }
+#define AB_LIKELY(x) (x)
+#define AB_UNLIKELY(x) (x)
+AB_FSM_FN bool ab_rare(lmask m) { return (m & 1ull) != 0ull; }
 #endif
 
 struct SqRegs { /* Squelch members that change per sample */
@@ -48,6 +61,7 @@ struct SqRegs { /* Squelch members that change per sample */
     float lvl;                    /* squelch_level() of the current noise_floor_ / recent_open_count_ */
     lmask active;                 /* lanes that own a channel */
     lmask using_post;             /* using_post_filter_ */
+    lmask recent_nz;              /* recent_open_count_ != 0 (kept beside the counter: it changes on three seldom-run paths only) */
     lmask cC, cOg, cCg, cA, cO;   /* current_state_ == CLOSED / OPENING / CLOSING / LOW_SIGNAL_ABORT / OPEN */
     lmask nC, nOg, nCg, nA, nO;   /* next_state_ */
     int delay, low_count, head, tail;
@@ -119,7 +133,7 @@ AB_FSM_FN lmask sq_advance(SqRegs& s, const Lane& L) {
     const lmask idle_closed = s.nC & same;
     lmask went_closed = 0;
     s.delay += ab_lane(staying) ? 1 : 0; /* the timer of OPENING / CLOSING / LOW_SIGNAL_ABORT */
-    if (ab_any(entering)) {
+    if (ab_rare(entering)) {
         /* delay_ is zeroed on entry to a timed state, except that ABORT entered from CLOSING keeps CLOSING's running delay */
         const lmask zero_delay = entering & timed & ~(s.nA & s.cCg);
         s.delay = ab_lane(zero_delay) ? 0 : s.delay;
@@ -132,10 +146,11 @@ AB_FSM_FN lmask sq_advance(SqRegs& s, const Lane& L) {
     /* current_state_ = next_state_ (when nothing is entered the two are equal already) */
     s.cC = s.nC; s.cOg = s.nOg; s.cCg = s.nCg; s.cA = s.nA; s.cO = s.nO;
     const lmask expired = staying & ab_ballot(s.delay >= 197); /* open_delay_ == close_delay_ == 197 */
-    if (ab_any(expired)) {
+    if (ab_rare(expired)) {
         /* OPENING delay over: count a recent open for flap detection before looking at the signal (:381-392) */
         const lmask bump = expired & s.nOg & ab_ballot(s.closed_count < 1000u);
         s.recent_open += ab_lane(bump) ? 1u : 0u;
+        s.recent_nz |= bump;
         s.flappy_count += ab_lane(bump & ab_ballot(s.recent_open >= 3u)) ? 1u : 0u;
         s.lvl = sq_level_compute(s, L);
         const lmask sig = sq_has_signal(s, L);
@@ -151,10 +166,11 @@ AB_FSM_FN lmask sq_advance(SqRegs& s, const Lane& L) {
     }
     /* CLOSED and staying there: count closed samples up to recent_sample_size_ = 1000, then forget the recent opens */
     const lmask below = ab_ballot(s.closed_count < 1000u);
-    const lmask forget = idle_closed & ~below & ab_ballot(s.recent_open != 0u);
+    const lmask forget = idle_closed & ~below & s.recent_nz;
     s.closed_count += ab_lane(idle_closed & below) ? 1u : 0u;
-    if (ab_any(forget)) {
+    if (ab_rare(forget)) {
         s.recent_open = ab_lane(forget) ? 0u : s.recent_open;
+        s.recent_nz &= ~forget;
         s.lvl = sq_level_compute(s, L);
     }
     if (L.track_delay_line) {
@@ -175,68 +191,80 @@ AB_FSM_FN void sq_avg(float cap, float& full, float& capped, float x) {
     capped = (capped >= cap && x >= cap) ? cap : vm; /* the reference short-circuits this case; the value is `cap` either way it is written */
 }
 
-/* Squelch::process_raw_sample (src/squelch.cpp:195-246) */
-AB_FSM_FN lmask sq_raw(SqRegs& s, const Lane& L, float x, float dly_new) {
-    lmask went_closed = 0;
-    if (s.quiet) {
-        /* update_current_state() when nothing is pending (:363-460): only the CLOSED lanes' closed-sample counter and the delay line move */
-        const lmask below = ab_ballot(s.closed_count < 1000u);
-        const lmask forget = s.cC & ~below & ab_ballot(s.recent_open != 0u);
-        s.closed_count += ab_lane(s.cC & below) ? 1u : 0u;
-        if (ab_any(forget)) {
-            s.recent_open = ab_lane(forget) ? 0u : s.recent_open;
-            s.lvl = sq_level_compute(s, L);
-        }
-        if (L.track_delay_line) {
-            s.tail = s.tail + 1 == AB_SQ_BUF ? 0 : s.tail + 1;
-            s.head = s.head + 1 == AB_SQ_BUF ? 0 : s.head + 1;
-        }
-    } else {
-        went_closed = sq_advance(s, L); /* evaluates the post-filter gate against buffer_[tail] BEFORE the tail moves */
-    }
-    s.dly = dly_new;                            /* ... everything after it sees the entry under the advanced tail */
-    s.sample_count++;
-    const lmask sweep = ab_ballot((s.sample_count & 15u) == 0u); /* calculate_noise_floor every 16th sample, :477-490 */
-    if (ab_any(sweep)) {
-        const float decay = 0.97f;
-        const float fresh = (float)(1.0 - (double)0.97f);
-        const float lo = s.pre_capped < s.noise_floor ? s.pre_capped : s.noise_floor;
-        const float nf = s.noise_floor * decay + lo * fresh + 1e-6f;
-        s.noise_floor = ab_lane(sweep) ? nf : s.noise_floor;
-        const float cap = ab_lane(L.m_manual) ? 1.5f * L.manual_level : 1.5f * L.normal_ratio * s.noise_floor;
-        s.cap = ab_lane(sweep) ? cap : s.cap;
+/* calculate_noise_floor(), every 16th sample (src/squelch.cpp:477-490).  sample_count_ starts at SIZE_MAX on every channel and counts
+ * every sample of every channel, so it is the same number on all lanes: the test is scalar and `sweep` is all lanes or none. */
+AB_FSM_FN void sq_noise_floor(SqRegs& s, const Lane& L) {
+    const float decay = 0.97f;
+    const float fresh = (float)(1.0 - (double)0.97f);
+    const float lo = s.pre_capped < s.noise_floor ? s.pre_capped : s.noise_floor;
+    s.noise_floor = s.noise_floor * decay + lo * fresh + 1e-6f;
+    s.cap = ab_lane(L.m_manual) ? 1.5f * L.manual_level : 1.5f * L.normal_ratio * s.noise_floor;
+    s.lvl = sq_level_compute(s, L);
+}
+
+/* Squelch::process_raw_sample (src/squelch.cpp:195-246) of a QUIET wavefront: every lane is CLOSED or OPEN and asks for nothing.
+ * update_current_state() (:363-460) then only counts the CLOSED lanes' closed samples and moves the delay line; afterwards the
+ * only requests a lane can raise are OPEN -> CLOSING (signal gone), OPEN -> LOW_SIGNAL_ABORT (:233-245) and CLOSED -> OPENING.
+ * Straight-line code but for three seldom-taken exits. */
+AB_FSM_FN void sq_raw_quiet(SqRegs& s, const Lane& L, float x, float dly_new) {
+    const lmask below = ab_ballot(s.closed_count < 1000u);
+    const lmask forget = s.cC & ~below & s.recent_nz;
+    s.closed_count += ab_lane(s.cC & below) ? 1u : 0u;
+    if (ab_rare(forget)) {
+        s.recent_open = ab_lane(forget) ? 0u : s.recent_open;
+        s.recent_nz &= ~forget;
         s.lvl = sq_level_compute(s, L);
     }
+    if (L.track_delay_line) {
+        s.tail = s.tail + 1 == AB_SQ_BUF ? 0 : s.tail + 1;
+        s.head = s.head + 1 == AB_SQ_BUF ? 0 : s.head + 1;
+    }
+    s.dly = dly_new;
+    s.sample_count++;
+    if (AB_UNLIKELY((s.sample_count & 15u) == 0u)) sq_noise_floor(s, L);
     sq_avg(s.cap, s.pre_full, s.pre_capped, x);
     if (L.may_post_filter && ab_any(L.m_lowpass)) {
         if (ab_lane(L.m_lowpass)) L.sqbuf[(long)s.head * L.S] = s.pre_capped * 0.9f; /* only ever read on the post-filter path */
     }
     const lmask sig = sq_has_signal(s, L);
-    if (s.quiet) {
-        /* the requests a steady lane can raise: OPEN -> CLOSING (signal gone) or LOW_SIGNAL_ABORT (:233-245), CLOSED -> OPENING */
+    const lmask low = s.cO & ab_ballot(!(x >= s.lvl));
+    const int run = s.low_count + 1;
+    const int idle = ab_lane(s.cO) ? 0 : s.low_count;
+    s.low_count = ab_lane(low) ? run : idle;
+    const lmask abort_now = low & ab_ballot(s.low_count >= 88); /* low_signal_abort_ */
+    /* an OPEN lane without signal or a CLOSED lane with one: the lanes whose state disagrees with `sig` */
+    const lmask any_req = ((sig ^ s.cO) & s.active) | abort_now;
+    if (ab_rare(any_req)) {
         const lmask to_closing = s.cO & ~sig;
-        const lmask to_opening = s.cC & sig;
-        const lmask low = s.cO & ab_ballot(!(x >= s.lvl));
-        s.low_count = ab_lane(low) ? s.low_count + 1 : (ab_lane(s.cO) ? 0 : s.low_count);
-        const lmask abort_now = low & ab_ballot(s.low_count >= 88); /* low_signal_abort_ */
-        const lmask any_req = to_closing | to_opening | abort_now;
-        if (ab_any(any_req)) {
-            s.nA = abort_now;
-            s.nCg = to_closing & ~abort_now;
-            s.nOg = to_opening;
-            s.nO &= ~any_req;
-            s.nC &= ~any_req;
-            s.quiet = false;
-        }
-        return went_closed;
+        s.nA = abort_now;
+        s.nCg = to_closing & ~abort_now;
+        s.nOg = s.cC & sig;
+        s.nO &= ~any_req;
+        s.nC &= ~any_req;
+        s.quiet = false;
     }
+}
+
+/* Squelch::process_raw_sample (src/squelch.cpp:195-246), general case.  Returns the lanes whose squelch just went CLOSED. */
+AB_FSM_FN lmask sq_raw_full(SqRegs& s, const Lane& L, float x, float dly_new) {
+    const lmask went_closed = sq_advance(s, L); /* evaluates the post-filter gate against buffer_[tail] BEFORE the tail moves */
+    s.dly = dly_new;                            /* ... everything after it sees the entry under the advanced tail */
+    s.sample_count++;
+    if ((s.sample_count & 15u) == 0u) sq_noise_floor(s, L);
+    sq_avg(s.cap, s.pre_full, s.pre_capped, x);
+    if (L.may_post_filter && ab_any(L.m_lowpass)) {
+        if (ab_lane(L.m_lowpass)) L.sqbuf[(long)s.head * L.S] = s.pre_capped * 0.9f;
+    }
+    const lmask sig = sq_has_signal(s, L);
     /* set_state() requests (:297-361), already clamped: OPEN -> CLOSING, CLOSED -> OPENING are legal as asked */
     const lmask to_closing = s.cO & ~sig;
     const lmask to_opening = s.cC & sig;
     /* low-signal abort (:233-245): LOW_SIGNAL_ABORT asked from OPENING is clamped to CLOSED, from CLOSING / OPEN it stands */
     const lmask counting = s.cOg | s.cCg | s.cO;
     const lmask low = counting & ab_ballot(!(x >= s.lvl));
-    s.low_count = ab_lane(low) ? s.low_count + 1 : (ab_lane(counting) ? 0 : s.low_count);
+    const int run = s.low_count + 1;
+    const int idle = ab_lane(counting) ? 0 : s.low_count;
+    s.low_count = ab_lane(low) ? run : idle;
     const lmask abort_now = low & ab_ballot(s.low_count >= 88); /* low_signal_abort_ */
     const lmask any_req = to_closing | to_opening | abort_now;
     if (ab_any(any_req)) {
@@ -248,6 +276,14 @@ AB_FSM_FN lmask sq_raw(SqRegs& s, const Lane& L, float x, float dly_new) {
     }
     s.quiet = sq_is_quiet(s);
     return went_closed;
+}
+
+AB_FSM_FN lmask sq_raw(SqRegs& s, const Lane& L, float x, float dly_new) {
+    if (AB_LIKELY(s.quiet)) {
+        sq_raw_quiet(s, L, x, dly_new);
+        return 0;
+    }
+    return sq_raw_full(s, L, x, dly_new);
 }
 
 AB_FSM_FN lmask sq_should_filter(const SqRegs& s) { return (sq_has_pre(s) | ~s.cC) & ~s.cA & s.active; } /* :136-138 */
@@ -270,7 +306,7 @@ AB_FSM_FN void sq_filtered(SqRegs& s, const Lane& L, lmask filt, float x) {
     s.post_full = ab_lane(run) ? full : s.post_full;
     s.post_capped = ab_lane(run) ? capped : s.post_capped;
     const lmask close = run & ab_ballot(capped < delayed);
-    if (ab_any(close)) { /* set_state(CLOSED): from OPEN that is clamped to CLOSING, from anywhere else it stands */
+    if (ab_rare(close)) { /* set_state(CLOSED): from OPEN that is clamped to CLOSING, from anywhere else it stands */
         s.nC = (s.nC & ~close) | (close & ~s.cO);
         s.nCg = (s.nCg & ~close) | (close & s.cO);
         s.nOg &= ~close;
@@ -289,8 +325,10 @@ AB_FSM_FN void sq_load(SqRegs& s, const Lane& L, const ChanState* sp, bool valid
     sq_set_next(s, valid ? sp->next : -1);
     sq_set_cur(s, valid ? sp->cur : -1);
     s.delay = sp->delay; s.low_count = sp->low_count;
-    s.head = sp->head; s.tail = sp->tail; s.sample_count = sp->sample_count; s.open_count = sp->open_count;
+    s.head = (int)ab_uniform((unsigned)sp->head); s.tail = (int)ab_uniform((unsigned)sp->tail); /* like sample_count_: the same on every channel */
+    s.sample_count = ab_uniform(sp->sample_count); s.open_count = sp->open_count;
     s.flappy_count = sp->flappy_count; s.recent_open = sp->recent_open; s.closed_count = sp->closed_count;
+    s.recent_nz = ab_ballot(valid && sp->recent_open != 0u);
     s.lvl = sq_level_compute(s, L);
     s.dly = 0.0f;
     s.quiet = sq_is_quiet(s);
