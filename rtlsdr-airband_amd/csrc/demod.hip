@@ -608,10 +608,18 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
     const long blk = wave >> 6;
     const float2* af = a.ct_af + (long)wave * B; /* this channel's batch, contiguous: 50 lanes fetch 400 consecutive bytes */
     unsigned long long* maskp = a.ct_mask + (blk * NG) * AB_SLOT_BLOCK + (wave & 63);
-    float2 cur = lane < TONE_GROUP ? af[lane] : make_float2(0.0f, 0.0f);
+    /* Step g + 1 is fetched while step g is worked through.  The loads are unconditional (lanes past the 50th re-read sample 49, the
+     * step after the last one re-reads the last): a load behind an `if` makes the compiler wait for everything in flight at the
+     * first use of the data -- right after it was asked for.  The verdict of a step is stored one step late, after the next fetch
+     * has been issued, so the wait at the top of a step never sits out a store that has only just left. */
+    const int ldlane = lane < TONE_GROUP ? lane : TONE_GROUP - 1;
+    float2 nxt = af[ldlane];
+    unsigned long long mask_prev = 0;
     for (int g = 0; g < NG; g++) {
-        float2 nxt = make_float2(0.0f, 0.0f);
-        if (g + 1 < NG && lane < TONE_GROUP) nxt = af[(g + 1) * TONE_GROUP + lane];
+        asm volatile("" ::"v"(nxt.x), "v"(nxt.y)); /* the data is needed now: the wait lands here, before the next fetch goes out */
+        const float2 cur = lane < TONE_GROUP ? nxt : make_float2(0.0f, 0.0f);
+        nxt = af[(g + 1 < NG ? g + 1 : NG - 1) * TONE_GROUP + ldlane];
+        if (g > 0 && lane == 0) maskp[(long)(g - 1) * AB_SLOT_BLOCK] = mask_prev;
         const float ax = cur.x;
         const unsigned fl = __float_as_uint(cur.y);
         unsigned long long mask = 0;
@@ -687,9 +695,9 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
                 if (tone) mask |= 1ull << u;
             }
         }
-        if (lane == 0) maskp[(long)g * AB_SLOT_BLOCK] = mask;
-        cur = nxt;
+        mask_prev = mask;
     }
+    if (lane == 0) maskp[(long)(NG - 1) * AB_SLOT_BLOCK] = mask_prev;
     if (t0) { qtab[lane] = q1f; qtab[AB_MAX_TONES + lane] = q2f; }
     if (t1) { qtab[2 * AB_MAX_TONES + lane] = q1s; qtab[3 * AB_MAX_TONES + lane] = q2s; }
     if (lane == 0) {
@@ -735,37 +743,48 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
     const float4* af = reinterpret_cast<const float4*>(a.ct_af + (long)(slot - a.ct_first_block * 64) * B);
     const unsigned long long* maskp = a.ct_mask + ((long)blockIdx.x * NG) * AB_SLOT_BLOCK + lane;
     const bool is_ct = (cc.flags & AB_F_CTCSS) != 0;
-    constexpr int PIECE = 8; /* samples fetched ahead */
+    constexpr int PIECE = 8; /* samples per fetch; WAVE_BATCH = 1000 / 2000 is a whole number of them */
+    /* A piece = 8 (audio, flags) pairs + the tone kernel's verdict masks of the one or two 50-sample steps it lies in.  Piece k + 1
+     * flies while piece k is worked through; every load is unconditional (the piece after the last re-reads the last one, a lane
+     * without CTCSS reads a mask nobody wrote and ignores it), the wait sits right at the top, and a finished output run leaves
+     * only after the next fetch is out -- see demod_wave for why each of these matters. */
     float4 nxt[PIECE / 2];
+    unsigned long long nm_lo, nm_hi;
+    auto fetch = [&](int j) {
 #pragma unroll
-    for (int q = 0; q < PIECE / 2; q++) nxt[q] = af[q];
-    unsigned long long mask = ~0ull;
-    int g = -1, jg = TONE_GROUP; /* tone-kernel step of the current sample and the sample's position in it */
+        for (int q = 0; q < PIECE / 2; q++) nxt[q] = af[j / 2 + q];
+        const int gl = j / TONE_GROUP;
+        nm_lo = maskp[(long)gl * AB_SLOT_BLOCK];
+        nm_hi = maskp[(long)(gl + 1 < NG ? gl + 1 : NG - 1) * AB_SLOT_BLOCK];
+    };
+    fetch(0);
+    int jg = 0; /* position of the current sample in its tone-kernel step */
     for (int j0 = 0; j0 < B; j0 += PIECE) {
+#pragma unroll
+        for (int q = 0; q < PIECE / 2; q++) asm volatile("" ::"v"(nxt[q].x), "v"(nxt[q].y), "v"(nxt[q].z), "v"(nxt[q].w));
+        asm volatile("" ::"v"(nm_lo), "v"(nm_hi));
         float4 cur[PIECE / 2];
 #pragma unroll
         for (int q = 0; q < PIECE / 2; q++) cur[q] = nxt[q];
-        if (j0 + PIECE < B) {
-#pragma unroll
-            for (int q = 0; q < PIECE / 2; q++) nxt[q] = af[(j0 + PIECE) / 2 + q];
-        }
+        unsigned long long mask = is_ct ? nm_lo : ~0ull;
+        const unsigned long long mask_hi = is_ct ? nm_hi : ~0ull;
+        fetch(j0 + PIECE < B ? j0 + PIECE : B - PIECE);
+        if (j0 > 0 && (j0 % RUN) == 0) wave_flush(w);
         if ((j0 % RUN) == 0) w.j0 = j0;
 #pragma unroll
         for (int u = 0; u < PIECE; u++) {
-            if (jg == TONE_GROUP) { /* wave-uniform: every lane is on the same sample */
-                jg = 0;
-                g++;
-                mask = is_ct ? maskp[(long)g * AB_SLOT_BLOCK] : ~0ull;
-            }
             const float4 p = cur[u >> 1];
             const float x = (u & 1) ? p.z : p.x;
             const unsigned f = __float_as_uint((u & 1) ? p.w : p.y);
             const bool tone = ((mask >> jg) & 1ull) != 0;
             emit_sample(a, cc, o, w, iqout, trace, j0 + u, (f & FL_AUDIO) != 0, (f & FL_FADE) != 0, tone, (int)((f >> FL_STATE_SHIFT) & 7u), x, 0.0f, 0.0f, false);
-            jg++;
+            if (++jg == TONE_GROUP) { /* wave-uniform: every lane is on the same sample */
+                jg = 0;
+                mask = mask_hi;
+            }
         }
-        if (((j0 + PIECE) % RUN) == 0) wave_flush(w);
     }
+    if ((B % RUN) == 0) wave_flush(w); /* the last whole run (a short one is handled below) */
     if ((B % RUN) != 0) wave_flush(w, B % RUN);
     if (o.axc != ' ') sp->active_counter++;
     sp->axc_prev = sp->axc;
