@@ -69,6 +69,16 @@ constexpr __host__ __device__ int c_sub(int hop_bytes, int win_bytes = 1024) { r
 /* AL: alignment every hop start is known to have inside the dongle's span (16, 8 or 4 bytes).  2.4 MS/s, the other common RTL-SDR
  * rate, hops 300 (WAVE_RATE 16000) or 600 bytes (8000): the stream is still staged in aligned 16-byte pieces -- the LDS image simply
  * starts up to 15 bytes before the first hop -- and the A fragments are assembled from 8- or 4-byte LDS reads. */
+/* s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the instruction takes an immediate */
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+#define AB_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        AB_W(1) AB_W(2) AB_W(3) AB_W(4) AB_W(5) AB_W(6) AB_W(7) AB_W(8) AB_W(9) AB_W(10) AB_W(11) AB_W(12) AB_W(13) AB_W(14)
+#undef AB_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
 template <int AL>
 __device__ __forceinline__ v4i lds_read16(const uint8_t* p) {
     if (AL >= 16) return *reinterpret_cast<const v4i*>(p);
@@ -200,27 +210,26 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     int cur = 0;
 
     const int row_l = lane & 15, grp = lane >> 4;
+    /* store instructions a whole tile issues (each is skipped when no lane wants it): |bin| = one 16-byte store, raw I/Q = two */
+    const int k_tile = ((__ballot(!(col & 1) && ch_valid && want_mag) != 0ull) ? 1 : 0) + ((__ballot(!(col & 1) && ch_valid && want_iq) != 0ull) ? 2 : 0);
+    int k_prev = 0; /* of them, issued since the previous wait (only whole tiles are counted: fewer than the truth is safe) */
     for (int st = st_begin; st < st_end; st++) {
         uint8_t* buf = lds + cur * lds_per_buf;
+        /* Vector-memory operations complete in issue order, so "at most N outstanding" proves step st has landed as soon as N operations
+         * YOUNGER than its transfer are known to have been issued: the n_dma pieces of step st + 1 (three buffers), and the output stores
+         * of the tiles computed since (k_prev instructions, counted below).  Leaving the stores out of N -- they are the youngest of all --
+         * would make every wait sit out their write acknowledgements, or, with three buffers, most of the step-(st+1) transfer. */
         if (nbuf == 3) {
-            /* Loads complete in issue order, so once at most n_dma vector-memory operations are outstanding none of them
-             * can belong to step st: the step-(st+1) transfer alone has n_dma pieces, all younger.  (Stores issued in
-             * between only add to the count, i.e. make this wait conservative.) */
-            switch (n_dma) {
-                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            }
-            if (st + 1 >= st_end) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* last step: nothing younger to hide behind */
+            if (st + 1 >= st_end) wait_vmcnt(k_prev); /* last step: only the stores are younger */
+            else wait_vmcnt(n_dma + k_prev);
             int nb = cur + 2;
             nb = nb >= 3 ? nb - 3 : nb;
             if (st + 2 < st_end) stage(st + 2, lds + nb * lds_per_buf); /* two steps ahead: the buffer step st-1 just left */
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this step's bytes have landed in LDS */
+            wait_vmcnt(k_prev); /* this step's bytes have landed in LDS */
             if (st + 1 < st_end) stage(st + 1, lds + (cur ^ 1) * lds_per_buf); /* next step streams in under this step's MFMAs */
         }
+        k_prev = 0;
       for (int sb = 0; sb < sub; sb++) {
         const int t = st * sub + sb;
         if (t >= tiles_total) break;
@@ -310,16 +319,17 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
         float im4[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) im4[r] = __shfl_xor(val[r], 1);
+        const bool whole_tile = t * TILE_HOPS - shift >= 0 && t * TILE_HOPS - shift + TILE_HOPS <= a.n_hops; /* wave-uniform: all 16 hops of the tile are stored */
 #ifdef AB_DFT_NO_STORE
         if (!(col & 1) && ch_valid && val[0] == 1.2345e-30f) {
 #else
+        if (whole_tile) k_prev += k_tile;
         if (!(col & 1) && ch_valid) {
 #endif
             int pt = ptile0 + t;
             pt = pt >= ring_tiles16 ? pt - ring_tiles16 : pt;
             const long off = slot_base + ab_tile_off(pt * TILE_HOPS + grp * 4); /* the lane's 4 hops never straddle a ring tile (4, 8 or 16 rows) */
             const int hop_first = t * TILE_HOPS - shift + grp * 4;
-            const bool whole_tile = t * TILE_HOPS - shift >= 0 && t * TILE_HOPS - shift + TILE_HOPS <= a.n_hops; /* wave-uniform: all 16 hops of the tile are stored */
             float m4[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) m4[r] = __builtin_amdgcn_sqrtf(val[r] * val[r] + im4[r] * im4[r]); /* v_sqrt_f32, 1 ulp: stage 1 is tolerance-bound anyway */
