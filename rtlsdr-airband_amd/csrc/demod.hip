@@ -583,7 +583,9 @@ __global__ __launch_bounds__(64, KIND == AB_KIND_AM ? AB_AM_WAVES : KIND == AB_K
  * SIMD hide the dependent-issue latency of the recurrence. */
 __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
     __shared__ float power[4][64];
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    /* the wave index is the same number on every lane: told so, the compiler keeps the channel's constants and counters in scalar
+     * registers and fetches them with scalar loads */
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
     const int lane = threadIdx.x & 63;
     if (wave >= a.ct_n_blocks * 64) return;
     const int slot = a.ct_first_block * 64 + wave;
