@@ -610,18 +610,21 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
     const long blk = wave >> 6;
     const float2* af = a.ct_af + (long)wave * B; /* this channel's batch, contiguous: 50 lanes fetch 400 consecutive bytes */
     unsigned long long* maskp = a.ct_mask + (blk * NG) * AB_SLOT_BLOCK + (wave & 63);
-    /* Step g + 1 is fetched while step g is worked through.  The loads are unconditional (lanes past the 50th re-read sample 49, the
-     * step after the last one re-reads the last): a load behind an `if` makes the compiler wait for everything in flight at the
-     * first use of the data -- right after it was asked for.  The verdict of a step is stored one step late, after the next fetch
-     * has been issued, so the wait at the top of a step never sits out a store that has only just left. */
+    /* The batch is walked DEPTH steps at a time: the (audio, flags) pairs of the next DEPTH steps are in flight while the current
+     * DEPTH are worked through.  A channel whose squelch is closed does next to nothing per step, so with one step ahead its
+     * wavefront walked the batch at one memory round trip per step.  The loads are unconditional (lanes past the 50th re-read
+     * sample 49, steps past the last re-read the last): a load behind an `if` makes the compiler wait for everything in flight at
+     * the first use of the data.  The verdicts of a group of steps are stored after the next group's loads have been issued, so
+     * the wait at the top of a group never sits out stores that have only just left. */
+    constexpr int DEPTH = 10; /* divides WAVE_BATCH / TONE_GROUP = 20 / 40 */
     const int ldlane = lane < TONE_GROUP ? lane : TONE_GROUP - 1;
-    float2 nxt = af[ldlane];
-    unsigned long long mask_prev = 0;
-    for (int g = 0; g < NG; g++) {
-        asm volatile("" ::"v"(nxt.x), "v"(nxt.y)); /* the data is needed now: the wait lands here, before the next fetch goes out */
-        const float2 cur = lane < TONE_GROUP ? nxt : make_float2(0.0f, 0.0f);
-        nxt = af[(g + 1 < NG ? g + 1 : NG - 1) * TONE_GROUP + ldlane];
-        if (g > 0 && lane == 0) maskp[(long)(g - 1) * AB_SLOT_BLOCK] = mask_prev;
+    auto fetch = [&](int g) { return af[(g < NG ? g : NG - 1) * TONE_GROUP + ldlane]; };
+    float2 ahead[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; k++) ahead[k] = fetch(k);
+    unsigned long long verdict[DEPTH]; /* wave-uniform: scalar registers */
+    auto step = [&](const int g, const float2 got, unsigned long long& mask_out) {
+        const float2 cur = lane < TONE_GROUP ? got : make_float2(0.0f, 0.0f);
         const float ax = cur.x;
         const unsigned fl = __float_as_uint(cur.y);
         unsigned long long mask = 0;
@@ -697,9 +700,27 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
                 if (tone) mask |= 1ull << u;
             }
         }
-        mask_prev = mask;
+        mask_out = mask;
+    };
+    for (int g = 0; g < NG; g += DEPTH) {
+        float2 now[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) asm volatile("" ::"v"(ahead[k].x), "v"(ahead[k].y)); /* the data is needed now: the wait lands here, before the next fetches go out */
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) now[k] = ahead[k];
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) ahead[k] = fetch(g + DEPTH + k);
+        if (g > 0 && lane == 0) {
+#pragma unroll
+            for (int k = 0; k < DEPTH; k++) maskp[(long)(g - DEPTH + k) * AB_SLOT_BLOCK] = verdict[k];
+        }
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) step(g + k, now[k], verdict[k]);
     }
-    if (lane == 0) maskp[(long)(NG - 1) * AB_SLOT_BLOCK] = mask_prev;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) maskp[(long)(NG - DEPTH + k) * AB_SLOT_BLOCK] = verdict[k];
+    }
     if (t0) { qtab[lane] = q1f; qtab[AB_MAX_TONES + lane] = q2f; }
     if (t1) { qtab[2 * AB_MAX_TONES + lane] = q1s; qtab[3 * AB_MAX_TONES + lane] = q2s; }
     if (lane == 0) {

@@ -7,7 +7,7 @@ if [ -n "$TESTS" ]; then timeout 900 python -m pytest tests -x -q -m gpu -k "$TE
 timeout 300 python bench.py --steps 30 --no-cpu-baseline --no-traffic --verify 8 2>/dev/null | tail -1 > $O/bench.json
 python -c "import json; j=json.load(open('$O/bench.json')); print('RESULT', j['ms_per_step'], {k:round(x,3) for k,x in j['stage_ms'].items()}, j.get('verified_dongles'), j['config']['build_defines'])"
 AIRBAND_BENCH_FLAGS=8 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --no-cpu-baseline --no-traffic --verify 0 --steps 6 --warmup 2 > /dev/null 2>&1
-AIRBAND_BENCH_FLAGS=8 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc -- python bench.py --no-cpu-baseline --no-traffic --verify 0 --steps 2 --warmup 1 > $O/pmc.log 2>&1
+AIRBAND_BENCH_FLAGS=8 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc -- python bench.py --no-cpu-baseline --no-traffic --verify 0 --steps 2 --warmup 1 > $O/pmc.log 2>&1
 python - <<'PY'
 import csv,glob,collections
 for f in glob.glob("gpurun_out/r02j/kt/*/*kernel_stats.csv"):
