@@ -677,10 +677,11 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         a.n_items = (int)p.item_dev.size();
         a.fft_size = p.fft_size;
         a.hop_bytes = (int)h->hop_bytes;
-        const int win_bytes = 2 * (p.fft_size > 512 ? 512 : p.fft_size) * p.dev[0].bytes_per_sample; /* per window piece (fft_size > 512: pieces of 512 samples) */
-        a.lds_per_buf = dft_lds_per_buf((int)h->hop_bytes, win_bytes);
-        a.nbuf = dft_nbuf((int)h->hop_bytes, win_bytes);
-        a.sub = dft_sub((int)h->hop_bytes, win_bytes);
+        const int win_bytes = 2 * p.fft_size * p.dev[0].bytes_per_sample; /* the whole window is staged, also when it is worked on in pieces of 512 samples */
+        const int np = p.fft_size > 512 ? p.fft_size / 512 : 1;
+        a.lds_per_buf = dft_lds_per_buf((int)h->hop_bytes, win_bytes, np);
+        a.nbuf = dft_nbuf((int)h->hop_bytes, win_bytes, np);
+        a.sub = dft_sub((int)h->hop_bytes, win_bytes, np);
         a.row0 = h->row0_front;
         a.ring_rows = h->R;
         a.first_row = first ? 0 : AB_AGC_EXTRA;

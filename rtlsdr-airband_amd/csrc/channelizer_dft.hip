@@ -49,11 +49,16 @@ constexpr __host__ __device__ int c_lds_for(int hop_bytes, int sub, int win_byte
     return ((TILE_HOPS * sub - 1) * hop_bytes + win_bytes + ((hop_bytes & 15) ? 16 : 0) + 1023) / 1024 * 1024; /* + the up-to-15 bytes in front of an unaligned step */
 }
 /* three small buffers (two steps in flight) when eight waves of them fit a CU's 160 KiB, else two larger ones */
-constexpr __host__ __device__ int c_nbuf(int hop_bytes, int win_bytes = 1024) { return 3 * c_lds_for(hop_bytes, 1, win_bytes) * 8 <= 160 * 1024 ? 3 : 2; }
-constexpr __host__ __device__ int c_lds_per_buf(int hop_bytes, int win_bytes = 1024) {
-    return c_nbuf(hop_bytes, win_bytes) == 3 ? c_lds_for(hop_bytes, 1, win_bytes) : c_lds_for(hop_bytes, c_sub_tiles(hop_bytes), win_bytes);
+/* (np = wavefronts sharing the buffers: fft_size > 512 runs one wave per window piece of 512 samples, 8 / np workgroups per CU -- fewer
+ * streams per CU, so a shared step is made two tiles long when three such buffers fit: more bytes in flight, half the barriers) */
+constexpr __host__ __device__ int c_nbuf(int hop_bytes, int win_bytes = 1024, int np = 1) { return 3 * c_lds_for(hop_bytes, 1, win_bytes) * (8 / np) <= 152 * 1024 ? 3 : 2; }
+constexpr __host__ __device__ bool c_long3(int hop_bytes, int win_bytes, int np) {
+    return np > 1 && c_sub_tiles(hop_bytes) >= 2 && 3 * c_lds_for(hop_bytes, 2, win_bytes) * (8 / np) <= 152 * 1024;
 }
-constexpr __host__ __device__ int c_sub(int hop_bytes, int win_bytes = 1024) { return c_nbuf(hop_bytes, win_bytes) == 3 ? 1 : c_sub_tiles(hop_bytes); }
+constexpr __host__ __device__ int c_sub(int hop_bytes, int win_bytes = 1024, int np = 1) {
+    return c_long3(hop_bytes, win_bytes, np) ? 2 : c_nbuf(hop_bytes, win_bytes, np) == 3 ? 1 : c_sub_tiles(hop_bytes);
+}
+constexpr __host__ __device__ int c_lds_per_buf(int hop_bytes, int win_bytes = 1024, int np = 1) { return c_lds_for(hop_bytes, c_sub(hop_bytes, win_bytes, np), win_bytes); }
 
 /* EDGE_HI_ZERO: the most significant coefficient digit is zero for every k-step in which the window is below 2^-8
  * (steps 0,1,14,15 of the 7-term cosine window at N = 512 -- checked on the host, see build_dft_tables): those four
@@ -74,6 +79,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
     switch (n) {
 #define AB_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
         AB_W(1) AB_W(2) AB_W(3) AB_W(4) AB_W(5) AB_W(6) AB_W(7) AB_W(8) AB_W(9) AB_W(10) AB_W(11) AB_W(12) AB_W(13) AB_W(14)
+        AB_W(15) AB_W(16) AB_W(17) AB_W(18) AB_W(19) AB_W(20) AB_W(21) AB_W(22) AB_W(23) AB_W(24)
 #undef AB_W
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
@@ -91,10 +97,18 @@ __device__ __forceinline__ v4i lds_read16(const uint8_t* p) {
     return (v4i){q[0], q[1], q[2], q[3]};
 }
 
-template <int FFT_N, bool EDGE_HI_ZERO, int HOPB, bool S16, int AL>
-__global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
+/* NP: window pieces of FFT_N samples = wavefronts per workgroup.  fft_size 1024 / 2048:
+ *   X[bin] = sum over pieces p of  sum_{n in piece p} x[n] w[n] e^{-2 pi i bin n / N}
+ * -- every piece is a 512-sample contraction of the same kind with its own coefficient table, 32 / 64 k-steps of B fragments do not
+ * fit one wave's registers, so wave p of the workgroup holds piece p's table.  The waves share ONE staged copy of the stream (wave 0
+ * runs the DMA; a workgroup barrier hands each step over), compute their piece's partial sums for the same 16 hops, and wave 0
+ * adds the partials up (through LDS) and writes the outputs: the stream is read once whatever the window length. */
+template <int FFT_N, bool EDGE_HI_ZERO, int HOPB, bool S16, int AL, int NP = 1>
+__global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) {
     constexpr int BPS = S16 ? 2 : 1;              /* bytes per sample component        */
-    constexpr int WIN_BYTES = 2 * FFT_N * BPS;    /* bytes per window                  */
+    constexpr int WIN_BYTES = 2 * FFT_N * BPS;    /* bytes per window piece            */
+    constexpr int WIN_ALL = WIN_BYTES * NP;       /* bytes per window                  */
+    static_assert(NP == 1 || (HOPB == 0 && FFT_N == 512), "window pieces are 512 samples long; the hop-specialised variants are single-piece");
     constexpr int KSTEPS = 2 * FFT_N / 64;        /* MFMA k-steps per window and plane */
     static_assert(KSTEPS == 16 || KSTEPS == 8, "B fragments (3 digits x KSTEPS x 4 VGPRs) must fit beside everything else: fft_size 256 or 512");
     static_assert(HOPB == 0 || (FFT_N == 512 && !S16 && AL == 16), "the hop-specialised variants are built for u8 at fft_size 512, 16-byte aligned hops");
@@ -103,7 +117,8 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
 
     /* one wavefront per workgroup: waves share nothing, and a 64-thread block lets the LDS budget (two staging
      * buffers per wave) rather than the block shape decide how many waves a CU holds */
-    const int lane = threadIdx.x;
+    const int lane = NP > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const int piece = NP > 1 ? (int)(threadIdx.x >> 6) : 0; /* wave p of the workgroup: window piece p */
     /* XCD-aware placement: workgroup b runs on XCD b % 8 (observed dispatch order; speed only).  16 consecutive
      * dongles write neighbouring slots of the same 128-byte lines, so they are given to the SAME XCD and meet in
      * one L2: inside every group of 128 dongles, workgroup i*8 + x takes dongle x*16 + i. */
@@ -122,7 +137,7 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     const int sub = HOPB ? c_sub(HOPB ? HOPB : 64) : a.sub;
     const int lds_per_buf = HOPB ? c_lds_per_buf(HOPB ? HOPB : 64) : a.lds_per_buf;
     const int step_hops = TILE_HOPS * sub;
-    const int buf_bytes = (step_hops - 1) * hop_bytes + WIN_BYTES + (AL >= 16 ? 0 : 16);
+    const int buf_bytes = (step_hops - 1) * hop_bytes + WIN_ALL + (AL >= 16 ? 0 : 16);
     uint8_t* lds = lds_all;                               /* two buffers of lds_per_buf bytes */
 
     /* MFMA tiles are aligned to the 16-row tiles of the output rings: tile t covers hops [16 t - shift, 16 t - shift + 16);
@@ -143,12 +158,11 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
 
     const uint8_t* src = a.iq + (long)d * a.iq_stride;    /* first byte of this batch's first hop */
     /* bytes of the batch span that may be read, rounded up to whole 16-byte pieces (geometry.lookahead_bytes includes the round-up) */
-    const long span_end = ((long)(a.n_hops - 1) * hop_bytes + WIN_BYTES + 15) & ~15L;
+    const long span_end = ((long)(a.n_hops - 1) * hop_bytes + WIN_ALL + 15) & ~15L;
 
     /* ---- B fragments: 3 digits x 16 k-steps, resident for the whole wave ---------------------------------- */
-    /* fft_size > 512: the window is cut into n_pass pieces of 512 samples, one launch per piece (see launch_channelizer_dft);
-     * each piece has its own coefficient table */
-    const int bset = a.item_bset[item] * a.n_pass + a.pass;
+    /* fft_size > 512: each window piece has its own coefficient table */
+    const int bset = a.item_bset[item] * NP + piece;
     const v4i* btab = reinterpret_cast<const v4i*>(a.bfrag) + (long)bset * 3 * KSTEPS * 64 + lane;
     v4i b0[KSTEPS], b1[KSTEPS], b2[KSTEPS];
 #pragma unroll
@@ -205,8 +219,12 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
     };
     /* staging ring of nbuf buffers: step st lives in buffer (st - st_begin) % nbuf; nbuf - 1 steps are in flight */
     const int nbuf = HOPB ? c_nbuf(HOPB ? HOPB : 64) : a.nbuf;
-    stage(st_begin, lds);
-    if (nbuf == 3 && st_begin + 1 < st_end) stage(st_begin + 1, lds + lds_per_buf);
+    /* partial sums of pieces 1 .. NP-1 on their way to wave 0: [tile parity][piece - 1][lane] x 4 floats, behind the staging buffers */
+    float4* exch = reinterpret_cast<float4*>(lds_all + nbuf * lds_per_buf);
+    if (piece == 0) {
+        stage(st_begin, lds);
+        if (nbuf == 3 && st_begin + 1 < st_end) stage(st_begin + 1, lds + lds_per_buf);
+    }
     int cur = 0;
 
     const int row_l = lane & 15, grp = lane >> 4;
@@ -219,15 +237,21 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
          * YOUNGER than its transfer are known to have been issued: the n_dma pieces of step st + 1 (three buffers), and the output stores
          * of the tiles computed since (k_prev instructions, counted below).  Leaving the stores out of N -- they are the youngest of all --
          * would make every wait sit out their write acknowledgements, or, with three buffers, most of the step-(st+1) transfer. */
+        /* NP > 1: wave 0 runs the transfers and the waits; the barrier hands step st to the other waves and tells wave 0 that they
+         * are done with the buffer the next transfer overwrites (they read it in step st - 1) */
         if (nbuf == 3) {
-            if (st + 1 >= st_end) wait_vmcnt(k_prev); /* last step: only the stores are younger */
-            else wait_vmcnt(n_dma + k_prev);
+            if (piece == 0) {
+                if (st + 1 >= st_end) wait_vmcnt(k_prev); /* last step: only the stores are younger */
+                else wait_vmcnt(n_dma + k_prev);
+            }
+            if (NP > 1) __syncthreads();
             int nb = cur + 2;
             nb = nb >= 3 ? nb - 3 : nb;
-            if (st + 2 < st_end) stage(st + 2, lds + nb * lds_per_buf); /* two steps ahead: the buffer step st-1 just left */
+            if (piece == 0 && st + 2 < st_end) stage(st + 2, lds + nb * lds_per_buf); /* two steps ahead: the buffer step st-1 just left */
         } else {
-            wait_vmcnt(k_prev); /* this step's bytes have landed in LDS */
-            if (st + 1 < st_end) stage(st + 1, lds + (cur ^ 1) * lds_per_buf); /* next step streams in under this step's MFMAs */
+            if (piece == 0) wait_vmcnt(k_prev); /* this step's bytes have landed in LDS */
+            if (NP > 1) __syncthreads();
+            if (piece == 0 && st + 1 < st_end) stage(st + 1, lds + (cur ^ 1) * lds_per_buf); /* next step streams in under this step's MFMAs */
         }
         k_prev = 0;
       for (int sb = 0; sb < sub; sb++) {
@@ -237,7 +261,7 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
         v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
         float val[4];
         if (!S16) {
-        const uint8_t* arow = buf + delta + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 16;
+        const uint8_t* arow = buf + delta + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 16 + piece * WIN_BYTES;
         /* A fragments are fetched two k-steps ahead of the MFMAs that consume them, so the LDS latency (and the 2-way
          * bank conflict of the strided rows) hides behind six MFMAs instead of stalling in front of them */
         v4i av[KSTEPS];
@@ -267,7 +291,7 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
         } else {
         /* CS16: plane k-step s of the lane = 16 plane bytes = 8 samples x (I, Q) = 32 raw bytes [Ilo Ihi Qlo Qhi] x 8 */
         v4i hc0 = {0, 0, 0, 0}, hc1 = {0, 0, 0, 0}, hc2 = {0, 0, 0, 0}; /* high-byte plane */
-        const uint8_t* arow = buf + delta + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 32;
+        const uint8_t* arow = buf + delta + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 32 + piece * WIN_BYTES;
         v4i ra[2], rb[2]; /* raw 32 bytes of k-step s in (ra, rb)[s & 1]; the next k-step is fetched under this one's MFMAs */
         ra[0] = lds_read16<AL>(arow);
         rb[0] = lds_read16<AL>(arow + 16);
@@ -302,18 +326,17 @@ __global__ __launch_bounds__(64, 2) void channelizer_dft_kernel(DftArgs a) {
             val[r] = (float)((h * 256.0 + l + corr) * unscale);
         }
         }
-        if (a.n_pass > 1) { /* wave-uniform.  Partial sums of the window pieces travel through the raw-I/Q ring (every slot has a row there) */
-            int ptp = ptile0 + t;
-            ptp = ptp >= ring_tiles16 ? ptp - ring_tiles16 : ptp;
-            float* part = reinterpret_cast<float*>(a.iq_bins + slot_base + ab_tile_off(ptp * TILE_HOPS + grp * 4)) + (col & 1);
-            const int hf = t * TILE_HOPS - shift + grp * 4;
+        if (NP > 1) { /* the other pieces' partial sums (same lane layout) reach wave 0 through LDS; two areas alternate so that a
+                         wave ahead by a tile never overwrites what wave 0 is still adding up */
+            float4* ex = exch + (t & 1) * (NP - 1) * 64;
+            if (piece > 0) ex[(piece - 1) * 64 + lane] = make_float4(val[0], val[1], val[2], val[3]);
+            __syncthreads();
+            if (piece > 0) continue;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const bool live = ch_valid && hf + r >= 0 && hf + r < a.n_hops;
-                if (a.pass > 0 && live) val[r] += part[2 * r];
-                if (a.pass + 1 < a.n_pass && live) part[2 * r] = val[r];
+            for (int q = 0; q < NP - 1; q++) {
+                const float4 o = ex[q * 64 + lane];
+                val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
             }
-            if (a.pass + 1 < a.n_pass) continue; /* only the last piece produces |bin| / raw I/Q */
         }
         /* lane pairs (2ch, 2ch+1) hold (re, im) of the same hop; even lanes write 4 consecutive rows of their slot */
         float im4[4];
@@ -380,48 +403,39 @@ bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch) {
     return false;
 }
 
-/* win_bytes = 2 * fft_size * bytes per sample component */
-int dft_sub(int hop_bytes, int win_bytes) { return c_sub(hop_bytes, win_bytes); }
-int dft_nbuf(int hop_bytes, int win_bytes) { return c_nbuf(hop_bytes, win_bytes); }
-int dft_lds_per_buf(int hop_bytes, int win_bytes) { return c_lds_per_buf(hop_bytes, win_bytes); }
+/* win_bytes = bytes of a whole window, np = its pieces of 512 samples (1 up to fft_size 512) */
+int dft_sub(int hop_bytes, int win_bytes, int np) { return c_sub(hop_bytes, win_bytes, np); }
+int dft_nbuf(int hop_bytes, int win_bytes, int np) { return c_nbuf(hop_bytes, win_bytes, np); }
+int dft_lds_per_buf(int hop_bytes, int win_bytes, int np) { return c_lds_per_buf(hop_bytes, win_bytes, np); }
 
-template <int FFT_N, int HOPB, bool S16, int AL>
+template <int FFT_N, int HOPB, bool S16, int AL, int NP = 1>
 static void launch_al(const DftArgs& a, hipStream_t stream) {
-    const long waves = (long)a.n_items * a.splits;
-    const size_t lds = (size_t)a.nbuf * a.lds_per_buf;
+    const long groups = (long)a.n_items * a.splits;
+    const size_t lds = (size_t)a.nbuf * a.lds_per_buf + (NP > 1 ? 2 * (NP - 1) * 64 * sizeof(float4) : 0);
     if (a.edge_hi_zero)
-        hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, true, HOPB, S16, AL>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, true, HOPB, S16, AL, NP>), dim3((unsigned)groups), dim3(64 * NP), lds, stream, a);
     else
-        hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, false, HOPB, S16, AL>), dim3((unsigned)waves), dim3(64), lds, stream, a);
+        hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, false, HOPB, S16, AL, NP>), dim3((unsigned)groups), dim3(64 * NP), lds, stream, a);
 }
 
-template <int FFT_N, bool S16>
+template <int FFT_N, bool S16, int NP = 1>
 static void launch_generic(const DftArgs& a, hipStream_t stream) {
-    if ((a.hop_bytes & 15) == 0) return launch_al<FFT_N, 0, S16, 16>(a, stream);
-    if ((a.hop_bytes & 7) == 0) return launch_al<FFT_N, 0, S16, 8>(a, stream);
-    launch_al<FFT_N, 0, S16, 4>(a, stream);
+    if ((a.hop_bytes & 15) == 0) return launch_al<FFT_N, 0, S16, 16, NP>(a, stream);
+    if ((a.hop_bytes & 7) == 0) return launch_al<FFT_N, 0, S16, 8, NP>(a, stream);
+    launch_al<FFT_N, 0, S16, 4, NP>(a, stream);
 }
 
 static void launch_one_piece(const DftArgs& a, hipStream_t stream);
 
 void launch_channelizer_dft(const DftArgs& a0, hipStream_t stream) {
-    if (a0.fft_size > 512) {
-        /* fft_size 1024 / 2048: X[bin] = sum over window pieces p of  sum_{n in piece p} x[n] w[n] e^{-2 pi i bin n / N}: every piece is a
-         * 512-sample contraction of the same kind (own coefficient table, input 1024 bytes further on), run as its own launch; the partial
-         * sums travel through the raw-I/Q ring as floats (1e-7 relative: stage 1 is tolerance-bound).  The stream is read once per piece. */
-        DftArgs a = a0;
-        a.n_pass = a0.fft_size / 512;
-        a.fft_size = 512;
-        for (int p = 0; p < a.n_pass; p++) {
-            a.pass = p;
-            a.iq = a0.iq + (long)p * 1024;
-            launch_one_piece(a, stream);
-        }
-        return;
-    }
     DftArgs a = a0;
     a.n_pass = 1;
     a.pass = 0;
+    if (a0.fft_size > 512) { /* one wavefront per window piece of 512 samples (u8 only, see dft_supported) */
+        a.fft_size = 512;
+        if (a0.fft_size == 1024) return launch_generic<512, false, 2>(a, stream);
+        return launch_generic<512, false, 4>(a, stream);
+    }
     launch_one_piece(a, stream);
 }
 

@@ -127,9 +127,9 @@ struct SiggenArgs {
 void launch_channelizer_fft(const ChannelizerArgs& a, hipStream_t stream);
 size_t fft_lds_bytes(int fft_log, int hop_samples, int bytes_per_sample); /* dynamic LDS per workgroup; must stay <= 64 KiB */
 bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch);
-int dft_lds_per_buf(int hop_bytes, int win_bytes);
-int dft_sub(int hop_bytes, int win_bytes);
-int dft_nbuf(int hop_bytes, int win_bytes);
+int dft_lds_per_buf(int hop_bytes, int win_bytes, int np);
+int dft_sub(int hop_bytes, int win_bytes, int np);
+int dft_nbuf(int hop_bytes, int win_bytes, int np);
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream);
 /* side: 3 extra streams, ev: 4 events (fork + 3 joins); both may be null -> everything on `stream`, one kind after the other */
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev);

@@ -479,7 +479,8 @@ def _convert(iq_u8, sfmt, capi, s16_gain=200.0):
     ("SFMT_S8", 9, 2_560_000, 8000), ("SFMT_S16", 9, 2_560_000, 16000), ("SFMT_F32", 9, 2_560_000, 16000),
     ("SFMT_U8", 8, 2_560_000, 16000), ("SFMT_U8", 10, 2_560_000, 8000), ("SFMT_U8", 11, 2_560_000, 16000), ("SFMT_S16", 13, 2_560_000, 8000),
     ("SFMT_U8", 9, 2_400_000, 16000), ("SFMT_U8", 9, 2_400_000, 8000), ("SFMT_U8", 9, 1_024_000, 8000), ("SFMT_S16", 9, 2_560_000, 8000), ("SFMT_S16", 8, 2_048_000, 16000),
-    ("SFMT_S16", 9, 2_400_000, 16000), ("SFMT_U8", 9, 3_200_000, 8000)])
+    ("SFMT_S16", 9, 2_400_000, 16000), ("SFMT_U8", 9, 3_200_000, 8000),
+    ("SFMT_U8", 10, 2_400_000, 16000), ("SFMT_U8", 11, 2_560_000, 8000), ("SFMT_U8", 10, 1_024_000, 16000)])
 def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sample_rate, wave_rate):
     """Sample formats s8/s16/f32, fft sizes 256..8192, sample rates whose hop is not a multiple of 16 bytes: the matrix-core path
     takes u8 at fft 256 / 512, everything else runs on the wavefront-FFT channelizer -- same parity bars either way."""
