@@ -217,6 +217,18 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
             __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(uintptr_t)(buf + i * 1024), 16, 0, 0);
         }
     };
+    /* experiment (AB_DFT_LDS_XOR): u8 -> int8 (flip the top bit) done to the staged copy by the LDS unit (ds_xor_b64, 512 bytes per
+     * instruction) instead of one v_xor per A-fragment dword in front of the MFMAs.  Correct, and slower everywhere (9.30 vs 9.09 ms
+     * at configs[2], CS16 22.1 vs 19.8): the LDS pipe is the busier one. */
+    auto flip = [&](uint8_t* buf) {
+#ifdef AB_DFT_LDS_XOR
+        const unsigned long long m = S16 ? 0x0080008000800080ull : 0x8080808080808080ull;
+        for (int i = 0; i < n_dma * 1024; i += 512)
+            (void)__hip_atomic_fetch_xor(reinterpret_cast<unsigned long long*>(buf + i) + lane, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+        (void)buf;
+#endif
+    };
     /* staging ring of nbuf buffers: step st lives in buffer (st - st_begin) % nbuf; nbuf - 1 steps are in flight */
     const int nbuf = HOPB ? c_nbuf(HOPB ? HOPB : 64) : a.nbuf;
     /* partial sums of pieces 1 .. NP-1 on their way to wave 0: [tile parity][piece - 1][lane] x 4 floats, behind the staging buffers */
@@ -243,13 +255,17 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
             if (piece == 0) {
                 if (st + 1 >= st_end) wait_vmcnt(k_prev); /* last step: only the stores are younger */
                 else wait_vmcnt(n_dma + k_prev);
+                flip(buf);
             }
             if (NP > 1) __syncthreads();
             int nb = cur + 2;
             nb = nb >= 3 ? nb - 3 : nb;
             if (piece == 0 && st + 2 < st_end) stage(st + 2, lds + nb * lds_per_buf); /* two steps ahead: the buffer step st-1 just left */
         } else {
-            if (piece == 0) wait_vmcnt(k_prev); /* this step's bytes have landed in LDS */
+            if (piece == 0) {
+                wait_vmcnt(k_prev); /* this step's bytes have landed in LDS */
+                flip(buf);
+            }
             if (NP > 1) __syncthreads();
             if (piece == 0 && st + 1 < st_end) stage(st + 1, lds + (cur ^ 1) * lds_per_buf); /* next step streams in under this step's MFMAs */
         }
@@ -276,7 +292,9 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
                 av[s + 5] = lds_read16<AL>(arow + (s + 5) * 64);
             }
             v4i x = av[s];
+#ifndef AB_DFT_LDS_XOR
             x.x ^= 0x80808080; x.y ^= 0x80808080; x.z ^= 0x80808080; x.w ^= 0x80808080; /* u8 -> b - 128 as int8 */
+#endif
             acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b0[s], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b1[s], acc1, 0, 0, 0);
             if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b2[s], acc2, 0, 0, 0);
@@ -307,7 +325,9 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
             lo.y = (int)__builtin_amdgcn_perm((unsigned)p.w, (unsigned)p.z, 0x06040200u); hi.y = (int)__builtin_amdgcn_perm((unsigned)p.w, (unsigned)p.z, 0x07050301u);
             lo.z = (int)__builtin_amdgcn_perm((unsigned)q.y, (unsigned)q.x, 0x06040200u); hi.z = (int)__builtin_amdgcn_perm((unsigned)q.y, (unsigned)q.x, 0x07050301u);
             lo.w = (int)__builtin_amdgcn_perm((unsigned)q.w, (unsigned)q.z, 0x06040200u); hi.w = (int)__builtin_amdgcn_perm((unsigned)q.w, (unsigned)q.z, 0x07050301u);
+#ifndef AB_DFT_LDS_XOR
             lo.x ^= 0x80808080; lo.y ^= 0x80808080; lo.z ^= 0x80808080; lo.w ^= 0x80808080; /* unsigned low byte -> lo - 128 as int8 */
+#endif
             acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, b0[s], acc0, 0, 0, 0);
             hc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, b0[s], hc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, b1[s], acc1, 0, 0, 0);
