@@ -413,9 +413,7 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
 
 bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch) {
     (void)max_ch; /* any channel count: dongles with more than 8 channels are split into groups of 8 */
-    if (fft_size == 1024 || fft_size == 2048) /* window pieces of 512 samples, one launch per piece: u8 only for now */
-        return sfmt == AIRBAND_SFMT_U8 && (hop_bytes % 4) == 0 && hop_bytes <= 1024 && hop_bytes >= 64;
-    if (fft_size != 512 && fft_size != 256) return false;
+    if (fft_size != 2048 && fft_size != 1024 && fft_size != 512 && fft_size != 256) return false; /* 1024 / 2048: window pieces of 512 samples, one wave each */
     /* hops must start on 4-byte boundaries (even hop_samples for u8: 2.4 MS/s -> 300 / 600 bytes); two staging buffers of 16 hops +
      * one window must leave room for 3+ waves per CU */
     if (sfmt == AIRBAND_SFMT_U8) return (hop_bytes % 4) == 0 && hop_bytes <= 1024 && hop_bytes >= 64;
@@ -451,10 +449,11 @@ void launch_channelizer_dft(const DftArgs& a0, hipStream_t stream) {
     DftArgs a = a0;
     a.n_pass = 1;
     a.pass = 0;
-    if (a0.fft_size > 512) { /* one wavefront per window piece of 512 samples (u8 only, see dft_supported) */
+    if (a0.fft_size > 512) { /* one wavefront per window piece of 512 samples */
         a.fft_size = 512;
-        if (a0.fft_size == 1024) return launch_generic<512, false, 2>(a, stream);
-        return launch_generic<512, false, 4>(a, stream);
+        const bool s16 = a.sfmt == AIRBAND_SFMT_S16;
+        if (a0.fft_size == 1024) return s16 ? launch_generic<512, true, 2>(a, stream) : launch_generic<512, false, 2>(a, stream);
+        return s16 ? launch_generic<512, true, 4>(a, stream) : launch_generic<512, false, 4>(a, stream);
     }
     launch_one_piece(a, stream);
 }

@@ -480,10 +480,11 @@ def _convert(iq_u8, sfmt, capi, s16_gain=200.0):
     ("SFMT_U8", 8, 2_560_000, 16000), ("SFMT_U8", 10, 2_560_000, 8000), ("SFMT_U8", 11, 2_560_000, 16000), ("SFMT_S16", 13, 2_560_000, 8000),
     ("SFMT_U8", 9, 2_400_000, 16000), ("SFMT_U8", 9, 2_400_000, 8000), ("SFMT_U8", 9, 1_024_000, 8000), ("SFMT_S16", 9, 2_560_000, 8000), ("SFMT_S16", 8, 2_048_000, 16000),
     ("SFMT_S16", 9, 2_400_000, 16000), ("SFMT_U8", 9, 3_200_000, 8000),
-    ("SFMT_U8", 10, 2_400_000, 16000), ("SFMT_U8", 11, 2_560_000, 8000), ("SFMT_U8", 10, 1_024_000, 16000)])
+    ("SFMT_U8", 10, 2_400_000, 16000), ("SFMT_U8", 11, 2_560_000, 8000), ("SFMT_U8", 10, 1_024_000, 16000),
+    ("SFMT_S16", 10, 2_560_000, 16000), ("SFMT_S16", 11, 2_400_000, 8000)])
 def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sample_rate, wave_rate):
     """Sample formats s8/s16/f32, fft sizes 256..8192, sample rates whose hop is not a multiple of 16 bytes: the matrix-core path
-    takes u8 at fft 256 / 512, everything else runs on the wavefront-FFT channelizer -- same parity bars either way."""
+    takes u8 and CS16 at fft 256 ... 2048, everything else runs on the wavefront-FFT channelizer -- same parity bars either way."""
     capi = pkg.capi
     sfmt = getattr(capi, sfmt_name)
     mixed = wave_rate == 16000
@@ -517,7 +518,7 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
     with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=capi.FLAG_TRACE_SQUELCH) as hip:
         hop_bytes = 2 * hop * capi.BYTES_PER_SAMPLE[sfmt]
         expect_dft = hop_bytes % 4 == 0 and ((sfmt == capi.SFMT_U8 and fft_log in (8, 9, 10, 11) and 64 <= hop_bytes <= 1024) or
-                                             (sfmt == capi.SFMT_S16 and fft_log in (8, 9) and 128 <= hop_bytes <= 1280))
+                                             (sfmt == capi.SFMT_S16 and fft_log in (8, 9, 10, 11) and 128 <= hop_bytes <= 1280))
         assert hip.channelizer_name() == ("dft_mfma_i8" if expect_dft else "fft_wave64")
         pos = [0] * n_dev
         for b in range(n_batches):
