@@ -18,6 +18,8 @@ timeout 300 python bench.py $N --sample-format s16 --ring 1 2>/dev/null | tail -
 timeout 300 python bench.py $N --sample-rate 2400000 2>/dev/null | tail -1 > $O/${R}_bench_cfg3_2400k.json
 timeout 300 python bench.py $N --fft-log 10 2>/dev/null | tail -1 > $O/${R}_bench_cfg3_fft1024.json
 timeout 300 python bench.py $N --fft-log 8 2>/dev/null | tail -1 > $O/${R}_bench_cfg3_fft256.json
+timeout 300 python bench.py $N --fft-log 11 2>/dev/null | tail -1 > $O/${R}_bench_cfg3_fft2048.json
+timeout 300 python bench.py $N --fft-log 10 --sample-format s16 --ring 1 2>/dev/null | tail -1 > $O/${R}_bench_cfg3_cs16_fft1024.json
 AIRBAND_BENCH_FLAGS=4 timeout 300 python bench.py --no-cpu-baseline --no-traffic --verify 4 --steps 6 --warmup 2 2>/dev/null | tail -1 > $O/${R}_bench_cfg3_force_fft.json
 K="--no-cpu-baseline --no-traffic --verify 0 --steps 8 --warmup 2"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg3 -- python bench.py $K > $O/kt_cfg3.log 2>&1
