@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
 }
 
 /* Back half of the split kinds: output gating (squelch open AND tone present), notch, ampfactor, clamp, AM fade-out
- * (reference: src/rtl_airband.cpp:532-547,589-620), one lane per channel, samples staged through LDS 25 at a time. */
+ * (reference: src/rtl_airband.cpp:532-547,589-620), one lane per channel, finished output runs of 32 samples staged through LDS and stored as whole lines. */
 __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
     __shared__ float staged[RUN][OSTRIDE];
     __shared__ int ext_of[64];
