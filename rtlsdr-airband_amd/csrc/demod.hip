@@ -217,6 +217,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     /* only channels with a lowpass filter ever touch the delay line: the other kinds move head/tail once per batch */
     L.track_delay_line = (KIND == AB_KIND_NFM_LOWPASS || KIND == AB_KIND_GENERIC);
     L.may_post_filter = (KIND == AB_KIND_NFM_LOWPASS || KIND == AB_KIND_GENERIC);
+    L.all_lowpass = (KIND == AB_KIND_NFM_LOWPASS);
 
     SqRegs s;
     sq_load(s, L, sp, true);
@@ -390,7 +391,10 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             }
             fade_m = sq_last_open(s) & m_am;
         }
-        const bool fade = Q ? false : ab_lane(fade_m);
+        /* (the compiler does not fold the lane test of a constant-zero mask: without the kind spelled out the NFM kinds keep the
+         * fade-out loop of emit_sample and test for it on every sample) */
+        constexpr bool KIND_IS_NFM = (KindBits<KIND>::value & AB_F_NFM) != 0;
+        const bool fade = (Q || KIND_IS_NFM) ? false : ab_lane(fade_m);
 
         float out = 0.0f;
         const bool audio = ab_lane(Q ? s.cO : sq_should_audio(s));

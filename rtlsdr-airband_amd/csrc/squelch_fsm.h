@@ -77,6 +77,7 @@ struct Lane { /* per-lane constants */
     bool prefetched_delay; /* SqRegs::dly is maintained by the caller instead of reading sqbuf from memory (compile-time per kind) */
     bool track_delay_line; /* head/tail advance per sample (only kinds that touch the delay line need them inside a batch) */
     bool may_post_filter;  /* some lane of this kind may have a lowpass filter, i.e. using_post_filter_ can ever be set (compile-time per kind) */
+    bool all_lowpass;      /* every lane of this kind has one (compile-time per kind) */
     lmask m_lowpass, m_manual, m_flappy_lower;
     float manual_level, normal_ratio, flappy_ratio;
     float* sqbuf; /* this lane's column of the 102-deep pre-filter delay line, stride S */
@@ -191,6 +192,18 @@ AB_FSM_FN void sq_avg(float cap, float& full, float& capped, float x) {
     capped = (capped >= cap && x >= cap) ? cap : vm; /* the reference short-circuits this case; the value is `cap` either way it is written */
 }
 
+/* buffer_[buffer_head_] = pre_filter_.capped_ * pre_vs_post_factor_ (src/squelch.cpp:218-219): only ever read on the post-filter path,
+ * i.e. by channels with a lowpass filter -- the other lanes skip the store.  (all_lowpass: the lane test of an all-ones mask is not
+ * folded by the compiler, so the kind that has the filter on every lane says so.) */
+AB_FSM_FN void sq_delay_line_push(const SqRegs& s, const Lane& L) {
+    if (!L.may_post_filter) return;
+    if (L.all_lowpass) {
+        L.sqbuf[(long)s.head * L.S] = s.pre_capped * 0.9f;
+    } else if (ab_any(L.m_lowpass)) {
+        if (ab_lane(L.m_lowpass)) L.sqbuf[(long)s.head * L.S] = s.pre_capped * 0.9f;
+    }
+}
+
 /* calculate_noise_floor(), every 16th sample (src/squelch.cpp:477-490).  sample_count_ starts at SIZE_MAX on every channel and counts
  * every sample of every channel, so it is the same number on all lanes: the test is scalar and `sweep` is all lanes or none. */
 AB_FSM_FN void sq_noise_floor(SqRegs& s, const Lane& L) {
@@ -223,9 +236,7 @@ AB_FSM_FN void sq_raw_quiet(SqRegs& s, const Lane& L, float x, float dly_new) {
     s.sample_count++;
     if (AB_UNLIKELY((s.sample_count & 15u) == 0u)) sq_noise_floor(s, L);
     sq_avg(s.cap, s.pre_full, s.pre_capped, x);
-    if (L.may_post_filter && ab_any(L.m_lowpass)) {
-        if (ab_lane(L.m_lowpass)) L.sqbuf[(long)s.head * L.S] = s.pre_capped * 0.9f; /* only ever read on the post-filter path */
-    }
+    sq_delay_line_push(s, L);
     const lmask sig = sq_has_signal(s, L);
     const lmask low = s.cO & ab_ballot(!(x >= s.lvl));
     const int run = s.low_count + 1;
@@ -252,9 +263,7 @@ AB_FSM_FN lmask sq_raw_full(SqRegs& s, const Lane& L, float x, float dly_new) {
     s.sample_count++;
     if ((s.sample_count & 15u) == 0u) sq_noise_floor(s, L);
     sq_avg(s.cap, s.pre_full, s.pre_capped, x);
-    if (L.may_post_filter && ab_any(L.m_lowpass)) {
-        if (ab_lane(L.m_lowpass)) L.sqbuf[(long)s.head * L.S] = s.pre_capped * 0.9f;
-    }
+    sq_delay_line_push(s, L);
     const lmask sig = sq_has_signal(s, L);
     /* set_state() requests (:297-361), already clamped: OPEN -> CLOSING, CLOSED -> OPENING are legal as asked */
     const lmask to_closing = s.cO & ~sig;

@@ -68,6 +68,7 @@ int hostfsm_run(float snr_db, int manual_dbfs, int mode, int chunk, const float*
     L.prefetched_delay = mode == 2;
     L.track_delay_line = mode != 0;
     L.may_post_filter = mode != 0;
+    L.all_lowpass = false;
 
     if (chunk <= 0) chunk = n;
     for (int i0 = 0; i0 < n; i0 += chunk) {

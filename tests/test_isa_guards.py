@@ -1,0 +1,89 @@
+"""Guards on the machine code of the stage-2 kernels (CPU only: hipcc cross-compiles gfx950 without a GPU).
+
+Round 2 found, in the ISA, that a prefetch written as `if (more) fetch(next); ... if (more) touch(next);` does not prefetch: the
+compiler cannot pair a wait with loads that sit behind a branch and puts `s_waitcnt vmcnt(0)` in front of the FIRST USE of a group --
+right after the next group's loads were issued -- so every other group paid a full memory round trip (DESIGN.md 4.2,
+profiles/r02_experiments.md row O; 0.65 ms of stage 2).  Nothing in the results shows such a regression (parity is unaffected), so
+the structure is pinned here: inside the hot loop of every lane-per-channel kernel the only full waits are the ones the source
+asks for with touch() -- one per group of samples.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "rtlsdr-airband_amd", "csrc", "demod.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def demod_asm(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
+    out = str(tmp_path_factory.mktemp("isa") / "demod.s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+           "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out, SRC]
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL, timeout=600)
+    return open(out).read().split("\n")
+
+
+def _function(lines, key):
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*:", l) and key in l)
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    return [l for l in lines[start:end] if not re.match(r"^\s*;", l)]
+
+
+def _outer_loops(body):
+    """(header index, back-edge index) of every depth-1 loop: the label a later `s_branch` / `s_cbranch` jumps back to."""
+    labels = {}
+    for i, l in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):.*Loop Header: Depth=1", l)
+        if m:
+            labels[m.group(1)] = i
+    loops = []
+    for name, head in labels.items():
+        back = [i for i, l in enumerate(body) if i > head and re.match(r"^\s*s_c?branch\w*\s+" + re.escape(name) + r"\s*$", l)]
+        if back:
+            loops.append((head, max(back)))
+    return loops
+
+
+def _hot_loop(body, needs):
+    """The depth-1 loop with the most instructions that contains `needs` (a regex: the loop's prefetch loads)."""
+    best = None
+    for head, back in _outer_loops(body):
+        seg = body[head:back + 1]
+        if sum(1 for l in seg if re.search(needs, l)) >= 2 and (best is None or back - head > best[1] - best[0]):
+            best = (head, back)
+    assert best is not None, "hot loop not found"
+    return body[best[0]:best[1] + 1]
+
+
+@pytest.mark.parametrize("kernel,per_iteration", [
+    ("demod_kernelILi0ELb0", 2),   # AM: two groups of four samples per iteration
+    ("demod_kernelILi2ELb0", 2),   # NFM + lowpass
+    ("demod_kernelILi3ELb1", 2),   # CTCSS front
+])
+def test_group_prefetch_is_waited_for_once_per_group(demod_asm, kernel, per_iteration):
+    loop = _hot_loop(_function(demod_asm, kernel), r"global_load_dwordx4")
+    full_waits = [l for l in loop if re.search(r"s_waitcnt\s+vmcnt\(0\)", l)]
+    # the rarely taken paths (AM fade-out, AGC bootstrap) sit out of line behind the loop thanks to their __builtin_expect hints;
+    # should a compiler place one inside again it brings its own load + wait along: allow one, not one per sample
+    assert per_iteration <= len(full_waits) <= per_iteration + 1, (
+        "%s: %d full vector-memory waits inside the hot loop, %d groups per iteration -- a wait in front of a group's first use means "
+        "the prefetch of the NEXT group is being waited for too (keep fetch()/touch() unconditional)" % (kernel, len(full_waits), per_iteration))
+    assert sum(1 for l in loop if "global_load_dwordx4" in l) >= 2 * per_iteration
+
+
+def test_tone_kernel_waits_once_per_group_of_steps(demod_asm):
+    loop = _hot_loop(_function(demod_asm, "tone_kernel"), r"global_load_dwordx2")
+    loads = [i for i, l in enumerate(loop) if "global_load_dwordx2" in l]
+    waits = [i for i, l in enumerate(loop) if re.search(r"s_waitcnt\s+vmcnt\(0\)", l)]
+    assert len(loads) == 10, "ten steps in flight"
+    assert loads[-1] < 0.2 * len(loop), "the next group's loads go out at the top of a group"
+    # the wait belongs to the group boundary: at the top, in front of the loads, and / or at the bottom where the registers rotate --
+    # never between the loads and the ten steps of work they are meant to fly under
+    assert 1 <= len(waits) <= 2 and all(w < loads[0] or w > 0.8 * len(loop) for w in waits), waits
