@@ -346,8 +346,10 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     constexpr bool SPLIT_REST = ((AB_SPLIT_REST_KINDS >> KIND) & 1) != 0;
     auto rest = [&](auto quiet_tag, const int j, float cur_mag, const float delayed_mag, float re, float im, const lmask went_closed) {
         constexpr bool Q = decltype(quiet_tag)::value;
-        if (ab_any(m_raw_iq)) { /* src/rtl_airband.cpp:510-530 */
-            const lmask filt = sq_should_filter(s) & m_raw_iq;
+        /* (in a specialised NFM kind every lane works on raw I/Q: m_raw_iq is the set of live lanes, which the compiler cannot know to be non-empty) */
+        constexpr bool ALL_RAW_IQ = (KindBits<KIND>::value & AB_F_RAW_IQ) != 0;
+        if (ALL_RAW_IQ || ab_any(m_raw_iq)) { /* src/rtl_airband.cpp:510-530 */
+            const lmask filt = ALL_RAW_IQ ? sq_should_filter(s) : sq_should_filter(s) & m_raw_iq;
             if (ab_lane(filt)) { /* per-lane float work only: lane masks are not touched inside divergent code */
                 const unsigned idx = dm_phi >> 16; /* sincosf_lut (src/util.cpp:113-127) */
                 const float fract = (float)(dm_phi & 0xffffu) / 65536.0f;
