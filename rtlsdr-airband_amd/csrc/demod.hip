@@ -221,6 +221,9 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
 
     SqRegs s;
     sq_load(s, L, sp, true);
+    /* sample_count_ starts at -1 (src/squelch.cpp:58) and every batch is a multiple of four samples long, so the noise floor's every-16th
+     * sample is always the first one of a group of four: the other three do not look (squelch_fsm.h, sq_raw_quiet) */
+    if (((s.sample_count + 1u) & 3u) != 0u) __builtin_trap();
     s.dly = (KIND == AB_KIND_NFM_LOWPASS) ? L.sqbuf[(long)s.tail * S] : 0.0f;
     float agc = sp->agcavgfast, pr = sp->pr, pj = sp->pj, prev_out = sp->prev_waveout;
     unsigned dm_phi = sp->dm_phi;
@@ -437,9 +440,9 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             emit_sample(a, cc, o, wrow, iqout, trace, j, audio, fade, true, state, out, re, im, true);
         }
     };
-    auto sample = [&](const int j, const float cur_mag, const float delayed_mag /* lowpass kind: the prefetched delay-line entry */, const float re, const float im) {
+    auto sample = [&](const int j, const float cur_mag, const float delayed_mag /* lowpass kind: the prefetched delay-line entry */, const float re, const float im, const bool first_of_group) {
         lmask went_closed = 0;
-        if (AB_LIKELY(s.quiet)) sq_raw_quiet(s, L, cur_mag, delayed_mag);
+        if (AB_LIKELY(s.quiet)) sq_raw_quiet(s, L, cur_mag, delayed_mag, first_of_group);
         else went_closed = sq_raw_full(s, L, cur_mag, delayed_mag);
         /* a request raised by this very sample ends the quiet spell at once: its last-open handling is in the general version */
         if (SPLIT_REST && AB_LIKELY(s.quiet)) rest(std::true_type{}, j, cur_mag, delayed_mag, re, im, went_closed); /* the sample that settles the last lane still reports who just closed */
@@ -469,7 +472,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             const int jq = j0 + 4 * g;
             if ((jq % RUN) == 0) wrow.j0 = jq;
 #pragma unroll
-            for (int r = 0; r < 4; r++) sample(jq + r, mcs[r], mds[r], qr[r], qi[r]);
+            for (int r = 0; r < 4; r++) sample(jq + r, mcs[r], mds[r], qr[r], qi[r], r == 0);
         }
     };
     /* finished output runs leave AFTER the next group's loads have been waited for: the compiler's wait is `s_waitcnt vmcnt(0)`, which

@@ -119,8 +119,15 @@ AB_FSM_FN lmask sq_has_signal(const SqRegs& s, const Lane& L) { /* src/squelch.c
     return sig;
 }
 
+/* CLOSED lanes that have counted their 1000 closed samples and still have recent opens on record: the next update_current_state()
+ * forgets those (src/squelch.cpp:444-452) and refreshes the squelch level -- work of the general version */
+AB_FSM_FN lmask sq_saturated(const SqRegs& s) { return s.cC & ~ab_ballot(s.closed_count < 1000u) & s.recent_nz; }
+
 AB_FSM_FN bool sq_is_quiet(const SqRegs& s) {
-    const lmask busy = (s.nC ^ s.cC) | (s.nO ^ s.cO) | s.cOg | s.cCg | s.cA | s.nOg | s.nCg | s.nA;
+    lmask busy = (s.nC ^ s.cC) | (s.nO ^ s.cO) | s.cOg | s.cCg | s.cA | s.nOg | s.nCg | s.nA;
+#ifndef AB_SQ_QUIET_V1
+    busy |= sq_saturated(s);
+#endif
     return !ab_any(busy & s.active);
 }
 
@@ -219,7 +226,42 @@ AB_FSM_FN void sq_noise_floor(SqRegs& s, const Lane& L) {
  * update_current_state() (:363-460) then only counts the CLOSED lanes' closed samples and moves the delay line; afterwards the
  * only requests a lane can raise are OPEN -> CLOSING (signal gone), OPEN -> LOW_SIGNAL_ABORT (:233-245) and CLOSED -> OPENING.
  * Straight-line code but for three seldom-taken exits. */
-AB_FSM_FN void sq_raw_quiet(SqRegs& s, const Lane& L, float x, float dly_new) {
+#ifndef AB_SQ_QUIET_V1
+/* may_sweep: false where the caller knows that this sample cannot be a 16th one (the demod kernels: sample_count_ + 1 is a multiple of
+ * 4 at the start of every batch, so only the first sample of a group of four can be).
+ * No branch but the noise-floor one: what the seldom events change is written with mask algebra that is a no-op when nothing happens
+ * (a quiet wavefront has no lane in next-state OPENING / CLOSING / ABORT, so assigning the freshly computed -- usually empty -- request
+ * masks is exact), and a CLOSED lane that is due to forget its recent opens ends the quiet spell instead of being handled here. */
+AB_FSM_FN void sq_raw_quiet(SqRegs& s, const Lane& L, float x, float dly_new, bool may_sweep = true) {
+    const lmask below = ab_ballot(s.closed_count < 1000u);
+    s.closed_count += ab_lane(s.cC & below) ? 1u : 0u;
+    if (L.track_delay_line) {
+        s.tail = s.tail + 1 == AB_SQ_BUF ? 0 : s.tail + 1;
+        s.head = s.head + 1 == AB_SQ_BUF ? 0 : s.head + 1;
+    }
+    s.dly = dly_new;
+    s.sample_count++;
+    if (may_sweep && AB_UNLIKELY((s.sample_count & 15u) == 0u)) sq_noise_floor(s, L);
+    sq_avg(s.cap, s.pre_full, s.pre_capped, x);
+    sq_delay_line_push(s, L);
+    const lmask sig = sq_has_signal(s, L);
+    const lmask low = s.cO & ab_ballot(!(x >= s.lvl));
+    const int run = s.low_count + 1;
+    const int idle = ab_lane(s.cO) ? 0 : s.low_count;
+    s.low_count = ab_lane(low) ? run : idle;
+    const lmask abort_now = low & ab_ballot(s.low_count >= 88); /* low_signal_abort_ */
+    const lmask to_closing = s.cO & ~sig, to_opening = s.cC & sig;
+    const lmask any_req = to_closing | to_opening | abort_now;
+    s.nA = abort_now;
+    s.nCg = to_closing & ~abort_now;
+    s.nOg = to_opening;
+    s.nO &= ~any_req;
+    s.nC &= ~any_req;
+    s.quiet = !ab_any((any_req | sq_saturated(s)) & s.active);
+}
+#else
+AB_FSM_FN void sq_raw_quiet(SqRegs& s, const Lane& L, float x, float dly_new, bool may_sweep = true) {
+    (void)may_sweep;
     const lmask below = ab_ballot(s.closed_count < 1000u);
     const lmask forget = s.cC & ~below & s.recent_nz;
     s.closed_count += ab_lane(s.cC & below) ? 1u : 0u;
@@ -255,6 +297,8 @@ AB_FSM_FN void sq_raw_quiet(SqRegs& s, const Lane& L, float x, float dly_new) {
         s.quiet = false;
     }
 }
+
+#endif
 
 /* Squelch::process_raw_sample (src/squelch.cpp:195-246), general case.  Returns the lanes whose squelch just went CLOSED. */
 AB_FSM_FN lmask sq_raw_full(SqRegs& s, const Lane& L, float x, float dly_new) {
