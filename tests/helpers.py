@@ -57,6 +57,48 @@ def afc_case(n_dev: int = 1):
     return [dict(channels=[dict(c) for c in chans]) for _ in range(n_dev)], out
 
 
+def convert_format(iq_u8, sfmt, capi, s16_gain=200.0):
+    """Re-express the synthetic u8 stream in the other sample formats the input drivers deliver (src/input-soapysdr.cpp:45-64,
+    src/input-mirisdr.cpp)."""
+    x = iq_u8.astype(np.float32) - 127.5
+    if sfmt == capi.SFMT_U8:
+        return iq_u8
+    if sfmt == capi.SFMT_S8:
+        return np.clip(np.round(x), -127, 127).astype(np.int8)  # -128 indexes a table entry the reference never initialises
+    if sfmt == capi.SFMT_S16:
+        return np.round(x * s16_gain).astype(np.int16)
+    return (x / 127.5).astype(np.float32)
+
+
+def format_case(pkg, sfmt, fft_log, sample_rate, wave_rate, n_dev, n_batches, first_dongle=0):
+    """n_dev dongles of the BASELINE channel plan re-expressed for another sample format / fft size / sample rate: channels scaled
+    into the dongle's passband, every transmitter placed where the reference LOOKS -- its bin formula divides by the integer
+    sample_rate / fft_size (src/config.cpp:666-667), which is off by many bins when that quotient is not exact (e.g. 2.56 MS/s /
+    8192).  Two CS16 sources of one handle need not share a full scale (a 12-bit and a 16-bit SoapySDR device): odd dongles deliver
+    the same signal at a quarter of the amplitude and say so in input->fullscale (src/rtl_airband.cpp:403).
+    Returns (devices, iq list in the format's dtype)."""
+    capi = pkg.capi
+    mixed = wave_rate == 16000
+    chans, _ = sg.baseline_plan(mixed=mixed)
+    scale = sample_rate / 2_560_000
+    for c in chans:  # keep every channel inside the dongle's (possibly narrower) passband
+        c["frequency"] = 120_000_000 + int((c["frequency"] - 120_000_000) * scale * 0.8)
+    carriers = []
+    probe = [dict(channels=[dict(c) for c in chans], sample_rate=sample_rate)]
+    n_fft = 1 << fft_log
+    for k, c in enumerate(chans):
+        b = int(pkg.derive_constants(probe, k, wave_rate=wave_rate, fft_log=fft_log)[0])
+        off = (b if b < n_fft // 2 else b - n_fft) * sample_rate / n_fft
+        carriers.append(sg.make_carrier(off, sample_rate, kind=c["modulation"], ctcss_hz=c["ctcss_freq"], key_slot=k, key_period_s=0.5, key_on_s=0.3, key_slot_s=0.04))
+    gains = [200.0 if d % 2 == 0 else 50.0 for d in range(n_dev)] if sfmt == capi.SFMT_S16 else [1.0] * n_dev
+    devices = [dict(channels=[dict(c) for c in chans], sample_rate=sample_rate, sfmt=sfmt, fullscale=0.0 if sfmt != capi.SFMT_S16 else 127.5 * gains[d])
+               for d in range(n_dev)]
+    hop = round(sample_rate / wave_rate)
+    n_samples = (n_batches * (wave_rate // 8) + 100) * hop + n_fft + 8  # + 8: hops of 300 / 600 bytes are staged in whole 16-byte pieces
+    iq = [convert_format(sg.generate_u8(first_dongle + d, 0, n_samples, carriers), sfmt, capi, gains[d]) for d in range(n_dev)]
+    return devices, iq
+
+
 def wait_for_gpu_memory(nbytes: int, timeout_s: float = 60.0) -> None:
     """The driver hands back a freed allocation of >100 GiB (the previous case's resident I/Q) with a delay: wait until that
     much device memory is actually free before asking for it again."""

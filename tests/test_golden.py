@@ -20,6 +20,10 @@ import make_golden  # noqa: E402
 CASES = sorted(make_golden.CASES)
 
 
+def _fft_log(c):
+    return c["format"][1] if "format" in c else 9
+
+
 def _load(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     c, devices, carriers, iq = make_golden.build_case(name)
@@ -31,7 +35,7 @@ def _load(name):
 @pytest.mark.parametrize("name", CASES)
 def test_oracle_reproduces_reference_golden(built, name):
     z, c, devices, iq = _load(name)
-    orc = pyoracle.Oracle(devices, wave_rate=c["wave_rate"], fm_demod=c["fm_demod"])
+    orc = pyoracle.Oracle(devices, wave_rate=c["wave_rate"], fm_demod=c["fm_demod"], fft_log=_fft_log(c))
     got = orc.run_device(0, iq, c["n_batches"])
     assert got["n_batches"] == c["n_batches"]
     assert np.array_equal(got["axc"], z["axc"])
@@ -51,7 +55,10 @@ def test_oracle_reproduces_reference_golden(built, name):
 @pytest.mark.parametrize("name", CASES)
 def test_hip_matches_reference_golden(pkg, built, name):
     z, c, devices, iq = _load(name)
-    with pkg.AirbandHip(devices, wave_rate=c["wave_rate"], fm_demod=c["fm_demod"]) as hip:
+    with pkg.AirbandHip(devices, wave_rate=c["wave_rate"], fm_demod=c["fm_demod"], fft_log=_fft_log(c)) as hip:
+        if "format" in c and c["format"][0] != "SFMT_S8":
+            assert hip.channelizer_name() == "dft_mfma_i8"  # every committed format case is one the matrix-core path claims
+        iq = iq.view(np.uint8)
         pos = 0
         for b in range(c["n_batches"]):
             pos += hip.submit(0, iq[pos:])  # the staging ring holds ~5 batches, like the reference's input ring

@@ -463,18 +463,6 @@ def test_ragged_shapes_and_empty_inputs(pkg, built):
         assert opened > 0
 
 
-def _convert(iq_u8, sfmt, capi, s16_gain=200.0):
-    """Re-express the synthetic u8 stream in the other sample formats the input drivers deliver (src/input-soapysdr.cpp:45-64)."""
-    x = iq_u8.astype(np.float32) - 127.5
-    if sfmt == capi.SFMT_U8:
-        return iq_u8
-    if sfmt == capi.SFMT_S8:
-        return np.clip(np.round(x), -127, 127).astype(np.int8)  # -128 indexes a table entry the reference never initialises
-    if sfmt == capi.SFMT_S16:
-        return np.round(x * s16_gain).astype(np.int16)
-    return (x / 127.5).astype(np.float32)
-
-
 @pytest.mark.parametrize("sfmt_name,fft_log,sample_rate,wave_rate", [
     ("SFMT_S8", 9, 2_560_000, 8000), ("SFMT_S16", 9, 2_560_000, 16000), ("SFMT_F32", 9, 2_560_000, 16000),
     ("SFMT_U8", 8, 2_560_000, 16000), ("SFMT_U8", 10, 2_560_000, 8000), ("SFMT_U8", 11, 2_560_000, 16000), ("SFMT_S16", 13, 2_560_000, 8000),
@@ -487,30 +475,9 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
     takes u8 and CS16 at fft 256 ... 2048, everything else runs on the wavefront-FFT channelizer -- same parity bars either way."""
     capi = pkg.capi
     sfmt = getattr(capi, sfmt_name)
-    mixed = wave_rate == 16000
     n_dev, n_batches = 2, 7
-    chans, _ = pkg.siggen.baseline_plan(mixed=mixed)
-    scale = sample_rate / 2_560_000
-    for c in chans:  # keep every channel inside the dongle's (possibly narrower) passband
-        c["frequency"] = 120_000_000 + int((c["frequency"] - 120_000_000) * scale * 0.8)
-    carriers = []
-    probe = [dict(channels=[dict(c) for c in chans], sample_rate=sample_rate)]
-    for k, c in enumerate(chans):
-        # put the transmitter where the reference LOOKS: its bin formula divides by the integer sample_rate / fft_size
-        # (src/config.cpp:666-667), which is off by many bins when that quotient is not exact (e.g. 2.56 MS/s / 8192)
-        b = int(pkg.derive_constants(probe, k, wave_rate=wave_rate, fft_log=fft_log)[0])
-        n_fft = 1 << fft_log
-        off = (b if b < n_fft // 2 else b - n_fft) * sample_rate / n_fft
-        kind = c["modulation"]
-        carriers.append(pkg.siggen.make_carrier(off, sample_rate, kind=kind, ctcss_hz=c["ctcss_freq"], key_slot=k, key_period_s=0.5, key_on_s=0.3, key_slot_s=0.04))
-    # two CS16 sources of one handle need not share a full scale (a 12-bit and a 16-bit SoapySDR device): the second dongle
-    # delivers the same signal at a quarter of the amplitude and says so in input->fullscale (src/rtl_airband.cpp:403)
-    gains = [200.0, 50.0] if sfmt == capi.SFMT_S16 else [1.0, 1.0]
-    devices = [dict(channels=[dict(c) for c in chans], sample_rate=sample_rate, sfmt=sfmt, fullscale=0.0 if sfmt != capi.SFMT_S16 else 127.5 * gains[d])
-               for d in range(n_dev)]
+    devices, iq = helpers.format_case(pkg, sfmt, fft_log, sample_rate, wave_rate, n_dev, n_batches)
     hop = round(sample_rate / wave_rate)
-    n_samples = (n_batches * (wave_rate // 8) + 100) * hop + (1 << fft_log) + 8  # + 8: hops of 300 / 600 bytes are staged in whole 16-byte pieces
-    iq = [_convert(pkg.siggen.generate_u8(d, 0, n_samples, carriers), sfmt, capi, gains[d]) for d in range(n_dev)]
     orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fft_log=fft_log)
     ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
     assert all(r["n_batches"] == n_batches for r in ref)

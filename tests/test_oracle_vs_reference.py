@@ -54,6 +54,42 @@ def test_stream_bit_exact(pkg, built, mixed, wave_rate, fm_demod, tmp_path):
         assert np.array_equal(tr["current_state"][:n_batches * B], (mine & 7).astype(np.intc)), j
 
 
+# (sample format, fft_size_log, sample rate, WAVE_RATE): every class of configuration the matrix-core channelizer claims (u8 / CS16 /
+# s8 at fft 256 ... 8192, hops that are not multiples of 16 bytes) plus f32 -- the restatement's convert x window (src/rtl_airband.cpp:402-455),
+# hop (:394) and bin (src/config.cpp:666-667) arithmetic outside u8 / fft 512 / 2.56 MS/s, against the reference itself.
+FORMAT_CASES = [("SFMT_S16", 9, 2_560_000, 16000), ("SFMT_U8", 10, 2_560_000, 8000), ("SFMT_U8", 8, 2_560_000, 16000), ("SFMT_S16", 10, 2_560_000, 16000),
+                ("SFMT_U8", 9, 2_400_000, 16000), ("SFMT_U8", 9, 2_400_000, 8000), ("SFMT_S8", 9, 2_560_000, 8000), ("SFMT_S8", 10, 2_400_000, 16000),
+                ("SFMT_F32", 9, 2_560_000, 16000), ("SFMT_U8", 11, 2_560_000, 16000), ("SFMT_U8", 12, 2_560_000, 8000), ("SFMT_S16", 13, 2_560_000, 8000),
+                ("SFMT_U8", 9, 1_024_000, 8000), ("SFMT_S16", 8, 2_048_000, 16000), ("SFMT_U8", 9, 3_200_000, 8000), ("SFMT_S16", 11, 2_400_000, 8000)]
+
+
+@need_ref
+@pytest.mark.parametrize("sfmt_name,fft_log,sample_rate,wave_rate", FORMAT_CASES)
+def test_stream_bit_exact_other_formats(pkg, built, sfmt_name, fft_log, sample_rate, wave_rate):
+    sfmt = getattr(pkg.capi, sfmt_name)
+    n_batches = 6
+    devices, iq = helpers.format_case(pkg, sfmt, fft_log, sample_rate, wave_rate, 2, n_batches, first_dongle=5)
+    # one reference process per dongle: demodulate() sleeps 10 ms whenever its round robin meets a device without a full hop
+    # (src/rtl_airband.cpp:395-400), so feeding two devices of one instance one after the other would take minutes
+    ref = [pyref.run_reference([devices[d]], [iq[d]], n_batches, nfm=wave_rate == 16000, fft_log=fft_log)[0] for d in range(2)]
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fft_log=fft_log)
+    opened = 0
+    for d in range(2):  # dongle 1 of a CS16 case has its own input->fullscale
+        got = orc.run_device(d, iq[d], n_batches)
+        assert ref[d]["n_batches"] == got["n_batches"] == n_batches
+        assert np.array_equal(ref[d]["axc"], got["axc"])
+        assert np.array_equal(ref[d]["waveout"].view(np.uint32), got["waveout"].view(np.uint32))
+        opened += int((ref[d]["axc"] == ord("*")).sum())
+        for j in range(8):
+            a, b = ref[d]["stats"][j], orc.stats(d, j)
+            for k in a:
+                if k != "squelch_state":
+                    assert a[k] == b[k], (d, j, k, a[k], b[k])
+            assert ref[d]["consts"][j][0] == orc.constants(d, j)[0]
+            assert ref[d]["consts"][j][1] == orc.constants(d, j)[1]
+    assert opened > 0
+
+
 @need_ref
 def test_tone_coefficients_all_standard_tones(built):
     ref = pyref.load_units(True)
