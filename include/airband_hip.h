@@ -171,6 +171,24 @@ int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const air
  * calls when a device fails (src/mixer.cpp:96-110, src/rtl_airband.cpp:377-391).  Takes effect from the next batch. */
 int airband_hip_mixer_enable_input(airband_hip_handle* h, int32_t input_index, int32_t enabled);
 
+/* Switches one dongle of the handle off (enabled = 0) or back on.  Replaces: what demodulate() does when input->state is no longer
+ * INPUT_RUNNING (reference: src/rtl_airband.cpp:383-391 -- the device is passed by from then on and its outputs are disabled;
+ * src/input-file.cpp:101-111 sets INPUT_FAILED at end of file, the drivers on a dead dongle).  A disabled dongle
+ *   - is not waited for by airband_hip_process()'s availability rule, and bytes submitted for it are dropped;
+ *   - is skipped by both stages: its channels' squelch / filter / AGC state stays frozen, its result rows are not written again,
+ *     its channels report axcindicate ' ' (NO_SIGNAL);
+ *   - adds nothing to any mixer it is wired into (mixer_disable_input() for each of its outputs, src/mixer.cpp:96-110).
+ * Takes effect with the next process call (a pipelined handle still runs stage 2 of the batch already under way).  Re-enabling is an
+ * extension (the reference's INPUT_DISABLED is final): the dongle rejoins at the handle's common stream position with the state it
+ * was frozen with; the AGC_EXTRA samples of lead-in the first batch back sees are unspecified.
+ * With every dongle disabled airband_hip_process() returns AIRBAND_HIP_EAGAIN -- the caller's cue to stop (the reference exits,
+ * src/rtl_airband.cpp:377-381). */
+int airband_hip_device_enable(airband_hip_handle* h, int32_t dev, int32_t enabled);
+
+/* Number of HIP devices visible to the process (0 when there is none / no runtime): lets a host without HIP headers spread its
+ * demodulate() shards over the GPUs of a node (reference: one demodulate thread per shard, src/rtl_airband.cpp:1052-1086,1110-1112). */
+int airband_hip_gpu_count(void);
+
 /* Replaces: gpu_fft_release() on do_exit (reference: src/rtl_airband.cpp:360-365). */
 void airband_hip_release(airband_hip_handle* h);
 

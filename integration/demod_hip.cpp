@@ -62,13 +62,28 @@ static airband_hip_channel_cfg channel_cfg_of(const channel_t* ch) {
     return c;
 }
 
-void* demodulate_hip(void* params) {
-    demod_params_t* dp = (demod_params_t*)params;  // device_start / device_end shard (rtl_airband.h demod_params_t)
-    const int n = dp->device_end - dp->device_start;
+// One library handle per CLASS of devices: libairband_hip batches the dongles of a handle through one launch, so they must share sample
+// format and hop (round(sample_rate / WAVE_RATE), rtl_airband.cpp:394); the reference takes both per device (input-common.h:39-57).
+struct hip_class {
+    airband_hip_handle* h;
+    std::vector<int> devs;  // indices into devices[]
+    airband_hip_geometry g;
+    std::vector<float> wave, iq;
+    std::vector<char> axc;
+    std::vector<airband_hip_channel_stats> st;
+};
+
+static bool same_class(const input_t* a, const input_t* b) {
+    return a->sfmt == b->sfmt && a->bytes_per_sample == b->bytes_per_sample &&
+           round((double)a->sample_rate / (double)WAVE_RATE) == round((double)b->sample_rate / (double)WAVE_RATE);
+}
+
+static void prepare_class(hip_class& k, int hip_device) {
+    const int n = (int)k.devs.size();
     std::vector<std::vector<airband_hip_channel_cfg> > ch(n);
     std::vector<airband_hip_device_cfg> dv(n);
     for (int i = 0; i < n; i++) {
-        device_t* dev = devices + dp->device_start + i;
+        device_t* dev = devices + k.devs[i];
         for (int j = 0; j < dev->channel_count; j++) ch[i].push_back(channel_cfg_of(dev->channels + j));
         memset(&dv[i], 0, sizeof(dv[i]));
         dv[i].sample_rate = dev->input->sample_rate;
@@ -87,11 +102,11 @@ void* demodulate_hip(void* params) {
 #ifdef NFM
     cfg.fm_demod = fm_demod == FM_QUADRI_DEMOD ? AIRBAND_FM_QUADRI_DEMOD : AIRBAND_FM_FAST_ATAN2;
 #endif
-    cfg.hip_device = 0;  // one GPU per process; several shards on several GPUs: device_start % <GPU count>
+    cfg.hip_device = hip_device;
     cfg.device_count = n;
     cfg.devices = dv.data();
-    airband_hip_handle* h = NULL;
-    switch (airband_hip_prepare(&cfg, &h)) {  // the convention of gpu_fft_prepare() (rtl_airband.cpp:296-310)
+    k.h = NULL;
+    switch (airband_hip_prepare(&cfg, &k.h)) {  // the convention of gpu_fft_prepare() (rtl_airband.cpp:296-310)
         case AIRBAND_HIP_OK:
             break;
         case AIRBAND_HIP_ENODEV:
@@ -110,65 +125,105 @@ void* demodulate_hip(void* params) {
             log(LOG_CRIT, "airband_hip: %s\n", airband_hip_last_error(NULL));
             error();
     }
-    airband_hip_geometry g;
-    airband_hip_get_geometry(h, &g);
-    std::vector<float> wave((size_t)g.total_channels * g.wave_batch), iq((size_t)g.total_channels * g.wave_batch * 2);
-    std::vector<char> axc(g.total_channels);
-    std::vector<airband_hip_channel_stats> st(g.total_channels);
+    airband_hip_get_geometry(k.h, &k.g);
+    k.wave.resize((size_t)k.g.total_channels * k.g.wave_batch);
+    k.iq.resize((size_t)k.g.total_channels * k.g.wave_batch * 2);
+    k.axc.resize(k.g.total_channels);
+    k.st.resize(k.g.total_channels);
+}
 
-    while (!do_exit) {
-        // 1. hand the bytes the rx threads appended (circbuffer_append, input-helpers.cpp:37-63) to the library.
-        //    Cursor discipline of rtl_airband.cpp:370-375 and :669: bufe is read under buffer_lock, bufs is ours.
-        for (int i = 0; i < n; i++) {
-            input_t* in = devices[dp->device_start + i].input;
-            pthread_mutex_lock(&in->buffer_lock);
-            const size_t bufe = in->bufe;
-            pthread_mutex_unlock(&in->buffer_lock);
-            while (in->bufs != bufe) {
-                const size_t run = (bufe > in->bufs ? bufe : in->buf_size) - in->bufs;  // contiguous part of the ring
-                const int64_t took = airband_hip_submit(h, i, in->buffer + in->bufs, run);
-                if (took <= 0) break;  // staging full: the GPU is behind, try again next round
-                in->bufs = (in->bufs + (size_t)took) % in->buf_size;
-            }
-        }
-        // 2. the output thread has not drained the previous batch yet: keep it (the reference counts an overrun and
-        //    overwrites, rtl_airband.cpp:649-654; holding back loses nothing, the staging ring absorbs the wait)
-        bool busy = false;
-        for (int i = 0; i < n; i++) busy |= devices[dp->device_start + i].waveavail != 0;
-        if (busy) {
-            SLEEP(1);
-            continue;
-        }
-        // 3. one WAVE_BATCH for every device of the shard, once all of them have the bytes (availability rule :394-400)
-        const int rc = airband_hip_process(h);
-        if (rc == AIRBAND_HIP_EAGAIN) {
-            SLEEP(1);
-            continue;
-        }
-        if (rc < 0) {
-            log(LOG_CRIT, "airband_hip: %s\n", airband_hip_last_error(h));
+void* demodulate_hip(void* params) {
+    demod_params_t* dp = (demod_params_t*)params;  // device_start / device_end shard (rtl_airband.h demod_params_t)
+    // one GPU per shard: with multiple_demod_threads a shard is one device (rtl_airband.cpp:1052-1086), spread round robin
+    const int gpus = airband_hip_gpu_count();
+    const int hip_device = gpus > 0 ? dp->device_start % gpus : 0;
+    std::vector<hip_class> classes;
+    for (int d = dp->device_start; d < dp->device_end; d++) {
+        if (devices[d].mode != R_MULTICHANNEL) {  // scan mode retunes the dongle between batches (rtl_airband.cpp:556-565 of the controller thread)
+            log(LOG_CRIT, "airband_hip: device %d is in scan mode; the GPU backend demodulates multichannel devices only\n", d);
             error();
         }
-        airband_hip_collect(h, wave.data(), iq.data(), axc.data(), st.data());
-        // 4. publish what the per-channel loop publishes (rtl_airband.cpp:549-619,:645-655); the library has already done
-        //    the consumer's tail copy (output.cpp:920), so the samples go where process_outputs() reads them
-        size_t k = 0;
-        for (int i = 0; i < n; i++) {
-            device_t* dev = devices + dp->device_start + i;
-            for (int j = 0; j < dev->channel_count; j++, k++) {
-                channel_t* c = dev->channels + j;
-                memcpy(c->waveout, &wave[k * g.wave_batch], sizeof(float) * g.wave_batch);
-                if (c->has_iq_outputs) memcpy(c->iq_out, &iq[k * g.wave_batch * 2], sizeof(float) * 2 * g.wave_batch);
-                c->axcindicate = (status)axc[k];
-                c->freqlist->active_counter = st[k].active_counter;
-                c->freqlist->agcavgfast = st[k].agcavgfast;
-                c->freqlist->squelch.mirror(st[k].noise_level, st[k].signal_level, st[k].squelch_level, st[k].open_count, st[k].flappy_count, st[k].ctcss_count,
-                                            st[k].no_ctcss_count);
-            }
-            dev->waveavail = 1;
-        }
-        dp->mp3_signal->send();  // rtl_airband.cpp:662
+        size_t c = 0;
+        while (c < classes.size() && !same_class(devices[classes[c].devs[0]].input, devices[d].input)) c++;
+        if (c == classes.size()) classes.push_back(hip_class());
+        classes[c].devs.push_back(d);
     }
-    airband_hip_release(h);  // like gpu_fft_release on do_exit (rtl_airband.cpp:360-365)
+    for (size_t c = 0; c < classes.size(); c++) prepare_class(classes[c], hip_device);
+
+    while (!do_exit) {
+        if (devices_running == 0) {  // rtl_airband.cpp:377-381
+            log(LOG_ERR, "All receivers failed, exiting\n");
+            do_exit = 1;
+            continue;
+        }
+        bool worked = false;
+        for (size_t c = 0; c < classes.size(); c++) {
+            hip_class& k = classes[c];
+            const int n = (int)k.devs.size();
+            // 1. per device: a failed input is taken out exactly as demodulate() does it (rtl_airband.cpp:383-391) -- and out of the
+            //    handle, so that the others are not held up waiting for its bytes; a running one hands over what its rx thread
+            //    appended (circbuffer_append, input-helpers.cpp:37-63).  Cursor discipline of rtl_airband.cpp:370-375 and :669: bufe
+            //    is read under buffer_lock, bufs is ours.
+            for (int i = 0; i < n; i++) {
+                device_t* dev = devices + k.devs[i];
+                input_t* in = dev->input;
+                if (in->state != INPUT_RUNNING) {
+                    if (in->state == INPUT_FAILED) {
+                        in->state = INPUT_DISABLED;
+                        disable_device_outputs(dev);
+                        devices_running--;
+                        airband_hip_device_enable(k.h, i, 0);
+                    }
+                    continue;
+                }
+                pthread_mutex_lock(&in->buffer_lock);
+                const size_t bufe = in->bufe;
+                pthread_mutex_unlock(&in->buffer_lock);
+                while (in->bufs != bufe) {
+                    const size_t run = (bufe > in->bufs ? bufe : in->buf_size) - in->bufs;  // contiguous part of the ring
+                    const int64_t took = airband_hip_submit(k.h, i, in->buffer + in->bufs, run);
+                    if (took <= 0) break;  // staging full: the GPU is behind, try again next round
+                    in->bufs = (in->bufs + (size_t)took) % in->buf_size;
+                }
+            }
+            // 2. one WAVE_BATCH for every running device of the class, once all of them have the bytes (availability rule :394-400)
+            const int rc = airband_hip_process(k.h);
+            if (rc == AIRBAND_HIP_EAGAIN) continue;
+            if (rc < 0) {
+                log(LOG_CRIT, "airband_hip: %s\n", airband_hip_last_error(k.h));
+                error();
+            }
+            if (airband_hip_collect(k.h, k.wave.data(), k.iq.data(), k.axc.data(), k.st.data()) != AIRBAND_HIP_OK) continue;  // nothing to publish
+            worked = true;
+            // 3. publish what the per-channel loop publishes (rtl_airband.cpp:549-619,:645-655); the library has already done the
+            //    consumer's tail copy (output.cpp:920), so the samples go where process_outputs() reads them
+            size_t q = 0;
+            for (int i = 0; i < n; i++) {
+                device_t* dev = devices + k.devs[i];
+                if (dev->input->state != INPUT_RUNNING) {  // taken out above: its channels keep what they last held
+                    q += dev->channel_count;
+                    continue;
+                }
+                for (int j = 0; j < dev->channel_count; j++, q++) {
+                    channel_t* ch = dev->channels + j;
+                    memcpy(ch->waveout, &k.wave[q * k.g.wave_batch], sizeof(float) * k.g.wave_batch);
+                    if (ch->has_iq_outputs) memcpy(ch->iq_out, &k.iq[q * k.g.wave_batch * 2], sizeof(float) * 2 * k.g.wave_batch);
+                    ch->axcindicate = (status)k.axc[q];
+                    ch->freqlist->active_counter = k.st[q].active_counter;
+                    ch->freqlist->agcavgfast = k.st[q].agcavgfast;
+                    ch->freqlist->squelch.mirror(k.st[q].noise_level, k.st[q].signal_level, k.st[q].squelch_level, k.st[q].open_count, k.st[q].flappy_count,
+                                                 k.st[q].ctcss_count, k.st[q].no_ctcss_count);
+                }
+                if (dev->waveavail == 1) {  // rtl_airband.cpp:649-654: the output thread has not drained the previous batch
+                    dev->output_overrun_count++;
+                } else {
+                    dev->waveavail = 1;
+                }
+            }
+            dp->mp3_signal->send();  // rtl_airband.cpp:662
+        }
+        if (!worked) SLEEP(1);
+    }
+    for (size_t c = 0; c < classes.size(); c++) airband_hip_release(classes[c].h);  // like gpu_fft_release on do_exit (rtl_airband.cpp:360-365)
     return NULL;
 }

@@ -170,10 +170,12 @@ def reference_throughput(devices, iq_list, seconds: float, threads: int, *, nfm:
     return res
 
 
-def _all_worker(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib):
+def _all_worker(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib, fail_after, end_of_streams):
     try:
         lib = _load(nfm, "patched" if hip_lib else False)
-        lib.refh_run_all.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        lib.refh_run_all.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.POINTER(C.c_int), C.c_double]
+        lib.refh_fail_all_and_wait_exit.argtypes = [C.c_double]
         lib.refh_start_hip.argtypes = [C.c_char_p]
         lib.refh_hip_channel_stats.argtypes = [C.c_int, C.c_int, C.POINTER(capi.ChannelStats)]
         wb = lib.refh_wave_batch()
@@ -191,7 +193,10 @@ def _all_worker(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib)
         axc = np.zeros((nd, n_batches, nch), np.uint8)
         bufs = [np.ascontiguousarray(x) for x in iq_list]
         ptrs = (C.c_void_p * nd)(*[b.ctypes.data for b in bufs])
-        got = lib.refh_run_all(ptrs, bufs[0].nbytes, n_batches, wave.ctypes.data, iqo.ctypes.data, axc.ctypes.data, 120.0)
+        sizes = (C.c_size_t * nd)(*[b.nbytes for b in bufs])
+        fa = (C.c_int * nd)(*[(-1 if fail_after is None or fail_after[d] is None else int(fail_after[d])) for d in range(nd)])
+        got = (C.c_int * nd)()
+        short = lib.refh_run_all(ptrs, sizes, fa, n_batches, wave.ctypes.data, iqo.ctypes.data, axc.ctypes.data, got, 120.0)
         stats = []
         for d in range(nd):
             row = []
@@ -200,20 +205,30 @@ def _all_worker(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib)
                 (lib.refh_hip_channel_stats if hip_lib else lib.refh_channel_stats)(d, j, C.byref(st))
                 row.append({f[0]: getattr(st, f[0]) for f in capi.ChannelStats._fields_})
             stats.append(row)
+        res = dict(n_batches=n_batches + short, batches=[int(g) for g in got], waveout=wave, iq_out=iqo, axc=axc, stats=stats,
+                   outputs_disabled=[lib.refh_outputs_disabled(d) for d in range(nd)], devices_running=lib.refh_devices_running(),
+                   input_state=[lib.refh_input_state(d) for d in range(nd)], output_overruns=[lib.refh_output_overruns(d) for d in range(nd)])
+        if end_of_streams:
+            res["exited_on_its_own"] = bool(lib.refh_fail_all_and_wait_exit(20.0))
+            res["devices_running_at_exit"] = lib.refh_devices_running()
+            res["outputs_disabled_at_exit"] = [lib.refh_outputs_disabled(d) for d in range(nd)]
         lib.refh_stop()
-        q.put(("ok", dict(n_batches=got, waveout=wave, iq_out=iqo, axc=axc, stats=stats)))
+        q.put(("ok", res))
     except BaseException as e:  # noqa: BLE001
         q.put(("err", repr(e)))
 
 
-def run_reference_all(devices, iq_list, n_batches, *, nfm: bool, fft_log: int = 9, fm_demod: int = 0, hip_lib: str | None = None):
+def run_reference_all(devices, iq_list, n_batches, *, nfm: bool, fft_log: int = 9, fm_demod: int = 0, hip_lib: str | None = None, fail_after=None,
+                      end_of_streams: bool = False):
     """All devices fed concurrently through the reference's own rings.  hip_lib=None: the reference's demodulate();
     hip_lib=path to libairband_hip.so: the harness built from the PATCHED reference (integration/airband_hip.patch applied to a
     scratch copy, integration/demod_hip.cpp compiled verbatim): demodulate_hip() instead of demodulate(), statistics read back
-    through the reference's own Squelch getters."""
+    through the reference's own Squelch getters.
+    fail_after[d] = k: device d's input reports INPUT_FAILED (a file input at end of file) after it has delivered k batches.
+    end_of_streams: afterwards every input fails; `exited_on_its_own` tells whether the demodulator then set do_exit and returned."""
     ctx = mp.get_context("spawn" if hip_lib else "fork")
     q = ctx.Queue()
-    p = ctx.Process(target=_all_worker, args=(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib))
+    p = ctx.Process(target=_all_worker, args=(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib, fail_after, end_of_streams))
     p.start()
     status, res = q.get()
     p.join()

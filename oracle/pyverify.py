@@ -103,3 +103,49 @@ class SpotCheck:
                     assert rel <= 1e-4, "%s channel %d: %s %r vs oracle %r" % (tag, j, f, g[f], o[f])
                     worst["level_rel"] = max(worst["level_rel"], rel)
         return worst
+
+
+# airband_hip_channel_stats as a numpy record (include/airband_hip.h:141-153): 4 floats, 5 uint64, 2 int32 = 64 bytes
+STATS_DT = np.dtype([("noise_level", "<f4"), ("signal_level", "<f4"), ("squelch_level", "<f4"), ("agcavgfast", "<f4"), ("open_count", "<u8"),
+                     ("flappy_count", "<u8"), ("ctcss_count", "<u8"), ("no_ctcss_count", "<u8"), ("active_counter", "<u8"), ("bin", "<i4"), ("squelch_state", "<i4")])
+assert STATS_DT.itemsize == 64
+
+
+def replica_check(hip, n_dev: int, n_ch: int, *, trace: bool = True, chunk: int = 2048) -> Dict[str, int]:
+    """WHOLE-handle check for a handle whose dongles were all given dongle 0's channel plan and dongle 0's bytes: dongles are
+    independent (src/rtl_airband.cpp:1052-1076), so every dongle's results of the last batch -- audio rows, axcindicate, every
+    statistic and (if recorded) the per-sample squelch trace -- must be BIT-identical to dongle 0's, wherever the dongle sits in
+    the handle (XCD placement group, slot block, ring offset beyond 2^31 elements).  Dongle 0 itself is tied to the oracle by a
+    SpotCheck.  Returns the number of dongles that differ per output (all zero = pass) and the first offender."""
+    import ctypes as C
+
+    L, B = hip.L, hip.B
+    bad = dict(waveout=0, axc=0, stats=0, trace=0, first_bad=-1, dongles=n_dev)
+    ref = None
+    wave = np.empty((chunk * n_ch, B), np.float32)
+    axc = np.empty((chunk * n_ch,), np.uint8)
+    st = np.empty((chunk * n_ch,), STATS_DT)
+    tr = np.empty((chunk * n_ch, B), np.uint8) if trace else None
+    for d0 in range(0, n_dev, chunk):
+        n = min(chunk, n_dev - d0)
+        rc = L.airband_hip_collect_channels(hip.h, d0 * n_ch, n * n_ch, wave.ctypes.data, None, axc.ctypes.data, C.c_void_p(st.ctypes.data))
+        assert rc == 0, rc
+        if trace:
+            rc = L.airband_hip_read_trace_channels(hip.h, d0 * n_ch, n * n_ch, tr.ctypes.data)
+            assert rc == 0, rc
+        if ref is None:
+            ref = dict(wave=wave[:n_ch].view(np.uint32).copy(), axc=axc[:n_ch].copy(), st=st[:n_ch].copy().view(np.uint8).reshape(n_ch, 64),
+                       tr=tr[:n_ch].copy() if trace else None)
+        diff = {
+            "waveout": (wave[:n * n_ch].view(np.uint32).reshape(n, n_ch, B) != ref["wave"]).any(axis=(1, 2)),
+            "axc": (axc[:n * n_ch].reshape(n, n_ch) != ref["axc"]).any(axis=1),
+            "stats": (st[:n * n_ch].view(np.uint8).reshape(n, n_ch, 64) != ref["st"]).any(axis=(1, 2)),
+        }
+        if trace:
+            diff["trace"] = (tr[:n * n_ch].reshape(n, n_ch, B) != ref["tr"]).any(axis=(1, 2))
+        for k, m in diff.items():
+            c = int(m.sum())
+            bad[k] += c
+            if c and bad["first_bad"] < 0:
+                bad["first_bad"] = d0 + int(np.argmax(m))
+    return bad

@@ -42,7 +42,11 @@ int parse_devices(libconfig::Setting&) { refh_unreachable("parse_devices"); retu
 int parse_mixers(libconfig::Setting&) { refh_unreachable("parse_mixers"); return 0; }
 lame_t airlame_init(mix_modes, int, int) { refh_unreachable("airlame_init"); return NULL; }
 void shout_setup(icecast_data*, mix_modes) { refh_unreachable("shout_setup"); }
-void disable_device_outputs(device_t*) {}
+static int g_outputs_disabled[4096]; /* disable_device_outputs() calls per device (src/output.cpp:591-596 is the real one) */
+void disable_device_outputs(device_t* dev) {
+    const long d = dev - devices;
+    if (d >= 0 && d < 4096) g_outputs_disabled[d]++;
+}
 void disable_channel_outputs(channel_t*) {}
 void* output_check_thread(void*) { refh_unreachable("output_check_thread"); return NULL; }
 void* output_thread(void*) { refh_unreachable("output_thread"); return NULL; }
@@ -266,6 +270,8 @@ struct HipApi {
     int64_t (*submit)(airband_hip_handle*, int32_t, const void*, size_t);
     int (*process)(airband_hip_handle*);
     int (*collect)(airband_hip_handle*, float*, float*, char*, airband_hip_channel_stats*);
+    int (*device_enable)(airband_hip_handle*, int32_t, int32_t);
+    int (*gpu_count)(void);
 };
 static HipApi g_hip;
 
@@ -277,6 +283,8 @@ const char* airband_hip_last_error(const airband_hip_handle* h) { return g_hip.l
 int64_t airband_hip_submit(airband_hip_handle* h, int32_t dev, const void* iq, size_t n) { return g_hip.submit(h, dev, iq, n); }
 int airband_hip_process(airband_hip_handle* h) { return g_hip.process(h); }
 int airband_hip_collect(airband_hip_handle* h, float* w, float* q, char* a, airband_hip_channel_stats* st) { return g_hip.collect(h, w, q, a, st); }
+int airband_hip_device_enable(airband_hip_handle* h, int32_t dev, int32_t on) { return g_hip.device_enable(h, dev, on); }
+int airband_hip_gpu_count(void) { return g_hip.gpu_count(); }
 }
 
 /* statistics exactly as the stats file / TUI would read them with the HIP backend: through the reference's own Squelch getters
@@ -309,7 +317,7 @@ int refh_start_hip(const char* lib_path) {
     *(void**)(&g_hip.field) = dlsym(g_hip.dl, "airband_hip_" name); \
     if (!g_hip.field) return -2;
     REFH_SYM(prepare, "prepare") REFH_SYM(release, "release") REFH_SYM(get_geometry, "get_geometry") REFH_SYM(last_error, "last_error")
-    REFH_SYM(submit, "submit") REFH_SYM(process, "process") REFH_SYM(collect, "collect")
+    REFH_SYM(submit, "submit") REFH_SYM(process, "process") REFH_SYM(collect, "collect") REFH_SYM(device_enable, "device_enable") REFH_SYM(gpu_count, "gpu_count")
 #undef REFH_SYM
     devices_running = device_count;
     g_demod_params[0].mp3_signal = &g_signal;
@@ -407,12 +415,18 @@ int refh_run_device(int d, const unsigned char* iq, size_t nbytes, int max_batch
     return nb;
 }
 
-/* Streams nbytes of I/Q into EVERY device concurrently (round-robin, like independent rx threads) and collects batches until each
- * device produced n_batches (or `timeout_s` passes).  Works with demodulate() and with demodulate_hip().
- * waveout [device][n_batches][C][WAVE_BATCH] with C = the (common) channel count, etc.  Returns the minimum batch count reached. */
-int refh_run_all(const unsigned char* const* iq, size_t nbytes, int n_batches, float* waveout, float* iq_out, char* axc, double timeout_s) {
+/* Streams I/Q into EVERY device concurrently (round-robin, like independent rx threads) and collects batches until each device produced
+ * its target.  Works with demodulate() and with demodulate_hip().  nbytes[d] = bytes of device d's stream; fail_after[d] >= 0 plays
+ * the file input at end of file (src/input-file.cpp:101-111): once device d has delivered that many batches its rx side stops and
+ * sets input->state = INPUT_FAILED; its target is then fail_after[d] batches instead of n_batches.  fail_after may be NULL.
+ * waveout [device][n_batches][C][WAVE_BATCH] with C = the (common) channel count, etc.; got[d] = batches device d produced.
+ * Returns the minimum over the devices of (batches produced - target), i.e. 0 when every device reached its target. */
+int refh_run_all(const unsigned char* const* iq, const size_t* nbytes, const int* fail_after, int n_batches, float* waveout, float* iq_out, char* axc, int* got,
+                 double timeout_s) {
     std::vector<size_t> off(device_count, 0);
-    std::vector<int> nb(device_count, 0);
+    std::vector<int> nb(device_count, 0), target(device_count, n_batches);
+    for (int d = 0; d < device_count; d++)
+        if (fail_after && fail_after[d] >= 0 && fail_after[d] < n_batches) target[d] = fail_after[d];
     struct timeval t0, t1;
     gettimeofday(&t0, NULL);
     const int C = devices[0].channel_count;
@@ -421,34 +435,61 @@ int refh_run_all(const unsigned char* const* iq, size_t nbytes, int n_batches, f
         for (int d = 0; d < device_count; d++) {
             device_t* dev = devices + d;
             input_t* in = dev->input;
-            if (dev->waveavail && nb[d] < n_batches) {
+            if (dev->waveavail && nb[d] < target[d]) {
                 const size_t o = ((size_t)d * n_batches + nb[d]) * C;
                 refh_drain(d, waveout ? waveout + o * WAVE_BATCH : NULL, iq_out ? iq_out + o * 2 * WAVE_BATCH : NULL, axc ? axc + o : NULL);
                 nb[d]++;
+                if (nb[d] == target[d] && target[d] < n_batches && in->state == INPUT_RUNNING) in->state = INPUT_FAILED; /* "hit end of file ... disabling" */
             }
             /* Never queue more than the batch that is about to be drained needs: the reference's hand-off (waveavail flag, tail
              * copy by the consumer, src/output.cpp:917-922) is racy by design when the demod thread can run a whole batch ahead of
              * the output thread, and a deterministic harness must not depend on who wins. */
             const size_t cap = ((size_t)(nb[d] + 1) * WAVE_BATCH + AGC_EXTRA + 1) * refh_bps(in) + fft_size * in->bytes_per_sample * 2;
-            if (off[d] < nbytes && off[d] < cap) {
+            if (nb[d] < target[d] && off[d] < nbytes[d] && off[d] < cap) {
                 const size_t room = in->buf_size - 1 - refh_available(in);
-                const size_t n = std::min(std::min(nbytes, cap) - off[d], std::min(room, refh_bps(in) * (size_t)WAVE_BATCH / 4));
+                const size_t n = std::min(std::min(nbytes[d], cap) - off[d], std::min(room, refh_bps(in) * (size_t)WAVE_BATCH / 4));
                 if (n > 0) {
                     circbuffer_append(in, const_cast<unsigned char*>(iq[d]) + off[d], n);
                     off[d] += n;
                 }
             }
-            if (nb[d] < n_batches) done = false;
+            if (nb[d] < target[d]) done = false;
         }
         if (done) break;
         gettimeofday(&t1, NULL);
         if ((t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec) > timeout_s) break;
         sched_yield();
     }
-    int mn = n_batches;
-    for (int d = 0; d < device_count; d++) mn = std::min(mn, nb[d]);
+    int mn = 0;
+    for (int d = 0; d < device_count; d++) {
+        if (got) got[d] = nb[d];
+        mn = std::min(mn, nb[d] - target[d]);
+    }
     return mn;
 }
+
+/* End of every stream: all inputs report INPUT_FAILED (file inputs at end of file).  The demodulator -- demodulate() or demodulate_hip() --
+ * must take each device out (disable_device_outputs, devices_running--) and, with none left, set do_exit and return
+ * (src/rtl_airband.cpp:377-391).  Returns 1 if the thread(s) ended on their own within timeout_s, 0 otherwise (they are then stopped). */
+int refh_fail_all_and_wait_exit(double timeout_s) {
+    for (int d = 0; d < device_count; d++)
+        if (devices[d].input->state == INPUT_RUNNING) devices[d].input->state = INPUT_FAILED;
+    struct timeval t0, t1;
+    gettimeofday(&t0, NULL);
+    while (!do_exit) {
+        gettimeofday(&t1, NULL);
+        if ((t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec) > timeout_s) return 0;
+        sched_yield();
+    }
+    for (int t = 0; t < g_threads_running; t++) pthread_join(g_demod_thread[t], NULL);
+    g_threads_running = 0;
+    return 1;
+}
+
+int refh_outputs_disabled(int d) { return (d >= 0 && d < 4096) ? g_outputs_disabled[d] : -1; }
+int refh_devices_running(void) { return devices_running; }
+int refh_input_state(int d) { return (int)devices[d].input->state; }
+unsigned refh_output_overruns(int d) { return (unsigned)devices[d].output_overrun_count; }
 
 /* stats mirror: what src/output.cpp:617-761 and the TUI read */
 int refh_channel_stats(int d, int j, airband_hip_channel_stats* out) {

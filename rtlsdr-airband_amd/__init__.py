@@ -29,7 +29,7 @@ EXPORTS = [
     "airband_hip_synchronize", "airband_hip_process_bins", "airband_hip_read_bins", "airband_hip_read_trace", "airband_hip_channel_constants",
     "airband_hip_derive_constants", "airband_hip_last_timings", "airband_hip_channelizer_name", "airband_hip_set_signal_plan", "airband_hip_generate_iq",
     "airband_hip_flush", "airband_hip_timing_totals", "airband_hip_stream_wait_results", "airband_hip_mixer_enable_input",
-    "airband_hip_build_info", "airband_hip_dft_selftest", "airband_hip_collect_channels", "airband_hip_read_bins_channels", "airband_hip_read_trace_channels",
+    "airband_hip_device_enable", "airband_hip_gpu_count", "airband_hip_build_info", "airband_hip_dft_selftest", "airband_hip_collect_channels", "airband_hip_read_bins_channels", "airband_hip_read_trace_channels",
 ]
 
 _lib = None
@@ -90,6 +90,8 @@ def load_library() -> C.CDLL:
     L.airband_hip_build_info.restype = C.c_char_p
     L.airband_hip_flush.argtypes = [vp]
     L.airband_hip_mixer_enable_input.argtypes = [vp, i32, i32]
+    L.airband_hip_device_enable.argtypes = [vp, i32, i32]
+    L.airband_hip_gpu_count.argtypes = []
     L.airband_hip_stream_wait_results.argtypes = [vp, vp]
     L.airband_hip_timing_totals.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     _lib = L
@@ -272,6 +274,10 @@ class AirbandHip:
 
     def mixer_enable_input(self, input_index: int, enabled: bool):
         self._check(self.L.airband_hip_mixer_enable_input(self.h, input_index, 1 if enabled else 0))
+
+    def device_enable(self, dev: int, enabled: bool):
+        """Switch a dongle off / on: the reference's handling of a failed input (src/rtl_airband.cpp:383-391)."""
+        self._check(self.L.airband_hip_device_enable(self.h, dev, 1 if enabled else 0))
 
     def collect_mixers(self):
         left = np.empty((self.n_mixers, self.B), np.float32)

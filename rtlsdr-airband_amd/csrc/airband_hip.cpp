@@ -113,7 +113,7 @@ struct airband_hip_handle {
      * straight into it -- the only CPU copy on the way -- and may be called for DIFFERENT dongles from several threads at once;
      * process() ships a batch with (at most two, where the span wraps) strided DMA transfers on a copy stream into one of two
      * device staging buffers while the kernels of the previous batch still read the other. */
-    uint8_t* h_ring = nullptr;
+    std::atomic<uint8_t*> h_ring{nullptr};                 /* published (release) by host_path_init() once ring_cap / stage_stride / the staging buffers exist; read (acquire) by submit() and process() */
     int64_t ring_cap = 0;                                  /* bytes per dongle */
     std::unique_ptr<std::atomic<uint64_t>[]> ring_wr;      /* per dongle: stream bytes accepted so far */
     uint64_t ring_rd = 0;                                  /* stream position of the next batch (common to all dongles: they advance in lockstep) */
@@ -125,9 +125,15 @@ struct airband_hip_handle {
     uint64_t host_batches = 0;
     std::mutex host_init_lock;
 
+    /* dongles switched off with airband_hip_device_enable(): skipped by the availability rule and by both stages */
+    std::vector<uint8_t> dev_enabled;
+    int n_enabled = 0;
+    std::vector<ChanConst> cc_slots; /* host copy of d_cc (slot order): the VALID bit of a dongle's slots follows its enable state */
+
     /* mixers */
     std::vector<int> mix_pos;       /* connection index (order of airband_hip_set_mixers) -> position in the per-mixer grouped arrays */
     std::vector<int> mix_chan_host; /* grouped external channel indices, for re-enabling an input */
+    std::vector<uint8_t> mix_user_on; /* by position: airband_hip_mixer_enable_input()'s say; an input counts while this AND its dongle are on */
     int n_mixers = 0;
     int n_mix_runs = 0;
     DevBuf<int> d_mix_chan, d_mix_first, d_mix_run_first, d_mix_run_mixer, d_mix_first_run;
@@ -182,7 +188,7 @@ void destroy(airband_hip_handle* h) {
     h->d_item_dev.release(); h->d_item_group.release(); h->d_item_bset.release(); h->d_bfrag.release(); h->d_bcorr.release();
     if (h->h2d) (void)hipStreamSynchronize(h->h2d);
     h->d_stage2[0].release(); h->d_stage2[1].release();
-    if (h->h_ring) (void)hipHostFree(h->h_ring);
+    if (h->h_ring.load()) (void)hipHostFree(h->h_ring.load());
     for (auto& e : h->ev_h2d)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : h->ev_stage_read)
@@ -287,7 +293,7 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
     if (h->any_afc && h->afc_spectrum_valid) { /* afc.finalize(), src/rtl_airband.cpp:626-630: may turn '*' into '<' / '>' */
         launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, s);
-        launch_axc(h->d_cs.p, h->d_slot_to_ext.p, h->d_out_axc.p, h->n_slots, s);
+        launch_axc(h->d_cc.p, h->d_cs.p, h->d_slot_to_ext.p, h->d_out_axc.p, h->n_slots, s);
     }
     (void)hipEventRecord(ev[3], s);
     if (h->d_out_iq.p) { /* handles with has_iq_outputs channels: raw I/Q rows -> channel-major */
@@ -332,6 +338,16 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     h->results_ready = true;
     harvest_timings(h, false);
     return AIRBAND_HIP_OK;
+}
+
+/* position k of the grouped mixer-input arrays: the channel it reads, or -1 while the connection (airband_hip_mixer_enable_input) or its dongle
+ * (airband_hip_device_enable) is switched off -- a masked input is skipped like mixer->input_mask[i] == false (src/mixer.cpp:96-110,192) */
+hipError_t write_mix_input(airband_hip_handle* h, int k) {
+    const int ch = h->mix_chan_host[k];
+    const int v = (h->mix_user_on[k] && h->dev_enabled[h->plan.cc[ch].dev]) ? ch : -1;
+    hipError_t e = hipMemcpyAsync(h->d_mix_chan.p + k, &v, sizeof(int), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(h->stream); /* `v` is a stack variable */
 }
 
 }  // namespace
@@ -559,6 +575,9 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     }
     h->ring_wr.reset(new std::atomic<uint64_t>[p.n_dev]);
     for (int d = 0; d < p.n_dev; d++) h->ring_wr[d].store(0);
+    h->dev_enabled.assign(p.n_dev, 1);
+    h->n_enabled = p.n_dev;
+    h->cc_slots = cc_slots;
 #undef PREP_TRY
     *out = h;
     return AIRBAND_HIP_OK;
@@ -636,7 +655,11 @@ int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const air
     HIP_TRY(h, h->d_mix_right.alloc((size_t)mixer_count * h->B), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, h->d_mix_signal.alloc((size_t)mixer_count), AIRBAND_HIP_ENOMEM);
     h->mix_chan_host = chan;
+    h->mix_user_on.assign(n_in, 1);
     h->n_mixers = mixer_count;
+    for (int k = 0; k < n_in; k++) /* inputs of dongles that are already switched off stay out */
+        if (!h->dev_enabled[p.cc[chan[k]].dev]) HIP_TRY(h, write_mix_input(h, k), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipStreamSynchronize(h->stream), AIRBAND_HIP_ERUNTIME);
     return AIRBAND_HIP_OK;
 }
 
@@ -645,10 +668,49 @@ int airband_hip_mixer_enable_input(airband_hip_handle* h, int32_t input_index, i
     if (input_index < 0 || input_index >= (int32_t)h->mix_pos.size()) return fail(h, AIRBAND_HIP_EINVAL, "mixer input index out of range");
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
     const int k = h->mix_pos[input_index];
-    const int v = enabled ? h->mix_chan_host[k] : -1; /* a masked input is skipped like mixer->input_mask[i] == false (src/mixer.cpp:96-110,192) */
-    HIP_TRY(h, hipMemcpyAsync(h->d_mix_chan.p + k, &v, sizeof(int), hipMemcpyHostToDevice, h->stream), AIRBAND_HIP_ERUNTIME);
+    h->mix_user_on[k] = enabled ? 1 : 0;
+    HIP_TRY(h, write_mix_input(h, k), AIRBAND_HIP_ERUNTIME);
     HIP_TRY(h, hipStreamSynchronize(h->stream), AIRBAND_HIP_ERUNTIME);
     return AIRBAND_HIP_OK;
+}
+
+int airband_hip_device_enable(airband_hip_handle* h, int32_t dev, int32_t enabled) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    const Plan& p = h->plan;
+    if (dev < 0 || dev >= p.n_dev) return fail(h, AIRBAND_HIP_EINVAL, "device index out of range");
+    const uint8_t on = enabled ? 1 : 0;
+    if (h->dev_enabled[dev] == on) return AIRBAND_HIP_OK;
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    hipStream_t s = h->stream;
+    order_behind_last_batch(h);
+    /* everything below is ordered on the handle's stream: the batches already enqueued still see the old state, the next one the new */
+    h->plan.dev[dev].disabled = on ? 0 : 1;
+    HIP_TRY(h, hipMemcpyAsync(&h->d_dev.p[dev], &h->plan.dev[dev], sizeof(DevConst), hipMemcpyHostToDevice, s), AIRBAND_HIP_ERUNTIME);
+    const int c0 = p.chan_base[dev], nc = p.dev[dev].n_ch;
+    std::vector<uint8_t> blank((size_t)nc, (uint8_t)' ');
+    for (int c = c0; c < c0 + nc; c++) { /* the demod kernels treat a slot without AB_F_VALID like padding: the lane leaves at once, its state stays as it is */
+        const int slot = h->ext_to_slot[c];
+        ChanConst& cc = h->cc_slots[slot];
+        cc.flags = on ? (cc.flags | AB_F_VALID) : (cc.flags & ~AB_F_VALID);
+        HIP_TRY(h, hipMemcpyAsync(&h->d_cc.p[slot].flags, &cc.flags, sizeof(cc.flags), hipMemcpyHostToDevice, s), AIRBAND_HIP_ERUNTIME);
+    }
+    /* channel->axcindicate of a device that is not demodulated any more: NO_SIGNAL */
+    if (!on) HIP_TRY(h, hipMemcpyAsync(h->d_out_axc.p + c0, blank.data(), (size_t)nc, hipMemcpyHostToDevice, s), AIRBAND_HIP_ERUNTIME);
+    h->dev_enabled[dev] = on;
+    h->n_enabled += on ? 1 : -1;
+    /* its mixer connections: mixer_disable_input() for every output of the device, as disable_device_outputs() does (src/output.cpp, src/mixer.cpp:96-110) */
+    for (size_t k = 0; k < h->mix_chan_host.size(); k++)
+        if (p.cc[h->mix_chan_host[k]].dev == dev) HIP_TRY(h, write_mix_input(h, (int)k), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipStreamSynchronize(s), AIRBAND_HIP_ERUNTIME); /* the host buffers above go out of scope */
+    /* host-ring path: a dongle that comes back joins the others at the common stream position with an empty queue */
+    if (on && h->ring_wr) h->ring_wr[dev].store(h->ring_rd, std::memory_order_release);
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_gpu_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
 }
 
 /* stage 1 of the next batch (index front_batches, ring rows from row0_front) on stream s */
@@ -792,7 +854,7 @@ int airband_hip_flush(airband_hip_handle* h) {
 /* first use of the host-ring path: pinned rings, device staging, copy stream */
 static int host_path_init(airband_hip_handle* h) {
     std::lock_guard<std::mutex> guard(h->host_init_lock);
-    if (h->h_ring) return AIRBAND_HIP_OK;
+    if (h->h_ring.load(std::memory_order_acquire)) return AIRBAND_HIP_OK;
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
     /* bounded like the reference's ring (MIN_BUF_SIZE = 2 560 000 bytes ~ 4 batches, src/rtl_airband.h:64): the first batch with its
      * lead-in, the batch in flight, one more being filled, and the look-ahead */
@@ -807,22 +869,25 @@ static int host_path_init(airband_hip_handle* h) {
         if (!e) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
     uint8_t* ring = nullptr;
     HIP_TRY(h, hipHostMalloc((void**)&ring, (size_t)h->ring_cap * h->plan.n_dev, hipHostMallocDefault), AIRBAND_HIP_ENOMEM);
-    h->h_ring = ring; /* published last: submit() / process() test this pointer without the lock */
+    h->h_ring.store(ring, std::memory_order_release); /* published last: submit() / process() test this pointer without the lock */
     return AIRBAND_HIP_OK;
 }
 
 int64_t airband_hip_submit(airband_hip_handle* h, int32_t dev, const void* iq, size_t nbytes) {
     if (!h || !iq) return fail(h, AIRBAND_HIP_EINVAL, "NULL argument");
     if (dev < 0 || dev >= h->plan.n_dev) return fail(h, AIRBAND_HIP_EINVAL, "device index out of range");
-    if (!h->h_ring) { /* the first submit of a handle sets the path up (callers that submit from several threads start with one) */
+    if (!h->dev_enabled[dev]) return (int64_t)nbytes; /* a disabled dongle's bytes are dropped, as nobody reads a failed input's ring any more */
+    uint8_t* ring = h->h_ring.load(std::memory_order_acquire);
+    if (!ring) { /* the first submit of a handle sets the path up; concurrent first submits for different dongles serialise on the lock inside */
         const int rc = host_path_init(h);
         if (rc != AIRBAND_HIP_OK) return rc;
+        ring = h->h_ring.load(std::memory_order_acquire);
     }
     const uint64_t wr = h->ring_wr[dev].load(std::memory_order_relaxed);
     const uint64_t used = wr - h->ring_free.load(std::memory_order_acquire);
     size_t take = nbytes;
     if (used + take > (uint64_t)h->ring_cap) take = (uint64_t)h->ring_cap > used ? (size_t)((uint64_t)h->ring_cap - used) : 0;
-    uint8_t* row = h->h_ring + (size_t)dev * h->ring_cap;
+    uint8_t* row = ring + (size_t)dev * h->ring_cap;
     const size_t pos = (size_t)(wr % (uint64_t)h->ring_cap);
     const size_t first = take < (size_t)h->ring_cap - pos ? take : (size_t)h->ring_cap - pos;
     std::memcpy(row + pos, iq, first);
@@ -834,15 +899,17 @@ int64_t airband_hip_submit(airband_hip_handle* h, int32_t dev, const void* iq, s
 int airband_hip_process(airband_hip_handle* h) {
     if (!h) return AIRBAND_HIP_EINVAL;
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
-    if (!h->h_ring) {
+    if (!h->h_ring.load(std::memory_order_acquire)) {
         const int rc = host_path_init(h);
         if (rc != AIRBAND_HIP_OK) return rc;
     }
+    uint8_t* const ring = h->h_ring.load(std::memory_order_acquire);
     const bool first = h->front_batches == 0;
     const int64_t consume = first ? h->first_batch_bytes : h->batch_bytes;
     const int64_t need = consume + h->lookahead_bytes; /* availability rule (src/rtl_airband.cpp:394-400) applied to a whole batch */
-    for (int d = 0; d < h->plan.n_dev; d++)
-        if ((int64_t)(h->ring_wr[d].load(std::memory_order_acquire) - h->ring_rd) < need) return AIRBAND_HIP_EAGAIN;
+    if (h->n_enabled == 0) return AIRBAND_HIP_EAGAIN; /* every dongle switched off: nothing to demodulate (the reference exits, src/rtl_airband.cpp:377-381) */
+    for (int d = 0; d < h->plan.n_dev; d++) /* dongles switched off (failed inputs) are not waited for: next_device() passes them by, src/rtl_airband.cpp:383-391 */
+        if (h->dev_enabled[d] && (int64_t)(h->ring_wr[d].load(std::memory_order_acquire) - h->ring_rd) < need) return AIRBAND_HIP_EAGAIN;
     const int b = (int)(h->host_batches & 1);
     /* the DMA of the previous batch has left the ring: its bytes (up to the look-ahead the next batch re-reads) may be overwritten */
     if (h->host_batches > 0) {
@@ -853,10 +920,10 @@ int airband_hip_process(airband_hip_handle* h) {
     if (h->host_batches >= 2) HIP_TRY(h, hipStreamWaitEvent(h->h2d, h->ev_stage_read[b], 0), AIRBAND_HIP_ERUNTIME);
     const size_t pos = (size_t)(h->ring_rd % (uint64_t)h->ring_cap);
     const size_t run = (size_t)need < (size_t)h->ring_cap - pos ? (size_t)need : (size_t)h->ring_cap - pos;
-    HIP_TRY(h, hipMemcpy2DAsync(h->d_stage2[b].p, (size_t)h->stage_stride, h->h_ring + pos, (size_t)h->ring_cap, run, (size_t)h->plan.n_dev, hipMemcpyHostToDevice, h->h2d),
+    HIP_TRY(h, hipMemcpy2DAsync(h->d_stage2[b].p, (size_t)h->stage_stride, ring + pos, (size_t)h->ring_cap, run, (size_t)h->plan.n_dev, hipMemcpyHostToDevice, h->h2d),
             AIRBAND_HIP_ERUNTIME);
     if (run < (size_t)need) /* the span wraps around the end of the rings */
-        HIP_TRY(h, hipMemcpy2DAsync(h->d_stage2[b].p + run, (size_t)h->stage_stride, h->h_ring, (size_t)h->ring_cap, (size_t)need - run, (size_t)h->plan.n_dev,
+        HIP_TRY(h, hipMemcpy2DAsync(h->d_stage2[b].p + run, (size_t)h->stage_stride, ring, (size_t)h->ring_cap, (size_t)need - run, (size_t)h->plan.n_dev,
                                     hipMemcpyHostToDevice, h->h2d),
                 AIRBAND_HIP_ERUNTIME);
     HIP_TRY(h, hipEventRecord(h->ev_h2d[b], h->h2d), AIRBAND_HIP_ERUNTIME);

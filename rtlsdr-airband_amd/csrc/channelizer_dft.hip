@@ -131,6 +131,7 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
     const int split = wave_global / a.n_items;
     if (split >= a.splits) return;
     const int d = a.item_dev[item], ch0 = a.item_group[item] * 8;
+    if (a.dev[d].disabled) return; /* a failed / disabled dongle (airband_hip_device_enable): workgroup-uniform, in front of every barrier */
     const int hop_bytes = HOPB ? HOPB : a.hop_bytes;
     /* a staging step feeds `sub` consecutive 16-hop MFMA tiles: ~10 KiB of stream per step whatever the hop size, so
      * the bytes a wave keeps in flight (one step ahead) do not shrink when the hop does */

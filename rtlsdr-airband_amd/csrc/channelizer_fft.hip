@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
     const int hops_here = min(HOPS_PER_TILE, a.n_hops - hop0);
     const int bps2 = 2 * a.bytes_per_sample; /* bytes per complex sample */
     const DevConst dev = a.dev[d];
+    if (dev.disabled) return; /* a failed / disabled dongle (airband_hip_device_enable): block-uniform, in front of every barrier */
 
     /* ---- stage the tile's raw bytes: coalesced 16 B per lane, HBM -> LDS -------------------------------- */
     const long span_begin = (long)hop0 * a.hop_samples * bps2; /* byte offset inside this batch's span */

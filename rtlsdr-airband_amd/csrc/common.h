@@ -87,7 +87,7 @@ struct DevConst {
     int32_t chan_base;     /* first internal slot of this dongle's channels */
     float scale;           /* 1/fullscale for S16/F32 (src/rtl_airband.cpp:403,421) */
     int32_t any_raw_iq;
-    int32_t pad;
+    int32_t disabled;      /* airband_hip_device_enable(h, dev, 0): both stages skip the dongle (a failed input, src/rtl_airband.cpp:377-391) */
 };
 
 /* Demod kinds: slots are sorted so that the 64 lanes of a demod wavefront run the same code path. */
@@ -98,7 +98,7 @@ enum { AB_KIND_AM = 0, AB_KIND_NFM = 1, AB_KIND_NFM_LOWPASS = 2, AB_KIND_NFM_CTC
  * contiguous region row by row (256 bytes per row), and a channelizer wavefront writes its dongle's few slots at a
  * 256-byte row stride inside that same region instead of at a multi-megabyte stride. */
 #define AB_SLOT_BLOCK 64
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define AB_HD __host__ __device__
 #else
 #define AB_HD

@@ -646,6 +646,9 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
             /* steady state: squelch open throughout and no detector window ends inside the step -> only the recurrences
              * (ToneDetector::process_sample, src/ctcss.cpp:44-54) */
             if (enough1) {
+#ifdef AB_TONE_UNROLL
+#pragma unroll AB_TONE_UNROLL
+#endif
                 for (int u = 0; u < TONE_GROUP; u++) {
                     const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
                     const float q0 = c1 * q1s - q2s + x;
@@ -653,6 +656,9 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
                     q1s = q0;
                 }
             } else { /* the fast detector runs until the slow one has a full window (src/squelch.cpp:288-293) */
+#ifdef AB_TONE_UNROLL
+#pragma unroll AB_TONE_UNROLL
+#endif
                 for (int u = 0; u < TONE_GROUP; u++) {
                     const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
                     const float q0 = c1 * q1s - q2s + x;
@@ -919,11 +925,11 @@ __global__ __launch_bounds__(256) void emit_iq_kernel(EmitArgs a) {
 }
 
 /* axcindicate after AFC has had its say (afc.finalize() may turn '*' into '<' / '>', src/rtl_airband.cpp:626-630) */
-__global__ void axc_kernel(const ChanState* cs, const int* slot_to_ext, uint8_t* out_axc, int n_slots) {
+__global__ void axc_kernel(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, uint8_t* out_axc, int n_slots) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots) return;
     const int ext = slot_to_ext[slot];
-    if (ext >= 0) out_axc[ext] = (uint8_t)cs[slot].axc;
+    if (ext >= 0 && (cc[slot].flags & AB_F_VALID)) out_axc[ext] = (uint8_t)cs[slot].axc; /* channels of a disabled dongle keep their NO_SIGNAL */
 }
 
 void launch_emit_iq(const EmitArgs& a, hipStream_t stream) {
@@ -936,8 +942,8 @@ void launch_emit_iq(const EmitArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(emit_iq_kernel, dim3(blocks, ysplit), dim3(256), 0, stream, a);
 }
 
-void launch_axc(const ChanState* cs, const int* slot_to_ext, uint8_t* out_axc, int n_slots, hipStream_t stream) {
-    hipLaunchKernelGGL(axc_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, cs, slot_to_ext, out_axc, n_slots);
+void launch_axc(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, uint8_t* out_axc, int n_slots, hipStream_t stream) {
+    hipLaunchKernelGGL(axc_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, cc, cs, slot_to_ext, out_axc, n_slots);
 }
 
 /* ---- stats mirror (reference getters: src/output.cpp:617-761) ---------------------------------------------- */

@@ -134,7 +134,7 @@ void launch_channelizer_dft(const DftArgs& a, hipStream_t stream);
 /* side: 3 extra streams, ev: 4 events (fork + 3 joins); both may be null -> everything on `stream`, one kind after the other */
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev);
 void launch_emit_iq(const EmitArgs& a, hipStream_t stream);
-void launch_axc(const ChanState* cs, const int* slot_to_ext, uint8_t* out_axc, int n_slots, hipStream_t stream);
+void launch_axc(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, uint8_t* out_axc, int n_slots, hipStream_t stream);
 void launch_mix(const MixArgs& a, hipStream_t stream);
 void launch_stats(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, int n_slots, airband_hip_channel_stats* out, hipStream_t stream);
 void launch_siggen(const SiggenArgs& a, hipStream_t stream);

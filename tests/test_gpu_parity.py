@@ -504,6 +504,64 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
     assert opened > 0
 
 
+def test_device_enable_takes_a_failed_dongle_out(pkg, built):
+    """airband_hip_device_enable(h, d, 0) = what demodulate() does with a failed input (src/rtl_airband.cpp:383-391): the dongle is
+    passed by -- not waited for, not demodulated, out of its mixers -- and the others go on exactly as before."""
+    capi = pkg.capi
+    n_dev, n_batches, wave_rate, off_at = 9, 7, 16000, 3   # 9 dongles: slot blocks with enabled and disabled lanes side by side
+    devices, carriers = helpers.plan_devices(n_dev, True, _tweak)
+    nbytes = helpers.stream_bytes(n_batches, wave_rate)
+    iq = [pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)]
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate)
+    ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
+    gone = [1, 8]
+    inputs = [(d, c, 0, 1.0, 0.0) for d in range(n_dev) for c in (0, 2)]
+    rest = [t for t in inputs if t[0] not in gone]
+    arr = (capi.MixerInput * len(rest))(*[capi.MixerInput(*t) for t in rest])
+    base = (np.arange(n_dev, dtype=np.int32) * 8)
+    L = pyoracle.lib()
+    with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=capi.FLAG_TRACE_SQUELCH) as hip:
+        hip.set_mixers(1, inputs)
+        pos = [0] * n_dev
+        frozen = None
+        for b in range(n_batches):
+            if b == off_at:
+                frozen = hip.collect(stats=True)["stats"]
+                for d in gone:
+                    hip.device_enable(d, False)
+                hip.device_enable(gone[0], False)  # idempotent
+            for d in range(n_dev):
+                if b < off_at or d not in gone:  # a failed input delivers nothing any more
+                    pos[d] += hip.submit(d, iq[d][pos[d]:])
+            assert hip.process(), "batch %d: the handle waited for a dongle that is switched off" % b
+            out = hip.collect(stats=True)
+            tr = hip.read_trace()
+            for d in range(n_dev):
+                sl = slice(8 * d, 8 * d + 8)
+                if b >= off_at and d in gone:
+                    assert (out["axc"][sl] == ord(" ")).all()
+                    for j in range(8):  # state frozen at the moment it was taken out
+                        for k in ("open_count", "active_counter", "noise_level", "signal_level", "squelch_state", "ctcss_count"):
+                            assert out["stats"][8 * d + j][k] == frozen[8 * d + j][k], (b, d, j, k)
+                    continue
+                assert np.array_equal(out["axc"][sl], ref[d]["axc"][b]), (b, d)
+                assert np.array_equal(tr[sl], ref[d]["trace"][b]), (b, d)
+                assert helpers.rms(out["waveout"][sl] - ref[d]["waveout"][b]) <= 1e-4
+            if b >= off_at:  # the mixer no longer hears the dongles that are gone (disable_device_outputs -> mixer_disable_input)
+                left, right, sig = hip.collect_mixers()
+                B = hip.B
+                wl, wr, ws = np.zeros((1, B), np.float32), np.zeros((1, B), np.float32), np.zeros(1, np.uint8)
+                w, a = np.ascontiguousarray(out["waveout"]), np.ascontiguousarray(out["axc"])
+                L.orc_mix(arr, len(rest), base.ctypes.data, w.ctypes.data, a.ctypes.data, B, 1, wl.ctypes.data, wr.ctypes.data, ws.ctypes.data)
+                assert np.array_equal(sig, ws) and np.array_equal(left[0].view(np.uint32), wl[0].view(np.uint32))
+        assert hip.submit(gone[0], iq[0][:1000]) == 1000  # dropped, not queued
+        for d in range(n_dev):
+            hip.device_enable(d, False)
+        assert hip.process() is False  # nothing left to demodulate: the caller's cue to stop (src/rtl_airband.cpp:377-381)
+        with pytest.raises(pkg.AirbandError):
+            hip.device_enable(n_dev, False)
+
+
 def test_afc(pkg, built):
     """AFC-enabled channels (wavefront-FFT path: needs the whole spectrum of each batch's last hop)."""
     n_dev, n_batches = 3, 14

@@ -126,3 +126,69 @@ def test_sampled_dongles_of_large_handles(pkg, built, n_dev, mixed, wave_rate, k
         hip.close()
         del iq
     print("%d dongles, %d sampled: worst audio RMS error %.3g" % (n_dev, len(dongles), worst))
+
+
+
+def _tweak_all(d, ch):
+    _tweak(1, ch)
+
+
+REPLICA_CASES = [
+    # n_dev, mixed, wave_rate, tweak (the same for every dongle), pipelined
+    pytest.param(5000, True, 16000, True, False, id="5000_mixed_tweaked_partial_group"),
+    pytest.param(4096, True, 16000, False, True, id="4096_mixed_pipelined"),
+    pytest.param(65536, True, 16000, False, False, id="configs2_65536_mixed"),
+    pytest.param(65536, False, 8000, False, False, id="65536_am"),
+]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n_dev,mixed,wave_rate,tweak,pipelined", REPLICA_CASES)
+def test_every_dongle_of_a_replicated_handle(pkg, built, n_dev, mixed, wave_rate, tweak, pipelined):
+    """The WHOLE handle, not a sample: every dongle gets dongle 0's channel plan and dongle 0's bytes, dongle 0 is checked against
+    the oracle (trace, axcindicate, counters exact, audio <= 1e-4 RMS) and ALL other dongles' result rows, axcindicate, statistics
+    and per-sample squelch traces must be bit-identical to dongle 0's (pyverify.replica_check)."""
+    torch = pytest.importorskip("torch")
+    n_batches = 7
+    devices, carriers = helpers.plan_devices(1, mixed, _tweak_all if tweak else None)
+    one = devices[0]
+    flags = pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_PIPELINE if pipelined else 0)
+    hip = pkg.AirbandHip([one] * n_dev, wave_rate=wave_rate, flags=flags)
+    iq = spot = None
+    try:
+        g = hip.geometry
+        lead = g.first_batch_bytes - g.batch_bytes
+        span = lead + (RING + 1) * g.batch_bytes + g.lookahead_bytes
+        stride = (span + 255) // 256 * 256
+        iq = _resident_iq(torch, n_dev * stride)[:n_dev * stride].view(n_dev, stride)
+        hip.set_signal_plan(carriers)
+        hip.generate_iq(iq.data_ptr(), stride, 0, span, seed=0x5EED)
+        hip.synchronize()
+        host0 = iq[0].cpu().numpy()
+        for d0 in range(1, n_dev, 4096):  # every dongle replays dongle 0's bytes
+            iq[d0:d0 + 4096] = iq[0:1]
+        torch.cuda.synchronize()
+        assert torch.equal(iq[n_dev - 1], iq[0])
+        spot = pyverify.SpotCheck([one], [0], wave_rate=wave_rate)
+
+        def offset(i):
+            return 0 if i == 0 else g.first_batch_bytes + ((i - 1) % RING) * g.batch_bytes
+
+        opened = 0
+        for i in range(n_batches):
+            hip.process_device(iq.data_ptr() + offset(i), stride)
+            j = i - 1 if pipelined else i
+            if j < 0:
+                continue
+            spot.feed([host0[offset(j):]])
+            spot.compare(hip, trace=True, what="replicated dongle 0 of %d" % n_dev)
+            opened += int((spot.last[0]["axc"] == ord("*")).sum())
+            if j in (0, 3, n_batches - 1):
+                bad = pyverify.replica_check(hip, n_dev, 8)
+                assert bad["waveout"] == bad["axc"] == bad["stats"] == bad["trace"] == 0, "batch %d: dongles that differ from dongle 0: %r" % (j, bad)
+        assert opened > 0
+    finally:
+        if spot is not None:
+            spot.close()
+        hip.close()
+        del iq
