@@ -218,18 +218,6 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
             __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(uintptr_t)(buf + i * 1024), 16, 0, 0);
         }
     };
-    /* experiment (AB_DFT_LDS_XOR): u8 -> int8 (flip the top bit) done to the staged copy by the LDS unit (ds_xor_b64, 512 bytes per
-     * instruction) instead of one v_xor per A-fragment dword in front of the MFMAs.  Correct, and slower everywhere (9.30 vs 9.09 ms
-     * at configs[2], CS16 22.1 vs 19.8): the LDS pipe is the busier one. */
-    auto flip = [&](uint8_t* buf) {
-#ifdef AB_DFT_LDS_XOR
-        const unsigned long long m = S16 ? 0x0080008000800080ull : 0x8080808080808080ull;
-        for (int i = 0; i < n_dma * 1024; i += 512)
-            (void)__hip_atomic_fetch_xor(reinterpret_cast<unsigned long long*>(buf + i) + lane, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#else
-        (void)buf;
-#endif
-    };
     /* staging ring of nbuf buffers: step st lives in buffer (st - st_begin) % nbuf; nbuf - 1 steps are in flight */
     const int nbuf = HOPB ? c_nbuf(HOPB ? HOPB : 64) : a.nbuf;
     /* partial sums of pieces 1 .. NP-1 on their way to wave 0: [tile parity][piece - 1][lane] x 4 floats, behind the staging buffers */
@@ -256,7 +244,6 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
             if (piece == 0) {
                 if (st + 1 >= st_end) wait_vmcnt(k_prev); /* last step: only the stores are younger */
                 else wait_vmcnt(n_dma + k_prev);
-                flip(buf);
             }
             if (NP > 1) __syncthreads();
             int nb = cur + 2;
@@ -265,7 +252,6 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
         } else {
             if (piece == 0) {
                 wait_vmcnt(k_prev); /* this step's bytes have landed in LDS */
-                flip(buf);
             }
             if (NP > 1) __syncthreads();
             if (piece == 0 && st + 1 < st_end) stage(st + 1, lds + (cur ^ 1) * lds_per_buf); /* next step streams in under this step's MFMAs */
@@ -293,9 +279,7 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
                 av[s + 5] = lds_read16<AL>(arow + (s + 5) * 64);
             }
             v4i x = av[s];
-#ifndef AB_DFT_LDS_XOR
             x.x ^= 0x80808080; x.y ^= 0x80808080; x.z ^= 0x80808080; x.w ^= 0x80808080; /* u8 -> b - 128 as int8 */
-#endif
             acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b0[s], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b1[s], acc1, 0, 0, 0);
             if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b2[s], acc2, 0, 0, 0);
@@ -326,9 +310,7 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
             lo.y = (int)__builtin_amdgcn_perm((unsigned)p.w, (unsigned)p.z, 0x06040200u); hi.y = (int)__builtin_amdgcn_perm((unsigned)p.w, (unsigned)p.z, 0x07050301u);
             lo.z = (int)__builtin_amdgcn_perm((unsigned)q.y, (unsigned)q.x, 0x06040200u); hi.z = (int)__builtin_amdgcn_perm((unsigned)q.y, (unsigned)q.x, 0x07050301u);
             lo.w = (int)__builtin_amdgcn_perm((unsigned)q.w, (unsigned)q.z, 0x06040200u); hi.w = (int)__builtin_amdgcn_perm((unsigned)q.w, (unsigned)q.z, 0x07050301u);
-#ifndef AB_DFT_LDS_XOR
             lo.x ^= 0x80808080; lo.y ^= 0x80808080; lo.z ^= 0x80808080; lo.w ^= 0x80808080; /* unsigned low byte -> lo - 128 as int8 */
-#endif
             acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, b0[s], acc0, 0, 0, 0);
             hc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, b0[s], hc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, b1[s], acc1, 0, 0, 0);
@@ -364,12 +346,8 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
 #pragma unroll
         for (int r = 0; r < 4; r++) im4[r] = __shfl_xor(val[r], 1);
         const bool whole_tile = t * TILE_HOPS - shift >= 0 && t * TILE_HOPS - shift + TILE_HOPS <= a.n_hops; /* wave-uniform: all 16 hops of the tile are stored */
-#ifdef AB_DFT_NO_STORE
-        if (!(col & 1) && ch_valid && val[0] == 1.2345e-30f) {
-#else
         if (whole_tile) k_prev += k_tile;
         if (!(col & 1) && ch_valid) {
-#endif
             int pt = ptile0 + t;
             pt = pt >= ring_tiles16 ? pt - ring_tiles16 : pt;
             const long off = slot_base + ab_tile_off(pt * TILE_HOPS + grp * 4); /* the lane's 4 hops never straddle a ring tile (4, 8 or 16 rows) */
@@ -378,22 +356,12 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
 #pragma unroll
             for (int r = 0; r < 4; r++) m4[r] = __builtin_amdgcn_sqrtf(val[r] * val[r] + im4[r] * im4[r]); /* v_sqrt_f32, 1 ulp: stage 1 is tolerance-bound anyway */
             if (whole_tile || (hop_first >= 0 && hop_first + 3 < a.n_hops)) {
-#ifdef AB_DFT_NT_STORE
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                if (want_mag) __builtin_nontemporal_store((v4f){m4[0], m4[1], m4[2], m4[3]}, reinterpret_cast<v4f*>(a.mag + off));
-                if (want_iq) {
-                    v4f* q = reinterpret_cast<v4f*>(a.iq_bins + off);
-                    __builtin_nontemporal_store((v4f){val[0], im4[0], val[1], im4[1]}, q);
-                    __builtin_nontemporal_store((v4f){val[2], im4[2], val[3], im4[3]}, q + 1);
-                }
-#else
                 if (want_mag) *reinterpret_cast<float4*>(a.mag + off) = make_float4(m4[0], m4[1], m4[2], m4[3]);
                 if (want_iq) {
                     float4* q = reinterpret_cast<float4*>(a.iq_bins + off);
                     q[0] = make_float4(val[0], im4[0], val[1], im4[1]);
                     q[1] = make_float4(val[2], im4[2], val[3], im4[3]);
                 }
-#endif
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -465,11 +433,9 @@ static void launch_one_piece(const DftArgs& a, hipStream_t stream) {
         return launch_generic<512, true>(a, stream);
     }
     if (a.fft_size == 256) return launch_generic<256, false>(a, stream);
-#ifndef AB_DFT_GENERIC_ONLY
     /* the host derives nbuf / sub / lds_per_buf with the same functions the specialised kernels fold in at compile time */
     if (a.hop_bytes == 320 && a.nbuf == c_nbuf(320) && a.sub == c_sub(320) && a.lds_per_buf == c_lds_per_buf(320)) return launch_al<512, 320, false, 16>(a, stream);
     if (a.hop_bytes == 640 && a.nbuf == c_nbuf(640) && a.sub == c_sub(640) && a.lds_per_buf == c_lds_per_buf(640)) return launch_al<512, 640, false, 16>(a, stream);
-#endif
     launch_generic<512, false>(a, stream);
 }
 

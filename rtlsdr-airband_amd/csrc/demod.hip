@@ -32,20 +32,6 @@
 
 namespace airband {
 
-#ifdef AB_DEMOD_TIMING /* experiment: shader-clock time per phase of a lane-per-channel wavefront, summed per demod kind */
-__device__ unsigned long long g_demod_cycles[AB_KIND_COUNT][8];
-#define AB_T0() unsigned long long t_prev_ = __builtin_readcyclecounter()
-#define AB_TICK(slot)                                                        \
-    do {                                                                      \
-        const unsigned long long t_now_ = __builtin_readcyclecounter();      \
-        t_acc_[slot] += t_now_ - t_prev_;                                     \
-        t_prev_ = t_now_;                                                     \
-    } while (0)
-#else
-#define AB_T0()
-#define AB_TICK(slot)
-#endif
-
 namespace {
 
 /* per-sample flag word parked in LDS between the phases */
@@ -196,7 +182,6 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     if (KIND != AB_KIND_GENERIC) cc.flags = (cc.flags & ~KIND_MASK) | KindBits<KIND>::value;
 
     if (!valid) return; /* padding slots of the last block: lanes share nothing (no barriers, per-lane LDS columns) */
-    AB_T0();
 
     const bool nfm = cc.flags & AB_F_NFM, raw_iq = cc.flags & AB_F_RAW_IQ, lowpass = cc.flags & AB_F_LOWPASS;
     /* feature bits as lane masks (compile-time all-or-nothing inside a specialised kind) */
@@ -222,8 +207,9 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     SqRegs s;
     sq_load(s, L, sp, true);
     /* sample_count_ starts at -1 (src/squelch.cpp:58) and every batch is a multiple of four samples long, so the noise floor's every-16th
-     * sample is always the first one of a group of four: the other three do not look (squelch_fsm.h, sq_raw_quiet) */
-    if (((s.sample_count + 1u) & 3u) != 0u) __builtin_trap();
+     * sample is always the first one of a group of four: the other three do not look (squelch_fsm.h, sq_raw_quiet).  Should a handle ever
+     * hold a count that is not aligned like that (wave-uniform test), every sample looks. */
+    const bool aligned4 = ((s.sample_count + 1u) & 3u) == 0u;
     s.dly = (KIND == AB_KIND_NFM_LOWPASS) ? L.sqbuf[(long)s.tail * S] : 0.0f;
     float agc = sp->agcavgfast, pr = sp->pr, pj = sp->pj, prev_out = sp->prev_waveout;
     unsigned dm_phi = sp->dm_phi;
@@ -294,9 +280,6 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         float dv[GS];
     };
     auto fetch = [&](Group& q, int j0, int tail0) { /* tail0 = squelch delay-line tail at the start of the group (lowpass kind) */
-#ifdef AB_DEMOD_FAKE_FETCH /* experiment (wrong results): every group re-reads the batch's first rows -- cache hits, i.e. what perfectly hidden memory latency would buy */
-        j0 &= 15;
-#endif
 #pragma unroll
         for (int g = 0; g < GQ; g++) {
             const int rc = ring_row(a.row0 + AB_AGC_EXTRA + j0 + 4 * g, R); /* current hops */
@@ -343,10 +326,8 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
      * Two versions of everything behind process_raw_sample(): the general one, and the one a QUIET wavefront takes (squelch_fsm.h:
      * every lane CLOSED or OPEN, nothing pending) -- there no sample is a first or last open one, audio is wanted by exactly the
      * OPEN lanes, and the code is one straight run with a few seldom-taken exits. */
-#ifndef AB_SPLIT_REST_KINDS
-#define AB_SPLIT_REST_KINDS 0x09 /* bit k: kind k gets the second version (it doubles the per-sample code: the register-hungry kinds lose more to spills than they gain) */
-#endif
-    constexpr bool SPLIT_REST = ((AB_SPLIT_REST_KINDS >> KIND) & 1) != 0;
+    /* the AM kind and the CTCSS front get the second version; it doubles the per-sample code, and the register-hungry kinds lose more to spills than they gain */
+    constexpr bool SPLIT_REST = KIND == AB_KIND_AM || KIND == AB_KIND_NFM_CTCSS;
     auto rest = [&](auto quiet_tag, const int j, float cur_mag, const float delayed_mag, float re, float im, const lmask went_closed) {
         constexpr bool Q = decltype(quiet_tag)::value;
         /* (in a specialised NFM kind every lane works on raw I/Q: m_raw_iq is the set of live lanes, which the compiler cannot know to be non-empty) */
@@ -442,7 +423,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     };
     auto sample = [&](const int j, const float cur_mag, const float delayed_mag /* lowpass kind: the prefetched delay-line entry */, const float re, const float im, const bool first_of_group) {
         lmask went_closed = 0;
-        if (AB_LIKELY(s.quiet)) sq_raw_quiet(s, L, cur_mag, delayed_mag, first_of_group);
+        if (AB_LIKELY(s.quiet)) sq_raw_quiet(s, L, cur_mag, delayed_mag, first_of_group || !aligned4);
         else went_closed = sq_raw_full(s, L, cur_mag, delayed_mag);
         /* a request raised by this very sample ends the quiet spell at once: its last-open handling is in the general version */
         if (SPLIT_REST && AB_LIKELY(s.quiet)) rest(std::true_type{}, j, cur_mag, delayed_mag, re, im, went_closed); /* the sample that settles the last lane still reports who just closed */
@@ -480,42 +461,26 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
      * full (write acknowledgements take microseconds) before the next group could start.  GS is 4 and the runs are 32 (audio)
      * or 16 (hand-off) samples long, so a run can only end with a group. */
     auto flush = [&](int j0) {
-#ifdef AB_DEMOD_NO_FLUSH /* experiment (no results leave the kernel): what the output path costs */
-        return;
-#endif
         if (!WAVE_HAS_CTCSS && ((j0 + GS) % RUN) == 0) wave_flush(wrow);
         if (WAVE_HAS_CTCSS && ((j0 + GS) % HAND_RUN) == 0) hand_flush(HAND_RUN, j0 + GS - HAND_RUN);
     };
 
     Group qa, qb;
-#ifdef AB_DEMOD_TIMING
-    unsigned long long t_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    AB_TICK(0); /* prologue: state load, tail copy */
     fetch(qa, 0, s.tail);
     touch(qa);
-    AB_TICK(2);
     /* WAVE_BATCH is 1000 or 2000 (params.cpp): a whole number of group PAIRS.  Every fetch and every touch below is unconditional --
      * behind an `if` the compiler can no longer pair a wait with its loads and falls back to waiting for everything in flight at the
      * first use of a group, which is right after the NEXT group's loads were issued.  The pair after the last one re-reads the
      * batch's last group instead (never used). */
     for (int j0 = 0; j0 < B; j0 += 2 * GS) {
         fetch(qb, j0 + GS, tail_in(GS)); /* flies under this group's samples */
-        AB_TICK(1);
         group(qa, j0);
-        AB_TICK(3);
         touch(qb);
-        AB_TICK(2);
         flush(j0);
-        AB_TICK(4);
         fetch(qa, j0 + 2 * GS < B ? j0 + 2 * GS : B - GS, tail_in(GS));
-        AB_TICK(1);
         group(qb, j0 + GS);
-        AB_TICK(3);
         touch(qa);
-        AB_TICK(2);
         flush(j0 + GS);
-        AB_TICK(4);
     }
 
     if (!WAVE_HAS_CTCSS && (B % RUN) != 0) wave_flush(wrow, B % RUN); /* WAVE_BATCH = 1000: the last run is a short one */
@@ -531,12 +496,6 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     sq_store(s, L, sp, B);
     sp->lxr[0] = lxr0; sp->lxr[1] = lxr1; sp->lxr[2] = lxr2; sp->lxi[0] = lxi0; sp->lxi[1] = lxi1; sp->lxi[2] = lxi2;
     sp->lyr[0] = lyr0; sp->lyr[1] = lyr1; sp->lyr[2] = lyr2; sp->lyi[0] = lyi0; sp->lyi[1] = lyi1; sp->lyi[2] = lyi2;
-#ifdef AB_DEMOD_TIMING
-    AB_TICK(5); /* epilogue */
-    if (lane == 0)
-        for (int k = 0; k < 6; k++) atomicAdd(&g_demod_cycles[KIND][k], t_acc_[k]);
-    if (lane == 0) atomicAdd(&g_demod_cycles[KIND][7], 1ull);
-#endif
 }
 
 constexpr int TONE_GROUP = 50; /* samples per tone-kernel step; divides WAVE_BATCH = 1000 and 2000, fits one wavefront's lanes */
@@ -547,15 +506,7 @@ constexpr int TONE_GROUP = 50; /* samples per tone-kernel step; divides WAVE_BAT
  * the AM kernel does not pay for the lowpass registers.  Slot blocks of one kind are contiguous.
  * CTCSS-capable kinds are split in three: this "front" (squelch + discriminator -> audio, flags), the tone kernel
  * (Goertzel banks, one wavefront per channel) and the back kernel (gate, notch, output). */
-#ifndef AB_DEMOD_WAVES
-#define AB_DEMOD_WAVES 3
-#endif
-#ifndef AB_AM_WAVES
-#define AB_AM_WAVES 4
-#endif
-#ifndef AB_FRONT_WAVES
-#define AB_FRONT_WAVES 4
-#endif
+constexpr int AB_DEMOD_WAVES = 3, AB_AM_WAVES = 4, AB_FRONT_WAVES = 4;
 template <int KIND, bool WAVE_HAS_CTCSS>
 __device__ __forceinline__ void demod_block(const DemodArgs& a, int block, float* lds_demod) {
     const int slot = block * 64 + threadIdx.x; /* padding slots carry flags == 0 */
@@ -646,9 +597,6 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
             /* steady state: squelch open throughout and no detector window ends inside the step -> only the recurrences
              * (ToneDetector::process_sample, src/ctcss.cpp:44-54) */
             if (enough1) {
-#ifdef AB_TONE_UNROLL
-#pragma unroll AB_TONE_UNROLL
-#endif
                 for (int u = 0; u < TONE_GROUP; u++) {
                     const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
                     const float q0 = c1 * q1s - q2s + x;
@@ -656,9 +604,6 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
                     q1s = q0;
                 }
             } else { /* the fast detector runs until the slow one has a full window (src/squelch.cpp:288-293) */
-#ifdef AB_TONE_UNROLL
-#pragma unroll AB_TONE_UNROLL
-#endif
                 for (int u = 0; u < TONE_GROUP; u++) {
                     const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
                     const float q0 = c1 * q1s - q2s + x;
@@ -835,16 +780,6 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
  * lane-per-channel kernel holds at most 4 waves per SIMD and the NFM kinds have only half that many wavefronts at BASELINE
  * config #3.  So the split chain (front -> tone -> back, the longest) goes on the caller's stream and the fused kinds run
  * beside it on side streams, forked and joined with events (works the same under graph capture). */
-#ifdef AB_DEMOD_TIMING
-extern "C" int airband_hip_debug_demod_cycles(unsigned long long* out40, int reset) {
-    if (hipMemcpyFromSymbol(out40, HIP_SYMBOL(g_demod_cycles), sizeof(unsigned long long) * AB_KIND_COUNT * 8) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[AB_KIND_COUNT * 8] = {0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_demod_cycles), z, sizeof(z));
-    }
-    return 0;
-}
-#endif
 
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev) {
     auto lds_of = [](int k) { /* sincos table, output-line staging, ext_of */

@@ -37,13 +37,8 @@ AB_FSM_FN lmask ab_ballot(bool b) { return __ballot(b); }                       
 AB_FSM_FN bool ab_lane(lmask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }          /* lane mask -> this lane's bool        */
 AB_FSM_FN bool ab_any(lmask m) { return m != 0ull; }
 AB_FSM_FN unsigned ab_uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); } /* a value every lane holds alike: keep it in a scalar register */
-#ifdef AB_NO_BRANCH_HINTS /* experiment: the layout the compiler picks on its own */
-#define AB_LIKELY(x) (x)
-#define AB_UNLIKELY(x) (x)
-#else
 #define AB_LIKELY(x) __builtin_expect(!!(x), 1)
 #define AB_UNLIKELY(x) __builtin_expect(!!(x), 0)
-#endif
 AB_FSM_FN bool ab_rare(lmask m) { return AB_UNLIKELY(m != 0ull); } /* ab_any() of an event that is seldom there: its code goes out of line */
 #else
 #define AB_FSM_FN static inline
@@ -124,10 +119,7 @@ AB_FSM_FN lmask sq_has_signal(const SqRegs& s, const Lane& L) { /* src/squelch.c
 AB_FSM_FN lmask sq_saturated(const SqRegs& s) { return s.cC & ~ab_ballot(s.closed_count < 1000u) & s.recent_nz; }
 
 AB_FSM_FN bool sq_is_quiet(const SqRegs& s) {
-    lmask busy = (s.nC ^ s.cC) | (s.nO ^ s.cO) | s.cOg | s.cCg | s.cA | s.nOg | s.nCg | s.nA;
-#ifndef AB_SQ_QUIET_V1
-    busy |= sq_saturated(s);
-#endif
+    const lmask busy = (s.nC ^ s.cC) | (s.nO ^ s.cO) | s.cOg | s.cCg | s.cA | s.nOg | s.nCg | s.nA | sq_saturated(s);
     return !ab_any(busy & s.active);
 }
 
@@ -226,9 +218,9 @@ AB_FSM_FN void sq_noise_floor(SqRegs& s, const Lane& L) {
  * update_current_state() (:363-460) then only counts the CLOSED lanes' closed samples and moves the delay line; afterwards the
  * only requests a lane can raise are OPEN -> CLOSING (signal gone), OPEN -> LOW_SIGNAL_ABORT (:233-245) and CLOSED -> OPENING.
  * Straight-line code but for three seldom-taken exits. */
-#ifndef AB_SQ_QUIET_V1
-/* may_sweep: false where the caller knows that this sample cannot be a 16th one (the demod kernels: sample_count_ + 1 is a multiple of
- * 4 at the start of every batch, so only the first sample of a group of four can be).
+/* may_sweep: false where the caller knows that this sample cannot be a 16th one (the demod kernels: while sample_count_ + 1 is a multiple
+ * of 4 at the start of a batch -- it always is, the count starts at -1 and batches are multiples of four samples long; the kernel checks it and
+ * looks on every sample otherwise -- only the first sample of a group of four can be).
  * No branch but the noise-floor one: what the seldom events change is written with mask algebra that is a no-op when nothing happens
  * (a quiet wavefront has no lane in next-state OPENING / CLOSING / ABORT, so assigning the freshly computed -- usually empty -- request
  * masks is exact), and a CLOSED lane that is due to forget its recent opens ends the quiet spell instead of being handled here. */
@@ -259,46 +251,6 @@ AB_FSM_FN void sq_raw_quiet(SqRegs& s, const Lane& L, float x, float dly_new, bo
     s.nC &= ~any_req;
     s.quiet = !ab_any((any_req | sq_saturated(s)) & s.active);
 }
-#else
-AB_FSM_FN void sq_raw_quiet(SqRegs& s, const Lane& L, float x, float dly_new, bool may_sweep = true) {
-    (void)may_sweep;
-    const lmask below = ab_ballot(s.closed_count < 1000u);
-    const lmask forget = s.cC & ~below & s.recent_nz;
-    s.closed_count += ab_lane(s.cC & below) ? 1u : 0u;
-    if (ab_rare(forget)) {
-        s.recent_open = ab_lane(forget) ? 0u : s.recent_open;
-        s.recent_nz &= ~forget;
-        s.lvl = sq_level_compute(s, L);
-    }
-    if (L.track_delay_line) {
-        s.tail = s.tail + 1 == AB_SQ_BUF ? 0 : s.tail + 1;
-        s.head = s.head + 1 == AB_SQ_BUF ? 0 : s.head + 1;
-    }
-    s.dly = dly_new;
-    s.sample_count++;
-    if (AB_UNLIKELY((s.sample_count & 15u) == 0u)) sq_noise_floor(s, L);
-    sq_avg(s.cap, s.pre_full, s.pre_capped, x);
-    sq_delay_line_push(s, L);
-    const lmask sig = sq_has_signal(s, L);
-    const lmask low = s.cO & ab_ballot(!(x >= s.lvl));
-    const int run = s.low_count + 1;
-    const int idle = ab_lane(s.cO) ? 0 : s.low_count;
-    s.low_count = ab_lane(low) ? run : idle;
-    const lmask abort_now = low & ab_ballot(s.low_count >= 88); /* low_signal_abort_ */
-    /* an OPEN lane without signal or a CLOSED lane with one: the lanes whose state disagrees with `sig` */
-    const lmask any_req = ((sig ^ s.cO) & s.active) | abort_now;
-    if (ab_rare(any_req)) {
-        const lmask to_closing = s.cO & ~sig;
-        s.nA = abort_now;
-        s.nCg = to_closing & ~abort_now;
-        s.nOg = s.cC & sig;
-        s.nO &= ~any_req;
-        s.nC &= ~any_req;
-        s.quiet = false;
-    }
-}
-
-#endif
 
 /* Squelch::process_raw_sample (src/squelch.cpp:195-246), general case.  Returns the lanes whose squelch just went CLOSED. */
 AB_FSM_FN lmask sq_raw_full(SqRegs& s, const Lane& L, float x, float dly_new) {

@@ -2,7 +2,7 @@
 # (gpurun MERGES into the local gpurun_out/, so remove the old copy first), then scripts/collect_profiles.py copies the summaries into profiles/.
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=r02
+R=r03
 O=gpurun_out/final; rm -rf $O; mkdir -p $O
 nproc > $O/host.txt; grep -m1 "model name" /proc/cpuinfo >> $O/host.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log

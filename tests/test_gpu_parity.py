@@ -523,10 +523,10 @@ def test_device_enable_takes_a_failed_dongle_out(pkg, built):
     with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=capi.FLAG_TRACE_SQUELCH) as hip:
         hip.set_mixers(1, inputs)
         pos = [0] * n_dev
-        frozen = None
+        frozen = out = None
         for b in range(n_batches):
             if b == off_at:
-                frozen = hip.collect(stats=True)["stats"]
+                frozen = out["stats"]  # of the last batch the dongles took part in
                 for d in gone:
                     hip.device_enable(d, False)
                 hip.device_enable(gone[0], False)  # idempotent

@@ -87,3 +87,17 @@ def test_tone_kernel_waits_once_per_group_of_steps(demod_asm):
     # the wait belongs to the group boundary: at the top, in front of the loads, and / or at the bottom where the registers rotate --
     # never between the loads and the ten steps of work they are meant to fly under
     assert 1 <= len(waits) <= 2 and all(w < loads[0] or w > 0.8 * len(loop) for w in waits), waits
+
+
+def test_tone_kernel_keeps_its_scalars_in_registers(demod_asm):
+    """Round 2 dropped a fully unrolled variant of the tone kernel's steady-state loops after ONE failing run of the bit-exact stage-2 test;
+    round 3 rebuilt that variant (50 constant-lane v_readlane in a row: 1 150 v_readlane, 38 spilled SGPRs against none) and could not make
+    it fail (profiles/r03_experiments.md: 48 of 48 runs bit-exact, and the 65 536-dongle whole-handle replica test), so no hazard was found in
+    the kernel -- but the variant that is validated at scale on every round is the one WITHOUT scalar spills: the channel's constants,
+    detector counters and the ten verdict masks of a group live in SGPRs.  Pin that."""
+    text = "\n".join(demod_asm)
+    m = re.search(r"\.name:\s+_ZN7airband11tone_kernelENS_9DemodArgsE\n(?:.*\n){0,12}?\s+\.sgpr_spill_count:\s+(\d+)", text)
+    assert m, "tone_kernel metadata not found"
+    assert int(m.group(1)) == 0, "tone_kernel spills %s scalar registers" % m.group(1)
+    body = _function(demod_asm, "tone_kernel")
+    assert not any(re.search(r"scratch_(load|store)|buffer_(load|store).*offen", l) for l in body), "tone_kernel uses scratch memory"
