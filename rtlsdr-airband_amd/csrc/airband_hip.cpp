@@ -94,7 +94,7 @@ struct airband_hip_handle {
     DevBuf<float> d_mag, d_sqbuf, d_ct_coeff, d_ct_q;
     DevBuf<float2> d_iq, d_iq_out, d_ct_af;
     DevBuf<unsigned long long> d_ct_mask;
-    int ct_first_block = 0, ct_n_blocks = 0;
+    int ct_first_block = 0, ct_n_blocks = 0, ct_pk_pitch = 0;
     DevBuf<uint8_t> d_trace;
     DevBuf<float> d_out_wave, d_out_iq;
     DevBuf<uint8_t> d_out_axc;
@@ -279,7 +279,13 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.ct_coeff = h->d_ct_coeff.p;
     da.ct_q = h->d_ct_q.p;
     da.trace = (h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH) ? h->d_trace.p : nullptr;
-    da.ct_af = h->d_ct_af.p;
+    da.ct_pk_first_block = h->kind_first_block[AB_KIND_NFM_CTCSS];
+    da.ct_pk_n_blocks = h->kind_n_blocks[AB_KIND_NFM_CTCSS];
+    da.ct_gen_first_block = h->kind_first_block[AB_KIND_GENERIC];
+    da.ct_gen_n_blocks = h->kind_n_blocks[AB_KIND_GENERIC];
+    da.ct_pk_pitch = h->ct_pk_pitch;
+    da.ct_ap = reinterpret_cast<unsigned*>(h->d_ct_af.p);                                                       /* one-word rows first ... */
+    da.ct_af = h->d_ct_af.p + (size_t)da.ct_pk_n_blocks * AB_SLOT_BLOCK * h->ct_pk_pitch / 2;                   /* ... then the pairs of the generic kind */
     da.ct_mask = h->d_ct_mask.p;
     da.ct_first_block = h->ct_first_block;
     da.ct_n_blocks = h->ct_n_blocks;
@@ -524,7 +530,10 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     h->ct_n_blocks = h->kind_n_blocks[AB_KIND_NFM_CTCSS] + h->kind_n_blocks[AB_KIND_GENERIC];
     h->ct_first_block = h->kind_n_blocks[AB_KIND_NFM_CTCSS] ? h->kind_first_block[AB_KIND_NFM_CTCSS] : h->kind_first_block[AB_KIND_GENERIC];
     if (h->ct_n_blocks > 0) {
-        PREP_TRY(h->d_ct_af.alloc((size_t)h->ct_n_blocks * AB_SLOT_BLOCK * h->B), AIRBAND_HIP_ENOMEM);
+        /* one 32-bit word per sample for the NFM + CTCSS kind (rows padded to whole 128-byte lines), (audio, flags) pairs for the generic kind */
+        h->ct_pk_pitch = (h->B + 31) / 32 * 32;
+        PREP_TRY(h->d_ct_af.alloc((size_t)h->kind_n_blocks[AB_KIND_NFM_CTCSS] * AB_SLOT_BLOCK * h->ct_pk_pitch / 2 + (size_t)h->kind_n_blocks[AB_KIND_GENERIC] * AB_SLOT_BLOCK * h->B),
+                 AIRBAND_HIP_ENOMEM);
         PREP_TRY(h->d_ct_mask.alloc((size_t)h->ct_n_blocks * (h->B / 50) * AB_SLOT_BLOCK), AIRBAND_HIP_ENOMEM);
     }
     if (h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH) {

@@ -39,6 +39,10 @@ constexpr unsigned FL_AUDIO = 1u;   /* Squelch::should_process_audio()          
 constexpr unsigned FL_FADE = 2u;    /* AM last_open_sample(): fade out the previous AGC_EXTRA */
 constexpr unsigned FL_RESET = 4u;   /* squelch went CLOSED on this sample: CTCSS::reset()      */
 constexpr int FL_STATE_SHIFT = 3;   /* bits 3..5: Squelch::State, for the trace                */
+/* one-word hand-off of the NFM + CTCSS kind (see demod_wave): */
+constexpr unsigned HAND_NAN = 0x7FC00000u;  /* an audio sample that is a NaN                                          */
+constexpr unsigned HAND_IDLE = 0xFFC00000u; /* no audio on this sample; | 1: the squelch went CLOSED on it            */
+__device__ __forceinline__ bool hand_is_audio(unsigned w) { return (w >> 1) != (HAND_IDLE >> 1); }
 
 /* fast_atan2 / polar_disc_fast / fm_quadri_demod (src/rtl_airband.cpp:141-176) */
 __device__ __forceinline__ float fast_atan2_dev(float y, float x) {
@@ -237,15 +241,39 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
     wrow.staged = ostage + lane; /* [RUN][OSTRIDE] floats behind the sincos table */
     if (!WAVE_HAS_CTCSS && a.tail_copy) wave_tail_copy(wrow.row, B); /* src/output.cpp:920; the back kernel does it for the split kinds */
-    /* split kinds: (audio, flags) for the tone / back kernels, channel-major [ct slot][sample] */
-    float2* ct_af = WAVE_HAS_CTCSS ? a.ct_af + (long)(slot - a.ct_first_block * 64) * B : nullptr;
-    /* the front kernel has no audio rows of its own, so the row staging area holds 16 samples of hand-off pairs instead:
-     * [HAND_RUN][OSTRIDE] float2, flushed like the audio rows (eight lanes store one channel's 128-byte line) */
-    constexpr int HAND_RUN = 16;
+    /* split kinds: what the tone / back kernels need of every sample, channel-major [ct slot][sample].
+     * NFM + CTCSS (the kind that matters: every CTCSS channel of a plain NFM plan): ONE 32-bit word per sample, HAND_WORD below.
+     * Generic kind (AM + CTCSS, raw-I/Q outputs, lowpass + CTCSS): (audio, flags) pairs -- it also has an AM fade-out flag to carry. */
+    constexpr bool PACKED = WAVE_HAS_CTCSS && KIND == AB_KIND_NFM_CTCSS;
+    float2* ct_af = (WAVE_HAS_CTCSS && !PACKED) ? a.ct_af + (long)(slot - a.ct_gen_first_block * 64) * B : nullptr;
+    unsigned* ct_ap = PACKED ? a.ct_ap + (long)(slot - a.ct_pk_first_block * 64) * a.ct_pk_pitch : nullptr; /* rows of whole 128-byte lines */
+    /* the front kernel has no audio rows of its own, so the row staging area holds hand-off samples instead: 16 pairs
+     * [HAND_RUN][OSTRIDE] float2 or 32 words [RUN][OSTRIDE], flushed like the audio rows (eight lanes store one channel's 128-byte line) */
+    constexpr int HAND_RUN = PACKED ? RUN : 16;
     float2* hand_base = reinterpret_cast<float2*>(ostage);
     float2* hand = hand_base + lane;
-    float2* ct_block = WAVE_HAS_CTCSS ? a.ct_af + (long)((slot & ~63) - a.ct_first_block * 64) * B : nullptr;
+    unsigned* handw_base = reinterpret_cast<unsigned*>(ostage);
+    unsigned* handw = handw_base + lane;
+    float2* ct_block = (WAVE_HAS_CTCSS && !PACKED) ? a.ct_af + (long)((slot & ~63) - a.ct_gen_first_block * 64) * B : nullptr;
+    unsigned* ct_blockw = PACKED ? a.ct_ap + (long)((slot & ~63) - a.ct_pk_first_block * 64) * a.ct_pk_pitch : nullptr;
     auto hand_flush = [&](int n, int jstart) { /* n samples starting at batch sample jstart */
+        if (PACKED) {
+            if (full_block) { /* wave-uniform */
+                const int q = lane & 7; /* samples 4q .. 4q + 3 */
+                if (4 * q < n) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int c = i * 8 + (lane >> 3);
+                        const unsigned* src = handw_base + (4 * q) * OSTRIDE + c;
+                        *reinterpret_cast<uint4*>(ct_blockw + (long)c * a.ct_pk_pitch + jstart + 4 * q) = make_uint4(src[0], src[OSTRIDE], src[2 * OSTRIDE], src[3 * OSTRIDE]);
+                    }
+                }
+            } else {
+                for (int i = 0; i < n; i += 4)
+                    *reinterpret_cast<uint4*>(ct_ap + jstart + i) = make_uint4(handw[i * OSTRIDE], handw[(i + 1) * OSTRIDE], handw[(i + 2) * OSTRIDE], handw[(i + 3) * OSTRIDE]);
+            }
+            return;
+        }
         if (full_block) { /* wave-uniform */
             const int q = lane & 7; /* samples 2q, 2q + 1 */
             if (2 * q < n) {
@@ -410,7 +438,16 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             }
         }
         const int state = !a.trace ? 0 : Q ? (ab_lane(s.cO) ? AB_ST_OPEN : AB_ST_CLOSED) : sq_cur(s);
-        if (WAVE_HAS_CTCSS) {
+        if (PACKED) {
+            /* HAND_WORD: the audio sample's own bits while the squelch wants audio (a NaN, which no finite input produces, as THE
+             * canonical quiet NaN: every NaN ends the same way downstream -- tone powers fail their comparisons, the notch state
+             * stays NaN, the output is forced to 0, src/rtl_airband.cpp:597); otherwise a negative quiet NaN no audio sample can
+             * equal, whose lowest bit says "the squelch went CLOSED on this sample" (CTCSS::reset).  Half the bytes of a pair, and the
+             * squelch state the trace records travels in the trace buffer itself (debug handles only). */
+            const unsigned w = audio ? ((out != out) ? HAND_NAN : __float_as_uint(out)) : (HAND_IDLE | (ab_lane(went_closed) ? 1u : 0u));
+            handw[(j & (HAND_RUN - 1)) * OSTRIDE] = w;
+            if (trace) trace[(long)j * S] = (uint8_t)((state & 7) | (audio ? 16 : 0));
+        } else if (WAVE_HAS_CTCSS) {
             /* front half of a CTCSS-capable kind: hand (pre-notch audio, flags) to the tone and back kernels.  Raw I/Q of
              * an open sample is written now; the back kernel zeroes it again if the tone gate turns out closed. */
             const unsigned f = (audio ? FL_AUDIO : 0u) | (fade ? FL_FADE : 0u) | (ab_lane(went_closed) ? FL_RESET : 0u) | ((unsigned)state << FL_STATE_SHIFT);
@@ -541,14 +578,15 @@ __global__ __launch_bounds__(64, KIND == AB_KIND_AM ? AB_AM_WAVES : KIND == AB_K
  * with the state in registers; audio and flags come from the front kernel 50 samples at a time (lane u fetches sample u,
  * v_readlane feeds the serial loop), the verdict leaves as a 50-bit mask per step.  Tiny register footprint -> 8 waves per
  * SIMD hide the dependent-issue latency of the recurrence. */
-__global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
+template <bool PACKED>
+__global__ __launch_bounds__(256) void tone_kernel(DemodArgs a, int first_block, int n_blocks) {
     __shared__ float power[4][64];
     /* the wave index is the same number on every lane: told so, the compiler keeps the channel's constants and counters in scalar
      * registers and fetches them with scalar loads */
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
     const int lane = threadIdx.x & 63;
-    if (wave >= a.ct_n_blocks * 64) return;
-    const int slot = a.ct_first_block * 64 + wave;
+    if (wave >= n_blocks * 64) return;
+    const int slot = first_block * 64 + wave;
     const unsigned flags = a.cc[slot].flags;
     if (!(flags & AB_F_VALID) || !(flags & AB_F_CTCSS)) return;
     const ChanConst cc = a.cc[slot];
@@ -567,8 +605,10 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
     float q1f = t0 ? qtab[lane] : 0.0f, q2f = t0 ? qtab[AB_MAX_TONES + lane] : 0.0f;
     float q1s = t1 ? qtab[2 * AB_MAX_TONES + lane] : 0.0f, q2s = t1 ? qtab[3 * AB_MAX_TONES + lane] : 0.0f;
 
-    const long blk = wave >> 6;
-    const float2* af = a.ct_af + (long)wave * B; /* this channel's batch, contiguous: 50 lanes fetch 400 consecutive bytes */
+    const long blk = (wave >> 6) + (first_block - a.ct_first_block); /* verdict masks: one table over both split kinds */
+    /* this channel's batch, contiguous: 50 lanes fetch 400 (one-word hand-off: 200) consecutive bytes */
+    const float2* af = PACKED ? nullptr : a.ct_af + (long)wave * B;
+    const unsigned* ap = PACKED ? a.ct_ap + (long)wave * a.ct_pk_pitch : nullptr;
     unsigned long long* maskp = a.ct_mask + (blk * NG) * AB_SLOT_BLOCK + (wave & 63);
     /* The batch is walked DEPTH steps at a time: the (audio, flags) pairs of the next DEPTH steps are in flight while the current
      * DEPTH are worked through.  A channel whose squelch is closed does next to nothing per step, so with one step ahead its
@@ -578,13 +618,23 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
      * the wait at the top of a group never sits out stores that have only just left. */
     constexpr int DEPTH = 10; /* divides WAVE_BATCH / TONE_GROUP = 20 / 40 */
     const int ldlane = lane < TONE_GROUP ? lane : TONE_GROUP - 1;
-    auto fetch = [&](int g) { return af[(g < NG ? g : NG - 1) * TONE_GROUP + ldlane]; };
+    /* either hand-off format ends up as (audio, flag word) in registers: the one-word format is decoded where it is consumed */
+    auto fetch = [&](int g) {
+        const int i = (g < NG ? g : NG - 1) * TONE_GROUP + ldlane;
+        if (PACKED) return make_float2(__uint_as_float(ap[i]), 0.0f);
+        return af[i];
+    };
     float2 ahead[DEPTH];
 #pragma unroll
     for (int k = 0; k < DEPTH; k++) ahead[k] = fetch(k);
     unsigned long long verdict[DEPTH]; /* wave-uniform: scalar registers */
     auto step = [&](const int g, const float2 got, unsigned long long& mask_out) {
-        const float2 cur = lane < TONE_GROUP ? got : make_float2(0.0f, 0.0f);
+        float2 cur = lane < TONE_GROUP ? got : make_float2(0.0f, 0.0f);
+        if (PACKED) { /* word -> (audio, FL_AUDIO | FL_RESET) */
+            const unsigned w = lane < TONE_GROUP ? __float_as_uint(got.x) : HAND_IDLE;
+            const bool au = hand_is_audio(w);
+            cur = make_float2(au ? __uint_as_float(w) : 0.0f, __uint_as_float(au ? FL_AUDIO : ((w & 1u) ? FL_RESET : 0u)));
+        }
         const float ax = cur.x;
         const unsigned fl = __float_as_uint(cur.y);
         unsigned long long mask = 0;
@@ -692,11 +742,12 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a) {
 
 /* Back half of the split kinds: output gating (squelch open AND tone present), notch, ampfactor, clamp, AM fade-out
  * (reference: src/rtl_airband.cpp:532-547,589-620), one lane per channel, finished output runs of 32 samples staged through LDS and stored as whole lines. */
-__global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
+template <bool PACKED>
+__global__ __launch_bounds__(64) void back_kernel(DemodArgs a, int first_block) {
     __shared__ float staged[RUN][OSTRIDE];
     __shared__ int ext_of[64];
     const int lane = threadIdx.x;
-    const int slot = (a.ct_first_block + blockIdx.x) * 64 + lane;
+    const int slot = (first_block + blockIdx.x) * 64 + lane;
     const ChanConst cc = a.cc[slot];
     ext_of[lane] = a.slot_to_ext[slot];
     const bool full_block = __ballot((cc.flags & AB_F_VALID) != 0) == ~0ull;
@@ -723,19 +774,21 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
     /* every lane walks its own contiguous (channel-major) hand-off row, 8 samples = 4 x 16 bytes ahead: all bytes of the
      * lines it touches are its own, the re-use is served by L2 */
-    const float4* af = reinterpret_cast<const float4*>(a.ct_af + (long)(slot - a.ct_first_block * 64) * B);
-    const unsigned long long* maskp = a.ct_mask + ((long)blockIdx.x * NG) * AB_SLOT_BLOCK + lane;
+    const float4* af = PACKED ? reinterpret_cast<const float4*>(a.ct_ap + (long)(slot - first_block * 64) * a.ct_pk_pitch)
+                              : reinterpret_cast<const float4*>(a.ct_af + (long)(slot - first_block * 64) * B);
+    const unsigned long long* maskp = a.ct_mask + ((long)(blockIdx.x + first_block - a.ct_first_block) * NG) * AB_SLOT_BLOCK + lane;
     const bool is_ct = (cc.flags & AB_F_CTCSS) != 0;
     constexpr int PIECE = 8; /* samples per fetch; WAVE_BATCH = 1000 / 2000 is a whole number of them */
     /* A piece = 8 (audio, flags) pairs + the tone kernel's verdict masks of the one or two 50-sample steps it lies in.  Piece k + 1
      * flies while piece k is worked through; every load is unconditional (the piece after the last re-reads the last one, a lane
      * without CTCSS reads a mask nobody wrote and ignores it), the wait sits right at the top, and a finished output run leaves
      * only after the next fetch is out -- see demod_wave for why each of these matters. */
-    float4 nxt[PIECE / 2];
+    constexpr int NQ = PACKED ? PIECE / 4 : PIECE / 2; /* 16-byte loads per piece */
+    float4 nxt[NQ];
     unsigned long long nm_lo, nm_hi;
     auto fetch = [&](int j) {
 #pragma unroll
-        for (int q = 0; q < PIECE / 2; q++) nxt[q] = af[j / 2 + q];
+        for (int q = 0; q < NQ; q++) nxt[q] = af[j / (PIECE / NQ) + q];
         const int gl = j / TONE_GROUP;
         nm_lo = maskp[(long)gl * AB_SLOT_BLOCK];
         nm_hi = maskp[(long)(gl + 1 < NG ? gl + 1 : NG - 1) * AB_SLOT_BLOCK];
@@ -744,11 +797,11 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
     int jg = 0; /* position of the current sample in its tone-kernel step */
     for (int j0 = 0; j0 < B; j0 += PIECE) {
 #pragma unroll
-        for (int q = 0; q < PIECE / 2; q++) asm volatile("" ::"v"(nxt[q].x), "v"(nxt[q].y), "v"(nxt[q].z), "v"(nxt[q].w));
+        for (int q = 0; q < NQ; q++) asm volatile("" ::"v"(nxt[q].x), "v"(nxt[q].y), "v"(nxt[q].z), "v"(nxt[q].w));
         asm volatile("" ::"v"(nm_lo), "v"(nm_hi));
-        float4 cur[PIECE / 2];
+        float4 cur[NQ];
 #pragma unroll
-        for (int q = 0; q < PIECE / 2; q++) cur[q] = nxt[q];
+        for (int q = 0; q < NQ; q++) cur[q] = nxt[q];
         unsigned long long mask = is_ct ? nm_lo : ~0ull;
         const unsigned long long mask_hi = is_ct ? nm_hi : ~0ull;
         fetch(j0 + PIECE < B ? j0 + PIECE : B - PIECE);
@@ -756,11 +809,20 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a) {
         if ((j0 % RUN) == 0) w.j0 = j0;
 #pragma unroll
         for (int u = 0; u < PIECE; u++) {
-            const float4 p = cur[u >> 1];
-            const float x = (u & 1) ? p.z : p.x;
-            const unsigned f = __float_as_uint((u & 1) ? p.w : p.y);
             const bool tone = ((mask >> jg) & 1ull) != 0;
-            emit_sample(a, cc, o, w, iqout, trace, j0 + u, (f & FL_AUDIO) != 0, (f & FL_FADE) != 0, tone, (int)((f >> FL_STATE_SHIFT) & 7u), x, 0.0f, 0.0f, false);
+            if (PACKED) {
+                const float4 p = cur[u >> 2];
+                const unsigned wd = __float_as_uint((u & 3) == 0 ? p.x : (u & 3) == 1 ? p.y : (u & 3) == 2 ? p.z : p.w);
+                const bool au = hand_is_audio(wd);
+                /* the squelch state the trace records was left in the trace buffer by the front kernel (debug handles only) */
+                const int st = trace ? (int)(trace[(long)(j0 + u) * AB_SLOT_BLOCK] & 7u) : 0;
+                emit_sample(a, cc, o, w, iqout, trace, j0 + u, au, false, tone, st, au ? __uint_as_float(wd) : 0.0f, 0.0f, 0.0f, false);
+            } else {
+                const float4 p = cur[u >> 1];
+                const float x = (u & 1) ? p.z : p.x;
+                const unsigned f = __float_as_uint((u & 1) ? p.w : p.y);
+                emit_sample(a, cc, o, w, iqout, trace, j0 + u, (f & FL_AUDIO) != 0, (f & FL_FADE) != 0, tone, (int)((f >> FL_STATE_SHIFT) & 7u), x, 0.0f, 0.0f, false);
+            }
             if (++jg == TONE_GROUP) { /* wave-uniform: every lane is on the same sample */
                 jg = 0;
                 mask = mask_hi;
@@ -804,10 +866,10 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
      * the higher priority), the fused kinds fill in beside it */
     launch_kind(AB_KIND_NFM_CTCSS, stream);
     launch_kind(AB_KIND_GENERIC, stream);
-    if (a.ct_n_blocks > 0) {
-        hipLaunchKernelGGL(tone_kernel, dim3((a.ct_n_blocks * 64 * 64 + 255) / 256), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(back_kernel, dim3(a.ct_n_blocks), dim3(64), 0, stream, a);
-    }
+    if (a.ct_pk_n_blocks > 0) hipLaunchKernelGGL(tone_kernel<true>, dim3((a.ct_pk_n_blocks * 64 * 64 + 255) / 256), dim3(256), 0, stream, a, a.ct_pk_first_block, a.ct_pk_n_blocks);
+    if (a.ct_gen_n_blocks > 0) hipLaunchKernelGGL(tone_kernel<false>, dim3((a.ct_gen_n_blocks * 64 * 64 + 255) / 256), dim3(256), 0, stream, a, a.ct_gen_first_block, a.ct_gen_n_blocks);
+    if (a.ct_pk_n_blocks > 0) hipLaunchKernelGGL(back_kernel<true>, dim3(a.ct_pk_n_blocks), dim3(64), 0, stream, a, a.ct_pk_first_block);
+    if (a.ct_gen_n_blocks > 0) hipLaunchKernelGGL(back_kernel<false>, dim3(a.ct_gen_n_blocks), dim3(64), 0, stream, a, a.ct_gen_first_block);
     /* the fused kinds as forked launches (one kernel per kind keeps each kind's own register budget: the AM kind runs four waves per
      * SIMD, the heavier ones three; a single launch with host-interleaved blocks was measured equal at best, 7.8 vs 7.7 ms);
      * without side streams (AIRBAND_HIP_FLAG_SERIAL_DEMOD, profiling) one after the other */

@@ -74,8 +74,14 @@ struct DemodArgs {
     float* ct_q;            /* [n_ctcss][2 detectors][q1|q2][AB_MAX_TONES] */
     uint8_t* trace;         /* [wave_batch][stride] or null */
     /* split (CTCSS-capable) kinds: front -> tone -> back hand-off */
-    float2* ct_af;                 /* [ct slots][wave_batch] (pre-notch audio, flag word), channel-major: the tone kernel reads a channel's samples across its lanes */
-    unsigned long long* ct_mask;   /* [ct blocks][wave_batch / 50][64] tone-present bits */
+    /* hand-off rows, channel-major (the tone kernel reads a channel's samples across its lanes):
+     *   generic kind  [slots of the generic blocks][wave_batch] (pre-notch audio, flag word) pairs
+     *   NFM + CTCSS   [slots of its blocks][ct_pk_pitch] one word per sample (demod.hip, HAND_WORD), rows of whole 128-byte lines */
+    float2* ct_af;
+    unsigned* ct_ap;
+    int ct_pk_pitch;
+    int ct_pk_first_block, ct_pk_n_blocks, ct_gen_first_block, ct_gen_n_blocks;
+    unsigned long long* ct_mask;   /* [ct blocks][wave_batch / 50][64] tone-present bits, blocks counted from ct_first_block (both split kinds) */
     int ct_first_block, ct_n_blocks;
     const float* sin_lut;   /* 257 */
     const float* cos_lut;   /* 257 */

@@ -78,9 +78,11 @@ def test_group_prefetch_is_waited_for_once_per_group(demod_asm, kernel, per_iter
     assert sum(1 for l in loop if "global_load_dwordx4" in l) >= 2 * per_iteration
 
 
-def test_tone_kernel_waits_once_per_group_of_steps(demod_asm):
-    loop = _hot_loop(_function(demod_asm, "tone_kernel"), r"global_load_dwordx2")
-    loads = [i for i, l in enumerate(loop) if "global_load_dwordx2" in l]
+@pytest.mark.parametrize("kernel,load", [("tone_kernelILb1E", r"global_load_dword\s"), ("tone_kernelILb0E", r"global_load_dwordx2\s")],
+                         ids=["one_word_hand_off", "pair_hand_off"])
+def test_tone_kernel_waits_once_per_group_of_steps(demod_asm, kernel, load):
+    loop = _hot_loop(_function(demod_asm, kernel), load)
+    loads = [i for i, l in enumerate(loop) if re.search(load, l)]
     waits = [i for i, l in enumerate(loop) if re.search(r"s_waitcnt\s+vmcnt\(0\)", l)]
     assert len(loads) == 10, "ten steps in flight"
     assert loads[-1] < 0.2 * len(loop), "the next group's loads go out at the top of a group"
@@ -96,8 +98,10 @@ def test_tone_kernel_keeps_its_scalars_in_registers(demod_asm):
     the kernel -- but the variant that is validated at scale on every round is the one WITHOUT scalar spills: the channel's constants,
     detector counters and the ten verdict masks of a group live in SGPRs.  Pin that."""
     text = "\n".join(demod_asm)
-    m = re.search(r"\.name:\s+_ZN7airband11tone_kernelENS_9DemodArgsE\n(?:.*\n){0,12}?\s+\.sgpr_spill_count:\s+(\d+)", text)
-    assert m, "tone_kernel metadata not found"
-    assert int(m.group(1)) == 0, "tone_kernel spills %s scalar registers" % m.group(1)
+    for name in ("_ZN7airband11tone_kernelILb1EEEvNS_9DemodArgsEii", "_ZN7airband11tone_kernelILb0EEEvNS_9DemodArgsEii"):
+        at = text.index(".name:           " + name)
+        m = re.search(r"\.sgpr_spill_count:\s+(\d+)", text[at:at + 1200])
+        assert m, "tone_kernel metadata not found"
+        assert int(m.group(1)) == 0, "%s spills %s scalar registers" % (name, m.group(1))
     body = _function(demod_asm, "tone_kernel")
     assert not any(re.search(r"scratch_(load|store)|buffer_(load|store).*offen", l) for l in body), "tone_kernel uses scratch memory"
