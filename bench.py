@@ -64,6 +64,7 @@ WORKLOADS = {
 }
 SAMPLES_PER_BATCH = 320_000  # complex samples per dongle per batch (2.56 MS/s / 8)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_I8_PEAK_TOPS = 5000.0   # MI355X_MICROARCH.md: int8 MFMA at 2x the dense bf16 rate (~2.5 PF); micro-benchmark ceiling >= 3 944 TOPS
 METRIC = "IQ Msamples/sec channelized+demodulated per node; % HBM roofline"
 CHANNELIZER_KERNEL = {"dft_mfma_i8": "channelizer_dft_kernel", "fft_wave64": "channelizer_fft_kernel"}
 
@@ -250,6 +251,8 @@ def main():
                     "300 / 600 bytes, not multiples of 16)")
     ap.add_argument("--fft-log", type=int, default=9, help="fft_size_log (BASELINE: 9 = 512 points)")
     ap.add_argument("--ring", type=int, default=3, help="distinct I/Q batches kept in HBM and cycled through")
+    ap.add_argument("--afc", type=int, default=0, help="channel 0 of every dongle gets `afc = N` (src/config.cpp:352 default 0): the group then owns its coefficient "
+                    "table and AFC's per-batch spectrum + re-tune kernels run (VERDICT r02 item 4)")
     ap.add_argument("--mixers", type=int, default=0, help="number of mixers (BASELINE configs[4]: 64). Default 0 at every N, so that per-GPU work is the same "
                     "from 1 to 8 GPUs (configs[1]-[3] have no exchange step); with mixers and N > 1 the per-rank sums are all-reduced over RCCL every step")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
@@ -309,6 +312,9 @@ def main():
     n_mixers = max(0, args.mixers)
 
     chans, carriers = pkg.siggen.baseline_plan(mixed=mixed)
+    if args.afc:
+        chans = [dict(c) for c in chans]
+        chans[0]["afc"] = args.afc
     s16 = args.sample_format == "s16"
     sr = args.sample_rate
     samples_per_batch = sr // 8
@@ -317,9 +323,9 @@ def main():
     flags = int(os.environ.get("AIRBAND_BENCH_FLAGS", "0"), 0) | (pkg.capi.FLAG_PIPELINE if args.pipelined else 0)
     hip = pkg.AirbandHip(devices, wave_rate=wave_rate, hip_device=local_rank, flags=flags, fft_log=args.fft_log)
     g = hip.geometry
-    if n_mixers:
-        base = rank * D
-        hip.set_mixers(n_mixers, [(d, c, ((base + d) * 8 + c) % n_mixers, 1.0, 0.0) for d in range(D) for c in range(8)])
+    mg = importlib.import_module("rtlsdr-airband_amd.multigpu")  # the host logic tests/test_distributed_gloo.py and tests/test_gpu_multi.py exercise
+    if n_mixers:  # BASELINE configs[4] wiring; weak scaling: rank r holds the global dongles [r D, (r + 1) D)
+        hip.set_mixers(n_mixers, mg.baseline_mixer_inputs(rank * D, (rank + 1) * D, 8, n_mixers))
     hip.set_signal_plan(carriers)
 
     # HBM-resident I/Q: lead-in + (ring + 1) batches + look-ahead per dongle, generated on the GPU
@@ -346,15 +352,10 @@ def main():
     hip.synchronize()
     torch.cuda.synchronize()
 
-    res = hip.device_results()
-    mix_t = None
+    mix_t = right_t = sig_t = None
     if n_mixers and use_dist:
-        # torch views over the library's device-side mixer sums, for the RCCL all-reduce
-        class _Ptr:  # __cuda_array_interface__ shim
-            def __init__(self, ptr, shape, typestr):
-                self.__cuda_array_interface__ = dict(shape=shape, typestr=typestr, data=(ptr, False), version=2)
-        mix_t = torch.as_tensor(_Ptr(res["mix_left"], (n_mixers, hip.B), "<f4"), device="cuda")
-        sig_t = torch.as_tensor(_Ptr(res["mix_signal"], (n_mixers,), "|u1"), device="cuda")
+        # torch views over the library's device-side mixer sums, for the RCCL all-reduce (the baseline wiring is mono: no right channel)
+        mix_t, right_t, sig_t = mg.device_mixer_views(hip, n_mixers, stereo=False)
 
     # the RCCL all-reduce is issued on torch's stream: that stream waits (on the GPU) for the batch's mixer sums, and the next
     # process call orders its overwrite of them behind the all-reduce -- no host synchronisation inside a step
@@ -369,8 +370,7 @@ def main():
         if mix_t is not None:
             hip.stream_wait_results(consumer)
             with torch.cuda.stream(cstream):
-                dist.all_reduce(mix_t, op=dist.ReduceOp.SUM)      # mixer sum over xGMI (src/mixer.cpp:133-140)
-                dist.all_reduce(sig_t, op=dist.ReduceOp.MAX)      # axcindicate of the mixer (src/mixer.cpp:209)
+                mg.allreduce_mixers(mix_t, right_t, sig_t, force=True)  # SUM of the mixer waveforms over xGMI, MAX of the signal flags (src/mixer.cpp:133-140,209)
 
     def sync():
         hip.synchronize()
@@ -413,16 +413,34 @@ def main():
     roofline = dict(bound="hbm", kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                     avg_launch_ms=round(ch_ms, 4), algorithmic_bytes_per_launch=alg_bytes_per_sample * D * samples_per_batch,
                     frac_read_only=round(read_only / HBM_PEAK_GBS, 4),
-                    read_only_note="input bytes only (2 B per I/Q sample) / launch time / peak: north_star words its target as READ bandwidth; `frac` uses SURVEY 8d's 2 B in + audio out")
+                    read_only_note="input bytes only (2 B per I/Q sample) / launch time / peak: north_star words its target as READ bandwidth; `frac` uses SURVEY 8d's 2 B in + audio out",
+                    # the whole step (both stages) against the same algorithmic bytes: what the path as a whole makes of the HBM roofline
+                    end_to_end_frac=round(alg_bytes_per_sample * D * samples_per_batch / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4))
+    if name == "dft_mfma_i8":
+        # matrix-core work of the pruned DFT per launch: 16-hop tiles x (3 digit tables x k-steps, minus the all-zero top digits at the window's edges
+        # for single-piece windows) x window pieces x byte planes, 16x16x64 int8 MFMAs of 32 768 operations each
+        n_fft = g.fft_size
+        pieces = max(1, n_fft // 512)
+        ksteps = min(n_fft, 512) // 32
+        per_tile = (3 * ksteps - (ksteps // 4 if pieces == 1 else 0)) * pieces * (2 if s16 else 1)
+        tiles = -(-(hip.B) // 16) + 1
+        tops = per_tile * tiles * D * 32768.0 / (ch_ms * 1e-3) / 1e12
+        roofline["mfma_int8_tops"] = round(tops, 1)
+        roofline["mfma_frac"] = round(tops / MFMA_I8_PEAK_TOPS, 4)
+        if n_fft >= 1024:
+            # two and more window pieces: 2x ... 16x the matrix work on the same bytes -- the matrix pipe, not HBM, bounds the kernel
+            roofline.update(bound="mfma", achieved=round(tops, 1), peak=MFMA_I8_PEAK_TOPS, unit="TFLOP/s", frac=round(tops / MFMA_I8_PEAK_TOPS, 4),
+                            hbm_frac=round(achieved / HBM_PEAK_GBS, 4),
+                            note="int8 operations / s of the 16x16x64 MFMAs; peak = 2x the dense bf16 rate (MI355X_MICROARCH.md; its micro-benchmark ceiling is 3 944)")
     out = dict(metric=METRIC, value=round(value, 2), unit="Msamples/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype="i8x3->i32->f64->f32 (stage 1), f32 (stage 2)" if name == "dft_mfma_i8" else "f32", data="synthetic",
+               dtype="i8x3->i32->f32 (stage 1), f32 (stage 2)" if name == "dft_mfma_i8" else "f32", data="synthetic",
                config=dict(workload=_describe(wl["desc"], D, wl["dongles"], g.fft_size, sr, args.sample_format), dongles_per_gpu=D, channels_per_dongle=8, fft_size=g.fft_size, wave_rate=wave_rate, sample_rate=sr,
-                           sample_format=args.sample_format, iq_resident="HBM", ring_batches=args.ring, mixers=n_mixers,
+                           sample_format=args.sample_format, iq_resident="HBM", ring_batches=args.ring, mixers=n_mixers, afc=args.afc,
                            schedule="pipelined: stage 1 of batch k beside stage 2 of batch k-1" if args.pipelined else "one batch at a time",
                            parallelism="dongle-sharded x%d, %s" % (world, "RCCL all-reduce of mixer sums" if mix_t is not None else "no collective"),
                            channelizer=name,
-                           arithmetic="stage 1: u8 x 24-bit window*twiddle as 3 int8 digits -> exact int32 MFMA sums -> f64 recombine -> f32 bins; stage 2: f32, reference operation order"
+                           arithmetic="stage 1: u8 x 24-bit window*twiddle as 3 int8 digits -> exact int32 MFMA sums -> 3 f32 FMAs -> f32 bins; stage 2: f32, reference operation order"
                            if name == "dft_mfma_i8" else "stage 1: f32 radix-2 FFT; stage 2: f32, reference operation order",
                            library=os.path.basename(pkg.LIB_PATH), build_defines=build),
                roofline=roofline,

@@ -577,7 +577,10 @@ orc_t* orc_create(const airband_hip_config* cfg) {
     o->dev = (odev_t*)calloc((size_t)o->n_dev, sizeof(odev_t));
     lut_init();
     for (int i = 0; i < 256; i++) o->lev_u8[i] = (i - 127.5f) / 127.5f; /* src/rtl_airband.cpp:319-321 */
-    for (int i = -127; i < 128; i++) o->lev_s8[(uint8_t)i] = i / 128.0f; /* :322-324 (entry 128 stays 0 here; uninitialised in the reference) */
+    /* :322-324.  The reference's loop starts at -127: entry 128 (the byte -128) is never written there and holds whatever the stack did.
+     * Any value refines that; this restatement -- and the library -- continue the table's own rule, -128 / 128 = -1.0 (the negative rail of
+     * an 8-bit ADC, symmetric to +127 / 128).  Every comparison with the reference itself uses streams without that byte. */
+    for (int i = -128; i < 128; i++) o->lev_s8[(uint8_t)i] = i / 128.0f;
     o->window = (float*)malloc(sizeof(float) * (size_t)o->fft_size);
     for (int i = 0; i < o->fft_size; i++) o->window[i] = orc_window_coeff(o->fft_size, i);
     o->fin = fftwf_alloc_complex((size_t)o->fft_size);

@@ -108,6 +108,11 @@ struct airband_hip_handle {
     DevBuf<int> d_item_dev, d_item_group, d_item_bset;
     DevBuf<int8_t> d_bfrag;
     DevBuf<double> d_bcorr;
+    DevBuf<float> d_dft_partial; /* fft_size 8192: partial sums between the two passes of eight window pieces */
+    DevBuf<int> d_bset_bin;      /* [n_bsets][8] bin each coefficient column pair is built for (AFC re-tunes private tables on the device) */
+    const void* last_iq = nullptr; /* input of the batch stage 1 ran last (AFC looks at its last hop once stage 2 has decided) */
+    size_t last_iq_stride = 0;
+    int last_n_hops = 0;
 
     /* host-ring path: one PINNED circular buffer per dongle (row d of h_ring, ring_cap bytes).  submit() copies the caller's bytes
      * straight into it -- the only CPU copy on the way -- and may be called for DIFFERENT dongles from several threads at once;
@@ -185,7 +190,7 @@ void destroy(airband_hip_handle* h) {
     h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release(); h->d_ct_af.release(); h->d_ct_mask.release();
     h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
     h->d_tmp_wavein.release(); h->d_tmp_iqin.release(); h->d_tmp_trace.release(); h->d_spectrum.release();
-    h->d_item_dev.release(); h->d_item_group.release(); h->d_item_bset.release(); h->d_bfrag.release(); h->d_bcorr.release();
+    h->d_item_dev.release(); h->d_item_group.release(); h->d_item_bset.release(); h->d_bfrag.release(); h->d_bcorr.release(); h->d_dft_partial.release(); h->d_bset_bin.release();
     if (h->h2d) (void)hipStreamSynchronize(h->h2d);
     h->d_stage2[0].release(); h->d_stage2[1].release();
     if (h->h_ring.load()) (void)hipHostFree(h->h_ring.load());
@@ -260,6 +265,55 @@ hipEvent_t* event_set(airband_hip_handle* h, uint64_t batch, int half) {
     return h->evp[i];
 }
 
+void launch_retune_tables(airband_hip_handle* h, hipStream_t s) {
+    RetuneArgs ra;
+    ra.cc = h->d_cc.p;
+    ra.cs = h->d_cs.p;
+    ra.dev = h->d_dev.p;
+    ra.ext_to_slot = h->d_ext_to_slot.p;
+    ra.item_dev = h->d_item_dev.p;
+    ra.item_group = h->d_item_group.p;
+    ra.item_bset = h->d_item_bset.p;
+    ra.bset_bin = h->d_bset_bin.p;
+    ra.bfrag = h->d_bfrag.p;
+    ra.corr = h->d_bcorr.p;
+    ra.window = h->d_window.p;
+    ra.n_items = (int)h->plan.item_dev.size();
+    ra.fft_size = h->plan.fft_size;
+    ra.n_shared = h->plan.n_shared_bsets;
+    launch_retune(ra, s);
+}
+
+/* matrix-core handles with AFC channels: the full spectrum of the batch's LAST hop, for the dongles that have one (one wavefront FFT per
+ * such dongle per batch -- afc.finalize(dev, i, fftout) runs once per batch on the output of its last FFT, src/rtl_airband.cpp:626-630) */
+void launch_last_hop_spectrum(airband_hip_handle* h, hipStream_t s) {
+    const Plan& p = h->plan;
+    ChannelizerArgs ca;
+    ca.iq = (const uint8_t*)h->last_iq + (size_t)(h->last_n_hops - 1) * (size_t)h->hop_bytes;
+    ca.iq_stride = (long)h->last_iq_stride;
+    ca.dev = h->d_dev.p;
+    ca.cs = h->d_cs.p;
+    ca.cc = h->d_cc.p;
+    ca.ext_to_slot = h->d_ext_to_slot.p;
+    ca.window = h->d_window.p;
+    ca.mag = h->d_mag.p;
+    ca.iq_bins = h->d_iq.p;
+    ca.last_spectrum = h->d_spectrum.p;
+    ca.n_dev = p.n_dev;
+    ca.fft_log = p.fft_log;
+    ca.hop_samples = p.dev[0].hop_samples;
+    ca.bytes_per_sample = p.dev[0].bytes_per_sample;
+    ca.sfmt = p.dev[0].sfmt;
+    ca.scale = p.dev[0].scale;
+    ca.row0 = 0;
+    ca.ring_rows = h->R;
+    ca.first_row = 0;
+    ca.n_hops = 1;
+    ca.max_ch = p.max_ch;
+    ca.spectrum_only = 1;
+    launch_channelizer_fft(ca, s);
+}
+
 /* stage 2 + emit (+ mixers) of the batch whose stage-1 rows are already in the rings */
 int run_back_half(airband_hip_handle* h, hipStream_t s) {
     hipEvent_t* ev = event_set(h, h->batches_done, 1);
@@ -298,7 +352,9 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.ring_rows = h->R;
     launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
     if (h->any_afc && h->afc_spectrum_valid) { /* afc.finalize(), src/rtl_airband.cpp:626-630: may turn '*' into '<' / '>' */
+        if (h->use_dft) launch_last_hop_spectrum(h, s);
         launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, s);
+        if (h->use_dft) launch_retune_tables(h, s); /* the next batch's stage 1 reads the moved channels' new columns */
         launch_axc(h->d_cc.p, h->d_cs.p, h->d_slot_to_ext.p, h->d_out_axc.p, h->n_slots, s);
     }
     (void)hipEventRecord(ev[3], s);
@@ -561,17 +617,32 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     /* AFC moves bins at run time and needs the full spectrum of each batch's last hop: that is the FFT kernel's job */
     h->any_afc = any_afc;
     if (any_afc) PREP_TRY(h->d_spectrum.alloc((size_t)p.n_dev * p.fft_size * 2), AIRBAND_HIP_ENOMEM);
-    h->use_dft = !any_afc && !(h->flags & AIRBAND_HIP_FLAG_FORCE_FFT) && dft_supported(p.fft_size, (int)h->hop_bytes, p.dev[0].sfmt, p.max_ch);
+    h->use_dft = !(h->flags & AIRBAND_HIP_FLAG_FORCE_FFT) && dft_supported(p.fft_size, (int)h->hop_bytes, p.dev[0].sfmt, p.max_ch);
     if (h->use_dft) {
-        build_dft_tables(h->plan);
-        if (p.n_bsets > 4096) {
-            h->use_dft = false; /* table would not stay cache resident; fall back */
+        build_dft_tables(h->plan, false);
+        if (p.n_shared_bsets > 4096) {
+            h->use_dft = false; /* that many different shared tables would not stay cache resident; fall back */
         } else {
             PREP_TRY(upload(h->d_item_dev, p.item_dev), AIRBAND_HIP_ENOMEM);
             PREP_TRY(upload(h->d_item_group, p.item_group), AIRBAND_HIP_ENOMEM);
             PREP_TRY(upload(h->d_item_bset, p.item_bset), AIRBAND_HIP_ENOMEM);
-            PREP_TRY(upload(h->d_bfrag, p.bfrag), AIRBAND_HIP_ENOMEM);
-            PREP_TRY(upload(h->d_bcorr, p.bcorr), AIRBAND_HIP_ENOMEM);
+            /* the host has built the shared tables; the private ones (groups with an AFC channel) follow them, zeroed, and are built by the
+             * re-tune kernel right here: every column of theirs still stands at bin -1 */
+            const int np_t = p.fft_size > 512 ? p.fft_size / 512 : 1;
+            const size_t tab_bytes = (size_t)3 * (p.fft_size > 512 ? 16 : p.fft_size / 32) * 64 * 16 * np_t;
+            PREP_TRY(h->d_bfrag.alloc((size_t)p.n_bsets * tab_bytes), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(h->d_bcorr.alloc((size_t)p.n_bsets * np_t * 16), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(hipMemset(h->d_bfrag.p, 0, h->d_bfrag.n), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(hipMemset(h->d_bcorr.p, 0, h->d_bcorr.n * sizeof(double)), AIRBAND_HIP_ENOMEM);
+            if (!p.bfrag.empty()) PREP_TRY(hipMemcpy(h->d_bfrag.p, p.bfrag.data(), p.bfrag.size(), hipMemcpyHostToDevice), AIRBAND_HIP_ENOMEM);
+            if (!p.bcorr.empty()) PREP_TRY(hipMemcpy(h->d_bcorr.p, p.bcorr.data(), p.bcorr.size() * sizeof(double), hipMemcpyHostToDevice), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(upload(h->d_bset_bin, p.bset_bins), AIRBAND_HIP_ENOMEM);
+            if (p.n_bsets > p.n_shared_bsets) {
+                launch_retune_tables(h, h->stream);
+                PREP_TRY(hipStreamSynchronize(h->stream), AIRBAND_HIP_ENODEV);
+            }
+            if (p.fft_size > 4096) /* [work items][tiles][64 lanes] float4 */
+                PREP_TRY(h->d_dft_partial.alloc((size_t)p.item_dev.size() * dft_partial_tiles(h->B + AB_AGC_EXTRA) * 64 * 4), AIRBAND_HIP_ENOMEM);
         }
     }
     if (!h->use_dft) {
@@ -739,7 +810,8 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         a.item_bset = h->d_item_bset.p;
         a.bfrag = h->d_bfrag.p;
         a.corr = h->d_bcorr.p;
-        a.unscale = p.dev[0].sfmt == AIRBAND_SFMT_S16 ? p.b_unscale * 127.5 : p.b_unscale;
+        /* table units -> sample units: u8 (b - 127.5) / 127.5; s8 i / 128; CS16 x / fullscale (the kernel multiplies by the dongle's 1 / fullscale) */
+        a.unscale = p.dev[0].sfmt == AIRBAND_SFMT_S16 ? p.b_unscale * 127.5 : p.dev[0].sfmt == AIRBAND_SFMT_S8 ? p.b_unscale * 127.5 / 128.0 : p.b_unscale;
         a.sfmt = p.dev[0].sfmt;
         a.edge_hi_zero = p.b_edge_hi_zero ? 1 : 0;
         a.mag = h->d_mag.p;
@@ -748,8 +820,10 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         a.n_items = (int)p.item_dev.size();
         a.fft_size = p.fft_size;
         a.hop_bytes = (int)h->hop_bytes;
-        const int win_bytes = 2 * p.fft_size * p.dev[0].bytes_per_sample; /* the whole window is staged, also when it is worked on in pieces of 512 samples */
-        const int np = p.fft_size > 512 ? p.fft_size / 512 : 1;
+        /* the whole window is staged, also when it is worked on in pieces of 512 samples -- up to eight of them per launch (fft_size 8192: two passes) */
+        const int np_total = p.fft_size > 512 ? p.fft_size / 512 : 1, np = np_total > 8 ? 8 : np_total;
+        const int win_bytes = 2 * p.fft_size * p.dev[0].bytes_per_sample / np_total * np;
+        a.partial = reinterpret_cast<float4*>(h->d_dft_partial.p);
         a.lds_per_buf = dft_lds_per_buf((int)h->hop_bytes, win_bytes, np);
         a.nbuf = dft_nbuf((int)h->hop_bytes, win_bytes, np);
         a.sub = dft_sub((int)h->hop_bytes, win_bytes, np);
@@ -766,6 +840,10 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         (void)hipEventRecord(ev[0], s);
         launch_channelizer_dft(a, s);
         (void)hipEventRecord(ev[1], s);
+        h->last_iq = d_iq;
+        h->last_iq_stride = stride_bytes;
+        h->last_n_hops = a.n_hops;
+        h->afc_spectrum_valid = h->any_afc; /* computed behind stage 2, from the same input (run_back_half) */
     } else {
         ChannelizerArgs ca;
         ca.iq = (const uint8_t*)d_iq;
@@ -789,6 +867,7 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         ca.first_row = first ? 0 : AB_AGC_EXTRA; /* the first batch also produces the AGC_EXTRA lead-in hops (waveend starts at 0, src/config.cpp:805) */
         ca.n_hops = first ? h->B + AB_AGC_EXTRA : h->B;
         ca.max_ch = p.max_ch;
+        ca.spectrum_only = 0;
         (void)hipEventRecord(ev[0], s);
         h->afc_spectrum_valid = h->any_afc;
         launch_channelizer_fft(ca, s);

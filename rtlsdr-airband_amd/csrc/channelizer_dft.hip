@@ -104,7 +104,7 @@ __device__ __forceinline__ v4i lds_read16(const uint8_t* p) {
  * runs the DMA; a workgroup barrier hands each step over), compute their piece's partial sums for the same 16 hops, and wave 0
  * adds the partials up (through LDS) and writes the outputs: the stream is read once whatever the window length. */
 template <int FFT_N, bool EDGE_HI_ZERO, int HOPB, bool S16, int AL, int NP = 1>
-__global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) {
+__global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kernel(DftArgs a) {
     constexpr int BPS = S16 ? 2 : 1;              /* bytes per sample component        */
     constexpr int WIN_BYTES = 2 * FFT_N * BPS;    /* bytes per window piece            */
     constexpr int WIN_ALL = WIN_BYTES * NP;       /* bytes per window                  */
@@ -118,7 +118,9 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
     /* one wavefront per workgroup: waves share nothing, and a 64-thread block lets the LDS budget (two staging
      * buffers per wave) rather than the block shape decide how many waves a CU holds */
     const int lane = NP > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
-    const int piece = NP > 1 ? (int)(threadIdx.x >> 6) : 0; /* wave p of the workgroup: window piece p */
+    /* wave p of the workgroup: window piece p -- the same number on every lane of the wave; told so, the compiler keeps everything that is
+     * decided per piece (who runs the transfers, the store accounting of the waits) in scalar registers and scalar branches */
+    const int piece = NP > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     /* XCD-aware placement: workgroup b runs on XCD b % 8 (observed dispatch order; speed only).  16 consecutive
      * dongles write neighbouring slots of the same 128-byte lines, so they are given to the SAME XCD and meet in
      * one L2: inside every group of 128 dongles, workgroup i*8 + x takes dongle x*16 + i. */
@@ -157,13 +159,15 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
     const int st_end = min(steps_total, st_begin + steps_per_split);
     if (st_begin >= st_end) return;
 
-    const uint8_t* src = a.iq + (long)d * a.iq_stride;    /* first byte of this batch's first hop */
-    /* bytes of the batch span that may be read, rounded up to whole 16-byte pieces (geometry.lookahead_bytes includes the round-up) */
-    const long span_end = ((long)(a.n_hops - 1) * hop_bytes + WIN_ALL + 15) & ~15L;
+    const uint8_t* src = a.iq + (long)d * a.iq_stride + (long)a.piece0 * WIN_BYTES;    /* first byte this pass reads of the batch's first hop */
+    /* bytes of the batch span that may be read, rounded up to whole 16-byte pieces (geometry.lookahead_bytes includes the round-up).
+     * fft_size 8192 runs as two passes of 8 window pieces (a.piece0 = 0, 8): a pass streams the part of every window that starts
+     * piece0 pieces in, so its addresses are relative to that byte and the readable span is what is left of the window behind it */
+    const long span_end = ((long)(a.n_hops - 1) * hop_bytes + (long)(a.np_total - a.piece0) * WIN_BYTES + 15) & ~15L;
 
     /* ---- B fragments: 3 digits x 16 k-steps, resident for the whole wave ---------------------------------- */
     /* fft_size > 512: each window piece has its own coefficient table */
-    const int bset = a.item_bset[item] * NP + piece;
+    const int bset = a.item_bset[item] * a.np_total + a.piece0 + piece;
     const v4i* btab = reinterpret_cast<const v4i*>(a.bfrag) + (long)bset * 3 * KSTEPS * 64 + lane;
     v4i b0[KSTEPS], b1[KSTEPS], b2[KSTEPS];
 #pragma unroll
@@ -222,6 +226,18 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
     const int nbuf = HOPB ? c_nbuf(HOPB ? HOPB : 64) : a.nbuf;
     /* partial sums of pieces 1 .. NP-1 on their way to wave 0: [tile parity][piece - 1][lane] x 4 floats, behind the staging buffers */
     float4* exch = reinterpret_cast<float4*>(lds_all + nbuf * lds_per_buf);
+    /* Vector-memory operations complete in issue order, so "at most N outstanding" proves a transfer has landed as soon as N operations
+     * YOUNGER than it are known to have been issued: the pieces of later transfers and the output stores issued since.  Leaving the stores
+     * out of N -- they are the youngest of all -- would make every wait sit out their write acknowledgements.  `stores` counts the store
+     * instructions issued so far (only those of whole tiles: fewer than the truth is safe), mark[b] what it stood at when the transfer
+     * into buffer b was issued. */
+    int stores = 0, mark0 = 0, mark1 = 0, mark2 = 0; /* (three scalars, not an array: a run-time index would send it to scratch memory) */
+    auto mark_get = [&](int b) { return b == 0 ? mark0 : b == 1 ? mark1 : mark2; };
+    auto mark_set = [&](int b, int v) {
+        mark0 = b == 0 ? v : mark0;
+        mark1 = b == 1 ? v : mark1;
+        mark2 = b == 2 ? v : mark2;
+    };
     if (piece == 0) {
         stage(st_begin, lds);
         if (nbuf == 3 && st_begin + 1 < st_end) stage(st_begin + 1, lds + lds_per_buf);
@@ -231,122 +247,105 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
     const int row_l = lane & 15, grp = lane >> 4;
     /* store instructions a whole tile issues (each is skipped when no lane wants it): |bin| = one 16-byte store, raw I/Q = two */
     const int k_tile = ((__ballot(!(col & 1) && ch_valid && want_mag) != 0ull) ? 1 : 0) + ((__ballot(!(col & 1) && ch_valid && want_iq) != 0ull) ? 2 : 0);
-    int k_prev = 0; /* of them, issued since the previous wait (only whole tiles are counted: fewer than the truth is safe) */
-    for (int st = st_begin; st < st_end; st++) {
-        uint8_t* buf = lds + cur * lds_per_buf;
-        /* Vector-memory operations complete in issue order, so "at most N outstanding" proves step st has landed as soon as N operations
-         * YOUNGER than its transfer are known to have been issued: the n_dma pieces of step st + 1 (three buffers), and the output stores
-         * of the tiles computed since (k_prev instructions, counted below).  Leaving the stores out of N -- they are the youngest of all --
-         * would make every wait sit out their write acknowledgements, or, with three buffers, most of the step-(st+1) transfer. */
-        /* NP > 1: wave 0 runs the transfers and the waits; the barrier hands step st to the other waves and tells wave 0 that they
-         * are done with the buffer the next transfer overwrites (they read it in step st - 1) */
-        if (nbuf == 3) {
-            if (piece == 0) {
-                if (st + 1 >= st_end) wait_vmcnt(k_prev); /* last step: only the stores are younger */
-                else wait_vmcnt(n_dma + k_prev);
-            }
-            if (NP > 1) __syncthreads();
-            int nb = cur + 2;
-            nb = nb >= 3 ? nb - 3 : nb;
-            if (piece == 0 && st + 2 < st_end) stage(st + 2, lds + nb * lds_per_buf); /* two steps ahead: the buffer step st-1 just left */
-        } else {
-            if (piece == 0) {
-                wait_vmcnt(k_prev); /* this step's bytes have landed in LDS */
-            }
-            if (NP > 1) __syncthreads();
-            if (piece == 0 && st + 1 < st_end) stage(st + 1, lds + (cur ^ 1) * lds_per_buf); /* next step streams in under this step's MFMAs */
-        }
-        k_prev = 0;
-      for (int sb = 0; sb < sub; sb++) {
-        const int t = st * sub + sb;
-        if (t >= tiles_total) break;
 
-        v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-        float val[4];
+    /* Recombination of the digit sums in single precision: every accumulator is an exact integer below 2^24 (exact as a float), and
+     *     value = ((acc2 * 2^16 + acc1 * 2^8 + acc0) + corr) * unscale          [+ 2^8 * the same of the high-byte plane for CS16]
+     * is three fused multiply-adds with the constants folded -- rounding at 2^-24 of partial sums that are never larger than the
+     * result's own full scale, the same error class as the final conversion to float (measured against the float64 oracle:
+     * tests/test_gpu_parity.py, stage-1 bar 1e-5 relative RMS).  Round 2 recombined in float64: 36 half- and quarter-rate
+     * instructions per tile against 12 full-rate ones. */
+    /* (the scale factors are the same number on every lane -- a.unscale, and for CS16 the wave's own dongle's 1 / fullscale: scalar registers) */
+    const int flipmask = a.sfmt == AIRBAND_SFMT_S8 ? 0 : (int)0x80808080;
+    auto uni = [](double v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)v))); };
+    const float u0 = uni(unscale), u1 = uni(unscale * 256.0), u2 = uni(unscale * 65536.0);
+    const float cu = a.sfmt == AIRBAND_SFMT_S8 ? 0.0f : (float)(corr * unscale); /* s8 samples are i / 128: nothing to restore */
+    const float w0 = u1, w1 = u2, w2 = uni(unscale * 16777216.0); /* CS16 high-byte plane */
+
+    struct TileAcc {
+        v4i a0, a1, a2, h0, h1, h2; /* h*: CS16 high-byte plane */
+    };
+    /* LDS -> MFMA for the 16 hops of tile (step buffer `buf`, sub-tile sb): leaves the integer digit sums in A */
+    auto tile_mfma = [&](const uint8_t* buf, int sb, TileAcc& A) {
+        A.a0 = (v4i){0, 0, 0, 0}; A.a1 = (v4i){0, 0, 0, 0}; A.a2 = (v4i){0, 0, 0, 0};
         if (!S16) {
-        const uint8_t* arow = buf + delta + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 16 + piece * WIN_BYTES;
-        /* A fragments are fetched two k-steps ahead of the MFMAs that consume them, so the LDS latency (and the 2-way
-         * bank conflict of the strided rows) hides behind six MFMAs instead of stalling in front of them */
-        v4i av[KSTEPS];
-        av[0] = lds_read16<AL>(arow);
-        av[1] = lds_read16<AL>(arow + 64);
-        av[2] = lds_read16<AL>(arow + 128);
-        av[3] = lds_read16<AL>(arow + 192);
+            const uint8_t* arow = buf + delta + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 16 + piece * WIN_BYTES;
+            /* A fragments are fetched ahead of the MFMAs that consume them, so the LDS latency (and the 2-way bank conflict of the
+             * strided rows) hides behind six MFMAs instead of stalling in front of them */
+            /* A fragments are fetched four k-steps ahead of the MFMAs that consume them, so the LDS latency (and the 2-way bank conflict of
+             * the strided rows) hides behind a dozen MFMAs instead of stalling in front of them; a scheduling fence every two k-steps keeps
+             * that distance as the source spells it out */
+            v4i av[KSTEPS];
+            av[0] = lds_read16<AL>(arow);
+            av[1] = lds_read16<AL>(arow + 64);
+            av[2] = lds_read16<AL>(arow + 128);
+            av[3] = lds_read16<AL>(arow + 192);
 #pragma unroll
-        for (int s = 0; s < KSTEPS; s++) {
-            if ((s & 1) == 0 && s + 4 < KSTEPS) {
-                av[s + 4] = lds_read16<AL>(arow + (s + 4) * 64);
-                av[s + 5] = lds_read16<AL>(arow + (s + 5) * 64);
+            for (int s = 0; s < KSTEPS; s++) {
+                if ((s & 1) == 0 && s + 4 < KSTEPS) {
+                    av[s + 4] = lds_read16<AL>(arow + (s + 4) * 64);
+                    av[s + 5] = lds_read16<AL>(arow + (s + 5) * 64);
+                }
+                v4i x = av[s];
+                x.x ^= flipmask; x.y ^= flipmask; x.z ^= flipmask; x.w ^= flipmask; /* u8 -> b - 128 as int8; s8 (mirisdr, SoapySDR CS8) is int8 already: the mask is zero */
+                A.a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b0[s], A.a0, 0, 0, 0);
+                A.a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b1[s], A.a1, 0, 0, 0);
+                if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) A.a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b2[s], A.a2, 0, 0, 0);
+                if (s & 1) __builtin_amdgcn_sched_barrier(0);
             }
-            v4i x = av[s];
-            x.x ^= 0x80808080; x.y ^= 0x80808080; x.z ^= 0x80808080; x.w ^= 0x80808080; /* u8 -> b - 128 as int8 */
-            acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b0[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b1[s], acc1, 0, 0, 0);
-            if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b2[s], acc2, 0, 0, 0);
-            if (s & 1) __builtin_amdgcn_sched_barrier(0); /* keep the prefetch distance the source order spells out */
-        }
-        /* recombine the digits exactly, restore the -127.5 offset of the reference's LUT, undo the fixed-point scale */
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const double y = ((double)acc2[r] * 65536.0 + (double)acc1[r] * 256.0 + (double)acc0[r] + corr) * unscale;
-            val[r] = (float)y;
-        }
         } else {
-        /* CS16: plane k-step s of the lane = 16 plane bytes = 8 samples x (I, Q) = 32 raw bytes [Ilo Ihi Qlo Qhi] x 8 */
-        v4i hc0 = {0, 0, 0, 0}, hc1 = {0, 0, 0, 0}, hc2 = {0, 0, 0, 0}; /* high-byte plane */
-        const uint8_t* arow = buf + delta + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 32 + piece * WIN_BYTES;
-        v4i ra[2], rb[2]; /* raw 32 bytes of k-step s in (ra, rb)[s & 1]; the next k-step is fetched under this one's MFMAs */
-        ra[0] = lds_read16<AL>(arow);
-        rb[0] = lds_read16<AL>(arow + 16);
+            /* CS16: plane k-step s of the lane = 16 plane bytes = 8 samples x (I, Q) = 32 raw bytes [Ilo Ihi Qlo Qhi] x 8 */
+            A.h0 = (v4i){0, 0, 0, 0}; A.h1 = (v4i){0, 0, 0, 0}; A.h2 = (v4i){0, 0, 0, 0};
+            const uint8_t* arow = buf + delta + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 32 + piece * WIN_BYTES;
+            v4i ra[2], rb[2]; /* raw 32 bytes of k-step s in (ra, rb)[s & 1]; the next k-step is fetched under this one's MFMAs */
+            ra[0] = lds_read16<AL>(arow);
+            rb[0] = lds_read16<AL>(arow + 16);
 #pragma unroll
-        for (int s = 0; s < KSTEPS; s++) {
-            if (s + 1 < KSTEPS) {
-                ra[(s + 1) & 1] = lds_read16<AL>(arow + (s + 1) * 128);
-                rb[(s + 1) & 1] = lds_read16<AL>(arow + (s + 1) * 128 + 16);
-            }
-            const v4i p = ra[s & 1], q = rb[s & 1];
-            v4i lo, hi; /* v_perm_b32(hi dword, lo dword, selector): selector bytes 0-3 index the second operand, 4-7 the first */
-            lo.x = (int)__builtin_amdgcn_perm((unsigned)p.y, (unsigned)p.x, 0x06040200u); hi.x = (int)__builtin_amdgcn_perm((unsigned)p.y, (unsigned)p.x, 0x07050301u);
-            lo.y = (int)__builtin_amdgcn_perm((unsigned)p.w, (unsigned)p.z, 0x06040200u); hi.y = (int)__builtin_amdgcn_perm((unsigned)p.w, (unsigned)p.z, 0x07050301u);
-            lo.z = (int)__builtin_amdgcn_perm((unsigned)q.y, (unsigned)q.x, 0x06040200u); hi.z = (int)__builtin_amdgcn_perm((unsigned)q.y, (unsigned)q.x, 0x07050301u);
-            lo.w = (int)__builtin_amdgcn_perm((unsigned)q.w, (unsigned)q.z, 0x06040200u); hi.w = (int)__builtin_amdgcn_perm((unsigned)q.w, (unsigned)q.z, 0x07050301u);
-            lo.x ^= 0x80808080; lo.y ^= 0x80808080; lo.z ^= 0x80808080; lo.w ^= 0x80808080; /* unsigned low byte -> lo - 128 as int8 */
-            acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, b0[s], acc0, 0, 0, 0);
-            hc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, b0[s], hc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, b1[s], acc1, 0, 0, 0);
-            hc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, b1[s], hc1, 0, 0, 0);
-            if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) {
-                acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, b2[s], acc2, 0, 0, 0);
-                hc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, b2[s], hc2, 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        /* value = sum lo c + 256 sum hi c, with lo = (lo - 128) + 128: corr = 128 * sum c (table units); all exact in float64 (< 2^50) */
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const double l = (double)acc2[r] * 65536.0 + (double)acc1[r] * 256.0 + (double)acc0[r];
-            const double h = (double)hc2[r] * 65536.0 + (double)hc1[r] * 256.0 + (double)hc0[r];
-            val[r] = (float)((h * 256.0 + l + corr) * unscale);
-        }
-        }
-        if (NP > 1) { /* the other pieces' partial sums (same lane layout) reach wave 0 through LDS; two areas alternate so that a
-                         wave ahead by a tile never overwrites what wave 0 is still adding up */
-            float4* ex = exch + (t & 1) * (NP - 1) * 64;
-            if (piece > 0) ex[(piece - 1) * 64 + lane] = make_float4(val[0], val[1], val[2], val[3]);
-            __syncthreads();
-            if (piece > 0) continue;
-#pragma unroll
-            for (int q = 0; q < NP - 1; q++) {
-                const float4 o = ex[q * 64 + lane];
-                val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
+            for (int s = 0; s < KSTEPS; s++) {
+                if (s + 1 < KSTEPS) {
+                    ra[(s + 1) & 1] = lds_read16<AL>(arow + (s + 1) * 128);
+                    rb[(s + 1) & 1] = lds_read16<AL>(arow + (s + 1) * 128 + 16);
+                }
+                const v4i p = ra[s & 1], q = rb[s & 1];
+                v4i lo, hi; /* v_perm_b32(hi dword, lo dword, selector): selector bytes 0-3 index the second operand, 4-7 the first */
+                lo.x = (int)__builtin_amdgcn_perm((unsigned)p.y, (unsigned)p.x, 0x06040200u); hi.x = (int)__builtin_amdgcn_perm((unsigned)p.y, (unsigned)p.x, 0x07050301u);
+                lo.y = (int)__builtin_amdgcn_perm((unsigned)p.w, (unsigned)p.z, 0x06040200u); hi.y = (int)__builtin_amdgcn_perm((unsigned)p.w, (unsigned)p.z, 0x07050301u);
+                lo.z = (int)__builtin_amdgcn_perm((unsigned)q.y, (unsigned)q.x, 0x06040200u); hi.z = (int)__builtin_amdgcn_perm((unsigned)q.y, (unsigned)q.x, 0x07050301u);
+                lo.w = (int)__builtin_amdgcn_perm((unsigned)q.w, (unsigned)q.z, 0x06040200u); hi.w = (int)__builtin_amdgcn_perm((unsigned)q.w, (unsigned)q.z, 0x07050301u);
+                lo.x ^= 0x80808080; lo.y ^= 0x80808080; lo.z ^= 0x80808080; lo.w ^= 0x80808080; /* unsigned low byte -> lo - 128 as int8 */
+                A.a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, b0[s], A.a0, 0, 0, 0);
+                A.h0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, b0[s], A.h0, 0, 0, 0);
+                A.a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, b1[s], A.a1, 0, 0, 0);
+                A.h1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, b1[s], A.h1, 0, 0, 0);
+                if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) {
+                    A.a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, b2[s], A.a2, 0, 0, 0);
+                    A.h2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, b2[s], A.h2, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        /* lane pairs (2ch, 2ch+1) hold (re, im) of the same hop; even lanes write 4 consecutive rows of their slot */
+    };
+    /* digit sums -> the lane's four values (hops grp * 4 .. + 3 of column col): recombine, restore the -127.5 offset of the reference's
+     * LUT (u8) / the + 128 of the low byte (CS16), undo the fixed-point scale */
+    auto tile_value = [&](const TileAcc& A, int r) {
+        float y = __builtin_fmaf((float)A.a0[r], u0, cu);
+        y = __builtin_fmaf((float)A.a1[r], u1, y);
+        y = __builtin_fmaf((float)A.a2[r], u2, y);
+        if (S16) {
+            y = __builtin_fmaf((float)A.h0[r], w0, y);
+            y = __builtin_fmaf((float)A.h1[r], w1, y);
+            y = __builtin_fmaf((float)A.h2[r], w2, y);
+        }
+        return y;
+    };
+    /* the neighbour lane's value: a DPP move inside the quad (quad_perm [1, 0, 3, 2]), no LDS round trip */
+    auto pair_swap = [&](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); };
+    /* values of tile t -> rings.  Lane pairs (2ch, 2ch+1) hold (re, im) of the same hop; even lanes write 4 consecutive rows of their slot */
+    auto tile_store = [&](int t, const float* val) {
         float im4[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) im4[r] = __shfl_xor(val[r], 1);
+        for (int r = 0; r < 4; r++) im4[r] = pair_swap(val[r]);
         const bool whole_tile = t * TILE_HOPS - shift >= 0 && t * TILE_HOPS - shift + TILE_HOPS <= a.n_hops; /* wave-uniform: all 16 hops of the tile are stored */
-        if (whole_tile) k_prev += k_tile;
+        if (whole_tile) stores += k_tile;
         if (!(col & 1) && ch_valid) {
             int pt = ptile0 + t;
             pt = pt >= ring_tiles16 ? pt - ring_tiles16 : pt;
@@ -373,7 +372,64 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
                 }
             }
         }
-      }
+    };
+
+    for (int st = st_begin; st < st_end; st++) {
+        uint8_t* buf = lds + cur * lds_per_buf;
+        /* NP > 1: wave 0 runs the transfers and the waits; the barrier hands step st to the other waves and tells wave 0 that they
+         * are done with the buffer the next transfer overwrites (they read it in step st - 1) */
+        if (nbuf == 3) {
+            if (piece == 0) wait_vmcnt((st + 1 < st_end ? n_dma : 0) + (stores - mark_get(cur))); /* younger than step st's transfer: step st + 1's pieces, the stores since */
+            if (NP > 1) __syncthreads();
+            int nb = cur + 2;
+            nb = nb >= 3 ? nb - 3 : nb;
+            if (piece == 0 && st + 2 < st_end) { /* two steps ahead: the buffer step st - 1 just left */
+                stage(st + 2, lds + nb * lds_per_buf);
+                mark_set(nb, stores);
+            }
+        } else {
+            if (piece == 0) wait_vmcnt(stores - mark_get(cur)); /* this step's bytes have landed in LDS */
+            if (NP > 1) __syncthreads();
+            if (piece == 0 && st + 1 < st_end) { /* next step streams in under this step's MFMAs */
+                stage(st + 1, lds + (cur ^ 1) * lds_per_buf);
+                mark_set(cur ^ 1, stores);
+            }
+        }
+        for (int sb = 0; sb < sub; sb++) {
+            const int t = st * sub + sb;
+            if (t >= tiles_total) break;
+            float val[4];
+            TileAcc now;
+            tile_mfma(buf, sb, now);
+#pragma unroll
+            for (int r = 0; r < 4; r++) val[r] = tile_value(now, r);
+            if (NP > 1) {
+                /* the other pieces' partial sums (same lane layout) reach wave 0 through LDS; two areas alternate so that a wave ahead by a
+                 * tile never overwrites what wave 0 is still adding up */
+                float4* ex = exch + (t & 1) * (NP - 1) * 64;
+                if (piece > 0) ex[(piece - 1) * 64 + lane] = make_float4(val[0], val[1], val[2], val[3]);
+                __syncthreads();
+                if (piece > 0) continue;
+#pragma unroll
+                for (int q = 0; q < NP - 1; q++) {
+                    const float4 o = ex[q * 64 + lane];
+                    val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
+                }
+            }
+            if (NP > 1 && a.partial) { /* fft_size 8192: the first pass parks its sums (whole-wave 1 KiB rows), the second adds them to its own */
+                /* (row base through scalar registers: left to itself the compiler keeps a per-lane 64-bit base alive across the whole loop) */
+                const unsigned long long rb = (unsigned long long)(a.partial + ((long)item * tiles_total + t) * 64);
+                const unsigned rb_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rb), rb_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rb >> 32));
+                float4* row = reinterpret_cast<float4*>(((unsigned long long)rb_hi << 32) | rb_lo) + lane;
+                if (a.piece0 == 0) {
+                    *row = make_float4(val[0], val[1], val[2], val[3]);
+                    continue;
+                }
+                const float4 o = *row;
+                val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
+            }
+            tile_store(t, val);
+        }
         cur = cur + 1 == nbuf ? 0 : cur + 1;
     }
 }
@@ -382,10 +438,10 @@ __global__ __launch_bounds__(64 * NP, 2) void channelizer_dft_kernel(DftArgs a) 
 
 bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch) {
     (void)max_ch; /* any channel count: dongles with more than 8 channels are split into groups of 8 */
-    if (fft_size != 2048 && fft_size != 1024 && fft_size != 512 && fft_size != 256) return false; /* 1024 / 2048: window pieces of 512 samples, one wave each */
+    if (fft_size < 256 || fft_size > 8192 || (fft_size & (fft_size - 1))) return false; /* >= 1024: window pieces of 512 samples, one wave each (8192: two passes of eight) */
     /* hops must start on 4-byte boundaries (even hop_samples for u8: 2.4 MS/s -> 300 / 600 bytes); two staging buffers of 16 hops +
      * one window must leave room for 3+ waves per CU */
-    if (sfmt == AIRBAND_SFMT_U8) return (hop_bytes % 4) == 0 && hop_bytes <= 1024 && hop_bytes >= 64;
+    if (sfmt == AIRBAND_SFMT_U8 || sfmt == AIRBAND_SFMT_S8) return (hop_bytes % 4) == 0 && hop_bytes <= 1024 && hop_bytes >= 64;
     if (sfmt == AIRBAND_SFMT_S16) return (hop_bytes % 4) == 0 && hop_bytes <= 1280 && hop_bytes >= 128;
     return false;
 }
@@ -394,11 +450,19 @@ bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch) {
 int dft_sub(int hop_bytes, int win_bytes, int np) { return c_sub(hop_bytes, win_bytes, np); }
 int dft_nbuf(int hop_bytes, int win_bytes, int np) { return c_nbuf(hop_bytes, win_bytes, np); }
 int dft_lds_per_buf(int hop_bytes, int win_bytes, int np) { return c_lds_per_buf(hop_bytes, win_bytes, np); }
+int dft_partial_tiles(int n_hops_max) { return (15 + n_hops_max + TILE_HOPS - 1) / TILE_HOPS + 1; }
 
 template <int FFT_N, int HOPB, bool S16, int AL, int NP = 1>
 static void launch_al(const DftArgs& a, hipStream_t stream) {
     const long groups = (long)a.n_items * a.splits;
     const size_t lds = (size_t)a.nbuf * a.lds_per_buf + (NP > 1 ? 2 * (NP - 1) * 64 * sizeof(float4) : 0);
+    /* more than the default 64 KiB of dynamic LDS (eight-piece windows): opt in to the CU's 160 KiB, once per kernel variant */
+    static bool big_lds[2] = {false, false};
+    if (lds > 64 * 1024 && !big_lds[a.edge_hi_zero ? 1 : 0]) {
+        const void* fn = a.edge_hi_zero ? reinterpret_cast<const void*>(&channelizer_dft_kernel<FFT_N, true, HOPB, S16, AL, NP>)
+                                        : reinterpret_cast<const void*>(&channelizer_dft_kernel<FFT_N, false, HOPB, S16, AL, NP>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) big_lds[a.edge_hi_zero ? 1 : 0] = true;
+    }
     if (a.edge_hi_zero)
         hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, true, HOPB, S16, AL, NP>), dim3((unsigned)groups), dim3(64 * NP), lds, stream, a);
     else
@@ -416,14 +480,25 @@ static void launch_one_piece(const DftArgs& a, hipStream_t stream);
 
 void launch_channelizer_dft(const DftArgs& a0, hipStream_t stream) {
     DftArgs a = a0;
-    a.n_pass = 1;
-    a.pass = 0;
+    a.np_total = a0.fft_size > 512 ? a0.fft_size / 512 : 1;
+    a.piece0 = 0;
     if (a0.fft_size > 512) { /* one wavefront per window piece of 512 samples */
         a.fft_size = 512;
         const bool s16 = a.sfmt == AIRBAND_SFMT_S16;
         if (a0.fft_size == 1024) return s16 ? launch_generic<512, true, 2>(a, stream) : launch_generic<512, false, 2>(a, stream);
-        return s16 ? launch_generic<512, true, 4>(a, stream) : launch_generic<512, false, 4>(a, stream);
+        if (a0.fft_size == 2048) return s16 ? launch_generic<512, true, 4>(a, stream) : launch_generic<512, false, 4>(a, stream);
+        /* 4096: eight pieces, eight waves -- a whole CU's register file (two waves of B fragments per SIMD).  8192: sixteen pieces do not
+         * fit one CU, so two passes of eight; the first parks its partial sums in a.partial, the second adds them and writes the rings.
+         * The stream is read once per pass: 2x the bytes of the smaller sizes, and 8x / 16x their matrix work -- these sizes are MFMA-bound. */
+        if (a0.fft_size == 4096) a.partial = nullptr;
+        for (int pass = 0; pass * 8 < a.np_total; pass++) {
+            a.piece0 = pass * 8;
+            if (s16) launch_generic<512, true, 8>(a, stream);
+            else launch_generic<512, false, 8>(a, stream);
+        }
+        return;
     }
+    a.partial = nullptr;
     launch_one_piece(a, stream);
 }
 

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
     const int bps2 = 2 * a.bytes_per_sample; /* bytes per complex sample */
     const DevConst dev = a.dev[d];
     if (dev.disabled) return; /* a failed / disabled dongle (airband_hip_device_enable): block-uniform, in front of every barrier */
+    if (a.spectrum_only && !dev.any_afc) return; /* AFC's look at the batch's last hop: only dongles with an AFC channel need it */
 
     /* ---- stage the tile's raw bytes: coalesced 16 B per lane, HBM -> LDS -------------------------------- */
     const long span_begin = (long)hop0 * a.hop_samples * bps2; /* byte offset inside this batch's span */
@@ -127,9 +128,10 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
 #pragma unroll
             for (int r = 0; r < P; r++) {
                 const char2 v = *reinterpret_cast<const char2*>(hp + 2 * (r * 64 + lane));
-                /* table entry for -128 is never initialised by the reference; the oracle reads it as 0 */
-                xr[r] = (v.x == -128 ? 0.0f : (float)v.x) * win[r];
-                xi[r] = (v.y == -128 ? 0.0f : (float)v.y) * win[r];
+                /* i / 128 for every byte: the reference never initialises its table entry for -128 (src/rtl_airband.cpp:322-324); -1.0
+                 * continues the table's own rule (oracle/airband_oracle.c says the same) */
+                xr[r] = (float)v.x * win[r];
+                xi[r] = (float)v.y * win[r];
             }
         } else if (a.sfmt == AIRBAND_SFMT_S16) {
 #pragma unroll
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
                 bim = vi;
             }
         }
-        if (my_slot >= 0) {
+        if (my_slot >= 0 && !a.spectrum_only) {
             int row = a.row0 + a.first_row + hop0 + h;
             if (row >= a.ring_rows) row -= a.ring_rows;
             const long off = ab_tile_base(my_slot, a.ring_rows / AB_TILE_ROWS) + ab_tile_off(row);

@@ -88,7 +88,13 @@ struct DevConst {
     float scale;           /* 1/fullscale for S16/F32 (src/rtl_airband.cpp:403,421) */
     int32_t any_raw_iq;
     int32_t disabled;      /* airband_hip_device_enable(h, dev, 0): both stages skip the dongle (a failed input, src/rtl_airband.cpp:377-391) */
+    int32_t any_afc;       /* some channel of the dongle has afc != 0: the spectrum of each batch's last hop is needed (src/rtl_airband.cpp:626-630) */
+    int32_t pad;
 };
+
+/* scale of the matrix-core channelizer's 24-bit coefficient tables (params.cpp builds them, misc_kernels.hip re-tunes a column when AFC moves a bin):
+ * max |coefficient| < 1  ->  |value| <= 127 * 65536 + 127 * 256 + 127 */
+#define AB_DFT_COEF_SCALE 8355000.0
 
 /* Demod kinds: slots are sorted so that the 64 lanes of a demod wavefront run the same code path. */
 enum { AB_KIND_AM = 0, AB_KIND_NFM = 1, AB_KIND_NFM_LOWPASS = 2, AB_KIND_NFM_CTCSS = 3, AB_KIND_GENERIC = 4, AB_KIND_COUNT = 5 };

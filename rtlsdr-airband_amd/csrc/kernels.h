@@ -34,6 +34,7 @@ struct ChannelizerArgs {
     int first_row;          /* first logical row to produce (0 on the first batch, AGC_EXTRA later) */
     int n_hops;             /* hops to produce */
     int max_ch;
+    int spectrum_only;      /* 1: no ring output, only last_spectrum of dongles with an AFC channel (handles whose batches run on the matrix-core channelizer) */
 };
 
 /* matrix-core channelizer (channelizer_dft.hip) */
@@ -47,12 +48,13 @@ struct DftArgs {
     const int* item_group;
     const int* item_bset;
     const int8_t* bfrag;    /* [n_bsets][window pieces][3 digits][k-steps][64 lanes][16 bytes] MFMA B fragments (k-steps = min(fft_size, 512) / 32) */
-    const double* corr;     /* [n_bsets][16] offset restoring (b - 127.5) from (b - 128), in table units */
+    const double* corr;     /* [n_bsets * window pieces][16] offset restoring (b - 127.5) from (b - 128), in table units */
     double unscale;         /* u8: 1 / (table scale * 127.5); CS16: 1 / table scale (the kernel multiplies by the dongle's 1 / fullscale) */
     float* mag;
     float2* iq_bins;
     int n_dev, n_items, splits, fft_size, sfmt;
-    int pass, n_pass;                /* fft_size > 512: window piece of this launch / number of pieces (set by launch_channelizer_dft) */
+    int piece0, np_total;            /* fft_size > 512: first window piece of this launch / number of pieces of the window (set by launch_channelizer_dft) */
+    float4* partial;                 /* fft_size 8192 only: [n_items][tiles][64] partial sums between the two passes (dft_partial_tiles() tiles per item) */
     int edge_hi_zero;                /* most significant digit is zero in k-steps 0,1,14,15 for every coefficient table */
     int hop_bytes, lds_per_buf, sub, nbuf; /* sub = 16-hop MFMA tiles per staging step; nbuf staging buffers */
     int row0, ring_rows, first_row, n_hops;
@@ -136,6 +138,7 @@ bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch);
 int dft_lds_per_buf(int hop_bytes, int win_bytes, int np);
 int dft_sub(int hop_bytes, int win_bytes, int np);
 int dft_nbuf(int hop_bytes, int win_bytes, int np);
+int dft_partial_tiles(int n_hops_max); /* 16-hop tiles a work item may touch in one launch (sizes DftArgs::partial) */
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream);
 /* side: 3 extra streams, ev: 4 events (fork + 3 joins); both may be null -> everything on `stream`, one kind after the other */
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev);
@@ -145,6 +148,23 @@ void launch_mix(const MixArgs& a, hipStream_t stream);
 void launch_stats(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, int n_slots, airband_hip_channel_stats* out, hipStream_t stream);
 void launch_siggen(const SiggenArgs& a, hipStream_t stream);
 void launch_afc(const ChanConst* cc, ChanState* cs, const float* spectrum, int fft_size, int n_slots, hipStream_t stream);
+/* matrix-core channelizer + AFC: (re)builds, in place, the coefficient columns of every channel whose table is not built for the bin the channel
+ * is tuned to now -- all columns of a private table at start-up (bset_bin = -1), the two columns of a channel AFC has just moved afterwards */
+struct RetuneArgs {
+    const ChanConst* cc;
+    const ChanState* cs;
+    const DevConst* dev;
+    const int* ext_to_slot;
+    const int* item_dev;
+    const int* item_group;
+    const int* item_bset;
+    int* bset_bin;          /* [n_bsets][8] */
+    int8_t* bfrag;
+    double* corr;
+    const float* window;    /* fft_size */
+    int n_items, fft_size, n_shared;
+};
+void launch_retune(const RetuneArgs& a, hipStream_t stream);
 /* scatter channel-major host-provided bins into the time-major rings (airband_hip_process_bins) */
 void launch_scatter_bins(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, int n_slots,
                          int wave_batch, int row0, int ring_rows, hipStream_t stream);

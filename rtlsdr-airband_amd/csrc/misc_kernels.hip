@@ -213,6 +213,66 @@ void launch_afc(const ChanConst* cc, ChanState* cs, const float* spectrum, int f
     hipLaunchKernelGGL(afc_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, cc, cs, reinterpret_cast<const float2*>(spectrum), fft_size, n_slots);
 }
 
+/* ---- AFC on the matrix-core channelizer: coefficient columns follow the bins ---------------------------------------------------
+ * The pruned DFT has the channel's bin baked into its coefficient table (params.cpp, build_dft_tables).  A group of channels with an AFC
+ * channel owns its table; one workgroup per such work item compares, channel by channel, the bin the table is built for with the bin the
+ * channel is tuned to (ChanState::bin, moved by afc_kernel) and rewrites the channel's (re, im) column pair where they differ: the same
+ * arithmetic as the host builder -- w[n] exp(-2 pi i bin n / N) scaled to 24 bits, three balanced base-256 digits, in the MFMA B-fragment
+ * layout -- plus the column's offset correction.  At start-up every column of a private table differs (-1): the kernel is the builder. */
+__global__ __launch_bounds__(256) void retune_kernel(RetuneArgs a) {
+    __shared__ long long sums[2];
+    const int item = blockIdx.x;
+    const int bset = a.item_bset[item];
+    if (bset < a.n_shared) return; /* shared table: its channels never move */
+    const int d = a.item_dev[item], g = a.item_group[item];
+    const DevConst dev = a.dev[d];
+    const int N = a.fft_size, NP = N > 512 ? N / 512 : 1, NS = N / NP, K = 2 * NS, KS = K / 64;
+    const size_t piece_bytes = (size_t)3 * KS * 64 * 16;
+    for (int c = 0; c < 8 && g * 8 + c < dev.n_ch; c++) {
+        const int slot = a.ext_to_slot[dev.chan_base + g * 8 + c];
+        const int bin = a.cs[slot].bin;
+        if (a.bset_bin[bset * 8 + c] == bin) continue; /* block-uniform */
+        for (int piece = 0; piece < NP; piece++) {
+            if (threadIdx.x < 2) sums[threadIdx.x] = 0;
+            __syncthreads();
+            int8_t* tab = a.bfrag + ((size_t)bset * NP + piece) * piece_bytes;
+            long long part_re = 0, part_im = 0;
+            for (int k = threadIdx.x; k < K; k += 256) {
+                const int n = piece * NS + (k >> 1);
+                double sn, cs_;
+                sincospi(2.0 * (double)(((long long)bin * n) % N) / (double)N, &sn, &cs_); /* the phase is reduced exactly in integers first */
+                const double wc = (double)a.window[n] * cs_ * AB_DFT_COEF_SCALE, ws = (double)a.window[n] * sn * AB_DFT_COEF_SCALE;
+                /* byte k = 2n + {0: I, 1: Q}:  (I + jQ) w e^{-j th} = (I w cos + Q w sin) + j (Q w cos - I w sin) */
+                const int v_re = (int)llround((k & 1) ? ws : wc), v_im = (int)llround((k & 1) ? wc : -ws);
+                part_re += v_re;
+                part_im += v_im;
+                const int s_ = k / 64, gg = (k % 64) / 16, jj = k % 16;
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    int rest = half ? v_im : v_re;
+                    const int lane = gg * 16 + 2 * c + half;
+#pragma unroll
+                    for (int t = 0; t < 3; t++) {
+                        const int lo = ((rest + 128) & 255) - 128; /* balanced digit */
+                        tab[(((size_t)t * KS + s_) * 64 + lane) * 16 + jj] = (int8_t)lo;
+                        rest = (rest - lo) / 256;
+                    }
+                }
+            }
+            atomicAdd((unsigned long long*)&sums[0], (unsigned long long)part_re); /* integer sums: exact, order-free */
+            atomicAdd((unsigned long long*)&sums[1], (unsigned long long)part_im);
+            __syncthreads();
+            if (threadIdx.x < 2) a.corr[((size_t)bset * NP + piece) * 16 + 2 * c + threadIdx.x] = 0.5 * (double)sums[threadIdx.x]; /* (b - 127.5) = (b - 128) + 0.5 */
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.bset_bin[bset * 8 + c] = bin;
+    }
+}
+
+void launch_retune(const RetuneArgs& a, hipStream_t stream) {
+    if (a.n_items > 0) hipLaunchKernelGGL(retune_kernel, dim3(a.n_items), dim3(256), 0, stream, a);
+}
+
 /* ---- layout shuffles for the introspection entry points -------------------------------------------------- */
 __global__ void scatter_bins_kernel(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, int n_slots,
                                     int wave_batch, int row0, int ring_rows) {

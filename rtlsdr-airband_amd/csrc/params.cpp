@@ -114,8 +114,8 @@ int build_plan(const airband_hip_config* cfg, Plan& p) {
 
     /* sample -> float tables (src/rtl_airband.cpp:316-324); s8 entry 128 is never written by the reference */
     for (int i = 0; i < 256; i++) p.lev_u8[i] = (i - 127.5f) / 127.5f;
-    std::memset(p.lev_s8, 0, sizeof(p.lev_s8));
-    for (int i = -127; i < 128; i++) p.lev_s8[(uint8_t)i] = i / 128.0f;
+    /* the reference's loop leaves the entry of the byte -128 uninitialised (src/rtl_airband.cpp:322-324); the library continues the table's rule */
+    for (int i = -128; i < 128; i++) p.lev_s8[(uint8_t)i] = i / 128.0f;
 
     /* window (src/rtl_airband.cpp:335-351): float literals widened to double, evaluated in double */
     {
@@ -181,6 +181,7 @@ int build_plan(const airband_hip_config* cfg, Plan& p) {
             c.chan = j;
             c.ext_index = p.total_ch;
             c.afc = ch.afc & 0xff;
+            if (c.afc) dev.any_afc = 1;
             c.ct_slot = -1;
             if (ch.modulation == AIRBAND_MOD_NFM) {
                 if (p.wave_rate != 16000) return fail(p, AIRBAND_HIP_EINVAL, "NFM channels need wave_rate 16000 (the reference's NFM build)");
@@ -291,74 +292,110 @@ int build_plan(const airband_hip_config* cfg, Plan& p) {
  *   (I + jQ) * w[n] * exp(-j theta) = (I w cos + Q w sin) + j (Q w cos - I w sin),  theta = 2 pi bin_c n / N
  * (same transform as src/rtl_airband.cpp:451-460 + :483-489 evaluated for one bin).  Values are scaled to 24-bit
  * integers and split into balanced base-256 digits d0 + 256 d1 + 65536 d2, each in [-128, 127]. */
-void build_dft_tables(Plan& p) {
+void build_dft_tables(Plan& p, bool host_private) {
     /* fft_size > 512: one table per window piece of 512 samples (NP pieces); a table then covers K = 1024 bytes of the window */
     const int N = p.fft_size, NP = N > 512 ? N / 512 : 1, NS = N / NP, K = 2 * NS, KS = K / 64;
-    const double S = 8355000.0; /* max |coefficient| < 1  ->  |value| <= 127*65536 + 127*256 + 127 */
+    const double S = AB_DFT_COEF_SCALE;
     p.b_unscale = 1.0 / (S * 127.5);
     p.item_dev.clear();
     p.item_group.clear();
     p.item_bset.clear();
     p.bfrag.clear();
     p.bcorr.clear();
-    std::vector<std::vector<int>> keys;
+    /* Tables are SHARED between work items with the same bins (a fleet of identical dongles has one) -- except those of a group with an
+     * AFC channel: AFC moves the channel's bin at run time (src/rtl_airband.cpp:224-250), the re-tune kernel then rewrites that channel's
+     * two columns in place, so such a group owns its table.  Shared tables take the indices [0, n_shared), private ones follow; private
+     * tables are built by the re-tune kernel itself on the device (host_private: and here, for the host-only self test). */
+    std::vector<std::vector<int>> shared_keys, private_keys;
+    auto build = [&](const std::vector<int>& key) {
+        for (int piece = 0; piece < NP; piece++) {
+            std::vector<int> q((size_t)K * 16, 0);
+            for (int c = 0; c < (int)key.size(); c++) {
+                for (int i = 0; i < NS; i++) {
+                    const int n = piece * NS + i;
+                    /* the phase is reduced exactly in integers before it meets a double */
+                    const double th = 2.0 * M_PI * (double)(((long long)key[c] * n) % N) / (double)N;
+                    const double wc = (double)p.window[n] * std::cos(th), ws = (double)p.window[n] * std::sin(th);
+                    q[(size_t)(2 * i) * 16 + 2 * c] = (int)std::llround(wc * S);       /* I -> re */
+                    q[(size_t)(2 * i + 1) * 16 + 2 * c] = (int)std::llround(ws * S);   /* Q -> re */
+                    q[(size_t)(2 * i) * 16 + 2 * c + 1] = (int)std::llround(-ws * S);  /* I -> im */
+                    q[(size_t)(2 * i + 1) * 16 + 2 * c + 1] = (int)std::llround(wc * S); /* Q -> im */
+                }
+            }
+            const size_t base = p.bfrag.size();
+            p.bfrag.resize(base + (size_t)3 * KS * 64 * 16, 0);
+            for (int col = 0; col < 16; col++) {
+                double sum = 0.0;
+                for (int k = 0; k < K; k++) {
+                    const int v = q[(size_t)k * 16 + col];
+                    sum += v;
+                    int dgt[3];
+                    int rest = v;
+                    for (int t = 0; t < 3; t++) {
+                        int lo = ((rest + 128) & 255) - 128; /* balanced digit */
+                        dgt[t] = lo;
+                        rest = (rest - lo) / 256;
+                    }
+                    const int s = k / 64, gg = (k % 64) / 16, jj = k % 16;
+                    const int lane = gg * 16 + col;
+                    for (int t = 0; t < 3; t++) p.bfrag[base + (((size_t)t * KS + s) * 64 + lane) * 16 + jj] = (int8_t)dgt[t];
+                }
+                p.bcorr.push_back(0.5 * sum); /* (b - 127.5) = (b - 128) + 0.5 */
+            }
+        }
+    };
+    int last_shared = -1;
     for (int d = 0; d < p.n_dev; d++) {
         for (int g = 0; g * 8 < p.dev[d].n_ch; g++) { /* one work item per group of 8 channels */
             std::vector<int> key;
-            for (int j = g * 8; j < p.dev[d].n_ch && j < g * 8 + 8; j++) key.push_back(p.cc[p.chan_base[d] + j].base_bin);
+            bool private_table = false;
+            for (int j = g * 8; j < p.dev[d].n_ch && j < g * 8 + 8; j++) {
+                key.push_back(p.cc[p.chan_base[d] + j].base_bin);
+                private_table |= p.cc[p.chan_base[d] + j].afc != 0;
+            }
             int found = -1;
-            if (!keys.empty() && keys.back() == key) found = (int)keys.size() - 1; /* fleets of identical dongles: the common case */
-            for (size_t i = 0; found < 0 && i < keys.size(); i++)
-                if (keys[i] == key) found = (int)i;
-            if (found < 0) {
-                found = (int)keys.size();
-                keys.push_back(key);
-              for (int piece = 0; piece < NP; piece++) {
-                std::vector<int> q((size_t)K * 16, 0);
-                for (int c = 0; c < (int)key.size(); c++) {
-                    for (int i = 0; i < NS; i++) {
-                        const int n = piece * NS + i;
-                        /* the phase is reduced exactly in integers before it meets a double */
-                        const double th = 2.0 * M_PI * (double)(((long long)key[c] * n) % N) / (double)N;
-                        const double wc = (double)p.window[n] * std::cos(th), ws = (double)p.window[n] * std::sin(th);
-                        q[(size_t)(2 * i) * 16 + 2 * c] = (int)std::llround(wc * S);       /* I -> re */
-                        q[(size_t)(2 * i + 1) * 16 + 2 * c] = (int)std::llround(ws * S);   /* Q -> re */
-                        q[(size_t)(2 * i) * 16 + 2 * c + 1] = (int)std::llround(-ws * S);  /* I -> im */
-                        q[(size_t)(2 * i + 1) * 16 + 2 * c + 1] = (int)std::llround(wc * S); /* Q -> im */
-                    }
+            if (private_table) {
+                found = -(int)private_keys.size() - 1; /* its final index is known once the shared tables are counted */
+                private_keys.push_back(key);
+            } else {
+                if (last_shared >= 0 && shared_keys[last_shared] == key) found = last_shared; /* fleets of identical dongles: the common case */
+                for (size_t i = 0; found < 0 && i < shared_keys.size(); i++)
+                    if (shared_keys[i] == key) found = (int)i;
+                if (found < 0) {
+                    found = (int)shared_keys.size();
+                    shared_keys.push_back(key);
+                    if (shared_keys.size() <= 4096) build(key); /* beyond that the caller falls back to the wavefront-FFT channelizer: no point in building on */
                 }
-                const size_t base = p.bfrag.size();
-                p.bfrag.resize(base + (size_t)3 * KS * 64 * 16, 0);
-                for (int col = 0; col < 16; col++) {
-                    double sum = 0.0;
-                    for (int k = 0; k < K; k++) {
-                        const int v = q[(size_t)k * 16 + col];
-                        sum += v;
-                        int dgt[3];
-                        int rest = v;
-                        for (int t = 0; t < 3; t++) {
-                            int lo = ((rest + 128) & 255) - 128; /* balanced digit */
-                            dgt[t] = lo;
-                            rest = (rest - lo) / 256;
-                        }
-                        const int s = k / 64, gg = (k % 64) / 16, jj = k % 16;
-                        const int lane = gg * 16 + col;
-                        for (int t = 0; t < 3; t++) p.bfrag[base + (((size_t)t * KS + s) * 64 + lane) * 16 + jj] = (int8_t)dgt[t];
-                    }
-                    p.bcorr.push_back(0.5 * sum); /* (b - 127.5) = (b - 128) + 0.5 */
-                }
-              }
+                last_shared = found;
             }
             p.item_dev.push_back(d);
             p.item_group.push_back(g);
             p.item_bset.push_back(found);
         }
     }
-    p.n_bsets = (int)keys.size();
+    p.n_shared_bsets = (int)shared_keys.size();
+    p.n_bsets = p.n_shared_bsets + (int)private_keys.size();
+    for (int& b : p.item_bset)
+        if (b < 0) b = p.n_shared_bsets + (-b - 1);
+    p.bset_bins.assign((size_t)p.n_bsets * 8, -1);
+    for (size_t b = 0; b < shared_keys.size(); b++)
+        for (size_t c = 0; c < shared_keys[b].size(); c++) p.bset_bins[b * 8 + c] = shared_keys[b][c];
+    if (host_private && p.n_shared_bsets <= 4096)
+        for (size_t b = 0; b < private_keys.size(); b++) {
+            build(private_keys[b]);
+            for (size_t c = 0; c < private_keys[b].size(); c++) p.bset_bins[(p.n_shared_bsets + b) * 8 + c] = private_keys[b][c];
+        }
     /* the window is below 2^-8 of full scale in the outer k-steps, so the top digit vanishes there: verify, don't assume */
     p.b_edge_hi_zero = NP == 1; /* window pieces have their small coefficients at one end only */
     const int edge = KS / 8;
-    for (int b = 0; b < p.n_bsets && p.b_edge_hi_zero; b++)
+    /* tables that AFC may re-tune to any bin: the top digit of an edge coefficient is zero whatever the bin iff the window itself is that small there */
+    for (int i = 0; !private_keys.empty() && p.b_edge_hi_zero && i < NS; i++) {
+        const int s_ = (2 * i) / 64;
+        if (s_ >= edge && s_ < KS - edge) continue;
+        if ((double)p.window[i] * S > 32639.0) p.b_edge_hi_zero = false;
+    }
+    const int n_built = (int)(p.bfrag.size() / ((size_t)3 * KS * 64 * 16 * NP));
+    for (int b = 0; b < n_built && p.b_edge_hi_zero; b++)
         for (int s = 0; s < KS; s++) {
             if (s >= edge && s < KS - edge) continue;
             for (int i = 0; i < 64 * 16; i++)
@@ -372,7 +409,7 @@ void build_dft_tables(Plan& p) {
  * evaluated directly in double.  Returns the largest error relative to the RMS of the exact values over all work items. */
 double dft_table_selftest(const Plan& p, int windows) {
     const int N = p.fft_size, NP = N > 512 ? N / 512 : 1, NS = N / NP, K = 2 * NS, KS = K / 64;
-    const bool s16 = p.dev[0].sfmt == AIRBAND_SFMT_S16;
+    const bool s16 = p.dev[0].sfmt == AIRBAND_SFMT_S16, s8 = p.dev[0].sfmt == AIRBAND_SFMT_S8;
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     auto next = [&]() {
         rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
@@ -385,8 +422,8 @@ double dft_table_selftest(const Plan& p, int windows) {
         const int d = p.item_dev[item], g = p.item_group[item], set = p.item_bset[item];
         const int nch = std::min(8, p.dev[d].n_ch - 8 * g);
         for (int w = 0; w < windows; w++) {
-            std::vector<int> raw(2 * N); /* u8: 0..255; CS16: -32768..32767 */
-            for (int k = 0; k < 2 * N; k++) raw[k] = s16 ? (int)(int16_t)(next() >> 17) : (int)((next() >> 23) & 255);
+            std::vector<int> raw(2 * N); /* u8: 0..255; s8: -128..127; CS16: -32768..32767 */
+            for (int k = 0; k < 2 * N; k++) raw[k] = s16 ? (int)(int16_t)(next() >> 17) : s8 ? (int)(int8_t)((next() >> 23) & 255) : (int)((next() >> 23) & 255);
             for (int c = 0; c < nch; c++) {
                 const int bin = p.cc[p.chan_base[d] + 8 * g + c].base_bin;
                 for (int comp = 0; comp < 2; comp++) {
@@ -400,17 +437,17 @@ double dft_table_selftest(const Plan& p, int windows) {
                             long long coef = 0;
                             for (int t = 2; t >= 0; t--) coef = coef * 256 + p.bfrag[base + (((size_t)t * KS + s_) * 64 + lane) * 16 + jj];
                             const int v = raw[piece * K + k];
-                            /* u8: (b - 128) + the 0.5 of the correction term; CS16: (lo - 128) + 256 hi + 128 = the sample itself */
-                            acc += (long long)(s16 ? v : v - 128) * coef;
+                            /* u8: (b - 128) + the 0.5 of the correction term; s8: the byte as it is; CS16: (lo - 128) + 256 hi + 128 = the sample itself */
+                            acc += (long long)((s16 || s8) ? v : v - 128) * coef;
                         }
-                        table_units += (double)acc + (s16 ? 0.0 : p.bcorr[((size_t)set * NP + piece) * 16 + col]);
+                        table_units += (double)acc + ((s16 || s8) ? 0.0 : p.bcorr[((size_t)set * NP + piece) * 16 + col]);
                     }
-                    const double got = table_units * (s16 ? p.b_unscale * 127.5 * (double)p.dev[d].scale : p.b_unscale);
+                    const double got = table_units * (s16 ? p.b_unscale * 127.5 * (double)p.dev[d].scale : s8 ? p.b_unscale * 127.5 / 128.0 : p.b_unscale);
                     double want = 0.0;
                     for (int n = 0; n < N; n++) {
                         const double th = 2.0 * M_PI * (double)(((long long)bin * n) % N) / (double)N;
-                        const double xi = s16 ? (double)p.dev[d].scale * raw[2 * n] : (double)p.lev_u8[raw[2 * n]];
-                        const double xq = s16 ? (double)p.dev[d].scale * raw[2 * n + 1] : (double)p.lev_u8[raw[2 * n + 1]];
+                        const double xi = s16 ? (double)p.dev[d].scale * raw[2 * n] : s8 ? (double)p.lev_s8[(uint8_t)raw[2 * n]] : (double)p.lev_u8[raw[2 * n]];
+                        const double xq = s16 ? (double)p.dev[d].scale * raw[2 * n + 1] : s8 ? (double)p.lev_s8[(uint8_t)raw[2 * n + 1]] : (double)p.lev_u8[raw[2 * n + 1]];
                         const double wn = (double)p.window[n];
                         want += comp == 0 ? wn * (xi * std::cos(th) + xq * std::sin(th)) : wn * (xq * std::cos(th) - xi * std::sin(th));
                     }

@@ -35,7 +35,8 @@ struct Plan {
     std::vector<double> bcorr;         /* [n_bsets][16] */
     double b_unscale = 0.0;
     bool b_edge_hi_zero = false;       /* digit 2 is zero in the outer k-steps (fft_size / 256 at either end) of every table */
-    int n_bsets = 0;
+    int n_bsets = 0, n_shared_bsets = 0; /* coefficient tables in all / those shared between work items (the rest belong to groups with an AFC channel) */
+    std::vector<int> bset_bins;          /* [n_bsets][8] the bin every column pair of a table is built for (-1: unused) */
     int64_t hop_bytes_max = 0;
     bool uniform_hop = true;           /* every dongle has the same sfmt / hop (needed by the batched launch) */
     std::string error;
@@ -44,8 +45,9 @@ struct Plan {
 /* Returns 0 or a negative AIRBAND_HIP_E* code (plan.error holds the text). No GPU needed. */
 int build_plan(const airband_hip_config* cfg, Plan& plan);
 
-/* Builds the int8 coefficient tables for the matrix-core channelizer (fft_size 512, u8, <= 8 channels/dongle). */
-void build_dft_tables(Plan& plan);
+/* Builds the int8 coefficient tables for the matrix-core channelizer.  host_private = false: tables of groups with an AFC channel are left
+ * to the device (retune kernel); their slots exist (item_bset, n_bsets) but plan.bfrag / bcorr hold the shared tables only. */
+void build_dft_tables(Plan& plan, bool host_private = true);
 
 /* The 16 "derived constants" slots documented at airband_hip_channel_constants(). */
 void channel_constants(const Plan& plan, int ext_index, double* out16);

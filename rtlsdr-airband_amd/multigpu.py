@@ -21,12 +21,32 @@ def baseline_mixer_inputs(d_start: int, d_end: int, channels_per_dongle: int, n_
     return [(d - d_start, c, (d * channels_per_dongle + c) % n_mixers, 1.0, 0.0) for d in range(d_start, d_end) for c in range(channels_per_dongle)]
 
 
-def allreduce_mixers(left, right, has_signal):
-    """In-place all-reduce of per-rank mixer partials: SUM for the waveforms, MAX for the signal flags
-    (mixer channel axcindicate, src/mixer.cpp:209).  Tensors may live on CPU (gloo) or GPU (nccl = RCCL)."""
+class _DevicePtr:
+    """__cuda_array_interface__ shim: a torch view over memory the library owns (no copy, no ownership)."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=2)
+
+
+def device_mixer_views(hip, n_mixers: int, stereo: bool = False):
+    """torch tensors over a handle's device-side mixer sums (airband_hip_device_results): (left [M][B] f32, right or None, has_signal [M] u8).
+    They alias the library's buffers: what an RCCL all-reduce writes is what airband_hip_collect_mixers() then reads."""
+    import torch
+
+    res = hip.device_results()
+    left = torch.as_tensor(_DevicePtr(res["mix_left"], (n_mixers, hip.B), "<f4"), device="cuda")
+    right = torch.as_tensor(_DevicePtr(res["mix_right"], (n_mixers, hip.B), "<f4"), device="cuda") if stereo else None
+    sig = torch.as_tensor(_DevicePtr(res["mix_signal"], (n_mixers,), "|u1"), device="cuda")
+    return left, right, sig
+
+
+def allreduce_mixers(left, right, has_signal, force: bool = False):
+    """In-place all-reduce of per-rank mixer partials: SUM for the waveforms (the right channel too when any mixer is stereo), MAX
+    for the signal flags (mixer channel axcindicate, src/mixer.cpp:209).  Tensors may live on CPU (gloo) or GPU (nccl = RCCL).
+    force: also at world size 1 (plumbing check of the collective leg)."""
     import torch.distributed as dist
 
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return
     dist.all_reduce(left, op=dist.ReduceOp.SUM)
     if right is not None:

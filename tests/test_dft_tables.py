@@ -8,7 +8,7 @@ import pytest
 import helpers
 
 
-@pytest.mark.parametrize("fft_log", [8, 9, 10, 11])
+@pytest.mark.parametrize("fft_log", [8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("mixed,wave_rate", [(False, 8000), (True, 16000)])
 def test_tables_reproduce_the_windowed_dft(pkg, built, fft_log, mixed, wave_rate):
     devices, _ = helpers.plan_devices(3, mixed)
@@ -37,11 +37,30 @@ def test_cs16_with_per_dongle_full_scale(pkg, built):
     assert pkg.dft_selftest(devices, wave_rate=16000, windows=2, fft_log=10) < 2e-6  # window pieces of 512 samples, same coefficient tables
 
 
-@pytest.mark.parametrize("kw", [dict(sfmt="SFMT_F32"), dict(sfmt="SFMT_S8"), dict(fft_log=12), dict(sfmt="SFMT_S16", fft_log=12)])
+def test_private_tables_of_afc_groups(pkg, built):
+    """Groups with an AFC channel own their coefficient table (it is re-tuned at run time); dongles without one keep sharing."""
+    devices, _ = helpers.afc_case(3)
+    plain, _ = helpers.plan_devices(2, False)
+    assert pkg.dft_selftest(devices + plain, wave_rate=8000, windows=2) < 2e-6
+
+
+def test_s8_tables(pkg, built):
+    """s8 (mirisdr, SoapySDR CS8): the byte is the int8 operand as it is, i / 128, nothing to restore -- at one and at several window pieces."""
+    devices, _ = helpers.plan_devices(2, False)
+    for d in devices:
+        d["sfmt"] = pkg.capi.SFMT_S8
+    assert pkg.dft_selftest(devices, wave_rate=8000, windows=3) < 2e-6
+    assert pkg.dft_selftest(devices, wave_rate=8000, windows=2, fft_log=12) < 2e-6
+
+
+@pytest.mark.parametrize("kw", [dict(sfmt="SFMT_F32"), dict(sfmt="SFMT_F32", fft_log=12), dict(sample_rate=2_408_000)])
 def test_configurations_of_the_fft_channelizer_are_refused(pkg, built, kw):
+    """f32 is not bytes; 2.408 MS/s at WAVE_RATE 8000 is a hop of 301 samples = 602 bytes, not a multiple of 4."""
     devices, _ = helpers.plan_devices(1, False)
     if "sfmt" in kw:
         devices[0]["sfmt"] = getattr(pkg.capi, kw["sfmt"])
+    if "sample_rate" in kw:
+        devices[0]["sample_rate"] = kw["sample_rate"]
     with pytest.raises(pkg.AirbandError) as e:
         pkg.dft_selftest(devices, wave_rate=8000, fft_log=kw.get("fft_log", 9))
     assert e.value.code == pkg.capi.EBADSIZE

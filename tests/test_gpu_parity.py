@@ -469,10 +469,12 @@ def test_ragged_shapes_and_empty_inputs(pkg, built):
     ("SFMT_U8", 9, 2_400_000, 16000), ("SFMT_U8", 9, 2_400_000, 8000), ("SFMT_U8", 9, 1_024_000, 8000), ("SFMT_S16", 9, 2_560_000, 8000), ("SFMT_S16", 8, 2_048_000, 16000),
     ("SFMT_S16", 9, 2_400_000, 16000), ("SFMT_U8", 9, 3_200_000, 8000),
     ("SFMT_U8", 10, 2_400_000, 16000), ("SFMT_U8", 11, 2_560_000, 8000), ("SFMT_U8", 10, 1_024_000, 16000),
-    ("SFMT_S16", 10, 2_560_000, 16000), ("SFMT_S16", 11, 2_400_000, 8000)])
+    ("SFMT_S16", 10, 2_560_000, 16000), ("SFMT_S16", 11, 2_400_000, 8000),
+    ("SFMT_U8", 12, 2_560_000, 16000), ("SFMT_U8", 13, 2_560_000, 8000), ("SFMT_S8", 10, 2_400_000, 16000), ("SFMT_S8", 12, 2_560_000, 8000), ("SFMT_S16", 12, 2_400_000, 16000)])
 def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sample_rate, wave_rate):
     """Sample formats s8/s16/f32, fft sizes 256..8192, sample rates whose hop is not a multiple of 16 bytes: the matrix-core path
-    takes u8 and CS16 at fft 256 ... 2048, everything else runs on the wavefront-FFT channelizer -- same parity bars either way."""
+    takes u8, s8 and CS16 at every fft size (window pieces of 512 samples on cooperating waves from 1024 up, two passes at 8192); f32 and
+    hops that are not multiples of 4 bytes run on the wavefront-FFT channelizer -- same parity bars either way."""
     capi = pkg.capi
     sfmt = getattr(capi, sfmt_name)
     n_dev, n_batches = 2, 7
@@ -484,8 +486,7 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
     opened = 0
     with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=capi.FLAG_TRACE_SQUELCH) as hip:
         hop_bytes = 2 * hop * capi.BYTES_PER_SAMPLE[sfmt]
-        expect_dft = hop_bytes % 4 == 0 and ((sfmt == capi.SFMT_U8 and fft_log in (8, 9, 10, 11) and 64 <= hop_bytes <= 1024) or
-                                             (sfmt == capi.SFMT_S16 and fft_log in (8, 9, 10, 11) and 128 <= hop_bytes <= 1280))
+        expect_dft = hop_bytes % 4 == 0 and ((sfmt in (capi.SFMT_U8, capi.SFMT_S8) and 64 <= hop_bytes <= 1024) or (sfmt == capi.SFMT_S16 and 128 <= hop_bytes <= 1280))
         assert hip.channelizer_name() == ("dft_mfma_i8" if expect_dft else "fft_wave64")
         pos = [0] * n_dev
         for b in range(n_batches):
@@ -502,6 +503,33 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
             assert helpers.rms(out["waveout"] - ww) <= 1e-4
             opened += int((out["axc"] == ord("*")).sum())
     assert opened > 0
+
+
+@pytest.mark.parametrize("force_fft", [False, True], ids=["dft_mfma", "fft_wave64"])
+def test_s8_negative_rail(pkg, built, force_fft):
+    """The byte -128 of an s8 source: the reference never initialises its table entry (src/rtl_airband.cpp:322-324); library and oracle
+    continue the table's rule (-128 / 128 = -1.0) on both channelizers.  A clipping signal: bursts driven into both rails."""
+    capi = pkg.capi
+    wave_rate, n_batches = 8000, 3
+    devices, iq = helpers.format_case(pkg, capi.SFMT_S8, 9, 2_560_000, wave_rate, 1, n_batches)
+    x = iq[0].astype(np.int32) * 6          # overdrive ...
+    clipped = np.clip(x, -128, 127).astype(np.int8)   # ... into an ADC that clips at its rails, -128 included
+    assert (clipped == -128).sum() > 1000
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate)
+    ref = orc.run_device(0, clipped, n_batches)
+    flags = capi.FLAG_TRACE_SQUELCH | (capi.FLAG_FORCE_FFT if force_fft else 0)
+    with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=flags) as hip:
+        assert hip.channelizer_name() == ("fft_wave64" if force_fft else "dft_mfma_i8")
+        raw = clipped.view(np.uint8)
+        pos = 0
+        for b in range(n_batches):
+            pos += hip.submit(0, raw[pos:])
+            assert hip.process()
+            out = hip.collect()
+            w, q = hip.read_bins()
+            assert helpers.rel_rms(w, ref["raw_wavein"][b]) <= 1e-5
+            assert np.array_equal(out["axc"], ref["axc"][b]) and np.array_equal(hip.read_trace(), ref["trace"][b])
+            assert helpers.rms(out["waveout"] - ref["waveout"][b]) <= 1e-4
 
 
 def test_device_enable_takes_a_failed_dongle_out(pkg, built):
@@ -562,8 +590,11 @@ def test_device_enable_takes_a_failed_dongle_out(pkg, built):
             hip.device_enable(n_dev, False)
 
 
-def test_afc(pkg, built):
-    """AFC-enabled channels (wavefront-FFT path: needs the whole spectrum of each batch's last hop)."""
+@pytest.mark.parametrize("force_fft", [False, True], ids=["dft_mfma", "fft_wave64"])
+def test_afc(pkg, built, force_fft):
+    """AFC-enabled channels (src/rtl_airband.cpp:180-251).  On the matrix-core channelizer a group with an AFC channel owns its coefficient
+    table, one wavefront FFT per dongle gives AFC the spectrum of the batch's last hop, and the re-tune kernel rewrites the moved
+    channel's columns; the wavefront-FFT channelizer reads the bin from the channel state."""
     n_dev, n_batches = 3, 14
     devices, carriers = helpers.afc_case(n_dev)
     nbytes = helpers.stream_bytes(n_batches, 8000)
@@ -571,8 +602,9 @@ def test_afc(pkg, built):
     orc = pyoracle.Oracle(devices, wave_rate=8000)
     ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
     moved = 0
-    with pkg.AirbandHip(devices, wave_rate=8000, flags=pkg.capi.FLAG_TRACE_SQUELCH) as hip:
-        assert hip.channelizer_name() == "fft_wave64"
+    flags = pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_FORCE_FFT if force_fft else 0)
+    with pkg.AirbandHip(devices, wave_rate=8000, flags=flags) as hip:
+        assert hip.channelizer_name() == ("fft_wave64" if force_fft else "dft_mfma_i8")
         pos = [0] * n_dev
         for b in range(n_batches):
             for d in range(n_dev):
