@@ -197,7 +197,7 @@ def measure_traffic(args, kernel_substr):
     for counter, mult in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
         out_dir = tempfile.mkdtemp(prefix="airband_pmc_", dir="/tmp")
         cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
-               "--child", "--workload", args.workload, "--steps", "3", "--warmup", "1", "--ring", "1"]
+               "--child", "--no-verify-all", "--workload", args.workload, "--steps", "3", "--warmup", "1", "--ring", "1"]
         if args.dongles:
             cmd += ["--dongles", str(args.dongles)]
         if args.sample_format != "u8":
@@ -258,6 +258,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", type=int, default=16, help="after the timed region, compare this many sampled dongles of the benchmarked handle with the CPU oracle (0 = off)")
+    ap.add_argument("--verify-all", dest="verify_all", action="store_true", default=True, help="after everything else: whole-handle replica check at the benchmarked size (default on at N = 1)")
+    ap.add_argument("--no-verify-all", dest="verify_all", action="store_false")
     ap.add_argument("--traffic", dest="traffic", action="store_true", default=None, help="measure the channelizer's HBM traffic with rocprofv3 PMC passes after the run (default at N = 1)")
     ap.add_argument("--no-traffic", dest="traffic", action="store_false")
     ap.add_argument("--traffic-timeout", type=float, default=240.0)
@@ -515,6 +517,38 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     hip.close()
+    if rank == 0 and world == 1 and args.verify_all and not s16:
+        # WHOLE-handle check at the benchmarked size (oracle/pyverify.replica_check): every dongle replays dongle 0's bytes (all dongles of a
+        # workload share one channel plan), dongle 0 is tied to the oracle, and every other dongle's rows / axcindicate / statistics must be
+        # bit-identical to dongle 0's.  A fresh handle (the benchmarked one has history), the resident I/Q re-used in place.
+        try:
+            import pyverify
+
+            for d0 in range(1, D, 4096):
+                iq[d0:d0 + 4096] = iq[0:1]
+            torch.cuda.synchronize()
+            host0 = iq[0].cpu().numpy()
+            rep = pkg.AirbandHip(devices, wave_rate=wave_rate, hip_device=local_rank, flags=flags & ~pkg.capi.FLAG_PIPELINE, fft_log=args.fft_log)
+            spot = pyverify.SpotCheck([devices[0]], [0], wave_rate=wave_rate, fft_log=args.fft_log)
+            nb_rep = 3
+            for i in range(nb_rep):
+                rep.process_device(iq.data_ptr() + offset(i), stride)
+                spot.feed([host0[offset(i):]], trace=False)
+                spot.compare(rep, trace=False, what="replica")
+            bad = pyverify.replica_check(rep, D, 8, trace=False)
+            spot.close()
+            rep.close()
+            ok = bad["waveout"] == bad["axc"] == bad["stats"] == 0
+            out["verify_all"] = dict(dongles=D, batches=nb_rep, differing=dict(waveout=bad["waveout"], axc=bad["axc"], stats=bad["stats"]), first_bad=bad["first_bad"],
+                                     checked="every dongle fed dongle 0's bytes: result rows, axcindicate and all statistics of all %d dongles bit-identical to dongle 0's "
+                                             "after %d batches; dongle 0 against the oracle each batch" % (D, nb_rep))
+            if not ok:
+                out["value"] = None
+        except AssertionError as e:
+            out["verify_all"] = dict(error=str(e)[:500])
+            out["value"] = None
+        except Exception as e:  # noqa: BLE001
+            out["verify_all"] = dict(error="whole-handle check could not run: %r" % (e,))
     del iq
     torch.cuda.empty_cache()
     if use_dist:

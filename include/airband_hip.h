@@ -271,7 +271,9 @@ int airband_hip_synchronize(airband_hip_handle* h);
 /* Stage-2 only: run the per-channel demod/squelch/filter batch on caller-provided stage-1 output
  * (HOST pointers): wavein [total_channels][wave_batch] magnitudes and iq_in [total_channels][2*wave_batch]
  * raw bin I/Q for the batch's WAVE_BATCH new hops.  Lets tests feed the oracle's exact stage-1 values
- * and demand bit-identical stage-2 results. */
+ * and demand bit-identical stage-2 results.  NFM channels: `wavein` is ignored -- stage 2 recomputes |bin| = sqrtf(re^2 + im^2) from
+ * iq_in, as the reference computes it from the same two floats (src/rtl_airband.cpp:484-487).  AFC is not run on these batches (there is
+ * no spectrum to look at).  Not available on pipelined handles. */
 int airband_hip_process_bins(airband_hip_handle* h, const float* wavein, const float* iq_in);
 
 /* Stage-1 output of the last batch, i.e. what the reference holds in channel->wavein[AGC_EXTRA..] / iq_in[2*AGC_EXTRA..] after

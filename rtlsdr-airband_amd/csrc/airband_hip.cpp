@@ -90,7 +90,7 @@ struct airband_hip_handle {
     DevBuf<ChanState> d_cs;
     DevBuf<int> d_slot_to_ext, d_ext_to_slot;
     DevBuf<uint8_t> d_block_kind;
-    DevBuf<float> d_window, d_sin, d_cos;
+    DevBuf<float> d_window, d_sin, d_cos, d_twiddle;
     DevBuf<float> d_mag, d_sqbuf, d_ct_coeff, d_ct_q;
     DevBuf<float2> d_iq, d_iq_out, d_ct_af;
     DevBuf<unsigned long long> d_ct_mask;
@@ -185,7 +185,7 @@ void destroy(airband_hip_handle* h) {
         if (st) (void)hipStreamSynchronize(st);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_dev.release(); h->d_cc.release(); h->d_cs.release(); h->d_slot_to_ext.release(); h->d_ext_to_slot.release(); h->d_block_kind.release();
-    h->d_window.release(); h->d_sin.release(); h->d_cos.release();
+    h->d_window.release(); h->d_sin.release(); h->d_cos.release(); h->d_twiddle.release();
     h->d_mag.release(); h->d_sqbuf.release(); h->d_ct_coeff.release(); h->d_ct_q.release();
     h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release(); h->d_ct_af.release(); h->d_ct_mask.release();
     h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
@@ -296,6 +296,7 @@ void launch_last_hop_spectrum(airband_hip_handle* h, hipStream_t s) {
     ca.cc = h->d_cc.p;
     ca.ext_to_slot = h->d_ext_to_slot.p;
     ca.window = h->d_window.p;
+    ca.twiddle = reinterpret_cast<const float2*>(h->d_twiddle.p);
     ca.mag = h->d_mag.p;
     ca.iq_bins = h->d_iq.p;
     ca.last_spectrum = h->d_spectrum.p;
@@ -557,6 +558,7 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     PREP_TRY(upload(h->d_block_kind, block_kind), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_window, p.window), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_sin, p.sin_lut), AIRBAND_HIP_ENOMEM);
+    PREP_TRY(upload(h->d_twiddle, p.twiddle), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_cos, p.cos_lut), AIRBAND_HIP_ENOMEM);
     /* CTCSS tables: [ct_slot][detector][tone] coefficients and [ct_slot][detector][q1|q2][tone] Goertzel state, so
      * that the 52 tone lanes of demod phase 2 read one contiguous run */
@@ -853,6 +855,7 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         ca.cc = h->d_cc.p;
         ca.ext_to_slot = h->d_ext_to_slot.p;
         ca.window = h->d_window.p;
+        ca.twiddle = reinterpret_cast<const float2*>(h->d_twiddle.p);
         ca.mag = h->d_mag.p;
         ca.iq_bins = h->d_iq.p;
         ca.last_spectrum = h->any_afc ? h->d_spectrum.p : nullptr;

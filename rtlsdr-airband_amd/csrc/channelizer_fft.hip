@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
      * ((first_)batch_bytes + lookahead_bytes) are fetched byte by byte: nothing outside the documented span is touched */
     const long avail_end = ((long)(a.n_hops - 1) * a.hop_samples + N) * bps2 - span_begin + mis; /* relative to src_al */
     const long avail_begin = span_begin == 0 ? mis : 0;
-    for (long i = threadIdx.x; i < n16; i += 256) {
+    for (long i = threadIdx.x; i < n16; i += blockDim.x) { /* (256 threads; 64 in the one-hop spectrum launches) */
         const long o = i << 4;
         if (o >= avail_begin && o + 16 <= avail_end) {
             *reinterpret_cast<uint4*>(lds_raw + o) = *reinterpret_cast<const uint4*>(src_al + o);
@@ -78,26 +78,25 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
     const float pre = a.sfmt == AIRBAND_SFMT_U8 ? (1.0f / 127.5f) : a.sfmt == AIRBAND_SFMT_S8 ? (1.0f / 128.0f) : dev.scale;
 #pragma unroll
     for (int r = 0; r < P; r++) win[r] = a.window[r * 64 + lane] * pre;
-    /* per-lane twiddles of the N = P x 64 decomposition, indexed by register (register rho holds k1 = bitrev(rho)) */
+    /* per-lane twiddles of the N = P x 64 decomposition, indexed by register (register rho holds k1 = bitrev(rho)): W_N^(lane k1), from the
+     * table the host evaluated in double (round 2 called sincosf P + 6 times per block and lane: a third of the kernel's instructions) */
     float twr[P], twi[P];
 #pragma unroll
     for (int rho = 0; rho < P; rho++) {
         const int k1 = bitrev(rho, LOGP);
-        float s, c;
-        sincosf(-2.0f * kPi * (float)(lane * k1) / (float)N, &s, &c);
-        twr[rho] = c;
-        twi[rho] = s;
+        const float2 w = a.twiddle[(lane * k1) & (N - 1)];
+        twr[rho] = w.x;
+        twi[rho] = w.y;
     }
-    /* cross-lane stage twiddles: distance dd = 32 >> st, W_(2dd)^(lane mod dd); lanes with the bit clear use 1 */
+    /* cross-lane stage twiddles: distance dd = 32 >> st, W_(2dd)^(lane mod dd) = W_N^((lane mod dd) N / (2 dd)); lanes with the bit clear use 1 */
     float cwr[6], cwi[6];
 #pragma unroll
     for (int st = 0; st < 6; st++) {
         const int dd = 32 >> st;
-        float s, c;
-        sincosf(-kPi * (float)(lane & (dd - 1)) / (float)dd, &s, &c);
+        const float2 w = a.twiddle[(lane & (dd - 1)) * (N / (2 * dd))];
         const bool lower = (lane & dd) != 0;
-        cwr[st] = lower ? c : 1.0f;
-        cwi[st] = lower ? s : 0.0f;
+        cwr[st] = lower ? w.x : 1.0f;
+        cwi[st] = lower ? w.y : 0.0f;
     }
     /* which (register, lane) holds this lane's channel bin */
     int my_rho = -1, my_src = 0, my_slot = -1;
@@ -113,7 +112,7 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
     __syncthreads();
 
     const uint8_t* lds = lds_raw + mis;
-    for (int h = wave; h < hops_here; h += 4) {
+    for (int h = wave; h < hops_here; h += (int)(blockDim.x >> 6)) {
         float xr[P], xi[P];
         const uint8_t* hp = lds + (long)h * a.hop_samples * bps2;
         /* convert + window (src/rtl_airband.cpp:402-455) */
@@ -233,8 +232,10 @@ void launch_one(const ChannelizerArgs& a, hipStream_t stream) {
     const size_t lds = fft_lds_bytes(a.fft_log, a.hop_samples, a.bytes_per_sample);
     const long blocks = (long)tiles * a.n_dev;
     /* wide formats at high sample rates: opt in to the CU's full 160 KiB (prepare() has checked the upper bound) */
+    /* (should the runtime refuse, the launch below fails with hipErrorInvalidValue and the batch driver reports it: airband_hip.cpp checks hipGetLastError) */
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_fft_kernel<LOGP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(channelizer_fft_kernel<LOGP>, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    /* a spectrum-only launch transforms ONE hop per dongle: one wavefront */
+    hipLaunchKernelGGL(channelizer_fft_kernel<LOGP>, dim3((unsigned)blocks), dim3(a.spectrum_only ? 64 : 256), lds, stream, a);
 }
 
 }  // namespace

@@ -24,6 +24,7 @@ struct ChannelizerArgs {
     const ChanConst* cc;
     const int* ext_to_slot; /* channel (device-major external index) -> demod slot */
     const float* window;    /* fft_size */
+    const float2* twiddle;  /* fft_size: exp(-2 pi i k / fft_size) */
     float* mag;             /* [ring_rows][stride] */
     float2* iq_bins;        /* [ring_rows][stride] */
     float* last_spectrum;   /* [n_dev][2*fft_size] full FFT of the batch's last hop (AFC), or null */
@@ -133,7 +134,7 @@ struct SiggenArgs {
 };
 
 void launch_channelizer_fft(const ChannelizerArgs& a, hipStream_t stream);
-size_t fft_lds_bytes(int fft_log, int hop_samples, int bytes_per_sample); /* dynamic LDS per workgroup; must stay <= 64 KiB */
+size_t fft_lds_bytes(int fft_log, int hop_samples, int bytes_per_sample); /* dynamic LDS per workgroup: prepare() refuses configurations above the CU's 160 KiB, the launch opts in above 64 KiB */
 bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch);
 int dft_lds_per_buf(int hop_bytes, int win_bytes, int np);
 int dft_sub(int hop_bytes, int win_bytes, int np);

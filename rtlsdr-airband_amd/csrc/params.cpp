@@ -135,6 +135,12 @@ int build_plan(const airband_hip_config* cfg, Plan& p) {
     for (uint32_t i = 0; i < 256; i++) sincosf((float)(2.0F * M_PI * (float)i / 256.0f), &p.sin_lut[i], &p.cos_lut[i]);
     p.sin_lut[256] = p.sin_lut[0];
     p.cos_lut[256] = p.cos_lut[0];
+    /* twiddles of the wavefront-FFT channelizer: W_N^k = exp(-2 pi i k / N), evaluated in double */
+    p.twiddle.resize((size_t)2 * p.fft_size);
+    for (int k = 0; k < p.fft_size; k++) {
+        p.twiddle[2 * k] = (float)std::cos(-2.0 * M_PI * (double)k / (double)p.fft_size);
+        p.twiddle[2 * k + 1] = (float)std::sin(-2.0 * M_PI * (double)k / (double)p.fft_size);
+    }
 
     const float global_alpha = (float)std::exp(-1.0f / (p.wave_rate * 2e-4)); /* src/rtl_airband.cpp:87 */
     const float rate = (float)p.wave_rate;

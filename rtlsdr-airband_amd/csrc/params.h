@@ -28,6 +28,7 @@ struct Plan {
     std::vector<ToneTable> tones;      /* by ct_slot */
     std::vector<float> window;         /* fft_size coefficients (src/rtl_airband.cpp:335-351) */
     std::vector<float> sin_lut, cos_lut; /* 257 entries each (src/util.cpp:105-110) */
+    std::vector<float> twiddle;          /* fft_size (cos, sin) pairs of exp(-2 pi i k / fft_size): the wavefront-FFT channelizer's table */
     float lev_u8[256], lev_s8[256];    /* src/rtl_airband.cpp:316-324 */
     /* matrix-core channelizer tables (channelizer_dft.hip); empty unless the configuration qualifies */
     std::vector<int> item_dev, item_group, item_bset; /* channelizer work items: (dongle, group of 8 channels, coefficient-table index) */

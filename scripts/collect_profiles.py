@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final")
 DST = os.path.join(ROOT, "profiles")
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def short(k):
@@ -53,8 +53,8 @@ def main():
     host = open(os.path.join(SRC, "host.txt")).read().split("\n") if os.path.exists(os.path.join(SRC, "host.txt")) else ["?", "?"]
     md.append("Host of the GPU box: %s hardware threads, %s.\n" % (host[0], host[1].split(":")[-1].strip() if len(host) > 1 else "?"))
     md.append("## bench.py lines\n")
-    md.append("| file | workload | Msamples/s | ms/step | channelizer ms | stage 2 ms | frac (8 TB/s) | read-only frac | verified | extra |")
-    md.append("|---|---|---|---|---|---|---|---|---|---|")
+    md.append("| file | workload | Msamples/s | ms/step | channelizer ms | stage 2 ms | bound | frac | read-only frac (8 TB/s) | end-to-end frac | verified | extra |")
+    md.append("|---|---|---|---|---|---|---|---|---|---|---|---|")
     for f in sorted(glob.glob(os.path.join(SRC, R + "_bench_*.json"))):
         try:
             j = json.load(open(f))
@@ -70,11 +70,16 @@ def main():
         if j["roofline"].get("traffic"):
             extra.append("PMC traffic %.2f GB / launch" % (j["roofline"]["traffic"] / 1e9))
         cfg = j["config"]
-        md.append("| `%s` | %s, %s, %s%s | %s | %s | %.3f | %.3f | %s | %s | %s | %s |" % (
-            os.path.basename(f), cfg["workload"].split(",")[0][:40], cfg.get("sample_format"), cfg["channelizer"], ", " + cfg["schedule"][:9] if "pipelined" in cfg["schedule"] else "",
-            j["value"], j["ms_per_step"], j["stage_ms"]["channelizer"], j["stage_ms"]["demod"], j["roofline"]["frac"], j["roofline"].get("frac_read_only"),
-            j.get("verified_dongles"), "; ".join(extra)))
+        if j.get("verify_all"):
+            v = j["verify_all"]
+            extra.append("whole handle: %s" % (("%d dongles, differing %s" % (v["dongles"], v["differing"])) if "dongles" in v else v))
+        md.append("| `%s` | %s, %s, fft %s, %s%s%s | %s | %s | %.3f | %.3f | %s | %s | %s | %s | %s | %s |" % (
+            os.path.basename(f), cfg["workload"].split(",")[0][:40], cfg.get("sample_format"), cfg.get("fft_size"), cfg["channelizer"], ", afc" if cfg.get("afc") else "",
+            ", " + cfg["schedule"][:9] if "pipelined" in cfg["schedule"] else "",
+            j["value"], j["ms_per_step"], j["stage_ms"]["channelizer"], j["stage_ms"]["demod"], j["roofline"]["bound"], j["roofline"]["frac"], j["roofline"].get("frac_read_only"),
+            j["roofline"].get("end_to_end_frac"), j.get("verified_dongles"), "; ".join(extra)))
     for name, title in (("kt_cfg3", "configs[2], default run (kinds side by side)"), ("kt_cfg3_serial", "configs[2], every stage-2 kernel alone (AIRBAND_BENCH_FLAGS=8)"),
+                        ("kt_cfg3_afc", "configs[2] with AFC on one channel of every dongle, stage-2 kernels alone (bench.py --afc 2)"),
                         ("kt_cfg3_force_fft", "configs[2] on the wavefront-FFT channelizer (AIRBAND_BENCH_FLAGS=4)"), ("kt_cfg2", "configs[1] (1 024 AM dongles)"),
                         ("kt_am65536", "65 536 AM dongles"), ("kt_cs16", "configs[2] with CS16 dongles")):
         rows = stats(name)
