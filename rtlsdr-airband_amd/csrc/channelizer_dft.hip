@@ -74,16 +74,32 @@ constexpr __host__ __device__ int c_lds_per_buf(int hop_bytes, int win_bytes = 1
 /* AL: alignment every hop start is known to have inside the dongle's span (16, 8 or 4 bytes).  2.4 MS/s, the other common RTL-SDR
  * rate, hops 300 (WAVE_RATE 16000) or 600 bytes (8000): the stream is still staged in aligned 16-byte pieces -- the LDS image simply
  * starts up to 15 bytes before the first hop -- and the A fragments are assembled from 8- or 4-byte LDS reads. */
-/* s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the instruction takes an immediate */
-__device__ __forceinline__ void wait_vmcnt(int n) {
-    switch (n) {
-#define AB_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-        AB_W(1) AB_W(2) AB_W(3) AB_W(4) AB_W(5) AB_W(6) AB_W(7) AB_W(8) AB_W(9) AB_W(10) AB_W(11) AB_W(12) AB_W(13) AB_W(14)
-        AB_W(15) AB_W(16) AB_W(17) AB_W(18) AB_W(19) AB_W(20) AB_W(21) AB_W(22) AB_W(23) AB_W(24)
-#undef AB_W
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
+/* s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the instruction takes an immediate.  Waiting for FEWER operations than n to be
+ * outstanding is always safe (it waits longer), so this is a ladder of compares, not a switch: the compiler lowers a 25-way switch to a
+ * cascade of ~25 scalar instructions and ten branches per tile, while the counts that occur in the steady state of a launch are one or
+ * two values near the top (hi ladder: three staging buffers, transfers two or three steps ahead) or 0..3 (lo ladder: two buffers). */
+#define AB_W(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+__device__ __forceinline__ void wait_vmcnt_lo(int n) {
+    if (n <= 0) AB_W(0);
+    else if (n == 1) AB_W(1);
+    else if (n == 2) AB_W(2);
+    else if (n == 3) AB_W(3);
+    else if (n < 6) AB_W(4);
+    else if (n < 8) AB_W(6);
+    else if (n < 12) AB_W(8);
+    else AB_W(12);
 }
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    if (n >= 18) AB_W(18);
+    else if (n >= 16) AB_W(16);
+    else if (n >= 14) AB_W(14);
+    else if (n >= 12) AB_W(12);
+    else if (n >= 10) AB_W(10);
+    else if (n >= 8) AB_W(8);
+    else if (n >= 6) AB_W(6);
+    else wait_vmcnt_lo(n);
+}
+#undef AB_W
 
 template <int AL>
 __device__ __forceinline__ v4i lds_read16(const uint8_t* p) {
@@ -265,35 +281,45 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
         v4i a0, a1, a2, h0, h1, h2; /* h*: CS16 high-byte plane */
     };
     /* LDS -> MFMA for the 16 hops of tile (step buffer `buf`, sub-tile sb): leaves the integer digit sums in A */
-    auto tile_mfma = [&](const uint8_t* buf, int sb, TileAcc& A) {
+    /* u8 / s8: the lane's row of the staged stream, and the first four k-steps' A fragments -- split off so that the pipelined loop can
+     * issue them for tile t + 1 before it recombines and stores tile t */
+    auto a_row = [&](const uint8_t* buf, int sb) { return buf + delta + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 16 + piece * WIN_BYTES; };
+    auto a_head = [&](const uint8_t* arow, v4i* pre) {
+        pre[0] = lds_read16<AL>(arow);
+        pre[1] = lds_read16<AL>(arow + 64);
+        pre[2] = lds_read16<AL>(arow + 128);
+        pre[3] = lds_read16<AL>(arow + 192);
+    };
+    auto tile_body = [&](const uint8_t* arow, const v4i* pre, TileAcc& A) {
         A.a0 = (v4i){0, 0, 0, 0}; A.a1 = (v4i){0, 0, 0, 0}; A.a2 = (v4i){0, 0, 0, 0};
-        if (!S16) {
-            const uint8_t* arow = buf + delta + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 16 + piece * WIN_BYTES;
-            /* A fragments are fetched ahead of the MFMAs that consume them, so the LDS latency (and the 2-way bank conflict of the
-             * strided rows) hides behind six MFMAs instead of stalling in front of them */
-            /* A fragments are fetched four k-steps ahead of the MFMAs that consume them, so the LDS latency (and the 2-way bank conflict of
-             * the strided rows) hides behind a dozen MFMAs instead of stalling in front of them; a scheduling fence every two k-steps keeps
-             * that distance as the source spells it out */
-            v4i av[KSTEPS];
-            av[0] = lds_read16<AL>(arow);
-            av[1] = lds_read16<AL>(arow + 64);
-            av[2] = lds_read16<AL>(arow + 128);
-            av[3] = lds_read16<AL>(arow + 192);
+        /* A fragments are fetched four k-steps ahead of the MFMAs that consume them, so the LDS latency (and the 2-way bank conflict of
+         * the strided rows) hides behind a dozen MFMAs instead of stalling in front of them; a scheduling fence every two k-steps keeps
+         * that distance as the source spells it out */
+        v4i av[KSTEPS];
+        av[0] = pre[0]; av[1] = pre[1]; av[2] = pre[2]; av[3] = pre[3];
 #pragma unroll
-            for (int s = 0; s < KSTEPS; s++) {
-                if ((s & 1) == 0 && s + 4 < KSTEPS) {
-                    av[s + 4] = lds_read16<AL>(arow + (s + 4) * 64);
-                    av[s + 5] = lds_read16<AL>(arow + (s + 5) * 64);
-                }
-                v4i x = av[s];
-                x.x ^= flipmask; x.y ^= flipmask; x.z ^= flipmask; x.w ^= flipmask; /* u8 -> b - 128 as int8; s8 (mirisdr, SoapySDR CS8) is int8 already: the mask is zero */
-                A.a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b0[s], A.a0, 0, 0, 0);
-                A.a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b1[s], A.a1, 0, 0, 0);
-                if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) A.a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b2[s], A.a2, 0, 0, 0);
-                if (s & 1) __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < KSTEPS; s++) {
+            if ((s & 1) == 0 && s + 4 < KSTEPS) {
+                av[s + 4] = lds_read16<AL>(arow + (s + 4) * 64);
+                av[s + 5] = lds_read16<AL>(arow + (s + 5) * 64);
             }
+            v4i x = av[s];
+            x.x ^= flipmask; x.y ^= flipmask; x.z ^= flipmask; x.w ^= flipmask; /* u8 -> b - 128 as int8; s8 (mirisdr, SoapySDR CS8) is int8 already: the mask is zero */
+            A.a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b0[s], A.a0, 0, 0, 0);
+            A.a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b1[s], A.a1, 0, 0, 0);
+            if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) A.a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b2[s], A.a2, 0, 0, 0);
+            if (s & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto tile_mfma = [&](const uint8_t* buf, int sb, TileAcc& A) {
+        if (!S16) {
+            const uint8_t* arow = a_row(buf, sb);
+            v4i pre[4];
+            a_head(arow, pre);
+            tile_body(arow, pre, A);
         } else {
             /* CS16: plane k-step s of the lane = 16 plane bytes = 8 samples x (I, Q) = 32 raw bytes [Ilo Ihi Qlo Qhi] x 8 */
+            A.a0 = (v4i){0, 0, 0, 0}; A.a1 = (v4i){0, 0, 0, 0}; A.a2 = (v4i){0, 0, 0, 0};
             A.h0 = (v4i){0, 0, 0, 0}; A.h1 = (v4i){0, 0, 0, 0}; A.h2 = (v4i){0, 0, 0, 0};
             const uint8_t* arow = buf + delta + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 32 + piece * WIN_BYTES;
             v4i ra[2], rb[2]; /* raw 32 bytes of k-step s in (ra, rb)[s & 1]; the next k-step is fetched under this one's MFMAs */
@@ -340,39 +366,113 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
     /* the neighbour lane's value: a DPP move inside the quad (quad_perm [1, 0, 3, 2]), no LDS round trip */
     auto pair_swap = [&](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); };
     /* values of tile t -> rings.  Lane pairs (2ch, 2ch+1) hold (re, im) of the same hop; even lanes write 4 consecutive rows of their slot */
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    /* the lane's own part of a ring offset: tile t puts its rows at physical 16-row tile pt = (ptile0 + t) mod ring_tiles16, i.e. element
+     * slot_base + ab_tile_off(16 pt + 4 grp) = lane_off + pt * (16 / AB_TILE_ROWS) * AB_SLOT_BLOCK * AB_TILE_ROWS -- a scalar multiple per tile */
+    const bool store_lane = !(col & 1) && ch_valid;
+    const long lane_off = slot_base + ab_tile_off(grp * 4);
+    float* const mag_lane = a.mag + lane_off;
+    float2* const iq_lane = a.iq_bins + lane_off;
+    constexpr long TILE16_PITCH = (long)TILE_HOPS * AB_SLOT_BLOCK; /* elements between consecutive 16-row tiles of one slot block */
     auto tile_store = [&](int t, const float* val) {
         float im4[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) im4[r] = pair_swap(val[r]);
         const bool whole_tile = t * TILE_HOPS - shift >= 0 && t * TILE_HOPS - shift + TILE_HOPS <= a.n_hops; /* wave-uniform: all 16 hops of the tile are stored */
-        if (whole_tile) stores += k_tile;
-        if (!(col & 1) && ch_valid) {
-            int pt = ptile0 + t;
-            pt = pt >= ring_tiles16 ? pt - ring_tiles16 : pt;
+        int pt = ptile0 + t;
+        pt = pt >= ring_tiles16 ? pt - ring_tiles16 : pt;
+        if (__builtin_expect(whole_tile, 1)) {
+            /* the common case, straight-line: no per-hop tests, one scalar offset per tile, the raw I/Q pairs in two register quads so that
+             * they leave as two 16-byte stores (the compiler, left alone, split them into 16 + 8 + 8) */
+            stores += k_tile;
+            if (store_lane) {
+                const long toff = (long)pt * TILE16_PITCH;
+                if (want_mag) {
+                    v4f m;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) m[r] = __builtin_amdgcn_sqrtf(val[r] * val[r] + im4[r] * im4[r]); /* v_sqrt_f32, 1 ulp: stage 1 is tolerance-bound anyway */
+                    *reinterpret_cast<v4f*>(mag_lane + toff) = m;
+                }
+                if (want_iq) {
+                    v4f qa = {val[0], im4[0], val[1], im4[1]}, qb = {val[2], im4[2], val[3], im4[3]};
+                    asm volatile("" : "+v"(qa), "+v"(qb));
+                    v4f* q = reinterpret_cast<v4f*>(iq_lane + toff);
+                    q[0] = qa;
+                    q[1] = qb;
+                }
+            }
+            return;
+        }
+        if (store_lane) { /* first / last tile of a batch: hops outside [0, n_hops) are computed and dropped */
             const long off = slot_base + ab_tile_off(pt * TILE_HOPS + grp * 4); /* the lane's 4 hops never straddle a ring tile (4, 8 or 16 rows) */
             const int hop_first = t * TILE_HOPS - shift + grp * 4;
-            float m4[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) m4[r] = __builtin_amdgcn_sqrtf(val[r] * val[r] + im4[r] * im4[r]); /* v_sqrt_f32, 1 ulp: stage 1 is tolerance-bound anyway */
-            if (whole_tile || (hop_first >= 0 && hop_first + 3 < a.n_hops)) {
-                if (want_mag) *reinterpret_cast<float4*>(a.mag + off) = make_float4(m4[0], m4[1], m4[2], m4[3]);
-                if (want_iq) {
-                    float4* q = reinterpret_cast<float4*>(a.iq_bins + off);
-                    q[0] = make_float4(val[0], im4[0], val[1], im4[1]);
-                    q[1] = make_float4(val[2], im4[2], val[3], im4[3]);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int hop = hop_first + r;
-                    if (hop >= 0 && hop < a.n_hops) {
-                        if (want_mag) a.mag[off + r] = m4[r];
-                        if (want_iq) a.iq_bins[off + r] = make_float2(val[r], im4[r]);
-                    }
+            for (int r = 0; r < 4; r++) {
+                const int hop = hop_first + r;
+                if (hop >= 0 && hop < a.n_hops) {
+                    if (want_mag) a.mag[off + r] = __builtin_amdgcn_sqrtf(val[r] * val[r] + im4[r] * im4[r]);
+                    if (want_iq) a.iq_bins[off + r] = make_float2(val[r], im4[r]);
                 }
             }
         }
     };
+
+    /* ---- u8 / s8, one wave, three staging buffers, one tile per step (the 320-byte hop of BASELINE configs[2] and every other hop whose
+     * three buffers fit): software-pipelined across tiles.  Per tile: MFMAs of tile t (its first A fragments were fetched during tile
+     * t - 1) -> the buffer tile t read is free: the transfer of step t + 3 goes out (three steps in flight, was two) -> wait for step
+     * t + 1's bytes, issue tile t + 1's first A fragments -> recombine and store tile t while those LDS reads fly.  The wave no longer
+     * stalls on LDS latency at the top of every tile, nor on the matrix pipe's drain with nothing else to issue. */
+    if (NP == 1 && !S16 && nbuf == 3 && sub == 1) {
+        /* steps whose transfer lies wholly inside the batch span (no lane's address needs clamping), as a range worked out once: the per-step
+         * test is two scalar compares and the source address one multiply-add */
+        const int st_in_lo = shift > 0 ? 1 : 0;
+        const long in_room = span_end - (long)n_dma * 1024;
+        const int st_in_hi = __builtin_amdgcn_readfirstlane(in_room < 0 ? -1 : (int)((in_room / hop_bytes + shift) / TILE_HOPS)); /* (the same number on every lane: keep it scalar) */
+        const uint8_t* const p_lane = src - (long)shift * hop_bytes + lane * 16; /* step st starts at p_lane + st * 16 hops */
+        const int step_bytes = TILE_HOPS * hop_bytes;
+        auto stage_fast = [&](int step, uint8_t* buf) {
+            if (AL >= 16 && step >= st_in_lo && step <= st_in_hi) {
+                const uint8_t* p = p_lane + (unsigned long long)(unsigned)step * (unsigned)step_bytes;
+#define AB_PIECE(K, BASE, OFF) \
+    if (n_dma > (K)) __builtin_amdgcn_global_load_lds((gptr_t)(p + (BASE)), (lptr_t)(uintptr_t)(buf + (BASE)), 16, (OFF), 0)
+                AB_PIECE(0, 0, 0); AB_PIECE(1, 0, 1024); AB_PIECE(2, 0, 2048); AB_PIECE(3, 0, 3072);
+                AB_PIECE(4, 4096, 0); AB_PIECE(5, 4096, 1024); AB_PIECE(6, 4096, 2048); AB_PIECE(7, 4096, 3072);
+                AB_PIECE(8, 8192, 0); AB_PIECE(9, 8192, 1024); AB_PIECE(10, 8192, 2048); AB_PIECE(11, 8192, 3072);
+#undef AB_PIECE
+                return;
+            }
+            stage(step, buf);
+        };
+        const int nst = st_end - st_begin;
+        if (nst > 2) stage(st_begin + 2, lds + 2 * lds_per_buf);
+        wait_vmcnt((nst > 2 ? 2 : nst - 1) * n_dma);
+        v4i pre[4];
+        a_head(a_row(lds, 0), pre);
+        /* `stores` at the time the transfers of steps st + 1 and st + 2 were issued (the three transfers of the prologue: 0) */
+        int mark_a = 0, mark_b = 0;
+        int buf_off = 0; /* LDS offset of step st's buffer */
+        for (int st = st_begin; st < st_end; st++) {
+            uint8_t* buf = lds + buf_off;
+            TileAcc now;
+            tile_body(a_row(buf, 0), pre, now);
+            const bool more3 = st + 3 < st_end;
+            if (more3) stage_fast(st + 3, buf); /* every LDS read of this buffer has returned (the MFMAs consumed them): it takes the step three ahead */
+            const int mark_c = stores;
+            buf_off = buf_off + lds_per_buf == 3 * lds_per_buf ? 0 : buf_off + lds_per_buf;
+            if (st + 1 < st_end) {
+                /* younger than step st + 1's transfer: the pieces of steps st + 2 and st + 3, the stores since it was issued */
+                wait_vmcnt((st + 2 < st_end ? n_dma : 0) + (more3 ? n_dma : 0) + (stores - mark_a));
+                a_head(a_row(lds + buf_off, 0), pre);
+            }
+            mark_a = mark_b;
+            mark_b = mark_c;
+            float val[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) val[r] = tile_value(now, r);
+            tile_store(st, val);
+        }
+        return;
+    }
 
     for (int st = st_begin; st < st_end; st++) {
         uint8_t* buf = lds + cur * lds_per_buf;

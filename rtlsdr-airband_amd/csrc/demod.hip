@@ -93,14 +93,22 @@ struct WaveRow {
     bool coop;
 };
 
+/* AGC_EXTRA = 100 floats in rounds of five 16-byte pieces: all 25 pieces at once were 100 live registers in front of the sample loop --
+ * they set the kernels' register counts (back kernel 126 -> 96, AM kind 121 -> 108, NFM + lowpass 166 -> 157) and the back kernel staged
+ * them through scratch memory */
 __device__ __forceinline__ void wave_tail_copy(float* row, int B) {
     const float4* src = reinterpret_cast<const float4*>(row + B);
     float4* dst = reinterpret_cast<float4*>(row);
-    float4 t[AB_AGC_EXTRA / 4];
+    constexpr int CH = 5;
+    static_assert((AB_AGC_EXTRA / 4) % CH == 0, "whole rounds");
+#pragma unroll 1
+    for (int c = 0; c < AB_AGC_EXTRA / 4; c += CH) {
+        float4 t[CH];
 #pragma unroll
-    for (int q = 0; q < AB_AGC_EXTRA / 4; q++) t[q] = src[q];
+        for (int q = 0; q < CH; q++) t[q] = src[c + q];
 #pragma unroll
-    for (int q = 0; q < AB_AGC_EXTRA / 4; q++) dst[q] = t[q];
+        for (int q = 0; q < CH; q++) dst[c + q] = t[q];
+    }
 }
 
 __device__ __forceinline__ void wave_flush(const WaveRow& w, int n = RUN) { /* the finished run (n samples) -> row[j0 + AGC_EXTRA ...): 16-byte aligned by construction */
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(64, KIND == AB_KIND_AM ? AB_AM_WAVES : KIND == AB_K
  * v_readlane feeds the serial loop), the verdict leaves as a 50-bit mask per step.  Tiny register footprint -> 8 waves per
  * SIMD hide the dependent-issue latency of the recurrence. */
 template <bool PACKED>
-__global__ __launch_bounds__(256) void tone_kernel(DemodArgs a, int first_block, int n_blocks) {
+__global__ __launch_bounds__(256) void tone_kernel(DemodArgs a, int first_block, int n_blocks) { /* blocks [first_block, first_block + n_blocks) of the kind: any sub-range */
     __shared__ float power[4][64];
     /* the wave index is the same number on every lane: told so, the compiler keeps the channel's constants and counters in scalar
      * registers and fetches them with scalar loads */
@@ -606,9 +614,10 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a, int first_block,
     float q1s = t1 ? qtab[2 * AB_MAX_TONES + lane] : 0.0f, q2s = t1 ? qtab[3 * AB_MAX_TONES + lane] : 0.0f;
 
     const long blk = (wave >> 6) + (first_block - a.ct_first_block); /* verdict masks: one table over both split kinds */
-    /* this channel's batch, contiguous: 50 lanes fetch 400 (one-word hand-off: 200) consecutive bytes */
-    const float2* af = PACKED ? nullptr : a.ct_af + (long)wave * B;
-    const unsigned* ap = PACKED ? a.ct_ap + (long)wave * a.ct_pk_pitch : nullptr;
+    /* this channel's batch, contiguous: 50 lanes fetch 400 (one-word hand-off: 200) consecutive bytes; rows are counted from the kind's first block */
+    const long hrow = wave + (long)(first_block - (PACKED ? a.ct_pk_first_block : a.ct_gen_first_block)) * 64;
+    const float2* af = PACKED ? nullptr : a.ct_af + hrow * B;
+    const unsigned* ap = PACKED ? a.ct_ap + hrow * a.ct_pk_pitch : nullptr;
     unsigned long long* maskp = a.ct_mask + (blk * NG) * AB_SLOT_BLOCK + (wave & 63);
     /* The batch is walked DEPTH steps at a time: the (audio, flags) pairs of the next DEPTH steps are in flight while the current
      * DEPTH are worked through.  A channel whose squelch is closed does next to nothing per step, so with one step ahead its
@@ -774,8 +783,8 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a, int first_block) 
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
     /* every lane walks its own contiguous (channel-major) hand-off row, 8 samples = 4 x 16 bytes ahead: all bytes of the
      * lines it touches are its own, the re-use is served by L2 */
-    const float4* af = PACKED ? reinterpret_cast<const float4*>(a.ct_ap + (long)(slot - first_block * 64) * a.ct_pk_pitch)
-                              : reinterpret_cast<const float4*>(a.ct_af + (long)(slot - first_block * 64) * B);
+    const float4* af = PACKED ? reinterpret_cast<const float4*>(a.ct_ap + (long)(slot - a.ct_pk_first_block * 64) * a.ct_pk_pitch)
+                              : reinterpret_cast<const float4*>(a.ct_af + (long)(slot - a.ct_gen_first_block * 64) * B);
     const unsigned long long* maskp = a.ct_mask + ((long)(blockIdx.x + first_block - a.ct_first_block) * NG) * AB_SLOT_BLOCK + lane;
     const bool is_ct = (cc.flags & AB_F_CTCSS) != 0;
     constexpr int PIECE = 8; /* samples per fetch; WAVE_BATCH = 1000 / 2000 is a whole number of them */
@@ -863,7 +872,9 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
     const int fused[3] = {AB_KIND_NFM_LOWPASS, AB_KIND_NFM, AB_KIND_AM};
     if (fork) (void)hipEventRecord(ev[0], stream); /* stage 1 is done at this point of the caller's stream */
     /* the split chain (front -> tone -> back) is the longest dependent sequence of stage 2: it is enqueued first (and its stream has
-     * the higher priority), the fused kinds fill in beside it */
+     * the higher priority), the fused kinds fill in beside it.  (Round 3 also ran the chain as 2 and 4 independent chains over block
+     * ranges on streams of their own, so that one range's tone and back kernels would overlap the next range's front: 6.81 / 6.92 and
+     * 6.50 / 6.69 ms against 6.70 / 6.62 -- nothing, profiles/r03_experiments.md; the stage is bound by the sum of its work.) */
     launch_kind(AB_KIND_NFM_CTCSS, stream);
     launch_kind(AB_KIND_GENERIC, stream);
     if (a.ct_pk_n_blocks > 0) hipLaunchKernelGGL(tone_kernel<true>, dim3((a.ct_pk_n_blocks * 64 * 64 + 255) / 256), dim3(256), 0, stream, a, a.ct_pk_first_block, a.ct_pk_n_blocks);
