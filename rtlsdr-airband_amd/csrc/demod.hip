@@ -97,17 +97,14 @@ struct WaveRow {
  * they set the kernels' register counts (back kernel 126 -> 96, AM kind 121 -> 108, NFM + lowpass 166 -> 157) and the back kernel staged
  * them through scratch memory */
 __device__ __forceinline__ void wave_tail_copy(float* row, int B) {
-    const float4* src = reinterpret_cast<const float4*>(row + B);
-    float4* dst = reinterpret_cast<float4*>(row);
-    constexpr int CH = 5;
-    static_assert((AB_AGC_EXTRA / 4) % CH == 0, "whole rounds");
+    typedef float v4f __attribute__((ext_vector_type(4))); /* (plain vector values: an array of float4 here ends up as dead stores to scratch memory) */
+    const v4f* src = reinterpret_cast<const v4f*>(row + B);
+    v4f* dst = reinterpret_cast<v4f*>(row);
+    static_assert((AB_AGC_EXTRA / 4) % 5 == 0, "whole rounds");
 #pragma unroll 1
-    for (int c = 0; c < AB_AGC_EXTRA / 4; c += CH) {
-        float4 t[CH];
-#pragma unroll
-        for (int q = 0; q < CH; q++) t[q] = src[c + q];
-#pragma unroll
-        for (int q = 0; q < CH; q++) dst[c + q] = t[q];
+    for (int c = 0; c < AB_AGC_EXTRA / 4; c += 5) {
+        const v4f t0 = src[c], t1 = src[c + 1], t2 = src[c + 2], t3 = src[c + 3], t4 = src[c + 4];
+        dst[c] = t0; dst[c + 1] = t1; dst[c + 2] = t2; dst[c + 3] = t3; dst[c + 4] = t4;
     }
 }
 
@@ -474,6 +471,98 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         if (SPLIT_REST && AB_LIKELY(s.quiet)) rest(std::true_type{}, j, cur_mag, delayed_mag, re, im, went_closed); /* the sample that settles the last lane still reports who just closed */
         else rest(std::false_type{}, j, cur_mag, delayed_mag, re, im, went_closed);
     };
+    /* ---- four samples of a QUIET wavefront as ONE basic block (AM kind, NFM + CTCSS front) -------------------------------------------
+     * sq_raw_quiet4() (squelch_fsm.h) runs the four squelch steps on a copy of the state and commits it only if the wavefront stayed
+     * quiet throughout: then no lane changed state, audio is wanted by exactly the OPEN lanes for all four samples, and what is left is
+     * the OPEN lanes' per-sample float chain -- one exec-masked region for the four samples instead of three per sample, no scalar
+     * mask algebra between them.  Round 3 measured that nothing but the NUMBER of instructions moves stage 2 (profiles/r03_experiments.md):
+     * the per-sample version issues ~60 vector + ~60 scalar + ~15 branch instructions per AM sample, most of the scalar ones and all
+     * of the branches for events that do not happen in a quiet group. */
+    constexpr bool SPEC4 = KIND == AB_KIND_AM || KIND == AB_KIND_NFM_CTCSS;
+    const bool wave_has_notch = ab_any(ab_ballot((cc.flags & AB_F_NOTCH) != 0));
+    const bool wave_has_iq_out = ab_any(ab_ballot((cc.flags & AB_F_IQ_OUT) != 0));
+    auto quiet_tail4 = [&](const int jq, const float* mcs, const float* mds, const float* qr, const float* qi) {
+        const bool open = ab_lane(s.cO); /* Squelch::should_process_audio() == is_open() for the four samples */
+        if (KIND == AB_KIND_AM) {
+            float out4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (open) {
+                const float lvl = sq_level(s);
+#pragma unroll
+                for (int r = 0; r < 4; r++) { /* src/rtl_airband.cpp:553-563, then :589-603 */
+                    if (mcs[r] > lvl) agc = agc * 0.995f + mcs[r] * 0.005f;
+                    float out = (mds[r] - agc) / (agc * 1.5f);
+                    if (fabsf(out) > 0.8f) {
+                        out *= 0.85f;
+                        agc *= 1.15f;
+                    }
+                    if (wave_has_notch) { /* wave-uniform; the lanes without a notch filter keep their value */
+                        if (cc.flags & AB_F_NOTCH) {
+                            o.nx0 = o.nx1; o.nx1 = o.nx2; o.nx2 = out;
+                            o.ny0 = o.ny1; o.ny1 = o.ny2;
+                            o.ny2 = cc.notch_d0 * o.nx2 - cc.notch_d1 * o.nx1 + cc.notch_d0 * o.nx0 + cc.notch_d1 * o.ny1 - cc.notch_d2 * o.ny0;
+                            out = o.ny2;
+                        }
+                    }
+                    out *= cc.ampfactor;
+                    out4[r] = (out != out) ? 0.0f : __builtin_amdgcn_fmed3f(out, -1.0f, 1.0f);
+                }
+                o.axc = '*';
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) wrow.staged[(jq + r - wrow.j0) * wrow.stride] = out4[r];
+            if (AB_UNLIKELY(wave_has_iq_out)) { /* an AM-kind channel has no raw I/Q: its iq_out rows are zeros, open or not (emit_sample) */
+                if (cc.flags & AB_F_IQ_OUT)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) iqout[(long)(jq + r) * S] = make_float2(0.0f, 0.0f);
+            }
+            if (AB_UNLIKELY(trace != nullptr)) {
+                const uint8_t tb = open ? (uint8_t)(AB_ST_OPEN | 8 | 16) : (uint8_t)AB_ST_CLOSED;
+#pragma unroll
+                for (int r = 0; r < 4; r++) trace[(long)(jq + r) * S] = tb;
+            }
+        } else { /* NFM + CTCSS front: derotation, discriminator, de-emphasis -> one hand-off word per sample (see rest()) */
+            unsigned w4[4] = {HAND_IDLE, HAND_IDLE, HAND_IDLE, HAND_IDLE};
+            if (open) { /* OPEN lanes are exactly the lanes whose should_filter_sample() holds: a CLOSED lane with signal would have ended the quiet spell */
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float re0 = qr[r], im0 = qi[r];
+                    const unsigned idx = dm_phi >> 16; /* sincosf_lut (src/util.cpp:113-127) */
+                    const float fract = (float)(dm_phi & 0xffffu) / 65536.0f;
+                    const float2 e0 = lut[idx], e1 = lut[idx + 1];
+                    const float s0 = e0.x, s1 = e1.x, c0 = e0.y, c1 = e1.y;
+                    const float swf = s0 + (s1 - s0) * fract;
+                    const float cwf = c0 + (c1 - c0) * fract;
+                    const float nswf = -swf;
+                    const float re = re0 * cwf - im0 * nswf; /* multiply(real, imag, cwf, -swf) */
+                    const float im = im0 * cwf + re0 * nswf;
+                    dm_phi = (dm_phi + cc.dm_dphi) & 0xffffffu;
+                    float out;
+                    if (!(cc.flags & AB_F_QUADRI)) {
+                        const float nbj = -pj;
+                        const float cr = re * pr - im * nbj;
+                        const float cj = im * pr + re * nbj;
+                        out = (float)((double)fast_atan2_dev(cj, cr) * 0.31830988618379067154);
+                    } else {
+                        out = (float)((double)((pr * im - re * pj) / (re * re + im * im + 1.0f)) * 0.31830988618379067154);
+                    }
+                    pr = re;
+                    pj = im;
+                    agc = agc * 0.995f + out * 0.005f;
+                    out -= agc;
+                    out = out * one_minus_alpha + prev_out * cc.alpha;
+                    prev_out = out;
+                    w4[r] = (out != out) ? HAND_NAN : __float_as_uint(out);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) handw[((jq + r) & (HAND_RUN - 1)) * OSTRIDE] = w4[r];
+            if (AB_UNLIKELY(trace != nullptr)) {
+                const uint8_t tb = open ? (uint8_t)(AB_ST_OPEN | 16) : (uint8_t)AB_ST_CLOSED;
+#pragma unroll
+                for (int r = 0; r < 4; r++) trace[(long)(jq + r) * S] = tb;
+            }
+        }
+    };
     auto group = [&](const Group& q, int j0) {
 #pragma unroll
         for (int g = 0; g < GQ; g++) {
@@ -497,6 +586,12 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             }
             const int jq = j0 + 4 * g;
             if ((jq % RUN) == 0) wrow.j0 = jq;
+            if (SPEC4 && AB_LIKELY(s.quiet && aligned4)) { /* wave-uniform */
+                if (AB_LIKELY(sq_raw_quiet4(s, L, mcs))) {
+                    quiet_tail4(jq, mcs, mds, qr, qi);
+                    continue;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; r++) sample(jq + r, mcs[r], mds[r], qr[r], qi[r], r == 0);
         }
@@ -551,7 +646,7 @@ constexpr int TONE_GROUP = 50; /* samples per tone-kernel step; divides WAVE_BAT
  * the AM kernel does not pay for the lowpass registers.  Slot blocks of one kind are contiguous.
  * CTCSS-capable kinds are split in three: this "front" (squelch + discriminator -> audio, flags), the tone kernel
  * (Goertzel banks, one wavefront per channel) and the back kernel (gate, notch, output). */
-constexpr int AB_DEMOD_WAVES = 3, AB_AM_WAVES = 4, AB_FRONT_WAVES = 4;
+constexpr int AB_DEMOD_WAVES = 3, AB_AM_WAVES = 4, AB_FRONT_WAVES = 3; /* (the front at four waves: 128 VGPRs with 18 of them spilled once it carries the quiet-group path -- 6.30 ms of stage 2 against 6.20 at three) */
 template <int KIND, bool WAVE_HAS_CTCSS>
 __device__ __forceinline__ void demod_block(const DemodArgs& a, int block, float* lds_demod) {
     const int slot = block * 64 + threadIdx.x; /* padding slots carry flags == 0 */

@@ -21,7 +21,8 @@ unsigned char flags_of(const SqRegs& s) { /* same bit layout as the oracle's sq_
 
 extern "C" {
 
-// mode: 0 = no lowpass (head/tail moved once at the end, as the AM/NFM kinds do), 1 = lowpass with the delay line read from
+// mode: 3 = as 0, but aligned groups of four samples of a quiet "wavefront" go through sq_raw_quiet4() (what the AM kind and the CTCSS front do);
+// 0 = no lowpass (head/tail moved once at the end, as the AM/NFM kinds do), 1 = lowpass with the delay line read from
 // memory (generic kind), 2 = lowpass with the delay-line entry prefetched before the call (NFM+lowpass kind).
 // `chunk` splits the run into pieces with a store/load of ChanState in between (what happens between batches).
 // out_state: cur, next, delay, low_count, head, tail, using_post, sample_count; counts: open, flappy, recent_open, closed_count
@@ -57,7 +58,8 @@ int hostfsm_run(float snr_db, int manual_dbfs, int mode, int chunk, const float*
 
     std::vector<float> sqbuf(AB_SQ_BUF, 0.0f);
     Lane L;
-    L.m_lowpass = ab_ballot(mode != 0);
+    const bool lowpass = mode == 1 || mode == 2;
+    L.m_lowpass = ab_ballot(lowpass);
     L.m_manual = ab_ballot((cc.flags & AB_F_MANUAL) != 0);
     L.manual_level = cc.sq_manual_level;
     L.normal_ratio = cc.sq_normal_ratio;
@@ -66,8 +68,8 @@ int hostfsm_run(float snr_db, int manual_dbfs, int mode, int chunk, const float*
     L.sqbuf = sqbuf.data();
     L.S = 1;
     L.prefetched_delay = mode == 2;
-    L.track_delay_line = mode != 0;
-    L.may_post_filter = mode != 0;
+    L.track_delay_line = lowpass;
+    L.may_post_filter = lowpass;
     L.all_lowpass = false;
 
     if (chunk <= 0) chunk = n;
@@ -77,10 +79,20 @@ int hostfsm_run(float snr_db, int manual_dbfs, int mode, int chunk, const float*
         sq_load(s, L, &st, true);
         if (mode == 2) s.dly = sqbuf[s.tail];
         for (int i = i0; i < i0 + m; i++) {
+            if (mode == 3 && s.quiet && ((s.sample_count + 1u) & 3u) == 0u && i + 4 <= i0 + m && sq_raw_quiet4(s, L, raw + i)) {
+                /* a committed quiet group: lane masks, noise floor and level are those of all four samples */
+                for (int r = 0; r < 4; r++) {
+                    if (flags) flags[i + r] = flags_of(s);
+                    if (noise) noise[i + r] = s.noise_floor;
+                    if (level) level[i + r] = sq_level(s);
+                }
+                i += 3;
+                continue;
+            }
             float dly_new = 0.0f;
             if (mode == 2) dly_new = sqbuf[(s.tail + 1) % AB_SQ_BUF]; /* the entry the sample sees after its tail increment */
             sq_raw(s, L, raw[i], dly_new);
-            if (mode != 0) sq_filtered(s, L, sq_should_filter(s), filtered[i]);
+            if (lowpass) sq_filtered(s, L, sq_should_filter(s), filtered[i]);
             if (flags) flags[i] = flags_of(s);
             if (noise) noise[i] = s.noise_floor;
             if (level) level[i] = sq_level(s);

@@ -91,13 +91,13 @@ CASES = [(-1.0, 0), (6.0, 0), (-1.0, -70), (-1.0, -62)]
 
 @pytest.mark.parametrize("kind", ["keyed", "bursty", "flappy", "marginal"])
 @pytest.mark.parametrize("snr,manual", CASES)
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_fsm_matches_oracle(harness, kind, snr, manual, mode):
     L = pyoracle.lib()
     n = 60000
     seed = 1000 * ["keyed", "bursty", "flappy", "marginal"].index(kind) + 100 * mode + 10 * int(abs(snr)) + abs(manual)
     raw, filt = streams(seed, n, kind)
-    want = run_oracle(L, "orc", snr, manual, mode != 0, raw, filt)
+    want = run_oracle(L, "orc", snr, manual, mode in (1, 2), raw, filt)
     for chunk in (0, 1000, 37):
         got = run_host(harness, snr, manual, mode, chunk, raw, filt)
         assert np.array_equal(got[0], want[0]), "flags differ at %d" % int(np.argmax(got[0] != want[0]))
@@ -110,7 +110,7 @@ def test_fsm_matches_oracle(harness, kind, snr, manual, mode):
     assert int(got[3][4]) == n % 102 and int(got[3][5]) == (n + 1) % 102
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 3])
 def test_fsm_matches_reference(harness, mode):
     if not pyref.have_ref(False):
         pytest.skip("oracle/_ref not built (no /root/reference here)")
@@ -118,7 +118,7 @@ def test_fsm_matches_reference(harness, mode):
     n = 40000
     for kind in ("keyed", "flappy"):
         raw, filt = streams(7 + mode, n, kind)
-        want = run_oracle(R, "refh", -1.0, 0, mode != 0, raw, filt)
+        want = run_oracle(R, "refh", -1.0, 0, mode == 1, raw, filt)
         got = run_host(harness, -1.0, 0, mode, 1000, raw, filt)
         assert np.array_equal(got[0], want[0])
         assert np.array_equal(got[1], want[1])

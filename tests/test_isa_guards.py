@@ -37,17 +37,24 @@ def _function(lines, key):
 
 
 def _outer_loops(body):
-    """(header index, back-edge index) of every depth-1 loop: the label a later `s_branch` / `s_cbranch` jumps back to."""
-    labels = {}
-    for i, l in enumerate(body):
-        m = re.match(r"^(\.LBB\d+_\d+):.*Loop Header: Depth=1", l)
-        if m:
-            labels[m.group(1)] = i
+    """(first index, back-edge index) of every depth-1 loop: from its header -- or from its latch, when the compiler has rotated the loop so
+    that the latch block sits in FRONT of the header and falls through into it -- to the last branch that jumps back to either.  Blocks
+    placed behind that branch (the seldom-taken paths the source marks with __builtin_expect) belong to the loop but not to its hot part."""
     loops = []
-    for name, head in labels.items():
-        back = [i for i, l in enumerate(body) if i > head and re.match(r"^\s*s_c?branch\w*\s+" + re.escape(name) + r"\s*$", l)]
+    label_at = [i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)]
+    for n, i in enumerate(label_at):
+        m = re.match(r"^(\.L(BB\d+_\d+)):.*Loop Header: Depth=1", body[i])
+        if not m:
+            continue
+        targets, first = [m.group(1)], i
+        if n > 0 and re.search(r"in Loop: Header=" + m.group(2) + r"\b", body[label_at[n - 1]]):
+            prev = label_at[n - 1]
+            if not any(re.match(r"^\s*(s_branch|s_endpgm|s_setpc)", l) for l in body[prev:i][-1:]):  # falls through into the header: the latch
+                targets.append(body[prev].split(":")[0])
+                first = prev
+        back = [k for k, l in enumerate(body) if k > i and any(re.match(r"^\s*s_c?branch\w*\s+" + re.escape(t) + r"\s*$", l) for t in targets)]
         if back:
-            loops.append((head, max(back)))
+            loops.append((first, max(back)))
     return loops
 
 
