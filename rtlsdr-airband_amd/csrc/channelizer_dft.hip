@@ -27,8 +27,6 @@
  */
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
-
 #include "common.h"
 #include "kernels.h"
 
@@ -97,9 +95,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
     else if (n >= 14) AB_W(14);
     else if (n >= 12) AB_W(12);
     else if (n >= 10) AB_W(10);
-    else if (n >= 9) AB_W(9);
     else if (n >= 8) AB_W(8);
-    else if (n >= 7) AB_W(7);
     else if (n >= 6) AB_W(6);
     else wait_vmcnt_lo(n);
 }
@@ -294,8 +290,7 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
         pre[2] = lds_read16<AL>(arow + 128);
         pre[3] = lds_read16<AL>(arow + 192);
     };
-    auto tile_body = [&](auto flipped_tag, const uint8_t* arow, const v4i* pre, TileAcc& A) {
-        constexpr bool FLIPPED = decltype(flipped_tag)::value; /* the staged copy already holds b - 128 (flip pass of the pipelined loop) */
+    auto tile_body = [&](const uint8_t* arow, const v4i* pre, TileAcc& A) {
         A.a0 = (v4i){0, 0, 0, 0}; A.a1 = (v4i){0, 0, 0, 0}; A.a2 = (v4i){0, 0, 0, 0};
         /* A fragments are fetched four k-steps ahead of the MFMAs that consume them, so the LDS latency (and the 2-way bank conflict of
          * the strided rows) hides behind a dozen MFMAs instead of stalling in front of them; a scheduling fence every two k-steps keeps
@@ -309,7 +304,7 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
                 av[s + 5] = lds_read16<AL>(arow + (s + 5) * 64);
             }
             v4i x = av[s];
-            if (!FLIPPED) { x.x ^= flipmask; x.y ^= flipmask; x.z ^= flipmask; x.w ^= flipmask; } /* u8 -> b - 128 as int8; s8 (mirisdr, SoapySDR CS8) is int8 already: the mask is zero */
+            x.x ^= flipmask; x.y ^= flipmask; x.z ^= flipmask; x.w ^= flipmask; /* u8 -> b - 128 as int8; s8 (mirisdr, SoapySDR CS8) is int8 already: the mask is zero */
             A.a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b0[s], A.a0, 0, 0, 0);
             A.a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b1[s], A.a1, 0, 0, 0);
             if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) A.a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b2[s], A.a2, 0, 0, 0);
@@ -321,7 +316,7 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
             const uint8_t* arow = a_row(buf, sb);
             v4i pre[4];
             a_head(arow, pre);
-            tile_body(std::false_type{}, arow, pre, A);
+            tile_body(arow, pre, A);
         } else {
             /* CS16: plane k-step s of the lane = 16 plane bytes = 8 samples x (I, Q) = 32 raw bytes [Ilo Ihi Qlo Qhi] x 8 */
             A.a0 = (v4i){0, 0, 0, 0}; A.a1 = (v4i){0, 0, 0, 0}; A.a2 = (v4i){0, 0, 0, 0};
@@ -448,57 +443,29 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
             }
             stage(step, buf);
         };
-        /* u8 -> int8 (b - 128) ONCE per staged byte, in LDS: a landed step is read back 16 bytes per lane, flipped and written in place --
-         * n_dma x (ds_read_b128, 4 v_xor, ds_write_b128) per step.  The MFMA loop then feeds the fragments as they come: the flip used to
-         * sit between every ds_read and its MFMAs, 64 v_xor per tile, because every staged byte is read 1024 / hop = 3.2 times; now 24.
-         * (Round 2 tried the same with ds_xor_b64 read-modify-writes and found it slower; this is plain reads and writes.)  LDS operations
-         * of one wave complete in order, so the fragments read later see the flipped bytes without a wait of their own. */
-        auto flip = [&](uint8_t* buf) {
-            if (flipmask == 0) return; /* s8: nothing to do (wave-uniform) */
-            /* three pieces at a time: twelve live registers, whatever the hop size (n_dma is a run-time value in the generic variants) */
-            for (int i0 = 0; i0 < n_dma; i0 += 3) {
-                v4i t[3];
-                uint8_t* q = buf + i0 * 1024 + lane * 16;
-#pragma unroll
-                for (int i = 0; i < 3; i++)
-                    if (i0 + i < n_dma) t[i] = *reinterpret_cast<const v4i*>(q + i * 1024);
-#pragma unroll
-                for (int i = 0; i < 3; i++)
-                    if (i0 + i < n_dma) {
-                        t[i].x ^= flipmask; t[i].y ^= flipmask; t[i].z ^= flipmask; t[i].w ^= flipmask;
-                        *reinterpret_cast<v4i*>(q + i * 1024) = t[i];
-                    }
-            }
-        };
         const int nst = st_end - st_begin;
         if (nst > 2) stage(st_begin + 2, lds + 2 * lds_per_buf);
         wait_vmcnt((nst > 2 ? 2 : nst - 1) * n_dma);
-        flip(lds);
-        if (nst > 1) {
-            wait_vmcnt(nst > 2 ? n_dma : 0);
-            flip(lds + lds_per_buf);
-        }
         v4i pre[4];
         a_head(a_row(lds, 0), pre);
-        int mark_prev = 0; /* `stores` at the time the transfer of step st + 2 was issued (the three transfers of the prologue: 0) */
-        int buf_off = 0;   /* LDS offset of step st's buffer */
+        /* `stores` at the time the transfers of steps st + 1 and st + 2 were issued (the three transfers of the prologue: 0) */
+        int mark_a = 0, mark_b = 0;
+        int buf_off = 0; /* LDS offset of step st's buffer */
         for (int st = st_begin; st < st_end; st++) {
             uint8_t* buf = lds + buf_off;
             TileAcc now;
-            tile_body(std::true_type{}, a_row(buf, 0), pre, now);
+            tile_body(a_row(buf, 0), pre, now);
             const bool more3 = st + 3 < st_end;
             if (more3) stage_fast(st + 3, buf); /* every LDS read of this buffer has returned (the MFMAs consumed them): it takes the step three ahead */
-            const int mark_now = stores;
-            const int off1 = buf_off + lds_per_buf == 3 * lds_per_buf ? 0 : buf_off + lds_per_buf;
-            const int off2 = off1 + lds_per_buf == 3 * lds_per_buf ? 0 : off1 + lds_per_buf;
-            if (st + 2 < st_end) {
-                /* step st + 2 (issued one tile ago) has to have landed to be flipped; younger than its transfer: step st + 3's pieces, the stores since */
-                wait_vmcnt((more3 ? n_dma : 0) + (stores - mark_prev));
-                flip(lds + off2);
+            const int mark_c = stores;
+            buf_off = buf_off + lds_per_buf == 3 * lds_per_buf ? 0 : buf_off + lds_per_buf;
+            if (st + 1 < st_end) {
+                /* younger than step st + 1's transfer: the pieces of steps st + 2 and st + 3, the stores since it was issued */
+                wait_vmcnt((st + 2 < st_end ? n_dma : 0) + (more3 ? n_dma : 0) + (stores - mark_a));
+                a_head(a_row(lds + buf_off, 0), pre);
             }
-            if (st + 1 < st_end) a_head(a_row(lds + off1, 0), pre); /* flipped during the previous tile */
-            mark_prev = mark_now;
-            buf_off = off1;
+            mark_a = mark_b;
+            mark_b = mark_c;
             float val[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) val[r] = tile_value(now, r);
