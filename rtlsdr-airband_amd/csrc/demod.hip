@@ -471,10 +471,10 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         if (SPLIT_REST && AB_LIKELY(s.quiet)) rest(std::true_type{}, j, cur_mag, delayed_mag, re, im, went_closed); /* the sample that settles the last lane still reports who just closed */
         else rest(std::false_type{}, j, cur_mag, delayed_mag, re, im, went_closed);
     };
-    /* ---- four samples of a QUIET wavefront as ONE basic block (AM kind, NFM + CTCSS front) -------------------------------------------
-     * sq_raw_quiet4() (squelch_fsm.h) runs the four squelch steps on a copy of the state and commits it only if the wavefront stayed
-     * quiet throughout: then no lane changed state, audio is wanted by exactly the OPEN lanes for all four samples, and what is left is
-     * the OPEN lanes' per-sample float chain -- one exec-masked region for the four samples instead of three per sample, no scalar
+    /* ---- four samples of a STABLE wavefront as ONE basic block (AM kind, NFM + CTCSS front) ------------------------------------------
+     * sq_raw_stable4() (squelch_fsm.h) runs the four squelch steps on a copy of the state and commits it only if no lane asked for a
+     * transition: then no lane changed state, audio is wanted by the same lanes (OPEN and CLOSING) for all four samples, and what is left
+     * is those lanes' per-sample float chain -- one exec-masked region for the four samples instead of three per sample, no scalar
      * mask algebra between them.  Round 3 measured that nothing but the NUMBER of instructions moves stage 2 (profiles/r03_experiments.md):
      * the per-sample version issues ~60 vector + ~60 scalar + ~15 branch instructions per AM sample, most of the scalar ones and all
      * of the branches for events that do not happen in a quiet group. */
@@ -482,7 +482,10 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     const bool wave_has_notch = ab_any(ab_ballot((cc.flags & AB_F_NOTCH) != 0));
     const bool wave_has_iq_out = ab_any(ab_ballot((cc.flags & AB_F_IQ_OUT) != 0));
     auto quiet_tail4 = [&](const int jq, const float* mcs, const float* mds, const float* qr, const float* qi) {
-        const bool open = ab_lane(s.cO); /* Squelch::should_process_audio() == is_open() for the four samples */
+        const bool open = ab_lane(sq_should_audio(s)); /* Squelch::should_process_audio() == is_open() (no tone gate in these kinds), the same lanes for the four samples */
+        /* Squelch::should_filter_sample() for the four samples: a CLOSED lane with signal would have ended the stable spell, so it is every lane that is not CLOSED or aborting */
+        const bool filt = ab_lane(~s.cC & ~s.cA & s.active);
+        const int st_lane = trace ? sq_cur(s) : 0;
         if (KIND == AB_KIND_AM) {
             float out4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (open) {
@@ -516,13 +519,13 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                     for (int r = 0; r < 4; r++) iqout[(long)(jq + r) * S] = make_float2(0.0f, 0.0f);
             }
             if (AB_UNLIKELY(trace != nullptr)) {
-                const uint8_t tb = open ? (uint8_t)(AB_ST_OPEN | 8 | 16) : (uint8_t)AB_ST_CLOSED;
+                const uint8_t tb = (uint8_t)((st_lane & 7) | (open ? (8 | 16) : 0));
 #pragma unroll
                 for (int r = 0; r < 4; r++) trace[(long)(jq + r) * S] = tb;
             }
         } else { /* NFM + CTCSS front: derotation, discriminator, de-emphasis -> one hand-off word per sample (see rest()) */
             unsigned w4[4] = {HAND_IDLE, HAND_IDLE, HAND_IDLE, HAND_IDLE};
-            if (open) { /* OPEN lanes are exactly the lanes whose should_filter_sample() holds: a CLOSED lane with signal would have ended the quiet spell */
+            if (filt) { /* OPENING lanes derotate (their phase accumulator runs) without producing audio; OPEN and CLOSING lanes do both */
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const float re0 = qr[r], im0 = qi[r];
@@ -536,28 +539,30 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                     const float re = re0 * cwf - im0 * nswf; /* multiply(real, imag, cwf, -swf) */
                     const float im = im0 * cwf + re0 * nswf;
                     dm_phi = (dm_phi + cc.dm_dphi) & 0xffffffu;
-                    float out;
-                    if (!(cc.flags & AB_F_QUADRI)) {
-                        const float nbj = -pj;
-                        const float cr = re * pr - im * nbj;
-                        const float cj = im * pr + re * nbj;
-                        out = (float)((double)fast_atan2_dev(cj, cr) * 0.31830988618379067154);
-                    } else {
-                        out = (float)((double)((pr * im - re * pj) / (re * re + im * im + 1.0f)) * 0.31830988618379067154);
+                    if (open) {
+                        float out;
+                        if (!(cc.flags & AB_F_QUADRI)) {
+                            const float nbj = -pj;
+                            const float cr = re * pr - im * nbj;
+                            const float cj = im * pr + re * nbj;
+                            out = (float)((double)fast_atan2_dev(cj, cr) * 0.31830988618379067154);
+                        } else {
+                            out = (float)((double)((pr * im - re * pj) / (re * re + im * im + 1.0f)) * 0.31830988618379067154);
+                        }
+                        pr = re;
+                        pj = im;
+                        agc = agc * 0.995f + out * 0.005f;
+                        out -= agc;
+                        out = out * one_minus_alpha + prev_out * cc.alpha;
+                        prev_out = out;
+                        w4[r] = (out != out) ? HAND_NAN : __float_as_uint(out);
                     }
-                    pr = re;
-                    pj = im;
-                    agc = agc * 0.995f + out * 0.005f;
-                    out -= agc;
-                    out = out * one_minus_alpha + prev_out * cc.alpha;
-                    prev_out = out;
-                    w4[r] = (out != out) ? HAND_NAN : __float_as_uint(out);
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) handw[((jq + r) & (HAND_RUN - 1)) * OSTRIDE] = w4[r];
             if (AB_UNLIKELY(trace != nullptr)) {
-                const uint8_t tb = open ? (uint8_t)(AB_ST_OPEN | 16) : (uint8_t)AB_ST_CLOSED;
+                const uint8_t tb = (uint8_t)((st_lane & 7) | (open ? 16 : 0));
 #pragma unroll
                 for (int r = 0; r < 4; r++) trace[(long)(jq + r) * S] = tb;
             }
@@ -586,8 +591,8 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             }
             const int jq = j0 + 4 * g;
             if ((jq % RUN) == 0) wrow.j0 = jq;
-            if (SPEC4 && AB_LIKELY(s.quiet && aligned4)) { /* wave-uniform */
-                if (AB_LIKELY(sq_raw_quiet4(s, L, mcs))) {
+            if (SPEC4 && AB_LIKELY(aligned4 && sq_stable4(s))) { /* wave-uniform */
+                if (AB_LIKELY(sq_raw_stable4(s, L, mcs))) {
                     quiet_tail4(jq, mcs, mds, qr, qi);
                     continue;
                 }

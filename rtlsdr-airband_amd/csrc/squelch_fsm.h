@@ -252,33 +252,45 @@ AB_FSM_FN void sq_raw_quiet(SqRegs& s, const Lane& L, float x, float dly_new, bo
     s.quiet = !ab_any((any_req | sq_saturated(s)) & s.active);
 }
 
-/* FOUR samples of a QUIET wavefront at once (kinds without a post-filter path whose delay-line cursors move once per batch: AM, NFM,
- * the NFM + CTCSS front).  While the wavefront stays quiet, its lane masks do not change at all -- every lane is CLOSED or OPEN and stays
- * so -- and what the four process_raw_sample() calls do is a straight run of vector arithmetic: the two moving averages, the low-signal
- * run length, the CLOSED lanes' closed-sample count (saturating at 1000, so four samples are one add and one min), and the noise floor on
- * a 16th sample, which the caller's alignment puts on the first of the four.  The only thing asked of the scalar unit per sample is to
- * collect the lanes that would END the quiet spell: a request (OPEN without signal, CLOSED with signal, the low-signal abort) or a CLOSED
- * lane that is due to forget its recent opens.  The samples are worked on a COPY of the state; if no lane ended the spell the copy is the
- * state after four reference calls, bit for bit, and is committed (returns true).  Otherwise nothing is committed (returns false) and
- * the caller runs the four samples one at a time through sq_raw(), as before -- the first of them still quiet, the one after the request
- * not.  One scalar branch per four samples instead of several per sample, and a basic block long enough to be scheduled.
- * Precondition: s.quiet, (s.sample_count + 1) % 4 == 0, !L.may_post_filter, !L.track_delay_line. */
-AB_FSM_FN bool sq_raw_quiet4(SqRegs& s, const Lane& L, const float* x) {
+/* FOUR samples of a STABLE wavefront at once (kinds without a post-filter path whose delay-line cursors move once per batch: AM, NFM,
+ * the NFM + CTCSS front).  Stable = no lane is entering a state (next_state_ == current_state_ everywhere), no timer of an OPENING /
+ * CLOSING / LOW_SIGNAL_ABORT lane runs out within the four samples, no CLOSED lane is due to forget its recent opens.  That is the quiet
+ * case (everything CLOSED or OPEN) plus the ~200-sample waits of the timed states -- at WAVE_RATE 8000 a third of a batch.  While the
+ * wavefront stays stable its lane masks do not change at all, and what the four process_raw_sample() calls do is a straight run of
+ * vector arithmetic: the two moving averages, the low-signal run length, the timers (+4), the CLOSED lanes' closed-sample count
+ * (saturating at 1000, so four samples are one add and one min), and the noise floor on a 16th sample, which the caller's alignment puts
+ * on the first of the four.  The only thing asked of the scalar unit per sample is to collect the lanes that END the stable spell: a
+ * request (OPEN without signal, CLOSED with signal, the low-signal abort of OPENING / CLOSING / OPEN).  The samples are worked on a COPY of
+ * the state; if no lane ended the spell the copy is the state after four reference calls, bit for bit, and is committed (returns true).
+ * Otherwise nothing is committed (returns false) and the caller runs the four samples one at a time through sq_raw(), as before.  One
+ * scalar branch per four samples instead of several per sample, and a basic block long enough to be scheduled.
+ * Precondition: sq_stable4(s), (s.sample_count + 1) % 4 == 0, !L.may_post_filter, !L.track_delay_line. */
+AB_FSM_FN bool sq_stable4(const SqRegs& s) {
+    const lmask moving = (s.nC ^ s.cC) | (s.nOg ^ s.cOg) | (s.nCg ^ s.cCg) | (s.nA ^ s.cA) | (s.nO ^ s.cO);
+    const lmask timed = s.cOg | s.cCg | s.cA;
+    const lmask expiring = timed & ab_ballot(s.delay > 197 - 1 - 4); /* the timer is tested after its increment (:381, :400, :415): delay + 4 must stay below 197 */
+    return !ab_any((moving | expiring | sq_saturated(s)) & s.active);
+}
+AB_FSM_FN bool sq_raw_stable4(SqRegs& s, const Lane& L, const float* x) {
     SqRegs t = s;
     const unsigned cc4 = t.closed_count + (ab_lane(t.cC) ? 4u : 0u);
     t.closed_count = cc4 < 1000u ? cc4 : 1000u;
+    t.delay += ab_lane(t.cOg | t.cCg | t.cA) ? 4 : 0;
     t.sample_count += 1u;
     if (AB_UNLIKELY((t.sample_count & 15u) == 0u)) sq_noise_floor(t, L);
     t.sample_count += 3u;
+    const lmask counting = t.cOg | t.cCg | t.cO; /* the lanes whose low-signal run length is kept (:233-245) */
+    const lmask want = t.cO;                     /* OPEN lanes ask for CLOSING without the signal, CLOSED lanes for OPENING with it; the timed states ask for nothing */
+    const lmask care = t.cO | t.cC;
     lmask bad = 0;
     for (int r = 0; r < 4; r++) {
         sq_avg(t.cap, t.pre_full, t.pre_capped, x[r]);
         const lmask sig = ab_ballot(t.pre_capped >= t.lvl);
-        const lmask low = t.cO & ab_ballot(!(x[r] >= t.lvl));
+        const lmask low = counting & ab_ballot(!(x[r] >= t.lvl));
         const int run = t.low_count + 1;
-        const int idle = ab_lane(t.cO) ? 0 : t.low_count;
+        const int idle = ab_lane(counting) ? 0 : t.low_count;
         t.low_count = ab_lane(low) ? run : idle;
-        bad |= (sig ^ t.cO) | (low & ab_ballot(t.low_count >= 88)); /* OPEN lanes want the signal, CLOSED lanes its absence; low_signal_abort_ */
+        bad |= ((sig ^ want) & care) | (low & ab_ballot(t.low_count >= 88)); /* low_signal_abort_ */
     }
     bad |= t.cC & ~ab_ballot(t.closed_count < 1000u) & t.recent_nz; /* sq_saturated(): the count is monotonic, so the end of the group tells */
     if (AB_UNLIKELY(ab_any(bad & t.active))) return false;

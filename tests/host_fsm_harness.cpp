@@ -21,7 +21,8 @@ unsigned char flags_of(const SqRegs& s) { /* same bit layout as the oracle's sq_
 
 extern "C" {
 
-// mode: 3 = as 0, but aligned groups of four samples of a quiet "wavefront" go through sq_raw_quiet4() (what the AM kind and the CTCSS front do);
+// mode: 3 = as 0, but aligned groups of four samples of a stable "wavefront" go through sq_raw_stable4() (what the AM kind and the CTCSS front do;
+// counts[4] = groups committed that way);
 // 0 = no lowpass (head/tail moved once at the end, as the AM/NFM kinds do), 1 = lowpass with the delay line read from
 // memory (generic kind), 2 = lowpass with the delay-line entry prefetched before the call (NFM+lowpass kind).
 // `chunk` splits the run into pieces with a store/load of ChanState in between (what happens between batches).
@@ -72,6 +73,7 @@ int hostfsm_run(float snr_db, int manual_dbfs, int mode, int chunk, const float*
     L.may_post_filter = lowpass;
     L.all_lowpass = false;
 
+    uint64_t groups_committed = 0, *groups = &groups_committed;
     if (chunk <= 0) chunk = n;
     for (int i0 = 0; i0 < n; i0 += chunk) {
         const int m = n - i0 < chunk ? n - i0 : chunk;
@@ -79,8 +81,9 @@ int hostfsm_run(float snr_db, int manual_dbfs, int mode, int chunk, const float*
         sq_load(s, L, &st, true);
         if (mode == 2) s.dly = sqbuf[s.tail];
         for (int i = i0; i < i0 + m; i++) {
-            if (mode == 3 && s.quiet && ((s.sample_count + 1u) & 3u) == 0u && i + 4 <= i0 + m && sq_raw_quiet4(s, L, raw + i)) {
-                /* a committed quiet group: lane masks, noise floor and level are those of all four samples */
+            if (mode == 3 && ((s.sample_count + 1u) & 3u) == 0u && i + 4 <= i0 + m && sq_stable4(s) && sq_raw_stable4(s, L, raw + i)) {
+                /* a committed stable group: lane masks, noise floor and level are those of all four samples */
+                ++*groups;
                 for (int r = 0; r < 4; r++) {
                     if (flags) flags[i + r] = flags_of(s);
                     if (noise) noise[i + r] = s.noise_floor;
@@ -101,7 +104,7 @@ int hostfsm_run(float snr_db, int manual_dbfs, int mode, int chunk, const float*
     }
     out_state[0] = st.cur; out_state[1] = st.next; out_state[2] = st.delay; out_state[3] = st.low_count; out_state[4] = st.head; out_state[5] = st.tail;
     out_state[6] = st.using_post; out_state[7] = st.sample_count;
-    counts[0] = st.open_count; counts[1] = st.flappy_count; counts[2] = st.recent_open; counts[3] = st.closed_count;
+    counts[0] = st.open_count; counts[1] = st.flappy_count; counts[2] = st.recent_open; counts[3] = st.closed_count; counts[4] = groups_committed;
     return 0;
 }
 }

@@ -62,7 +62,7 @@ def run_host(lib, snr, manual, mode, chunk, raw, filt):
     noise = np.zeros(n, np.float32)
     level = np.zeros(n, np.float32)
     st = np.zeros(8, np.int64)
-    cnt = np.zeros(4, np.uint64)
+    cnt = np.zeros(5, np.uint64)
     rc = lib.hostfsm_run(snr, manual, mode, chunk, raw.ctypes.data, filt.ctypes.data, n, flags.ctypes.data, noise.ctypes.data, level.ctypes.data, st.ctypes.data,
                          cnt.ctypes.data)
     assert rc == 0
@@ -106,6 +106,8 @@ def test_fsm_matches_oracle(harness, kind, snr, manual, mode):
         assert got[4][0] == want[3][0] and got[4][1] == want[3][1]
     if kind != "marginal":
         assert want[0].max() > 0  # the squelch did open
+    if mode == 3 and kind == "keyed":  # the group path is the common one, also through the timed states: (almost) everything but the transitions themselves
+        assert int(run_host(harness, snr, manual, mode, 0, raw, filt)[4][4]) > 0.9 * (n // 4)
     # head/tail bookkeeping: every sample advances both by one (mod 102)
     assert int(got[3][4]) == n % 102 and int(got[3][5]) == (n + 1) % 102
 
