@@ -14,9 +14,9 @@
  * LUT is restored with a per-column constant.  Result = the exact DFT with coefficients rounded at 2^-24 of full
  * scale -- the same class of error as a float FFT (~1e-7 relative), no accumulation round-off at all.
  *
- * u8 and CS16 take this path (s8's LUT has an uninitialised entry, f32 is not bytes), at fft_size 256 or 512; dongles with
- * more than 8 channels are processed in groups of 8 (one wavefront per group); everything else -- other FFT sizes, odd hop
- * sizes -- uses channelizer_fft.hip.
+ * u8, s8 and CS16 take this path (f32 is not bytes), at fft_size 256 ... 8192 (windows longer than 512 samples as pieces of 512 on cooperating
+ * waves); dongles with more than 8 channels are processed in groups of 8 (one wavefront per group); f32 samples and odd hop sizes use
+ * channelizer_fft.hip.
  *
  * Mapping (wave64, CDNA4): one wavefront owns one dongle and a range of 16-hop tiles.
  *   A (16 hops x 64 bytes per MFMA): lane l reads the 16 consecutive stream bytes at hop (l&15), k-chunk (l>>4)
