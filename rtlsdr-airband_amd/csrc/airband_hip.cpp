@@ -265,7 +265,7 @@ hipEvent_t* event_set(airband_hip_handle* h, uint64_t batch, int half) {
     return h->evp[i];
 }
 
-void launch_retune_tables(airband_hip_handle* h, hipStream_t s) {
+void launch_retune_tables(airband_hip_handle* h, hipStream_t s, int epoch) {
     RetuneArgs ra;
     ra.cc = h->d_cc.p;
     ra.cs = h->d_cs.p;
@@ -281,6 +281,8 @@ void launch_retune_tables(airband_hip_handle* h, hipStream_t s) {
     ra.n_items = (int)h->plan.item_dev.size();
     ra.fft_size = h->plan.fft_size;
     ra.n_shared = h->plan.n_shared_bsets;
+    ra.moved_epoch = h->d_bset_bin.p + (size_t)h->plan.n_bsets * 8; /* one more int behind the table */
+    ra.epoch = epoch;
     launch_retune(ra, s);
 }
 
@@ -354,8 +356,9 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
     if (h->any_afc && h->afc_spectrum_valid) { /* afc.finalize(), src/rtl_airband.cpp:626-630: may turn '*' into '<' / '>' */
         if (h->use_dft) launch_last_hop_spectrum(h, s);
-        launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, s);
-        if (h->use_dft) launch_retune_tables(h, s); /* the next batch's stage 1 reads the moved channels' new columns */
+        const int epoch = (int)(h->batches_done % 0x7fffffff) + 1; /* never 0: that is the start-up build's */
+        launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, h->use_dft ? h->d_bset_bin.p + (size_t)h->plan.n_bsets * 8 : nullptr, epoch, s);
+        if (h->use_dft) launch_retune_tables(h, s, epoch); /* the next batch's stage 1 reads the moved channels' new columns */
         launch_axc(h->d_cc.p, h->d_cs.p, h->d_slot_to_ext.p, h->d_out_axc.p, h->n_slots, s);
     }
     (void)hipEventRecord(ev[3], s);
@@ -638,9 +641,13 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
             PREP_TRY(hipMemset(h->d_bcorr.p, 0, h->d_bcorr.n * sizeof(double)), AIRBAND_HIP_ENOMEM);
             if (!p.bfrag.empty()) PREP_TRY(hipMemcpy(h->d_bfrag.p, p.bfrag.data(), p.bfrag.size(), hipMemcpyHostToDevice), AIRBAND_HIP_ENOMEM);
             if (!p.bcorr.empty()) PREP_TRY(hipMemcpy(h->d_bcorr.p, p.bcorr.data(), p.bcorr.size() * sizeof(double), hipMemcpyHostToDevice), AIRBAND_HIP_ENOMEM);
-            PREP_TRY(upload(h->d_bset_bin, p.bset_bins), AIRBAND_HIP_ENOMEM);
+            {
+                std::vector<int> with_epoch(p.bset_bins);
+                with_epoch.push_back(0); /* the "last moved in batch" stamp: 0 = the start-up build below */
+                PREP_TRY(upload(h->d_bset_bin, with_epoch), AIRBAND_HIP_ENOMEM);
+            }
             if (p.n_bsets > p.n_shared_bsets) {
-                launch_retune_tables(h, h->stream);
+                launch_retune_tables(h, h->stream, 0);
                 PREP_TRY(hipStreamSynchronize(h->stream), AIRBAND_HIP_ENODEV);
             }
             if (p.fft_size > 4096) /* [work items][tiles][64 lanes] float4 */

@@ -148,7 +148,7 @@ void launch_axc(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext
 void launch_mix(const MixArgs& a, hipStream_t stream);
 void launch_stats(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, int n_slots, airband_hip_channel_stats* out, hipStream_t stream);
 void launch_siggen(const SiggenArgs& a, hipStream_t stream);
-void launch_afc(const ChanConst* cc, ChanState* cs, const float* spectrum, int fft_size, int n_slots, hipStream_t stream);
+void launch_afc(const ChanConst* cc, ChanState* cs, const float* spectrum, int fft_size, int n_slots, int* moved_epoch, int epoch, hipStream_t stream);
 /* matrix-core channelizer + AFC: (re)builds, in place, the coefficient columns of every channel whose table is not built for the bin the channel
  * is tuned to now -- all columns of a private table at start-up (bset_bin = -1), the two columns of a channel AFC has just moved afterwards */
 struct RetuneArgs {
@@ -164,6 +164,8 @@ struct RetuneArgs {
     double* corr;
     const float* window;    /* fft_size */
     int n_items, fft_size, n_shared;
+    const int* moved_epoch; /* the batch number afc_kernel stamped when it last moved a channel; the kernel works only if it equals `epoch` (start-up build: both 0) */
+    int epoch;
 };
 void launch_retune(const RetuneArgs& a, hipStream_t stream);
 /* scatter channel-major host-provided bins into the time-major rings (airband_hip_process_bins) */

@@ -185,7 +185,7 @@ __device__ int afc_walk(const float2* fft, int fft_size, int base, float base_va
     return bin;
 }
 
-__global__ void afc_kernel(const ChanConst* cc, ChanState* cs, const float2* spectrum, int fft_size, int n_slots) {
+__global__ void afc_kernel(const ChanConst* cc, ChanState* cs, const float2* spectrum, int fft_size, int n_slots, int* moved_epoch, int epoch) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots) return;
     const ChanConst c = cc[slot];
@@ -201,16 +201,18 @@ __global__ void afc_kernel(const ChanConst* cc, ChanState* cs, const float2* spe
         if (bin == base) bin = afc_walk(fft, fft_size, base, base_value, c.afc, 1);
         if (s->bin != bin) {
             s->bin = bin;
+            if (moved_epoch) *moved_epoch = epoch; /* some channel moved in this batch: the re-tune kernel has work (every writer stores the same number) */
             if (bin > base) s->axc = '<';      /* AFC_UP   (enum status, src/rtl_airband.h:99) */
             else if (bin < base) s->axc = '>'; /* AFC_DOWN */
         }
     } else if (axc == ' ' && prev != ' ') {
+        if (s->bin != c.base_bin && moved_epoch) *moved_epoch = epoch;
         s->bin = c.base_bin;
     }
 }
 
-void launch_afc(const ChanConst* cc, ChanState* cs, const float* spectrum, int fft_size, int n_slots, hipStream_t stream) {
-    hipLaunchKernelGGL(afc_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, cc, cs, reinterpret_cast<const float2*>(spectrum), fft_size, n_slots);
+void launch_afc(const ChanConst* cc, ChanState* cs, const float* spectrum, int fft_size, int n_slots, int* moved_epoch, int epoch, hipStream_t stream) {
+    hipLaunchKernelGGL(afc_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, cc, cs, reinterpret_cast<const float2*>(spectrum), fft_size, n_slots, moved_epoch, epoch);
 }
 
 /* ---- AFC on the matrix-core channelizer: coefficient columns follow the bins ---------------------------------------------------
@@ -221,6 +223,9 @@ void launch_afc(const ChanConst* cc, ChanState* cs, const float* spectrum, int f
  * layout -- plus the column's offset correction.  At start-up every column of a private table differs (-1): the kernel is the builder. */
 __global__ __launch_bounds__(256) void retune_kernel(RetuneArgs a) {
     __shared__ long long sums[2];
+    /* no channel of the handle moved in this batch (afc_kernel would have stamped the batch's number): nothing to compare, let alone rebuild --
+     * the common case, and 65 536 workgroups comparing eight bins each were 0.3 - 0.6 ms of it */
+    if (*a.moved_epoch != a.epoch) return;
     const int item = blockIdx.x;
     const int bset = a.item_bset[item];
     if (bset < a.n_shared) return; /* shared table: its channels never move */

@@ -112,3 +112,23 @@ def test_tone_kernel_keeps_its_scalars_in_registers(demod_asm):
         assert int(m.group(1)) == 0, "%s spills %s scalar registers" % (name, m.group(1))
     body = _function(demod_asm, "tone_kernel")
     assert not any(re.search(r"scratch_(load|store)|buffer_(load|store).*offen", l) for l in body), "tone_kernel uses scratch memory"
+
+
+@pytest.mark.parametrize("kernel", ["demod_kernelILi0ELb0E", "demod_kernelILi3ELb1E"], ids=["am", "ctcss_front"])
+def test_stable_group_is_one_block_of_four_samples(demod_asm, kernel):
+    """Round 3: four samples of a stable wavefront run as one basic block (squelch_fsm.h sq_raw_stable4, demod.hip quiet_tail4).  What makes it pay is
+    its shape: the four squelch steps sit in ONE basic block, no branch between them (the per-sample path has several per sample).  A squelch step
+    has three `not >=` float compares (sample against cap and level, average against cap): twelve of them in one block is the group."""
+    body = _function(demod_asm, kernel)
+    blocks, cur = [], []
+    for l in body:  # basic blocks: cut at labels and after branches
+        if re.match(r"^\.LBB", l) and cur:
+            blocks.append(cur)
+            cur = []
+        cur.append(l)
+        if re.match(r"^\s*s_(c?branch|endpgm|setpc)", l):
+            blocks.append(cur)
+            cur = []
+    blocks.append(cur)
+    most = max(sum(1 for l in b if "v_cmp_nge_f32" in l) for b in blocks)
+    assert most >= 12, "no basic block holds four squelch steps (%d `not >=` compares in the fullest one)" % most
