@@ -56,6 +56,7 @@ struct airband_hip_handle {
     hipStream_t front = nullptr;
     hipEvent_t ev_in = nullptr, ev_back = nullptr, ev_wait = nullptr, front_done[2] = {nullptr, nullptr};
     hipStream_t last_stream = nullptr; /* stream the last sequential batch ran on (the caller's or ours) */
+    hipEvent_t ev_spec[2] = {nullptr, nullptr}; /* AFC on the matrix-core channelizer: the last hop's spectrum runs on a side stream beside stage 1 (fork, done) */
     hipEvent_t ev_last = nullptr;      /* recorded behind every batch that ran on a CALLER's stream: collect / read_* / synchronize / release
                                           order themselves behind it (the caller's stream itself may be gone by then, our event is not) */
     bool ev_last_pending = false;
@@ -105,7 +106,7 @@ struct airband_hip_handle {
     int ct_stride = 0;
     /* matrix-core channelizer */
     bool use_dft = false;
-    DevBuf<int> d_item_dev, d_item_group, d_item_bset;
+    DevBuf<int> d_item_dev, d_item_group, d_item_bset, d_item_private, d_item_home; /* d_item_bset: what stage 1 reads (the re-tune kernel switches AFC groups between their home and private tables) */
     DevBuf<int8_t> d_bfrag;
     DevBuf<double> d_bcorr;
     DevBuf<float> d_dft_partial; /* fft_size 8192: partial sums between the two passes of eight window pieces */
@@ -190,7 +191,7 @@ void destroy(airband_hip_handle* h) {
     h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release(); h->d_ct_af.release(); h->d_ct_mask.release();
     h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
     h->d_tmp_wavein.release(); h->d_tmp_iqin.release(); h->d_tmp_trace.release(); h->d_spectrum.release();
-    h->d_item_dev.release(); h->d_item_group.release(); h->d_item_bset.release(); h->d_bfrag.release(); h->d_bcorr.release(); h->d_dft_partial.release(); h->d_bset_bin.release();
+    h->d_item_dev.release(); h->d_item_group.release(); h->d_item_bset.release(); h->d_item_private.release(); h->d_item_home.release(); h->d_bfrag.release(); h->d_bcorr.release(); h->d_dft_partial.release(); h->d_bset_bin.release();
     if (h->h2d) (void)hipStreamSynchronize(h->h2d);
     h->d_stage2[0].release(); h->d_stage2[1].release();
     if (h->h_ring.load()) (void)hipHostFree(h->h_ring.load());
@@ -211,6 +212,8 @@ void destroy(airband_hip_handle* h) {
     if (h->ev_back) (void)hipEventDestroy(h->ev_back);
     if (h->ev_wait) (void)hipEventDestroy(h->ev_wait);
     if (h->ev_last) (void)hipEventDestroy(h->ev_last);
+    for (auto& e : h->ev_spec)
+        if (e) (void)hipEventDestroy(e);
     for (auto& e : h->front_done)
         if (e) (void)hipEventDestroy(e);
     if (h->front) (void)hipStreamDestroy(h->front);
@@ -274,6 +277,8 @@ void launch_retune_tables(airband_hip_handle* h, hipStream_t s, int epoch) {
     ra.item_dev = h->d_item_dev.p;
     ra.item_group = h->d_item_group.p;
     ra.item_bset = h->d_item_bset.p;
+    ra.item_private = h->d_item_private.p;
+    ra.item_home = h->d_item_home.p;
     ra.bset_bin = h->d_bset_bin.p;
     ra.bfrag = h->d_bfrag.p;
     ra.corr = h->d_bcorr.p;
@@ -355,7 +360,7 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.ring_rows = h->R;
     launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
     if (h->any_afc && h->afc_spectrum_valid) { /* afc.finalize(), src/rtl_airband.cpp:626-630: may turn '*' into '<' / '>' */
-        if (h->use_dft) launch_last_hop_spectrum(h, s);
+        if (h->use_dft) (void)hipStreamWaitEvent(s, h->ev_spec[1], 0); /* the last hop's spectrum, computed beside stage 1 */
         const int epoch = (int)(h->batches_done % 0x7fffffff) + 1; /* never 0: that is the start-up build's */
         launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, h->use_dft ? h->d_bset_bin.p + (size_t)h->plan.n_bsets * 8 : nullptr, epoch, s);
         if (h->use_dft) launch_retune_tables(h, s, epoch); /* the next batch's stage 1 reads the moved channels' new columns */
@@ -630,7 +635,9 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
         } else {
             PREP_TRY(upload(h->d_item_dev, p.item_dev), AIRBAND_HIP_ENOMEM);
             PREP_TRY(upload(h->d_item_group, p.item_group), AIRBAND_HIP_ENOMEM);
-            PREP_TRY(upload(h->d_item_bset, p.item_bset), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(upload(h->d_item_bset, p.item_home), AIRBAND_HIP_ENOMEM); /* every channel starts on its base bin */
+            PREP_TRY(upload(h->d_item_private, p.item_bset), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(upload(h->d_item_home, p.item_home), AIRBAND_HIP_ENOMEM);
             /* the host has built the shared tables; the private ones (groups with an AFC channel) follow them, zeroed, and are built by the
              * re-tune kernel right here: every column of theirs still stands at bin -1 */
             const int np_t = p.fft_size > 512 ? p.fft_size / 512 : 1;
@@ -846,13 +853,24 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         if (splits > steps / 4) splits = steps / 4;
         if (splits < 1) splits = 1;
         a.splits = splits;
-        (void)hipEventRecord(ev[0], s);
-        launch_channelizer_dft(a, s);
-        (void)hipEventRecord(ev[1], s);
         h->last_iq = d_iq;
         h->last_iq_stride = stride_bytes;
         h->last_n_hops = a.n_hops;
-        h->afc_spectrum_valid = h->any_afc; /* computed behind stage 2, from the same input (run_back_half) */
+        h->afc_spectrum_valid = h->any_afc;
+        if (h->any_afc) {
+            /* AFC::finalize looks at the spectrum of the batch's last hop (src/rtl_airband.cpp:626-630): it depends on the input only, so it is
+             * computed on a side stream BESIDE stage 1 (behind the previous batch's AFC, which read the buffer it overwrites) and joined in
+             * front of afc_kernel (run_back_half) */
+            for (auto& e : h->ev_spec)
+                if (!e) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
+            (void)hipEventRecord(h->ev_spec[0], s);
+            (void)hipStreamWaitEvent(h->side[0], h->ev_spec[0], 0);
+            launch_last_hop_spectrum(h, h->side[0]);
+            (void)hipEventRecord(h->ev_spec[1], h->side[0]);
+        }
+        (void)hipEventRecord(ev[0], s);
+        launch_channelizer_dft(a, s);
+        (void)hipEventRecord(ev[1], s);
     } else {
         ChannelizerArgs ca;
         ca.iq = (const uint8_t*)d_iq;

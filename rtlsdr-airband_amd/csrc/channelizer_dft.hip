@@ -428,10 +428,12 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
         const int st_in_lo = shift > 0 ? 1 : 0;
         const long in_room = span_end - (long)n_dma * 1024;
         const int st_in_hi = __builtin_amdgcn_readfirstlane(in_room < 0 ? -1 : (int)((in_room / hop_bytes + shift) / TILE_HOPS)); /* (the same number on every lane: keep it scalar) */
-        const uint8_t* const p_lane = src - (long)shift * hop_bytes + lane * 16; /* step st starts at p_lane + st * 16 hops */
+        /* step st's image starts at p_lane + st * 16 hops; hops that are not multiples of 16 bytes: `delta` bytes in front of the step's first hop, the same
+         * for every step (a step is 16 hops), so that every transfer is 16-byte aligned -- the interior test stays valid, it only gets more cautious */
+        const uint8_t* const p_lane = src - (long)shift * hop_bytes - delta + lane * 16;
         const int step_bytes = TILE_HOPS * hop_bytes;
         auto stage_fast = [&](int step, uint8_t* buf) {
-            if (AL >= 16 && step >= st_in_lo && step <= st_in_hi) {
+            if (step >= st_in_lo && step <= st_in_hi) {
                 const uint8_t* p = p_lane + (unsigned long long)(unsigned)step * (unsigned)step_bytes;
 #define AB_PIECE(K, BASE, OFF) \
     if (n_dma > (K)) __builtin_amdgcn_global_load_lds((gptr_t)(p + (BASE)), (lptr_t)(uintptr_t)(buf + (BASE)), 16, (OFF), 0)

@@ -471,14 +471,14 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         if (SPLIT_REST && AB_LIKELY(s.quiet)) rest(std::true_type{}, j, cur_mag, delayed_mag, re, im, went_closed); /* the sample that settles the last lane still reports who just closed */
         else rest(std::false_type{}, j, cur_mag, delayed_mag, re, im, went_closed);
     };
-    /* ---- four samples of a STABLE wavefront as ONE basic block (AM kind, NFM + CTCSS front) ------------------------------------------
+    /* ---- four samples of a STABLE wavefront as ONE basic block (AM kind, plain NFM, NFM + CTCSS front) ------------------------------
      * sq_raw_stable4() (squelch_fsm.h) runs the four squelch steps on a copy of the state and commits it only if no lane asked for a
      * transition: then no lane changed state, audio is wanted by the same lanes (OPEN and CLOSING) for all four samples, and what is left
      * is those lanes' per-sample float chain -- one exec-masked region for the four samples instead of three per sample, no scalar
      * mask algebra between them.  Round 3 measured that nothing but the NUMBER of instructions moves stage 2 (profiles/r03_experiments.md):
      * the per-sample version issues ~60 vector + ~60 scalar + ~15 branch instructions per AM sample, most of the scalar ones and all
      * of the branches for events that do not happen in a quiet group. */
-    constexpr bool SPEC4 = KIND == AB_KIND_AM || KIND == AB_KIND_NFM_CTCSS;
+    constexpr bool SPEC4 = KIND == AB_KIND_AM || KIND == AB_KIND_NFM || KIND == AB_KIND_NFM_CTCSS;
     const bool wave_has_notch = ab_any(ab_ballot((cc.flags & AB_F_NOTCH) != 0));
     const bool wave_has_iq_out = ab_any(ab_ballot((cc.flags & AB_F_IQ_OUT) != 0));
     auto quiet_tail4 = [&](const int jq, const float* mcs, const float* mds, const float* qr, const float* qi) {
@@ -523,8 +523,9 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
 #pragma unroll
                 for (int r = 0; r < 4; r++) trace[(long)(jq + r) * S] = tb;
             }
-        } else { /* NFM + CTCSS front: derotation, discriminator, de-emphasis -> one hand-off word per sample (see rest()) */
+        } else { /* NFM kinds: derotation, discriminator, de-emphasis -> one hand-off word per sample (CTCSS front, see rest()) or the output path (plain NFM) */
             unsigned w4[4] = {HAND_IDLE, HAND_IDLE, HAND_IDLE, HAND_IDLE};
+            float out4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (filt) { /* OPENING lanes derotate (their phase accumulator runs) without producing audio; OPEN and CLOSING lanes do both */
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -555,14 +556,31 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                         out -= agc;
                         out = out * one_minus_alpha + prev_out * cc.alpha;
                         prev_out = out;
-                        w4[r] = (out != out) ? HAND_NAN : __float_as_uint(out);
+                        if (PACKED) {
+                            w4[r] = (out != out) ? HAND_NAN : __float_as_uint(out);
+                        } else { /* src/rtl_airband.cpp:589-603 */
+                            if (wave_has_notch) {
+                                if (cc.flags & AB_F_NOTCH) {
+                                    o.nx0 = o.nx1; o.nx1 = o.nx2; o.nx2 = out;
+                                    o.ny0 = o.ny1; o.ny1 = o.ny2;
+                                    o.ny2 = cc.notch_d0 * o.nx2 - cc.notch_d1 * o.nx1 + cc.notch_d0 * o.nx0 + cc.notch_d1 * o.ny1 - cc.notch_d2 * o.ny0;
+                                    out = o.ny2;
+                                }
+                            }
+                            out *= cc.ampfactor;
+                            out4[r] = (out != out) ? 0.0f : __builtin_amdgcn_fmed3f(out, -1.0f, 1.0f);
+                        }
                     }
                 }
+                if (!PACKED && open) o.axc = '*';
             }
 #pragma unroll
-            for (int r = 0; r < 4; r++) handw[((jq + r) & (HAND_RUN - 1)) * OSTRIDE] = w4[r];
+            for (int r = 0; r < 4; r++) {
+                if (PACKED) handw[((jq + r) & (HAND_RUN - 1)) * OSTRIDE] = w4[r];
+                else wrow.staged[(jq + r - wrow.j0) * wrow.stride] = out4[r];
+            }
             if (AB_UNLIKELY(trace != nullptr)) {
-                const uint8_t tb = (uint8_t)((st_lane & 7) | (open ? 16 : 0));
+                const uint8_t tb = (uint8_t)((st_lane & 7) | (open ? (PACKED ? 16 : (8 | 16)) : 0));
 #pragma unroll
                 for (int r = 0; r < 4; r++) trace[(long)(jq + r) * S] = tb;
             }
@@ -974,7 +992,8 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
     /* the split chain (front -> tone -> back) is the longest dependent sequence of stage 2: it is enqueued first (and its stream has
      * the higher priority), the fused kinds fill in beside it.  (Round 3 also ran the chain as 2 and 4 independent chains over block
      * ranges on streams of their own, so that one range's tone and back kernels would overlap the next range's front: 6.81 / 6.92 and
-     * 6.50 / 6.69 ms against 6.70 / 6.62 -- nothing, profiles/r03_experiments.md; the stage is bound by the sum of its work.) */
+     * 6.50 / 6.69 ms against 6.70 / 6.62 -- nothing; and the AM kind BEHIND the chain on this stream instead of beside it: 6.10 against 5.85 - 5.97,
+     * worse -- profiles/r03_experiments.md B, H; the stage is bound by the sum of its work.) */
     launch_kind(AB_KIND_NFM_CTCSS, stream);
     launch_kind(AB_KIND_GENERIC, stream);
     if (a.ct_pk_n_blocks > 0) hipLaunchKernelGGL(tone_kernel<true>, dim3((a.ct_pk_n_blocks * 64 * 64 + 255) / 256), dim3(256), 0, stream, a, a.ct_pk_first_block, a.ct_pk_n_blocks);

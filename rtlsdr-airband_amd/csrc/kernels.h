@@ -158,7 +158,9 @@ struct RetuneArgs {
     const int* ext_to_slot;
     const int* item_dev;
     const int* item_group;
-    const int* item_bset;
+    int* item_bset;         /* what the channelizer reads: item_home while every channel of the group sits on its base bin, item_private otherwise */
+    const int* item_private;/* the group's own table (>= n_shared), or its shared one for groups without an AFC channel */
+    const int* item_home;
     int* bset_bin;          /* [n_bsets][8] */
     int8_t* bfrag;
     double* corr;

@@ -220,22 +220,26 @@ void launch_afc(const ChanConst* cc, ChanState* cs, const float* spectrum, int f
  * channel owns its table; one workgroup per such work item compares, channel by channel, the bin the table is built for with the bin the
  * channel is tuned to (ChanState::bin, moved by afc_kernel) and rewrites the channel's (re, im) column pair where they differ: the same
  * arithmetic as the host builder -- w[n] exp(-2 pi i bin n / N) scaled to 24 bits, three balanced base-256 digits, in the MFMA B-fragment
- * layout -- plus the column's offset correction.  At start-up every column of a private table differs (-1): the kernel is the builder. */
+ * layout -- plus the column's offset correction.  At start-up every column of a private table differs (-1): the kernel is the builder.
+ * The work item is pointed at its private table only while one of its channels is away from its base bin; at home it reads the shared
+ * table of the base bins like every group without AFC (no moved channel, no extra coefficient traffic). */
 __global__ __launch_bounds__(256) void retune_kernel(RetuneArgs a) {
     __shared__ long long sums[2];
     /* no channel of the handle moved in this batch (afc_kernel would have stamped the batch's number): nothing to compare, let alone rebuild --
      * the common case, and 65 536 workgroups comparing eight bins each were 0.3 - 0.6 ms of it */
     if (*a.moved_epoch != a.epoch) return;
     const int item = blockIdx.x;
-    const int bset = a.item_bset[item];
+    const int bset = a.item_private[item];
     if (bset < a.n_shared) return; /* shared table: its channels never move */
     const int d = a.item_dev[item], g = a.item_group[item];
     const DevConst dev = a.dev[d];
     const int N = a.fft_size, NP = N > 512 ? N / 512 : 1, NS = N / NP, K = 2 * NS, KS = K / 64;
     const size_t piece_bytes = (size_t)3 * KS * 64 * 16;
+    bool away = false; /* some channel of the group is off its base bin (block-uniform) */
     for (int c = 0; c < 8 && g * 8 + c < dev.n_ch; c++) {
         const int slot = a.ext_to_slot[dev.chan_base + g * 8 + c];
         const int bin = a.cs[slot].bin;
+        away |= bin != a.cc[slot].base_bin;
         if (a.bset_bin[bset * 8 + c] == bin) continue; /* block-uniform */
         for (int piece = 0; piece < NP; piece++) {
             if (threadIdx.x < 2) sums[threadIdx.x] = 0;
@@ -272,6 +276,8 @@ __global__ __launch_bounds__(256) void retune_kernel(RetuneArgs a) {
         }
         if (threadIdx.x == 0) a.bset_bin[bset * 8 + c] = bin;
     }
+    /* the table the next batch's stage 1 reads for this work item: the fleet's shared one while the group is at home */
+    if (threadIdx.x == 0) a.item_bset[item] = away ? bset : a.item_home[item];
 }
 
 void launch_retune(const RetuneArgs& a, hipStream_t stream) {

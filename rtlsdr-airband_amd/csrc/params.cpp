@@ -306,12 +306,15 @@ void build_dft_tables(Plan& p, bool host_private) {
     p.item_dev.clear();
     p.item_group.clear();
     p.item_bset.clear();
+    p.item_home.clear();
     p.bfrag.clear();
     p.bcorr.clear();
-    /* Tables are SHARED between work items with the same bins (a fleet of identical dongles has one) -- except those of a group with an
-     * AFC channel: AFC moves the channel's bin at run time (src/rtl_airband.cpp:224-250), the re-tune kernel then rewrites that channel's
-     * two columns in place, so such a group owns its table.  Shared tables take the indices [0, n_shared), private ones follow; private
-     * tables are built by the re-tune kernel itself on the device (host_private: and here, for the host-only self test). */
+    /* Tables are SHARED between work items with the same bins (a fleet of identical dongles has one).  A group with an AFC channel ALSO owns
+     * a private table: AFC moves the channel's bin at run time (src/rtl_airband.cpp:224-250), the re-tune kernel then rewrites that channel's
+     * two columns there -- and points the work item at the private table only while some channel of the group is away from its base bin
+     * (item_home: the shared table of the base bins, which it reads otherwise; 65 536 private tables are 3.2 GB of coefficient reads per
+     * batch).  Shared tables take the indices [0, n_shared), private ones follow; private tables are built by the re-tune kernel itself on
+     * the device (host_private: and here, for the host-only self test). */
     std::vector<std::vector<int>> shared_keys, private_keys;
     auto build = [&](const std::vector<int>& key) {
         for (int piece = 0; piece < NP; piece++) {
@@ -359,21 +362,23 @@ void build_dft_tables(Plan& p, bool host_private) {
                 key.push_back(p.cc[p.chan_base[d] + j].base_bin);
                 private_table |= p.cc[p.chan_base[d] + j].afc != 0;
             }
-            int found = -1;
+            int found = -1, home = -1;
+            if (last_shared >= 0 && shared_keys[last_shared] == key) home = last_shared; /* fleets of identical dongles: the common case */
+            for (size_t i = 0; home < 0 && i < shared_keys.size(); i++)
+                if (shared_keys[i] == key) home = (int)i;
+            if (home < 0) {
+                home = (int)shared_keys.size();
+                shared_keys.push_back(key);
+                if (shared_keys.size() <= 4096) build(key); /* beyond that the caller falls back to the wavefront-FFT channelizer: no point in building on */
+            }
+            last_shared = home;
             if (private_table) {
                 found = -(int)private_keys.size() - 1; /* its final index is known once the shared tables are counted */
                 private_keys.push_back(key);
             } else {
-                if (last_shared >= 0 && shared_keys[last_shared] == key) found = last_shared; /* fleets of identical dongles: the common case */
-                for (size_t i = 0; found < 0 && i < shared_keys.size(); i++)
-                    if (shared_keys[i] == key) found = (int)i;
-                if (found < 0) {
-                    found = (int)shared_keys.size();
-                    shared_keys.push_back(key);
-                    if (shared_keys.size() <= 4096) build(key); /* beyond that the caller falls back to the wavefront-FFT channelizer: no point in building on */
-                }
-                last_shared = found;
+                found = home;
             }
+            p.item_home.push_back(home);
             p.item_dev.push_back(d);
             p.item_group.push_back(g);
             p.item_bset.push_back(found);

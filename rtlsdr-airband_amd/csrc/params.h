@@ -32,6 +32,7 @@ struct Plan {
     float lev_u8[256], lev_s8[256];    /* src/rtl_airband.cpp:316-324 */
     /* matrix-core channelizer tables (channelizer_dft.hip); empty unless the configuration qualifies */
     std::vector<int> item_dev, item_group, item_bset; /* channelizer work items: (dongle, group of 8 channels, coefficient-table index) */
+    std::vector<int> item_home;                       /* the SHARED table of the item's base bins: what a group with an AFC channel reads while none of its channels has moved */
     std::vector<int8_t> bfrag;         /* [n_bsets][3][fft_size / 32][64][16] */
     std::vector<double> bcorr;         /* [n_bsets][16] */
     double b_unscale = 0.0;
