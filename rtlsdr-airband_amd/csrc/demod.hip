@@ -481,7 +481,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     constexpr bool SPEC4 = KIND == AB_KIND_AM || KIND == AB_KIND_NFM || KIND == AB_KIND_NFM_CTCSS;
     const bool wave_has_notch = ab_any(ab_ballot((cc.flags & AB_F_NOTCH) != 0));
     const bool wave_has_iq_out = ab_any(ab_ballot((cc.flags & AB_F_IQ_OUT) != 0));
-    auto quiet_tail4 = [&](const int jq, const float* mcs, const float* mds, const float* qr, const float* qi) {
+    auto stable_tail4 = [&](const int jq, const float* mcs, const float* mds, const float* qr, const float* qi) {
         const bool open = ab_lane(sq_should_audio(s)); /* Squelch::should_process_audio() == is_open() (no tone gate in these kinds), the same lanes for the four samples */
         /* Squelch::should_filter_sample() for the four samples: a CLOSED lane with signal would have ended the stable spell, so it is every lane that is not CLOSED or aborting */
         const bool filt = ab_lane(~s.cC & ~s.cA & s.active);
@@ -611,7 +611,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             if ((jq % RUN) == 0) wrow.j0 = jq;
             if (SPEC4 && AB_LIKELY(aligned4 && sq_stable4(s))) { /* wave-uniform */
                 if (AB_LIKELY(sq_raw_stable4(s, L, mcs))) {
-                    quiet_tail4(jq, mcs, mds, qr, qi);
+                    stable_tail4(jq, mcs, mds, qr, qi);
                     continue;
                 }
             }

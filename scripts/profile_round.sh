@@ -8,7 +8,8 @@ nproc > $O/host.txt; grep -m1 "model name" /proc/cpuinfo >> $O/host.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -n 1 $O/smoke.log
 timeout 900 python bench.py 2>$O/bench_cfg3.err | tail -n 1 > $O/${R}_bench_cfg3.json; cut -c1-300 $O/${R}_bench_cfg3.json
 N="--no-cpu-baseline --no-traffic --no-verify-all --verify 4 --steps 40"
-timeout 300 python bench.py $N --workload cfg2 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg2.json
+timeout 300 python bench.py $N --workload cfg2 --steps 400 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg2.json
+timeout 300 python bench.py $N --workload cfg2 --steps 400 --pipelined 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg2_pipelined.json
 timeout 300 python bench.py $N --workload cfg2 --dongles 65536 2>/dev/null | tail -n 1 > $O/${R}_bench_am65536.json
 timeout 300 python bench.py $N --workload cfg4 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg4_shard.json
 timeout 300 python bench.py $N --pipelined 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg3_pipelined.json

@@ -116,7 +116,7 @@ def test_tone_kernel_keeps_its_scalars_in_registers(demod_asm):
 
 @pytest.mark.parametrize("kernel", ["demod_kernelILi0ELb0E", "demod_kernelILi3ELb1E"], ids=["am", "ctcss_front"])
 def test_stable_group_is_one_block_of_four_samples(demod_asm, kernel):
-    """Round 3: four samples of a stable wavefront run as one basic block (squelch_fsm.h sq_raw_stable4, demod.hip quiet_tail4).  What makes it pay is
+    """Round 3: four samples of a stable wavefront run as one basic block (squelch_fsm.h sq_raw_stable4, demod.hip stable_tail4).  What makes it pay is
     its shape: the four squelch steps sit in ONE basic block, no branch between them (the per-sample path has several per sample).  A squelch step
     has three `not >=` float compares (sample against cap and level, average against cap): twelve of them in one block is the group."""
     body = _function(demod_asm, kernel)
