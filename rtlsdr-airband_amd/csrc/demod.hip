@@ -1003,12 +1003,17 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
     /* the fused kinds as forked launches (one kernel per kind keeps each kind's own register budget: the AM kind runs four waves per
      * SIMD, the heavier ones three; a single launch with host-interleaved blocks was measured equal at best, 7.8 vs 7.7 ms);
      * without side streams (AIRBAND_HIP_FLAG_SERIAL_DEMOD, profiling) one after the other */
+    /* a handle without CTCSS-capable channels has nothing on the caller's stream: its first fused kind runs there, not on a side stream behind
+     * two cross-queue dependencies (BASELINE configs[1], AM only: 0.05 ms of a 0.32 ms stage) */
+    bool caller_stream_free = a.ct_pk_n_blocks <= 0 && a.ct_gen_n_blocks <= 0 && kind_n_blocks[AB_KIND_NFM_CTCSS] <= 0 && kind_n_blocks[AB_KIND_GENERIC] <= 0;
     for (int i = 0; i < 3; i++) {
         if (kind_n_blocks[fused[i]] <= 0) continue;
-        hipStream_t s = fork ? side[i] : stream;
-        if (fork) (void)hipStreamWaitEvent(s, ev[0], 0);
+        const bool on_side = fork && !caller_stream_free;
+        caller_stream_free = false;
+        hipStream_t s = on_side ? side[i] : stream;
+        if (on_side) (void)hipStreamWaitEvent(s, ev[0], 0);
         launch_kind(fused[i], s);
-        if (fork) {
+        if (on_side) {
             (void)hipEventRecord(ev[1 + i], s);
             (void)hipStreamWaitEvent(stream, ev[1 + i], 0);
         }
