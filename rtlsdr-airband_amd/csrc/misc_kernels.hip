@@ -103,28 +103,46 @@ void launch_siggen(const SiggenArgs& a, hipStream_t stream) {
  * Two stages so that mixers with hundreds of thousands of inputs (BASELINE config #5) parallelise: stage A sums runs of
  * up to MIX_RUN consecutive inputs of one mixer in connection order, stage B adds the run sums in order.  A mixer with
  * <= MIX_RUN inputs (every mixer in the reference's example configs) is therefore summed in exactly the reference's order. */
+/* (a thread sums FOUR consecutive samples, and the rows of eight inputs are in flight before the first of them is added: one dependent 4-byte load per
+ * input and thread was a memory round trip per input -- 1.46 ms for 524 288 inputs where the bytes take 0.5.  The additions keep the connection order.) */
 __global__ __launch_bounds__(256) void mix_runs_kernel(MixArgs a) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
     const int run = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = (blockIdx.x * 256 + threadIdx.x) * 4; /* WAVE_BATCH is a multiple of four; rows start 16-byte aligned (AB_OUT_PAD) */
     const int first = a.run_first[run], last = a.run_first[run + 1];
     const bool stereo = a.mixer_stereo[a.run_mixer[run]] != 0;
-    float l = 0.0f, r = 0.0f;
+    const bool mine = t < a.wave_batch;
+    v4f l = {0.0f, 0.0f, 0.0f, 0.0f}, r = {0.0f, 0.0f, 0.0f, 0.0f};
     bool any = false;
-    for (int i = first; i < last; i++) {
-        const int ch = a.in_chan[i];
-        if (ch < 0) continue;               /* input masked out (mixer_disable_input, src/mixer.cpp:96-110) */
-        if (a.out_axc[ch] == ' ') continue; /* has_signal == false: nothing is added (src/mixer.cpp:119-122,203) */
-        any = true;
-        if (t < a.wave_batch) {
-            const float w = a.out_wave[(long)ch * a.wave_stride + t];
-            const float ml = a.in_ml[i], mr = a.in_mr[i];
-            if (ml != 0.0f) l += w * ml;
-            if (stereo && mr != 0.0f) r += w * mr;
+    constexpr int G = 8;
+    for (int i0 = first; i0 < last; i0 += G) {
+        v4f w[G];
+        float ml[G], mr[G];
+        bool use[G];
+#pragma unroll
+        for (int k = 0; k < G; k++) { /* block-uniform conditions: scalar branches around the loads */
+            const int i = i0 + k;
+            const int ch = i < last ? a.in_chan[i] : -1; /* < 0: input masked out (mixer_disable_input, src/mixer.cpp:96-110) */
+            use[k] = ch >= 0 && a.out_axc[ch] != ' ';    /* has_signal == false: nothing is added (src/mixer.cpp:119-122,203) */
+            w[k] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+            ml[k] = mr[k] = 0.0f;
+            if (use[k]) {
+                ml[k] = a.in_ml[i];
+                mr[k] = a.in_mr[i];
+                if (mine) w[k] = *reinterpret_cast<const v4f*>(a.out_wave + (long)ch * a.wave_stride + t);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            if (!use[k]) continue;
+            any = true;
+            if (ml[k] != 0.0f) l += w[k] * ml[k];
+            if (stereo && mr[k] != 0.0f) r += w[k] * mr[k];
         }
     }
-    if (t < a.wave_batch) {
-        a.run_left[(long)run * a.wave_batch + t] = l;
-        a.run_right[(long)run * a.wave_batch + t] = r;
+    if (mine) {
+        *reinterpret_cast<v4f*>(a.run_left + (long)run * a.wave_batch + t) = l;
+        *reinterpret_cast<v4f*>(a.run_right + (long)run * a.wave_batch + t) = r;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) a.run_signal[run] = any ? 1 : 0;
 }
@@ -156,7 +174,7 @@ __global__ __launch_bounds__(256) void mix_final_kernel(MixArgs a) {
 
 void launch_mix(const MixArgs& a, hipStream_t stream) {
     const int bx = (a.wave_batch + 255) / 256;
-    hipLaunchKernelGGL(mix_runs_kernel, dim3(bx, a.n_runs), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(mix_runs_kernel, dim3((a.wave_batch / 4 + 255) / 256, a.n_runs), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(mix_final_kernel, dim3(bx, a.n_mixers), dim3(256), 0, stream, a);
 }
 
@@ -217,36 +235,47 @@ void launch_afc(const ChanConst* cc, ChanState* cs, const float* spectrum, int f
 
 /* ---- AFC on the matrix-core channelizer: coefficient columns follow the bins ---------------------------------------------------
  * The pruned DFT has the channel's bin baked into its coefficient table (params.cpp, build_dft_tables).  A group of channels with an AFC
- * channel owns its table; one workgroup per such work item compares, channel by channel, the bin the table is built for with the bin the
+ * channel owns its table; one wavefront per such work item compares, a lane per channel, the bin the table is built for with the bin the
  * channel is tuned to (ChanState::bin, moved by afc_kernel) and rewrites the channel's (re, im) column pair where they differ: the same
  * arithmetic as the host builder -- w[n] exp(-2 pi i bin n / N) scaled to 24 bits, three balanced base-256 digits, in the MFMA B-fragment
  * layout -- plus the column's offset correction.  At start-up every column of a private table differs (-1): the kernel is the builder.
  * The work item is pointed at its private table only while one of its channels is away from its base bin; at home it reads the shared
  * table of the base bins like every group without AFC (no moved channel, no extra coefficient traffic). */
 __global__ __launch_bounds__(256) void retune_kernel(RetuneArgs a) {
-    __shared__ long long sums[2];
-    /* no channel of the handle moved in this batch (afc_kernel would have stamped the batch's number): nothing to compare, let alone rebuild --
-     * the common case, and 65 536 workgroups comparing eight bins each were 0.3 - 0.6 ms of it */
+    __shared__ long long sums[4][2];
+    /* no channel of the handle moved in this batch (afc_kernel would have stamped the batch's number): nothing to compare, let alone rebuild */
     if (*a.moved_epoch != a.epoch) return;
-    const int item = blockIdx.x;
+    /* one WAVEFRONT per work item (four per workgroup, no workgroup barriers): lane c < 8 compares channel c's bin with the bin its column pair is built
+     * for -- one round of loads per item; the first form walked the eight channels one after the other with 256 threads looking on, 0.5 ms per batch
+     * at 65 536 items whenever anything had moved anywhere */
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.n_items) return;
     const int bset = a.item_private[item];
     if (bset < a.n_shared) return; /* shared table: its channels never move */
     const int d = a.item_dev[item], g = a.item_group[item];
     const DevConst dev = a.dev[d];
     const int N = a.fft_size, NP = N > 512 ? N / 512 : 1, NS = N / NP, K = 2 * NS, KS = K / 64;
     const size_t piece_bytes = (size_t)3 * KS * 64 * 16;
-    bool away = false; /* some channel of the group is off its base bin (block-uniform) */
-    for (int c = 0; c < 8 && g * 8 + c < dev.n_ch; c++) {
-        const int slot = a.ext_to_slot[dev.chan_base + g * 8 + c];
-        const int bin = a.cs[slot].bin;
-        away |= bin != a.cc[slot].base_bin;
-        if (a.bset_bin[bset * 8 + c] == bin) continue; /* block-uniform */
+    int my_bin = -1;
+    bool my_away = false, my_stale = false;
+    if (lane < 8 && g * 8 + lane < dev.n_ch) {
+        const int slot = a.ext_to_slot[dev.chan_base + g * 8 + lane];
+        my_bin = a.cs[slot].bin;
+        my_away = my_bin != a.cc[slot].base_bin;
+        my_stale = a.bset_bin[bset * 8 + lane] != my_bin;
+    }
+    const bool away = __ballot(my_away) != 0ull; /* some channel of the group is off its base bin */
+    const unsigned stale = (unsigned)__ballot(my_stale);
+    for (int c = 0; c < 8; c++) {
+        if (!((stale >> c) & 1u)) continue; /* wave-uniform */
+        const int bin = __shfl(my_bin, c);
         for (int piece = 0; piece < NP; piece++) {
-            if (threadIdx.x < 2) sums[threadIdx.x] = 0;
-            __syncthreads();
+            if (lane < 2) sums[wave][lane] = 0;
+            __builtin_amdgcn_wave_barrier();
             int8_t* tab = a.bfrag + ((size_t)bset * NP + piece) * piece_bytes;
             long long part_re = 0, part_im = 0;
-            for (int k = threadIdx.x; k < K; k += 256) {
+            for (int k = lane; k < K; k += 64) {
                 const int n = piece * NS + (k >> 1);
                 double sn, cs_;
                 sincospi(2.0 * (double)(((long long)bin * n) % N) / (double)N, &sn, &cs_); /* the phase is reduced exactly in integers first */
@@ -259,29 +288,30 @@ __global__ __launch_bounds__(256) void retune_kernel(RetuneArgs a) {
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     int rest = half ? v_im : v_re;
-                    const int lane = gg * 16 + 2 * c + half;
+                    const int ln = gg * 16 + 2 * c + half;
 #pragma unroll
                     for (int t = 0; t < 3; t++) {
                         const int lo = ((rest + 128) & 255) - 128; /* balanced digit */
-                        tab[(((size_t)t * KS + s_) * 64 + lane) * 16 + jj] = (int8_t)lo;
+                        tab[(((size_t)t * KS + s_) * 64 + ln) * 16 + jj] = (int8_t)lo;
                         rest = (rest - lo) / 256;
                     }
                 }
             }
-            atomicAdd((unsigned long long*)&sums[0], (unsigned long long)part_re); /* integer sums: exact, order-free */
-            atomicAdd((unsigned long long*)&sums[1], (unsigned long long)part_im);
-            __syncthreads();
-            if (threadIdx.x < 2) a.corr[((size_t)bset * NP + piece) * 16 + 2 * c + threadIdx.x] = 0.5 * (double)sums[threadIdx.x]; /* (b - 127.5) = (b - 128) + 0.5 */
-            __syncthreads();
+            atomicAdd((unsigned long long*)&sums[wave][0], (unsigned long long)part_re); /* integer sums: exact, order-free */
+            atomicAdd((unsigned long long*)&sums[wave][1], (unsigned long long)part_im);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* LDS operations of one wave complete in order; this keeps the compiler from reordering them */
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 2) a.corr[((size_t)bset * NP + piece) * 16 + 2 * c + lane] = 0.5 * (double)sums[wave][lane]; /* (b - 127.5) = (b - 128) + 0.5 */
+            __builtin_amdgcn_wave_barrier();
         }
-        if (threadIdx.x == 0) a.bset_bin[bset * 8 + c] = bin;
+        if (lane == 0) a.bset_bin[bset * 8 + c] = bin;
     }
     /* the table the next batch's stage 1 reads for this work item: the fleet's shared one while the group is at home */
-    if (threadIdx.x == 0) a.item_bset[item] = away ? bset : a.item_home[item];
+    if (lane == 0) a.item_bset[item] = away ? bset : a.item_home[item];
 }
 
 void launch_retune(const RetuneArgs& a, hipStream_t stream) {
-    if (a.n_items > 0) hipLaunchKernelGGL(retune_kernel, dim3(a.n_items), dim3(256), 0, stream, a);
+    if (a.n_items > 0) hipLaunchKernelGGL(retune_kernel, dim3((a.n_items + 3) / 4), dim3(256), 0, stream, a);
 }
 
 /* ---- layout shuffles for the introspection entry points -------------------------------------------------- */
