@@ -132,3 +132,33 @@ def test_stable_group_is_one_block_of_four_samples(demod_asm, kernel):
     blocks.append(cur)
     most = max(sum(1 for l in b if "v_cmp_nge_f32" in l) for b in blocks)
     assert most >= 12, "no basic block holds four squelch steps (%d `not >=` compares in the fullest one)" % most
+
+
+@pytest.fixture(scope="module")
+def dft_asm(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
+    out = str(tmp_path_factory.mktemp("isa") / "dft.s")
+    src = os.path.join(ROOT, "rtlsdr-airband_amd", "csrc", "channelizer_dft.hip")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-std=c++17", "-O3", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out, src]
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL, timeout=900)
+    return open(out).read().split("\n")
+
+
+def test_channelizer_waits_count_the_stores_it_really_issues(dft_asm):
+    """The pipelined loop of the hop-320 channelizer proves that a staging transfer has landed by counting the memory operations issued since -- the
+    pieces of later transfers and the OUTPUT STORES (channelizer_dft.hip, `stores` / k_tile: one 16-byte store for |bin|, two for raw I/Q per whole
+    tile).  Counting more stores than the machine code issues would let a wait return early, so the shape is pinned: the whole-tile path of the hot loop
+    issues at least three 16-byte stores, the loop carries the DMA pieces of one step, 44 MFMAs, 64 sign flips, and its steady-state wait (two steps of
+    six pieces + two tiles of three stores = 18) exists as an immediate."""
+    body = _function(dft_asm, "channelizer_dft_kernelILi512ELb1ELi320ELb0ELi16ELi1E")
+    loop = _hot_loop(body, r"v_mfma_i32_16x16x64_i8")
+    assert sum(1 for l in loop if "v_mfma_i32_16x16x64_i8" in l) == 44
+    assert sum(1 for l in loop if re.search(r"global_store_dwordx4", l)) >= 3
+    assert sum(1 for l in loop if "global_load_lds_dwordx4" in l) >= 6
+    assert sum(1 for l in loop if re.match(r"^\s*v_xor_b32", l)) == 64
+    assert any(re.search(r"s_waitcnt\s+vmcnt\(18\)", l) for l in loop)
+    meta = "\n".join(dft_asm)
+    at = meta.index(".name:           _ZN7airband12_GLOBAL__N_122channelizer_dft_kernelILi512ELb1ELi320ELb0ELi16ELi1E")
+    assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta[at:at + 1500]).group(1)) == 0
+    assert int(re.search(r"\.vgpr_count:\s+(\d+)", meta[at:at + 1500]).group(1)) <= 256  # two waves per SIMD
