@@ -75,7 +75,10 @@ struct ChanState {
     int32_t ct_enough[2], ct_count[2], ct_has_tone[2];
     uint32_t ct_found[2], ct_not_found[2];
     int32_t axc_prev; /* axcindicate before the last batch (what `AFC afc(dev, i)` captures, src/rtl_airband.cpp:222,496) */
-    int32_t pad[2];
+    /* the pre-filter average and noise floor as they stood 101 samples ago (squelch_fsm.h, SqShadow): the NFM + lowpass kind recomputes the
+     * squelch's delay line from them instead of storing and re-reading it */
+    float sh_nf, sh_cap, sh_capped;
+    int32_t pad[3];
 };
 
 /* Per-dongle constants for the channelizer. */

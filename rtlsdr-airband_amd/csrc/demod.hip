@@ -212,6 +212,9 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     L.track_delay_line = (KIND == AB_KIND_NFM_LOWPASS || KIND == AB_KIND_GENERIC);
     L.may_post_filter = (KIND == AB_KIND_NFM_LOWPASS || KIND == AB_KIND_GENERIC);
     L.all_lowpass = (KIND == AB_KIND_NFM_LOWPASS);
+    /* ... and that kind no longer stores the delay line at all: a shadow of the pre-filter average, fed the AGC_EXTRA-delayed input, holds its entries
+     * (squelch_fsm.h, SqShadow): 8 bytes of traffic per sample and channel less, 2.1 GB per batch at BASELINE configs[2] */
+    L.shadow_delay = (KIND == AB_KIND_NFM_LOWPASS);
 
     SqRegs s;
     sq_load(s, L, sp, true);
@@ -219,7 +222,9 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
      * sample is always the first one of a group of four: the other three do not look (squelch_fsm.h, sq_raw_quiet).  Should a handle ever
      * hold a count that is not aligned like that (wave-uniform test), every sample looks. */
     const bool aligned4 = ((s.sample_count + 1u) & 3u) == 0u;
-    s.dly = (KIND == AB_KIND_NFM_LOWPASS) ? L.sqbuf[(long)s.tail * S] : 0.0f;
+    SqShadow sh = {sp->sh_nf, sp->sh_cap, sp->sh_capped};
+    const bool first_batch = a.tail_copy == 0; /* the stream's first 101 samples read the zeros the reference's delay line starts with (src/squelch.cpp:69) */
+    s.dly = (KIND == AB_KIND_NFM_LOWPASS && !first_batch) ? sq_shadow_value(sh) : 0.0f;
     float agc = sp->agcavgfast, pr = sp->pr, pj = sp->pj, prev_out = sp->prev_waveout;
     unsigned dm_phi = sp->dm_phi;
     OutRegs o;
@@ -310,7 +315,6 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     constexpr int GQ = GS / 4;
     struct Group {
         float4 mc[GQ], md[GQ], c01[GQ], c23[GQ], q01[GQ], q23[GQ];
-        float dv[GS];
     };
     auto fetch = [&](Group& q, int j0, int tail0) { /* tail0 = squelch delay-line tail at the start of the group (lowpass kind) */
 #pragma unroll
@@ -331,14 +335,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                 q.q23[g] = qp[1];
             }
         }
-        if (KIND == AB_KIND_NFM_LOWPASS) { /* delay-line entries the samples will see after their tail increment (written >= 101 samples ago) */
-#pragma unroll
-            for (int r = 0; r < GS; r++) {
-                int e = tail0 + 1 + r;
-                e = e >= AB_SQ_BUF ? e - AB_SQ_BUF : e;
-                q.dv[r] = L.sqbuf[(long)e * S];
-            }
-        }
+        (void)tail0; /* (the NFM + lowpass kind used to fetch its four delay-line entries here; it recomputes them now: SqShadow) */
     };
     /* "these registers are needed now": the compiler puts its wait for the group's loads here, BEFORE the next group's loads are issued */
     auto touch = [&](const Group& q) {
@@ -348,7 +345,6 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             else asm volatile("" ::"v"(q.c01[g].x), "v"(q.c01[g].y), "v"(q.c01[g].z), "v"(q.c01[g].w), "v"(q.c23[g].x), "v"(q.c23[g].y), "v"(q.c23[g].z), "v"(q.c23[g].w));
             if (raw_iq) asm volatile("" ::"v"(q.q01[g].x), "v"(q.q01[g].y), "v"(q.q01[g].z), "v"(q.q01[g].w), "v"(q.q23[g].x), "v"(q.q23[g].y), "v"(q.q23[g].z), "v"(q.q23[g].w));
         }
-        if (KIND == AB_KIND_NFM_LOWPASS) asm volatile("" ::"v"(q.dv[0]), "v"(q.dv[1]), "v"(q.dv[2]), "v"(q.dv[3]));
     };
     auto tail_in = [&](int n) { /* the delay-line tail advances once per sample (sq_advance) */
         int t = s.tail + n;
@@ -471,14 +467,16 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         if (SPLIT_REST && AB_LIKELY(s.quiet)) rest(std::true_type{}, j, cur_mag, delayed_mag, re, im, went_closed); /* the sample that settles the last lane still reports who just closed */
         else rest(std::false_type{}, j, cur_mag, delayed_mag, re, im, went_closed);
     };
-    /* ---- four samples of a STABLE wavefront as ONE basic block (AM kind, plain NFM, NFM + CTCSS front) ------------------------------
+    /* ---- four samples of a STABLE wavefront as ONE basic block (AM kind, NFM + CTCSS front) ------------------------------------------
      * sq_raw_stable4() (squelch_fsm.h) runs the four squelch steps on a copy of the state and commits it only if no lane asked for a
      * transition: then no lane changed state, audio is wanted by the same lanes (OPEN and CLOSING) for all four samples, and what is left
      * is those lanes' per-sample float chain -- one exec-masked region for the four samples instead of three per sample, no scalar
      * mask algebra between them.  Round 3 measured that nothing but the NUMBER of instructions moves stage 2 (profiles/r03_experiments.md):
      * the per-sample version issues ~60 vector + ~60 scalar + ~15 branch instructions per AM sample, most of the scalar ones and all
      * of the branches for events that do not happen in a quiet group. */
-    constexpr bool SPEC4 = KIND == AB_KIND_AM || KIND == AB_KIND_NFM || KIND == AB_KIND_NFM_CTCSS;
+    /* (the plain NFM kind was given the same block and lost it again: with the fused output path behind the discriminator it needs 143 spilled registers
+     * at three waves per SIMD) */
+    constexpr bool SPEC4 = KIND == AB_KIND_AM || KIND == AB_KIND_NFM_CTCSS;
     const bool wave_has_notch = ab_any(ab_ballot((cc.flags & AB_F_NOTCH) != 0));
     const bool wave_has_iq_out = ab_any(ab_ballot((cc.flags & AB_F_IQ_OUT) != 0));
     auto stable_tail4 = [&](const int jq, const float* mcs, const float* mds, const float* qr, const float* qi) {
@@ -523,9 +521,8 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
 #pragma unroll
                 for (int r = 0; r < 4; r++) trace[(long)(jq + r) * S] = tb;
             }
-        } else { /* NFM kinds: derotation, discriminator, de-emphasis -> one hand-off word per sample (CTCSS front, see rest()) or the output path (plain NFM) */
+        } else { /* NFM + CTCSS front: derotation, discriminator, de-emphasis -> one hand-off word per sample (see rest()) */
             unsigned w4[4] = {HAND_IDLE, HAND_IDLE, HAND_IDLE, HAND_IDLE};
-            float out4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (filt) { /* OPENING lanes derotate (their phase accumulator runs) without producing audio; OPEN and CLOSING lanes do both */
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -556,31 +553,14 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                         out -= agc;
                         out = out * one_minus_alpha + prev_out * cc.alpha;
                         prev_out = out;
-                        if (PACKED) {
-                            w4[r] = (out != out) ? HAND_NAN : __float_as_uint(out);
-                        } else { /* src/rtl_airband.cpp:589-603 */
-                            if (wave_has_notch) {
-                                if (cc.flags & AB_F_NOTCH) {
-                                    o.nx0 = o.nx1; o.nx1 = o.nx2; o.nx2 = out;
-                                    o.ny0 = o.ny1; o.ny1 = o.ny2;
-                                    o.ny2 = cc.notch_d0 * o.nx2 - cc.notch_d1 * o.nx1 + cc.notch_d0 * o.nx0 + cc.notch_d1 * o.ny1 - cc.notch_d2 * o.ny0;
-                                    out = o.ny2;
-                                }
-                            }
-                            out *= cc.ampfactor;
-                            out4[r] = (out != out) ? 0.0f : __builtin_amdgcn_fmed3f(out, -1.0f, 1.0f);
-                        }
+                        w4[r] = (out != out) ? HAND_NAN : __float_as_uint(out);
                     }
                 }
-                if (!PACKED && open) o.axc = '*';
             }
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                if (PACKED) handw[((jq + r) & (HAND_RUN - 1)) * OSTRIDE] = w4[r];
-                else wrow.staged[(jq + r - wrow.j0) * wrow.stride] = out4[r];
-            }
+            for (int r = 0; r < 4; r++) handw[((jq + r) & (HAND_RUN - 1)) * OSTRIDE] = w4[r];
             if (AB_UNLIKELY(trace != nullptr)) {
-                const uint8_t tb = (uint8_t)((st_lane & 7) | (open ? (PACKED ? 16 : (8 | 16)) : 0));
+                const uint8_t tb = (uint8_t)((st_lane & 7) | (open ? 16 : 0));
 #pragma unroll
                 for (int r = 0; r < 4; r++) trace[(long)(jq + r) * S] = tb;
             }
@@ -603,11 +583,19 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                 qr[0] = q.q01[g].x; qi[0] = q.q01[g].y; qr[1] = q.q01[g].z; qi[1] = q.q01[g].w;
                 qr[2] = q.q23[g].x; qi[2] = q.q23[g].y; qr[3] = q.q23[g].z; qi[3] = q.q23[g].w;
             }
-            if (KIND == AB_KIND_NFM_LOWPASS) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) mds[r] = q.dv[4 * g + r];
-            }
             const int jq = j0 + 4 * g;
+            if (KIND == AB_KIND_NFM_LOWPASS) {
+                /* the delay-line entry each sample sees -- what sample n - 101 pushed -- from the shadow average (squelch_fsm.h, SqShadow), which then
+                 * takes in this iteration's AGC_EXTRA-delayed sample, the squelch's input of 100 samples ago: the magnitude of the very raw bin the
+                 * squelch computed it from.  (The first 101 samples of a stream see the zeros of a fresh buffer; the shadow starts with squelch sample 0.) */
+                const unsigned c0 = s.sample_count; /* before the group's first increment */
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int j = jq + r;
+                    mds[r] = (first_batch && j < 101) ? 0.0f : sq_shadow_value(sh);
+                    if (!(first_batch && j < AB_AGC_EXTRA)) sq_shadow_step(sh, L, sqrtf(qr[r] * qr[r] + qi[r] * qi[r]), c0 + (unsigned)r + 2u);
+                }
+            }
             if ((jq % RUN) == 0) wrow.j0 = jq;
             if (SPEC4 && AB_LIKELY(aligned4 && sq_stable4(s))) { /* wave-uniform */
                 if (AB_LIKELY(sq_raw_stable4(s, L, mcs))) {
@@ -656,6 +644,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         sp->nx[0] = o.nx0; sp->nx[1] = o.nx1; sp->nx[2] = o.nx2; sp->ny[0] = o.ny0; sp->ny[1] = o.ny1; sp->ny[2] = o.ny2;
     }
     sp->agcavgfast = agc; sp->pr = pr; sp->pj = pj; sp->prev_waveout = prev_out; sp->dm_phi = dm_phi;
+    if (KIND == AB_KIND_NFM_LOWPASS) { sp->sh_nf = sh.nf; sp->sh_cap = sh.cap; sp->sh_capped = sh.capped; }
     sq_store(s, L, sp, B);
     sp->lxr[0] = lxr0; sp->lxr[1] = lxr1; sp->lxr[2] = lxr2; sp->lxi[0] = lxi0; sp->lxi[1] = lxi1; sp->lxi[2] = lxi2;
     sp->lyr[0] = lyr0; sp->lyr[1] = lyr1; sp->lyr[2] = lyr2; sp->lyi[0] = lyi0; sp->lyi[1] = lyi1; sp->lyi[2] = lyi2;

@@ -73,6 +73,7 @@ struct Lane { /* per-lane constants */
     bool track_delay_line; /* head/tail advance per sample (only kinds that touch the delay line need them inside a batch) */
     bool may_post_filter;  /* some lane of this kind may have a lowpass filter, i.e. using_post_filter_ can ever be set (compile-time per kind) */
     bool all_lowpass;      /* every lane of this kind has one (compile-time per kind) */
+    bool shadow_delay;     /* the caller recomputes the delay line's entries (SqShadow) instead of storing them: nothing is pushed (compile-time per kind) */
     lmask m_lowpass, m_manual, m_flappy_lower;
     float manual_level, normal_ratio, flappy_ratio;
     float* sqbuf; /* this lane's column of the 102-deep pre-filter delay line, stride S */
@@ -195,7 +196,7 @@ AB_FSM_FN void sq_avg(float cap, float& full, float& capped, float x) {
  * i.e. by channels with a lowpass filter -- the other lanes skip the store.  (all_lowpass: the lane test of an all-ones mask is not
  * folded by the compiler, so the kind that has the filter on every lane says so.) */
 AB_FSM_FN void sq_delay_line_push(const SqRegs& s, const Lane& L) {
-    if (!L.may_post_filter) return;
+    if (!L.may_post_filter || L.shadow_delay) return;
     if (L.all_lowpass) {
         L.sqbuf[(long)s.head * L.S] = s.pre_capped * 0.9f;
     } else if (ab_any(L.m_lowpass)) {
@@ -212,6 +213,35 @@ AB_FSM_FN void sq_noise_floor(SqRegs& s, const Lane& L) {
     s.noise_floor = s.noise_floor * decay + lo * fresh + 1e-6f;
     s.cap = ab_lane(L.m_manual) ? 1.5f * L.manual_level : 1.5f * L.normal_ratio * s.noise_floor;
     s.lvl = sq_level_compute(s, L);
+}
+
+/* The squelch's delay line WITHOUT the delay line.  buffer_[buffer_head_] = pre_filter_.capped_ * 0.9 is written once per sample and read 101
+ * samples later (buffer_size_ 102, tail one ahead of head: src/squelch.cpp:66-69,218-219,453-456): 8 bytes of memory traffic per sample and channel
+ * for a value that is a pure function of the input stream -- the capped moving average depends on the samples, on its cap, and the cap on the
+ * noise floor, which depends on the capped average (calculate_noise_floor, every 16th sample).  The demod kernels have the input of 100 samples
+ * ago in hand anyway (the AGC_EXTRA-delayed stream that feeds the audio path), so a second copy of that little machine, fed one sample per
+ * sample and running 101 samples behind the squelch, holds the very floats the delay line would return: same operations, same order, same inputs.
+ * `phase` = the squelch's sample_count_ AFTER its increment; the shadow's own count is phase - 101, and it sweeps its noise floor when that is a
+ * multiple of 16.  The first 101 samples of a stream read the calloc'ed zeros of the reference's buffer: the caller returns 0 for them and starts
+ * feeding the shadow with squelch sample 0. */
+struct SqShadow {
+    float nf, cap, capped;
+};
+AB_FSM_FN float sq_shadow_value(const SqShadow& h) { return h.capped * 0.9f; }
+AB_FSM_FN void sq_shadow_step(SqShadow& h, const Lane& L, float x, unsigned phase) {
+    if (((phase - 101u) & 15u) == 0u) { /* calculate_noise_floor + calculate_moving_avg_cap: sq_noise_floor() without the level cache */
+        const float decay = 0.97f;
+        const float fresh = (float)(1.0 - (double)0.97f);
+        const float lo = h.capped < h.nf ? h.capped : h.nf;
+        h.nf = h.nf * decay + lo * fresh + 1e-6f;
+        h.cap = ab_lane(L.m_manual) ? 1.5f * L.manual_level : 1.5f * L.normal_ratio * h.nf;
+    }
+    const float decay = 0.99f;
+    const float fresh = (float)(1.0 - (double)0.99f);
+    const float xf = x * fresh;
+    const float v = h.capped * decay + xf;
+    const float vm = h.cap < v ? h.cap : v;
+    h.capped = (h.capped >= h.cap && x >= h.cap) ? h.cap : vm;
 }
 
 /* Squelch::process_raw_sample (src/squelch.cpp:195-246) of a QUIET wavefront: every lane is CLOSED or OPEN and asks for nothing.

@@ -21,7 +21,8 @@ unsigned char flags_of(const SqRegs& s) { /* same bit layout as the oracle's sq_
 
 extern "C" {
 
-// mode: 3 = as 0, but aligned groups of four samples of a stable "wavefront" go through sq_raw_stable4() (what the AM kind and the CTCSS front do;
+// mode: 5 = as 2, but the delay-line entry comes from the shadow moving average (squelch_fsm.h, SqShadow) instead of the stored line;
+// 3 = as 0, but aligned groups of four samples of a stable "wavefront" go through sq_raw_stable4() (what the AM kind and the CTCSS front do;
 // counts[4] = groups committed that way);
 // 0 = no lowpass (head/tail moved once at the end, as the AM/NFM kinds do), 1 = lowpass with the delay line read from
 // memory (generic kind), 2 = lowpass with the delay-line entry prefetched before the call (NFM+lowpass kind).
@@ -59,7 +60,7 @@ int hostfsm_run(float snr_db, int manual_dbfs, int mode, int chunk, const float*
 
     std::vector<float> sqbuf(AB_SQ_BUF, 0.0f);
     Lane L;
-    const bool lowpass = mode == 1 || mode == 2;
+    const bool lowpass = mode == 1 || mode == 2 || mode == 5;
     L.m_lowpass = ab_ballot(lowpass);
     L.m_manual = ab_ballot((cc.flags & AB_F_MANUAL) != 0);
     L.manual_level = cc.sq_manual_level;
@@ -68,10 +69,11 @@ int hostfsm_run(float snr_db, int manual_dbfs, int mode, int chunk, const float*
     L.m_flappy_lower = ab_ballot(cc.sq_flappy_ratio < cc.sq_normal_ratio);
     L.sqbuf = sqbuf.data();
     L.S = 1;
-    L.prefetched_delay = mode == 2;
+    L.prefetched_delay = mode == 2 || mode == 5;
     L.track_delay_line = lowpass;
     L.may_post_filter = lowpass;
     L.all_lowpass = false;
+    L.shadow_delay = mode == 5;
 
     uint64_t groups_committed = 0, *groups = &groups_committed;
     if (chunk <= 0) chunk = n;
@@ -80,6 +82,8 @@ int hostfsm_run(float snr_db, int manual_dbfs, int mode, int chunk, const float*
         SqRegs s;
         sq_load(s, L, &st, true);
         if (mode == 2) s.dly = sqbuf[s.tail];
+        SqShadow sh = {st.sh_nf, st.sh_cap, st.sh_capped};
+        if (mode == 5) s.dly = i0 >= 102 ? sq_shadow_value(sh) : 0.0f; /* what buffer_[tail] holds in front of sample i0: written by sample i0 - 102 */
         for (int i = i0; i < i0 + m; i++) {
             if (mode == 3 && ((s.sample_count + 1u) & 3u) == 0u && i + 4 <= i0 + m && sq_stable4(s) && sq_raw_stable4(s, L, raw + i)) {
                 /* a committed stable group: lane masks, noise floor and level are those of all four samples */
@@ -94,6 +98,10 @@ int hostfsm_run(float snr_db, int manual_dbfs, int mode, int chunk, const float*
             }
             float dly_new = 0.0f;
             if (mode == 2) dly_new = sqbuf[(s.tail + 1) % AB_SQ_BUF]; /* the entry the sample sees after its tail increment */
+            if (mode == 5) { /* sample i sees what sample i - 101 wrote: feed the shadow that sample, then read it */
+                if (i >= 101) sq_shadow_step(sh, L, raw[i - 101], (unsigned)i);
+                dly_new = i >= 101 ? sq_shadow_value(sh) : 0.0f;
+            }
             sq_raw(s, L, raw[i], dly_new);
             if (lowpass) sq_filtered(s, L, sq_should_filter(s), filtered[i]);
             if (flags) flags[i] = flags_of(s);
@@ -101,6 +109,7 @@ int hostfsm_run(float snr_db, int manual_dbfs, int mode, int chunk, const float*
             if (level) level[i] = sq_level(s);
         }
         sq_store(s, L, &st, m);
+        st.sh_nf = sh.nf; st.sh_cap = sh.cap; st.sh_capped = sh.capped;
     }
     out_state[0] = st.cur; out_state[1] = st.next; out_state[2] = st.delay; out_state[3] = st.low_count; out_state[4] = st.head; out_state[5] = st.tail;
     out_state[6] = st.using_post; out_state[7] = st.sample_count;

@@ -91,13 +91,13 @@ CASES = [(-1.0, 0), (6.0, 0), (-1.0, -70), (-1.0, -62)]
 
 @pytest.mark.parametrize("kind", ["keyed", "bursty", "flappy", "marginal"])
 @pytest.mark.parametrize("snr,manual", CASES)
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 5])
 def test_fsm_matches_oracle(harness, kind, snr, manual, mode):
     L = pyoracle.lib()
     n = 60000
     seed = 1000 * ["keyed", "bursty", "flappy", "marginal"].index(kind) + 100 * mode + 10 * int(abs(snr)) + abs(manual)
     raw, filt = streams(seed, n, kind)
-    want = run_oracle(L, "orc", snr, manual, mode in (1, 2), raw, filt)
+    want = run_oracle(L, "orc", snr, manual, mode in (1, 2, 5), raw, filt)
     for chunk in (0, 1000, 37):
         got = run_host(harness, snr, manual, mode, chunk, raw, filt)
         assert np.array_equal(got[0], want[0]), "flags differ at %d" % int(np.argmax(got[0] != want[0]))

@@ -162,3 +162,15 @@ def test_channelizer_waits_count_the_stores_it_really_issues(dft_asm):
     at = meta.index(".name:           _ZN7airband12_GLOBAL__N_122channelizer_dft_kernelILi512ELb1ELi320ELb0ELi16ELi1E")
     assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta[at:at + 1500]).group(1)) == 0
     assert int(re.search(r"\.vgpr_count:\s+(\d+)", meta[at:at + 1500]).group(1)) <= 256  # two waves per SIMD
+
+
+def test_specialised_demod_kinds_do_not_spill(demod_asm):
+    """The four specialised lane-per-channel kinds (AM, NFM, NFM + lowpass, CTCSS front) keep their per-channel state in registers: a change that makes one
+    of them spill vector registers (round 3: the stable-group block on the plain NFM kind, 143 of them) is a regression no parity test shows."""
+    text = "\n".join(demod_asm)
+    for k, ct in ((0, 0), (1, 0), (2, 0), (3, 1)):
+        name = "_ZN7airband12demod_kernelILi%dELb%dEEEvNS_9DemodArgsEi" % (k, ct)
+        at = text.index(".name:           " + name)
+        meta = text[at:at + 1500]
+        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1)) == 0, name
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1)) == 0, name
