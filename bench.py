@@ -235,6 +235,30 @@ def measure_traffic(args, kernel_substr):
             shutil.rmtree(out_dir, ignore_errors=True)
     detail["other_kernels"] = per_kernel
     detail["method"] = "rocprofv3 --pmc FETCH_SIZE x1024x2 + WRITE_SIZE x1024 (separate passes, launches 2.. of a 4-step child run of this command)"
+    # a third child pass, counters off: the profiler's own clock on the dominant kernel (`rocprofv3 --kernel-trace --stats`), next to the HIP events of
+    # the timed region -- the two disagree by a few per cent in either direction from box to box, so the line carries both
+    out_dir = tempfile.mkdtemp(prefix="airband_kt_", dir="/tmp")
+    try:
+        cmd = [rocprof, "--kernel-trace", "--stats", "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
+               "--child", "--no-verify-all", "--workload", args.workload, "--steps", "10", "--warmup", "2", "--ring", "1"]
+        if args.dongles:
+            cmd += ["--dongles", str(args.dongles)]
+        if args.sample_format != "u8":
+            cmd += ["--sample-format", args.sample_format]
+        if args.sample_rate != 2_560_000:
+            cmd += ["--sample-rate", str(args.sample_rate)]
+        if args.fft_log != 9:
+            cmd += ["--fft-log", str(args.fft_log)]
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=args.traffic_timeout, check=False)
+        for f in glob.glob(os.path.join(out_dir, "**", "*kernel_stats.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if kernel_substr in row.get("Name", ""):
+                    detail["rocprof_kernel_trace"] = dict(launches=int(row["Calls"]), avg_launch_ms=round(float(row["AverageNs"]) / 1e6, 4),
+                                                          min_launch_ms=round(float(row["MinNs"]) / 1e6, 4), max_launch_ms=round(float(row["MaxNs"]) / 1e6, 4))
+    except Exception as e:  # noqa: BLE001
+        detail["rocprof_kernel_trace"] = dict(error=repr(e))
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
     return total, detail
 
 
@@ -559,6 +583,17 @@ def main():
         traffic, detail = measure_traffic(args, CHANNELIZER_KERNEL.get(name, name))
         out["roofline"]["traffic"] = traffic
         out["roofline"]["traffic_detail"] = detail
+        kt = detail.pop("rocprof_kernel_trace", None) if isinstance(detail, dict) else None
+        if kt and "avg_launch_ms" in kt:  # the same algorithmic bytes over the profiler's average launch time
+            r = out["roofline"]
+            alg = r.get("algorithmic_bytes_per_launch")
+            if alg and r.get("bound") == "hbm":
+                kt["frac"] = round(alg / (kt["avg_launch_ms"] * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)
+                if r.get("frac_read_only") and r.get("avg_launch_ms"):
+                    kt["frac_read_only"] = round(r["frac_read_only"] * r["avg_launch_ms"] / kt["avg_launch_ms"], 4)
+            kt["note"] = "separate 12-step child run under rocprofv3 --kernel-trace --stats; `frac` above is from HIP events over the timed region"
+        if kt:
+            out["roofline"]["rocprof"] = kt
     if rank == 0:
         # RCCL prints its version banner through C stdio, which a pipe buffers until exit: push it out first so that the JSON is the LAST line
         try:

@@ -69,6 +69,9 @@ def main():
             extra.append("CPU reference %s Msamples/s on %s threads (%s; 1 thread %s; f64-FFT %s)" % (c["value"], c["cores"], c.get("fft"), c.get("value_1_thread"), c.get("value_f64_fft")))
         if j["roofline"].get("traffic"):
             extra.append("PMC traffic %.2f GB / launch" % (j["roofline"]["traffic"] / 1e9))
+        if j["roofline"].get("rocprof", {}).get("avg_launch_ms"):
+            rp = j["roofline"]["rocprof"]
+            extra.append("rocprofv3 clock on the channelizer: %.3f ms avg over %d launches = frac %s (read-only %s)" % (rp["avg_launch_ms"], rp["launches"], rp.get("frac"), rp.get("frac_read_only")))
         cfg = j["config"]
         if j.get("verify_all"):
             v = j["verify_all"]
