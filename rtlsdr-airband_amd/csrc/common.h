@@ -78,7 +78,10 @@ struct ChanState {
     /* the pre-filter average and noise floor as they stood 101 samples ago (squelch_fsm.h, SqShadow): the NFM + lowpass kind recomputes the
      * squelch's delay line from them instead of storing and re-reading it */
     float sh_nf, sh_cap, sh_capped;
-    int32_t pad[3];
+    /* what the channel's result row holds: bit 0 = its AGC_EXTRA carry is all zeros, bit 1 = its batch area is -- a channel that stays closed
+     * leaves both alone instead of rewriting 8 KiB of zeros per batch (demod.hip, RowZero) */
+    int32_t row_zero;
+    int32_t pad[2];
 };
 
 /* Per-dongle constants for the channelizer. */

@@ -91,7 +91,24 @@ struct WaveRow {
     float* out_wave;
     int wave_stride;
     bool coop;
+    int* skip_of;            /* LDS [64]: this run of the lane's channel is zeros over zeros (cooperative flush: the storing lanes look it up) */
 };
+
+/* Rows that stay zero are left alone.  A channel whose squelch is closed writes 0.0f for every sample -- 8 KiB of zeros per batch over the zeros of the
+ * batch before, plus the tail copy of zeros onto zeros: 40 % of the audio traffic at the BASELINE duty cycle.  ChanState::row_zero remembers what the
+ * row holds (bit 0: the AGC_EXTRA carry is all zeros, bit 1: the batch area is); a run of samples during which the channel was never open is skipped when
+ * the batch area was all zeros already, the tail copy when both are.  "Never open" means every sample was the literal 0.0f of the closed branch
+ * (emit_sample); an open sample that happens to be 0 counts as content. */
+struct RowZero {
+    int held;        /* ChanState::row_zero as loaded (after the tail copy: bit 0 = bit 1) */
+    bool run_open;   /* the channel was open somewhere in the run being staged */
+    bool batch_open; /* ... somewhere in the batch */
+};
+__device__ __forceinline__ bool row_skip_run(const RowZero& z) { return (z.held & 2) && !z.run_open; }
+__device__ __forceinline__ void row_run_done(RowZero& z) {
+    z.batch_open = z.batch_open || z.run_open;
+    z.run_open = false;
+}
 
 /* AGC_EXTRA = 100 floats in rounds of five 16-byte pieces: all 25 pieces at once were 100 live registers in front of the sample loop --
  * they set the kernels' register counts (back kernel 126 -> 96, AM kind 121 -> 108, NFM + lowpass 166 -> 157) and the back kernel staged
@@ -108,13 +125,22 @@ __device__ __forceinline__ void wave_tail_copy(float* row, int B) {
     }
 }
 
-__device__ __forceinline__ void wave_flush(const WaveRow& w, int n = RUN) { /* the finished run (n samples) -> row[j0 + AGC_EXTRA ...): 16-byte aligned by construction */
+__device__ __forceinline__ void row_tail_copy(RowZero& z, float* row, int B) { /* src/output.cpp:920, unless it would copy zeros onto zeros */
+    if ((z.held & 3) != 3) wave_tail_copy(row, B);
+    z.held = (z.held & 2) ? 3 : 0; /* the carry now holds the previous batch's tail: zeros if that batch was all zeros, else unknown */
+}
+
+__device__ __forceinline__ void wave_flush(const WaveRow& w, RowZero& z, int n = RUN) { /* the finished run (n samples) -> row[j0 + AGC_EXTRA ...): 16-byte aligned by construction */
+    const bool skip = row_skip_run(z);
+    row_run_done(z);
     if (w.coop) { /* wave-uniform */
         const int lane = threadIdx.x & 63, q = lane & 7;
+        w.skip_of[lane] = skip ? 1 : 0; /* (LDS operations of one wave complete in order: the lanes that store this channel's line read it below) */
         if (4 * q < n) {
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int c = i * 8 + (lane >> 3);
+                if (w.skip_of[c]) continue;
                 const float* src = w.stage_base + (4 * q) * OSTRIDE + c;
                 float4* dst = reinterpret_cast<float4*>(w.out_wave + (long)w.ext_of[c] * w.wave_stride + AB_OUT_PAD + AB_AGC_EXTRA + w.j0 + 4 * q);
                 *dst = make_float4(src[0], src[OSTRIDE], src[2 * OSTRIDE], src[3 * OSTRIDE]);
@@ -122,6 +148,7 @@ __device__ __forceinline__ void wave_flush(const WaveRow& w, int n = RUN) { /* t
         }
         return;
     }
+    if (skip) return;
     float4* dst = reinterpret_cast<float4*>(w.row + AB_AGC_EXTRA + w.j0);
 #pragma unroll
     for (int q = 0; q < RUN / 4; q++)
@@ -129,10 +156,11 @@ __device__ __forceinline__ void wave_flush(const WaveRow& w, int n = RUN) { /* t
         dst[q] = make_float4(w.staged[(4 * q) * w.stride], w.staged[(4 * q + 1) * w.stride], w.staged[(4 * q + 2) * w.stride], w.staged[(4 * q + 3) * w.stride]);
 }
 
-__device__ __forceinline__ void emit_sample(const DemodArgs& a, const ChanConst& cc, OutRegs& o, const WaveRow& w, float2* iqout, uint8_t* trace, int j, bool audio, bool fade,
+__device__ __forceinline__ void emit_sample(const DemodArgs& a, const ChanConst& cc, OutRegs& o, const WaveRow& w, RowZero& z, float2* iqout, uint8_t* trace, int j, bool audio, bool fade,
                                             bool tone, int state, float out, float re, float im, bool write_iq_always) {
     constexpr long S = AB_SLOT_BLOCK;
     if (AB_UNLIKELY(fade)) { /* AM, squelch just closing: waveout[k] = waveout[k-1] * 0.94 over the previous AGC_EXTRA-1 samples */
+        z.run_open = true; /* rewrites samples of the run being staged (and of runs that are in the row already) */
         float prev = w.row[j]; /* = output of sample j - AGC_EXTRA: left its run long ago */
 #pragma nounroll
         for (int k = j + 1; k < j + AB_AGC_EXTRA; k++) {
@@ -157,6 +185,7 @@ __device__ __forceinline__ void emit_sample(const DemodArgs& a, const ChanConst&
          * inputs, unchanged -- in a single instruction */
         out = (out != out) ? 0.0f : __builtin_amdgcn_fmed3f(out, -1.0f, 1.0f);
         o.axc = '*';
+        z.run_open = true;
     } else {
         out = 0.0f;
     }
@@ -182,7 +211,7 @@ struct KindBits {
 };
 
 template <int KIND, bool WAVE_HAS_CTCSS>
-__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, const float2* lut, float* ostage, const int* ext_of, bool full_block) {
+__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, const float2* lut, float* ostage, const int* ext_of, int* skip_of, bool full_block) {
     const int lane = threadIdx.x & 63;
     constexpr long S = AB_SLOT_BLOCK;
     const int R = a.ring_rows, B = a.wave_batch;
@@ -247,10 +276,12 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     wrow.out_wave = a.out_wave;
     wrow.wave_stride = a.wave_stride;
     wrow.coop = full_block;
+    wrow.skip_of = skip_of;
+    RowZero rz = {sp->row_zero, false, false};
     float2* iqout = a.iq_out + ab_ring_base(slot, B);
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
     wrow.staged = ostage + lane; /* [RUN][OSTRIDE] floats behind the sincos table */
-    if (!WAVE_HAS_CTCSS && a.tail_copy) wave_tail_copy(wrow.row, B); /* src/output.cpp:920; the back kernel does it for the split kinds */
+    if (!WAVE_HAS_CTCSS && a.tail_copy) row_tail_copy(rz, wrow.row, B); /* src/output.cpp:920; the back kernel does it for the split kinds */
     /* split kinds: what the tone / back kernels need of every sample, channel-major [ct slot][sample].
      * NFM + CTCSS (the kind that matters: every CTCSS channel of a plain NFM plan): ONE 32-bit word per sample, HAND_WORD below.
      * Generic kind (AM + CTCSS, raw-I/Q outputs, lowpass + CTCSS): (audio, flags) pairs -- it also has an AM fade-out flag to carry. */
@@ -456,7 +487,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             hand[((j & (HAND_RUN - 1)) * OSTRIDE)] = make_float2(out, __uint_as_float(f));
             if ((cc.flags & AB_F_IQ_OUT) && audio) iqout[(long)j * S] = make_float2(re, im);
         } else {
-            emit_sample(a, cc, o, wrow, iqout, trace, j, audio, fade, true, state, out, re, im, true);
+            emit_sample(a, cc, o, wrow, rz, iqout, trace, j, audio, fade, true, state, out, re, im, true);
         }
     };
     auto sample = [&](const int j, const float cur_mag, const float delayed_mag /* lowpass kind: the prefetched delay-line entry */, const float re, const float im, const bool first_of_group) {
@@ -508,6 +539,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                     out4[r] = (out != out) ? 0.0f : __builtin_amdgcn_fmed3f(out, -1.0f, 1.0f);
                 }
                 o.axc = '*';
+                rz.run_open = true;
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) wrow.staged[(jq + r - wrow.j0) * wrow.stride] = out4[r];
@@ -612,7 +644,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
      * full (write acknowledgements take microseconds) before the next group could start.  GS is 4 and the runs are 32 (audio)
      * or 16 (hand-off) samples long, so a run can only end with a group. */
     auto flush = [&](int j0) {
-        if (!WAVE_HAS_CTCSS && ((j0 + GS) % RUN) == 0) wave_flush(wrow);
+        if (!WAVE_HAS_CTCSS && ((j0 + GS) % RUN) == 0) wave_flush(wrow, rz);
         if (WAVE_HAS_CTCSS && ((j0 + GS) % HAND_RUN) == 0) hand_flush(HAND_RUN, j0 + GS - HAND_RUN);
     };
 
@@ -634,7 +666,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         flush(j0 + GS);
     }
 
-    if (!WAVE_HAS_CTCSS && (B % RUN) != 0) wave_flush(wrow, B % RUN); /* WAVE_BATCH = 1000: the last run is a short one */
+    if (!WAVE_HAS_CTCSS && (B % RUN) != 0) wave_flush(wrow, rz, B % RUN); /* WAVE_BATCH = 1000: the last run is a short one */
     if (WAVE_HAS_CTCSS && (B % HAND_RUN) != 0) hand_flush(B % HAND_RUN, B - B % HAND_RUN);
     if (!WAVE_HAS_CTCSS) { /* the back kernel owns these in the split kinds */
         if (o.axc != ' ') sp->active_counter++;
@@ -642,6 +674,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         sp->axc = o.axc;
         a.out_axc[ext] = (uint8_t)o.axc;
         sp->nx[0] = o.nx0; sp->nx[1] = o.nx1; sp->nx[2] = o.nx2; sp->ny[0] = o.ny0; sp->ny[1] = o.ny1; sp->ny[2] = o.ny2;
+        sp->row_zero = rz.batch_open ? 0 : ((rz.held & 1) | 2); /* an open batch may also have faded into the carry */
     }
     sp->agcavgfast = agc; sp->pr = pr; sp->pj = pj; sp->prev_waveout = prev_out; sp->dm_phi = dm_phi;
     if (KIND == AB_KIND_NFM_LOWPASS) { sp->sh_nf = sh.nf; sp->sh_cap = sh.cap; sp->sh_capped = sh.capped; }
@@ -672,10 +705,11 @@ __device__ __forceinline__ void demod_block(const DemodArgs& a, int block, float
     }
     float* ostage = reinterpret_cast<float*>(lut + (KIND == AB_KIND_AM ? 0 : 258));
     int* ext_of = reinterpret_cast<int*>(ostage + RUN * OSTRIDE);
+    int* skip_of = ext_of + 64;
     ext_of[threadIdx.x] = a.slot_to_ext[slot];
     const bool full_block = __ballot((cc.flags & AB_F_VALID) != 0) == ~0ull; /* padding lanes leave early and cannot take part in a cooperative store */
     __syncthreads();
-    demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lut, ostage, ext_of, full_block);
+    demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lut, ostage, ext_of, skip_of, full_block);
 }
 
 template <int KIND, bool WAVE_HAS_CTCSS>
@@ -862,6 +896,7 @@ template <bool PACKED>
 __global__ __launch_bounds__(64) void back_kernel(DemodArgs a, int first_block) {
     __shared__ float staged[RUN][OSTRIDE];
     __shared__ int ext_of[64];
+    __shared__ int skip_of[64];
     const int lane = threadIdx.x;
     const int slot = (first_block + blockIdx.x) * 64 + lane;
     const ChanConst cc = a.cc[slot];
@@ -885,7 +920,9 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a, int first_block) 
     w.out_wave = a.out_wave;
     w.wave_stride = a.wave_stride;
     w.coop = full_block;
-    if (a.tail_copy) wave_tail_copy(w.row, B); /* src/output.cpp:920 */
+    w.skip_of = skip_of;
+    RowZero rz = {sp->row_zero, false, false};
+    if (a.tail_copy) row_tail_copy(rz, w.row, B); /* src/output.cpp:920 */
     float2* iqout = a.iq_out + ab_ring_base(slot, B);
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
     /* every lane walks its own contiguous (channel-major) hand-off row, 8 samples = 4 x 16 bytes ahead: all bytes of the
@@ -921,7 +958,7 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a, int first_block) 
         unsigned long long mask = is_ct ? nm_lo : ~0ull;
         const unsigned long long mask_hi = is_ct ? nm_hi : ~0ull;
         fetch(j0 + PIECE < B ? j0 + PIECE : B - PIECE);
-        if (j0 > 0 && (j0 % RUN) == 0) wave_flush(w);
+        if (j0 > 0 && (j0 % RUN) == 0) wave_flush(w, rz);
         if ((j0 % RUN) == 0) w.j0 = j0;
 #pragma unroll
         for (int u = 0; u < PIECE; u++) {
@@ -932,12 +969,12 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a, int first_block) 
                 const bool au = hand_is_audio(wd);
                 /* the squelch state the trace records was left in the trace buffer by the front kernel (debug handles only) */
                 const int st = trace ? (int)(trace[(long)(j0 + u) * AB_SLOT_BLOCK] & 7u) : 0;
-                emit_sample(a, cc, o, w, iqout, trace, j0 + u, au, false, tone, st, au ? __uint_as_float(wd) : 0.0f, 0.0f, 0.0f, false);
+                emit_sample(a, cc, o, w, rz, iqout, trace, j0 + u, au, false, tone, st, au ? __uint_as_float(wd) : 0.0f, 0.0f, 0.0f, false);
             } else {
                 const float4 p = cur[u >> 1];
                 const float x = (u & 1) ? p.z : p.x;
                 const unsigned f = __float_as_uint((u & 1) ? p.w : p.y);
-                emit_sample(a, cc, o, w, iqout, trace, j0 + u, (f & FL_AUDIO) != 0, (f & FL_FADE) != 0, tone, (int)((f >> FL_STATE_SHIFT) & 7u), x, 0.0f, 0.0f, false);
+                emit_sample(a, cc, o, w, rz, iqout, trace, j0 + u, (f & FL_AUDIO) != 0, (f & FL_FADE) != 0, tone, (int)((f >> FL_STATE_SHIFT) & 7u), x, 0.0f, 0.0f, false);
             }
             if (++jg == TONE_GROUP) { /* wave-uniform: every lane is on the same sample */
                 jg = 0;
@@ -945,8 +982,9 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a, int first_block) 
             }
         }
     }
-    if ((B % RUN) == 0) wave_flush(w); /* the last whole run (a short one is handled below) */
-    if ((B % RUN) != 0) wave_flush(w, B % RUN);
+    if ((B % RUN) == 0) wave_flush(w, rz); /* the last whole run (a short one is handled below) */
+    if ((B % RUN) != 0) wave_flush(w, rz, B % RUN);
+    sp->row_zero = rz.batch_open ? 0 : ((rz.held & 1) | 2);
     if (o.axc != ' ') sp->active_counter++;
     sp->axc_prev = sp->axc;
     sp->axc = o.axc;
@@ -961,7 +999,7 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a, int first_block) 
 
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev) {
     auto lds_of = [](int k) { /* sincos table, output-line staging, ext_of */
-        return (size_t)(k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)RUN * OSTRIDE * sizeof(float) + 64 * sizeof(int);
+        return (size_t)(k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)RUN * OSTRIDE * sizeof(float) + 2 * 64 * sizeof(int); /* ext_of, skip_of */
     };
     auto launch_kind = [&](int k, hipStream_t s) {
         const size_t lds = lds_of(k);

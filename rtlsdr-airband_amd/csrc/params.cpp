@@ -224,6 +224,7 @@ int build_plan(const airband_hip_config* cfg, Plan& p) {
             s.cap = manual ? 1.5f * c.sq_manual_level : 1.5f * c.sq_normal_ratio * s.noise_floor; /* src/squelch.cpp:492-499 */
             s.pre_full = s.pre_capped = s.post_full = s.post_capped = 0.001f;
             s.sh_nf = s.noise_floor; s.sh_cap = s.cap; s.sh_capped = s.pre_capped; /* the same machine, 101 samples behind */
+            s.row_zero = 2; /* result rows start as zeros behind a carry prefilled with 0.5 (airband_hip.cpp, src/config.cpp:313-316) */
             s.level_cache = 0.0f;
             s.next = s.cur = AB_ST_CLOSED;
             s.sample_count = 0xffffffffu;
