@@ -52,7 +52,8 @@ struct ChanConst {
     int32_t ct_slot;                           /* index into the CTCSS tone tables, -1 = none */
     int32_t ct_ntones[2];                      /* [0] fast detector, [1] slow detector */
     int32_t ct_window[2];
-    int32_t pad[2];
+    float lp_rgain;     /* RN(1 / lp_gain) when x * r corrected once is the correctly rounded x / lp_gain for every x (params.cpp, div_const_reciprocal), else 0 */
+    int32_t pad[1];
 };
 
 /* Per-channel mutable state that survives from batch to batch. */

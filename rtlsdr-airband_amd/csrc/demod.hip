@@ -29,6 +29,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "squelch_fsm.h"
+#include "exact_math.h"
 
 namespace airband {
 
@@ -263,6 +264,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     float lyr0 = sp->lyr[0], lyr1 = sp->lyr[1], lyr2 = sp->lyr[2], lyi0 = sp->lyi[0], lyi1 = sp->lyi[1], lyi2 = sp->lyi[2];
 
     const float one_minus_alpha = 1.0f - cc.alpha;
+    const float div_lo = cc.lp_rgain != 0.0f ? AB_DIV_CONST_LO : __builtin_inff(); /* exact_math.h: the range in which x / lp_gain is three instructions */
 
     float* mag = a.mag + ab_tile_base(slot, R / AB_TILE_ROWS);        /* tile-transposed rings: row r at ab_tile_off(r) */
     const float2* iqin = a.iq + ab_tile_base(slot, R / AB_TILE_ROWS);
@@ -408,7 +410,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                 if (lowpass) { /* LowpassFilter::apply (src/filters.cpp:146-163) */
                     lxr0 = lxr1; lxi0 = lxi1;
                     lxr1 = lxr2; lxi1 = lxi2;
-                    lxr2 = tr / cc.lp_gain; lxi2 = ti / cc.lp_gain;
+                    ab_div_const2(tr, ti, cc.lp_gain, cc.lp_rgain, div_lo, lxr2, lxi2); /* tr / gain, ti / gain */
                     lyr0 = lyr1; lyi0 = lyi1;
                     lyr1 = lyr2; lyi1 = lyi2;
                     lyr2 = (lxr0 + lxr2) + (2.0f * lxr1) + (cc.lp_yc0 * lyr0) + (cc.lp_yc1 * lyr1);
@@ -418,7 +420,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                 }
                 re = tr;
                 im = ti;
-                cur_mag = sqrtf(re * re + im * im); /* double sqrt rounded to float == correctly rounded sqrtf */
+                cur_mag = ab_sqrt_rn(re * re + im * im); /* double sqrt rounded to float == correctly rounded sqrtf (exact_math.h) */
                 /* the reference overwrites wavein[j] here (src/rtl_airband.cpp:524); only AM reads it back later */
                 if (!nfm) mag[ab_tile_off(ring_row(a.row0 + AB_AGC_EXTRA + j, R))] = cur_mag;
             }
@@ -606,10 +608,9 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                 mcs[0] = q.mc[g].x; mcs[1] = q.mc[g].y; mcs[2] = q.mc[g].z; mcs[3] = q.mc[g].w;
                 mds[0] = q.md[g].x; mds[1] = q.md[g].y; mds[2] = q.md[g].z; mds[3] = q.md[g].w;
             } else {
-                mcs[0] = sqrtf(q.c01[g].x * q.c01[g].x + q.c01[g].y * q.c01[g].y);
-                mcs[1] = sqrtf(q.c01[g].z * q.c01[g].z + q.c01[g].w * q.c01[g].w);
-                mcs[2] = sqrtf(q.c23[g].x * q.c23[g].x + q.c23[g].y * q.c23[g].y);
-                mcs[3] = sqrtf(q.c23[g].z * q.c23[g].z + q.c23[g].w * q.c23[g].w);
+                const float pw[4] = {q.c01[g].x * q.c01[g].x + q.c01[g].y * q.c01[g].y, q.c01[g].z * q.c01[g].z + q.c01[g].w * q.c01[g].w,
+                                     q.c23[g].x * q.c23[g].x + q.c23[g].y * q.c23[g].y, q.c23[g].z * q.c23[g].z + q.c23[g].w * q.c23[g].w};
+                ab_sqrt_rn4(pw, mcs); /* sqrtf of each, correctly rounded (exact_math.h) */
             }
             if (raw_iq) {
                 qr[0] = q.q01[g].x; qi[0] = q.q01[g].y; qr[1] = q.q01[g].z; qi[1] = q.q01[g].w;
@@ -621,11 +622,14 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                  * takes in this iteration's AGC_EXTRA-delayed sample, the squelch's input of 100 samples ago: the magnitude of the very raw bin the
                  * squelch computed it from.  (The first 101 samples of a stream see the zeros of a fresh buffer; the shadow starts with squelch sample 0.) */
                 const unsigned c0 = s.sample_count; /* before the group's first increment */
+                const float dpw[4] = {qr[0] * qr[0] + qi[0] * qi[0], qr[1] * qr[1] + qi[1] * qi[1], qr[2] * qr[2] + qi[2] * qi[2], qr[3] * qr[3] + qi[3] * qi[3]};
+                float dmag[4];
+                ab_sqrt_rn4(dpw, dmag);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int j = jq + r;
                     mds[r] = (first_batch && j < 101) ? 0.0f : sq_shadow_value(sh);
-                    if (!(first_batch && j < AB_AGC_EXTRA)) sq_shadow_step(sh, L, sqrtf(qr[r] * qr[r] + qi[r] * qi[r]), c0 + (unsigned)r + 2u);
+                    if (!(first_batch && j < AB_AGC_EXTRA)) sq_shadow_step(sh, L, dmag[r], c0 + (unsigned)r + 2u);
                 }
             }
             if ((jq % RUN) == 0) wrow.j0 = jq;

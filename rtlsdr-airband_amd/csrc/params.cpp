@@ -6,12 +6,14 @@
  * very same float constants.
  */
 #include "params.h"
+#include "exact_math.h"
 
 #include <algorithm>
 #include <climits>
 #include <cmath>
 #include <complex>
 #include <cstring>
+#include <map>
 
 namespace airband {
 
@@ -89,6 +91,23 @@ void design_lowpass(float cutoff, float rate, float& gain, float& yc0, float& yc
     yc1 = (float)(-(bot[1].real() / bot[2].real()));
 }
 
+}  // namespace
+
+/* exact_math.h, ab_div_const_core(): the reciprocal to hand the kernels for divisor g, or 0 if the three-instruction division is not the IEEE one
+ * for every dividend.  Every significand of one binade of x is tried (the operations scale exactly with x's exponent inside the range the
+ * kernels use them in); sign symmetry holds operation by operation. */
+float div_const_reciprocal(float g) {
+    if (!(g >= 0x1p-40f && g <= 0x1p40f)) return 0.0f; /* (also NaN) keeps q, e and their products far from the ends of the exponent range */
+    const float r = (float)(1.0 / (double)g);          /* double division, one more rounding: RN(1 / g) (1 / g is never within 2^-53 of a float midpoint) */
+    for (uint32_t m = 0; m < (1u << 23); m++) {
+        const float x = ab_float(0x3f800000u | m);
+        if (ab_bits(ab_div_const_core(x, g, r)) != ab_bits(x / g)) return 0.0f;
+    }
+    return r;
+}
+
+namespace {
+
 int fail(Plan& p, int code, const std::string& msg) {
     p.error = msg;
     return code;
@@ -105,6 +124,7 @@ int build_plan(const airband_hip_config* cfg, Plan& p) {
     if (cfg->device_count < 1 || !cfg->devices) return fail(p, AIRBAND_HIP_EBADSIZE, "device_count must be >= 1");
     if (cfg->fm_demod != AIRBAND_FM_FAST_ATAN2 && cfg->fm_demod != AIRBAND_FM_QUADRI_DEMOD) return fail(p, AIRBAND_HIP_EINVAL, "unknown fm_demod");
 
+    std::map<uint32_t, float> rgain_of; /* lowpass gain (bits) -> div_const_reciprocal(): a plan has a handful of distinct gains, the check takes ~70 ms each */
     p.fft_log = cfg->fft_size_log;
     p.fft_size = 1 << cfg->fft_size_log;
     p.wave_rate = cfg->wave_rate;
@@ -260,6 +280,9 @@ int build_plan(const airband_hip_config* cfg, Plan& p) {
                 if (ch.bandwidth_hz > 0) {
                     design_lowpass((float)ch.bandwidth_hz / 2, rate, c.lp_gain, c.lp_yc0, c.lp_yc1);
                     c.flags |= AB_F_LOWPASS;
+                    auto known = rgain_of.find(ab_bits(c.lp_gain));
+                    if (known == rgain_of.end()) known = rgain_of.emplace(ab_bits(c.lp_gain), div_const_reciprocal(c.lp_gain)).first;
+                    c.lp_rgain = known->second;
                 }
             }
             if (ch.has_iq_outputs) c.flags |= AB_F_IQ_OUT | AB_F_RAW_IQ;

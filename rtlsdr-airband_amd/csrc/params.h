@@ -51,6 +51,9 @@ int build_plan(const airband_hip_config* cfg, Plan& plan);
  * to the device (retune kernel); their slots exist (item_bset, n_bsets) but plan.bfrag / bcorr hold the shared tables only. */
 void build_dft_tables(Plan& plan, bool host_private = true);
 
+/* exact_math.h: RN(1 / g) if x * r corrected once equals the IEEE x / g for every x (all 2^23 significands are tried, ~70 ms), else 0 */
+float div_const_reciprocal(float g);
+
 /* The 16 "derived constants" slots documented at airband_hip_channel_constants(). */
 void channel_constants(const Plan& plan, int ext_index, double* out16);
 /* host-only: largest error (relative to the RMS of the exact values) of the matrix-core coefficient tables on `windows` pseudo-random windows per work item */
