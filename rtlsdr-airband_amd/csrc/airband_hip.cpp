@@ -132,7 +132,7 @@ struct airband_hip_handle {
     std::mutex host_init_lock;
 
     /* dongles switched off with airband_hip_device_enable(): skipped by the availability rule and by both stages */
-    std::vector<uint8_t> dev_enabled;
+    std::unique_ptr<std::atomic<uint8_t>[]> dev_enabled; /* (atomic: a feeder thread's submit() reads its dongle's flag while the demod thread switches it) */
     int n_enabled = 0;
     std::vector<ChanConst> cc_slots; /* host copy of d_cc (slot order): the VALID bit of a dongle's slots follows its enable state */
 
@@ -223,12 +223,6 @@ void destroy(airband_hip_handle* h) {
         if (st) (void)hipStreamDestroy(st);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
-}
-
-template <class T>
-hipError_t fill(T* p, size_t n, T value, hipStream_t s) {
-    std::vector<T> v(n, value);
-    return hipMemcpyAsync(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice, s);
 }
 
 /* Results of a batch that ran on a caller's stream: make the handle's own stream (on which collect / read_* / the stats kernel
@@ -587,8 +581,12 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     PREP_TRY(h->d_iq.alloc(ring), AIRBAND_HIP_ENOMEM);
     PREP_TRY(h->d_iq_out.alloc((size_t)h->B * h->n_slots), AIRBAND_HIP_ENOMEM);
     PREP_TRY(h->d_sqbuf.alloc((size_t)AB_SQ_BUF * h->n_slots), AIRBAND_HIP_ENOMEM);
-    PREP_TRY(fill(h->d_mag.p, ring, 20.0f, h->stream), AIRBAND_HIP_ENOMEM);
-    PREP_TRY(hipStreamSynchronize(h->stream), AIRBAND_HIP_ENOMEM);
+    {
+        const float lead_in = 20.0f; /* wavein[0 .. AGC_EXTRA) = 20.0f, src/config.cpp:313-316 (as a 32-bit pattern: no host copy of the rings, 4 GB at 65 536 dongles) */
+        int bits;
+        std::memcpy(&bits, &lead_in, sizeof(bits));
+        PREP_TRY(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(h->d_mag.p), bits, ring), AIRBAND_HIP_ENOMEM);
+    }
     PREP_TRY(hipMemset(h->d_iq.p, 0, ring * sizeof(float2)), AIRBAND_HIP_ENOMEM);
     PREP_TRY(hipMemset(h->d_iq_out.p, 0, (size_t)h->B * h->n_slots * sizeof(float2)), AIRBAND_HIP_ENOMEM);
     PREP_TRY(hipMemset(h->d_sqbuf.p, 0, (size_t)AB_SQ_BUF * h->n_slots * sizeof(float)), AIRBAND_HIP_ENOMEM);
@@ -611,10 +609,17 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
      * WAVE_BATCH entries.  Config-time prefill of the lead-in as in src/config.cpp:313-316 (waveout[0..AGC_EXTRA) = 0.5). */
     h->wave_stride = (AB_OUT_PAD + AB_AGC_EXTRA + h->B + AB_OUT_RUN - 1) / AB_OUT_RUN * AB_OUT_RUN; /* whole 128-byte lines per row */
     {
-        std::vector<float> rows((size_t)p.total_ch * h->wave_stride, 0.0f);
-        for (int c = 0; c < p.total_ch; c++)
-            for (int k = 0; k < AB_AGC_EXTRA; k++) rows[(size_t)c * h->wave_stride + AB_OUT_PAD + k] = 0.5f;
-        PREP_TRY(upload(h->d_out_wave, rows), AIRBAND_HIP_ENOMEM);
+        PREP_TRY(h->d_out_wave.alloc((size_t)p.total_ch * h->wave_stride), AIRBAND_HIP_ENOMEM);
+        PREP_TRY(hipMemset(h->d_out_wave.p, 0, h->d_out_wave.n * sizeof(float)), AIRBAND_HIP_ENOMEM);
+        /* the lead-in columns, a few thousand rows per strided copy (not a host image of every row: 4.5 GB at 65 536 dongles) */
+        const int chunk = p.total_ch < 4096 ? p.total_ch : 4096;
+        const std::vector<float> lead((size_t)chunk * AB_AGC_EXTRA, 0.5f);
+        for (int c = 0; c < p.total_ch; c += chunk) {
+            const int rows = p.total_ch - c < chunk ? p.total_ch - c : chunk;
+            PREP_TRY(hipMemcpy2D(h->d_out_wave.p + (size_t)c * h->wave_stride + AB_OUT_PAD, (size_t)h->wave_stride * sizeof(float), lead.data(), AB_AGC_EXTRA * sizeof(float),
+                                 AB_AGC_EXTRA * sizeof(float), (size_t)rows, hipMemcpyHostToDevice),
+                     AIRBAND_HIP_ENOMEM);
+        }
     }
     PREP_TRY(h->d_out_axc.alloc((size_t)p.total_ch), AIRBAND_HIP_ENOMEM);
     bool any_iq_out = false;
@@ -671,7 +676,8 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     }
     h->ring_wr.reset(new std::atomic<uint64_t>[p.n_dev]);
     for (int d = 0; d < p.n_dev; d++) h->ring_wr[d].store(0);
-    h->dev_enabled.assign(p.n_dev, 1);
+    h->dev_enabled.reset(new std::atomic<uint8_t>[p.n_dev]);
+    for (int d = 0; d < p.n_dev; d++) h->dev_enabled[d].store(1);
     h->n_enabled = p.n_dev;
     h->cc_slots = cc_slots;
 #undef PREP_TRY
@@ -721,6 +727,10 @@ int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const air
         ml[k] = in[i].ampfactor * fminf(1.0f, 1.0f - in[i].balance); /* src/mixer.cpp:82-83,203-208 */
         mr[k] = in[i].ampfactor * fminf(1.0f, 1.0f + in[i].balance);
     }
+    order_behind_last_batch(h);
+    HIP_TRY(h, hipStreamSynchronize(h->stream), AIRBAND_HIP_ERUNTIME); /* a batch under way still sums the old wiring */
+    h->n_mixers = 0; /* until the new wiring is complete: a failure below leaves a handle without mixers, not one with freed tables */
+    h->n_mix_runs = 0;
     h->d_mix_chan.release(); h->d_mix_first.release(); h->d_mix_ml.release(); h->d_mix_mr.release();
     h->d_mix_left.release(); h->d_mix_right.release(); h->d_mix_stereo.release(); h->d_mix_signal.release();
     h->d_mix_run_first.release(); h->d_mix_run_mixer.release(); h->d_mix_first_run.release();
@@ -735,13 +745,13 @@ int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const air
     }
     first_run[mixer_count] = (int)run_mixer.size();
     run_first.push_back(n_in);
-    h->n_mix_runs = (int)run_mixer.size();
+    const int n_runs = (int)run_mixer.size();
     HIP_TRY(h, upload(h->d_mix_run_first, run_first), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, upload(h->d_mix_run_mixer, run_mixer), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, upload(h->d_mix_first_run, first_run), AIRBAND_HIP_ENOMEM);
-    HIP_TRY(h, h->d_mix_run_left.alloc((size_t)h->n_mix_runs * h->B), AIRBAND_HIP_ENOMEM);
-    HIP_TRY(h, h->d_mix_run_right.alloc((size_t)h->n_mix_runs * h->B), AIRBAND_HIP_ENOMEM);
-    HIP_TRY(h, h->d_mix_run_signal.alloc((size_t)h->n_mix_runs), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, h->d_mix_run_left.alloc((size_t)n_runs * h->B), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, h->d_mix_run_right.alloc((size_t)n_runs * h->B), AIRBAND_HIP_ENOMEM);
+    HIP_TRY(h, h->d_mix_run_signal.alloc((size_t)n_runs), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, upload(h->d_mix_chan, chan), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, upload(h->d_mix_first, first), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, upload(h->d_mix_ml, ml), AIRBAND_HIP_ENOMEM);
@@ -752,10 +762,11 @@ int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const air
     HIP_TRY(h, h->d_mix_signal.alloc((size_t)mixer_count), AIRBAND_HIP_ENOMEM);
     h->mix_chan_host = chan;
     h->mix_user_on.assign(n_in, 1);
-    h->n_mixers = mixer_count;
     for (int k = 0; k < n_in; k++) /* inputs of dongles that are already switched off stay out */
         if (!h->dev_enabled[p.cc[chan[k]].dev]) HIP_TRY(h, write_mix_input(h, k), AIRBAND_HIP_ERUNTIME);
     HIP_TRY(h, hipStreamSynchronize(h->stream), AIRBAND_HIP_ERUNTIME);
+    h->n_mix_runs = n_runs;
+    h->n_mixers = mixer_count;
     return AIRBAND_HIP_OK;
 }
 
@@ -775,7 +786,7 @@ int airband_hip_device_enable(airband_hip_handle* h, int32_t dev, int32_t enable
     const Plan& p = h->plan;
     if (dev < 0 || dev >= p.n_dev) return fail(h, AIRBAND_HIP_EINVAL, "device index out of range");
     const uint8_t on = enabled ? 1 : 0;
-    if (h->dev_enabled[dev] == on) return AIRBAND_HIP_OK;
+    if (h->dev_enabled[dev].load() == on) return AIRBAND_HIP_OK;
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
     hipStream_t s = h->stream;
     order_behind_last_batch(h);
@@ -792,7 +803,7 @@ int airband_hip_device_enable(airband_hip_handle* h, int32_t dev, int32_t enable
     }
     /* channel->axcindicate of a device that is not demodulated any more: NO_SIGNAL */
     if (!on) HIP_TRY(h, hipMemcpyAsync(h->d_out_axc.p + c0, blank.data(), (size_t)nc, hipMemcpyHostToDevice, s), AIRBAND_HIP_ERUNTIME);
-    h->dev_enabled[dev] = on;
+    h->dev_enabled[dev].store(on);
     h->n_enabled += on ? 1 : -1;
     /* its mixer connections: mixer_disable_input() for every output of the device, as disable_device_outputs() does (src/output.cpp, src/mixer.cpp:96-110) */
     for (size_t k = 0; k < h->mix_chan_host.size(); k++)
@@ -914,7 +925,8 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
     if (!h->pipeline) {
         hipStream_t s = stream ? (hipStream_t)stream : h->stream;
         h->last_stream = s;
-        launch_front(h, d_iq, stride_bytes, s);
+        const int rc_front = launch_front(h, d_iq, stride_bytes, s);
+        if (rc_front != AIRBAND_HIP_OK) return rc_front;
         const int rc = run_back_half(h, s);
         if (s != h->stream) { /* collect() and friends run on h->stream: give them something to wait for */
             if (!h->ev_last) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
@@ -939,7 +951,8 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
         HIP_TRY(h, hipStreamWaitEvent(h->front, h->ev_back, 0), AIRBAND_HIP_ERUNTIME);
     }
     const uint64_t k = h->front_batches;
-    launch_front(h, d_iq, stride_bytes, h->front);
+    const int rc_front = launch_front(h, d_iq, stride_bytes, h->front);
+    if (rc_front != AIRBAND_HIP_OK) return rc_front;
     HIP_TRY(h, hipEventRecord(h->front_done[k & 1], h->front), AIRBAND_HIP_ERUNTIME);
     /* nothing to demodulate yet -- the very first call, or the first call after airband_hip_flush() drained the pipeline:
      * the results of this batch appear with the next call (or flush) */
