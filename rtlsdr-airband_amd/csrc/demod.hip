@@ -35,6 +35,17 @@ namespace airband {
 
 namespace {
 
+/* "These vector registers are needed now": an empty asm statement that names them, so that the compiler's wait for the loads that fill them lands
+ * HERE (see demod_wave: before the next group's loads are issued).  The file also compiles as plain C++ for tests/host_demod_harness.cpp, where there
+ * is nothing to wait for. */
+#if defined(__HIPCC__)
+#define AB_NEEDED_NOW(...) asm volatile("" ::__VA_ARGS__)
+#define AB_V(x) "v"(x)
+#else
+#define AB_NEEDED_NOW(...) ((void)0)
+#define AB_V(x) 0
+#endif
+
 /* per-sample flag word parked in LDS between the phases */
 constexpr unsigned FL_AUDIO = 1u;   /* Squelch::should_process_audio()                        */
 constexpr unsigned FL_FADE = 2u;    /* AM last_open_sample(): fade out the previous AGC_EXTRA */
@@ -374,9 +385,9 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     auto touch = [&](const Group& q) {
 #pragma unroll
         for (int g = 0; g < GQ; g++) {
-            if (!nfm) asm volatile("" ::"v"(q.mc[g].x), "v"(q.mc[g].y), "v"(q.mc[g].z), "v"(q.mc[g].w), "v"(q.md[g].x), "v"(q.md[g].y), "v"(q.md[g].z), "v"(q.md[g].w));
-            else asm volatile("" ::"v"(q.c01[g].x), "v"(q.c01[g].y), "v"(q.c01[g].z), "v"(q.c01[g].w), "v"(q.c23[g].x), "v"(q.c23[g].y), "v"(q.c23[g].z), "v"(q.c23[g].w));
-            if (raw_iq) asm volatile("" ::"v"(q.q01[g].x), "v"(q.q01[g].y), "v"(q.q01[g].z), "v"(q.q01[g].w), "v"(q.q23[g].x), "v"(q.q23[g].y), "v"(q.q23[g].z), "v"(q.q23[g].w));
+            if (!nfm) AB_NEEDED_NOW(AB_V(q.mc[g].x), AB_V(q.mc[g].y), AB_V(q.mc[g].z), AB_V(q.mc[g].w), AB_V(q.md[g].x), AB_V(q.md[g].y), AB_V(q.md[g].z), AB_V(q.md[g].w));
+            else AB_NEEDED_NOW(AB_V(q.c01[g].x), AB_V(q.c01[g].y), AB_V(q.c01[g].z), AB_V(q.c01[g].w), AB_V(q.c23[g].x), AB_V(q.c23[g].y), AB_V(q.c23[g].z), AB_V(q.c23[g].w));
+            if (raw_iq) AB_NEEDED_NOW(AB_V(q.q01[g].x), AB_V(q.q01[g].y), AB_V(q.q01[g].z), AB_V(q.q01[g].w), AB_V(q.q23[g].x), AB_V(q.q23[g].y), AB_V(q.q23[g].z), AB_V(q.q23[g].w));
         }
     };
     auto tail_in = [&](int n) { /* the delay-line tail advances once per sample (sq_advance) */
@@ -869,7 +880,7 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a, int first_block,
     for (int g = 0; g < NG; g += DEPTH) {
         float2 now[DEPTH];
 #pragma unroll
-        for (int k = 0; k < DEPTH; k++) asm volatile("" ::"v"(ahead[k].x), "v"(ahead[k].y)); /* the data is needed now: the wait lands here, before the next fetches go out */
+        for (int k = 0; k < DEPTH; k++) AB_NEEDED_NOW(AB_V(ahead[k].x), AB_V(ahead[k].y)); /* the data is needed now: the wait lands here, before the next fetches go out */
 #pragma unroll
         for (int k = 0; k < DEPTH; k++) now[k] = ahead[k];
 #pragma unroll
@@ -954,8 +965,8 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a, int first_block) 
     int jg = 0; /* position of the current sample in its tone-kernel step */
     for (int j0 = 0; j0 < B; j0 += PIECE) {
 #pragma unroll
-        for (int q = 0; q < NQ; q++) asm volatile("" ::"v"(nxt[q].x), "v"(nxt[q].y), "v"(nxt[q].z), "v"(nxt[q].w));
-        asm volatile("" ::"v"(nm_lo), "v"(nm_hi));
+        for (int q = 0; q < NQ; q++) AB_NEEDED_NOW(AB_V(nxt[q].x), AB_V(nxt[q].y), AB_V(nxt[q].z), AB_V(nxt[q].w));
+        AB_NEEDED_NOW(AB_V(nm_lo), AB_V(nm_hi));
         float4 cur[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) cur[q] = nxt[q];

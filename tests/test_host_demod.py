@@ -1,0 +1,160 @@
+"""The stage-2 kernel SOURCE (csrc/demod.hip) compiled as plain C++ for the host -- one lane per "wavefront", through the shim in
+tests/hostshim/ -- and run on the oracle's stage-1 output: squelch trace, axcindicate, audio and statistics must equal the oracle's,
+bit for bit, batch after batch.  Covers the lane-per-channel kinds that have no cross-lane step (AM, NFM, NFM + lowpass; notch, manual
+squelch, quadri discriminator, de-emphasis).  CPU only: it checks the ARITHMETIC and the bookkeeping (ring rotation, tail copy, zero rows
+left alone, runs flushed through the staging columns) of the code the GPU runs; the GPU parity tests check the kernels themselves, and
+are the only ones that reach the CTCSS chain and the channelizer.  Test infrastructure: nothing here is a code path of the library.
+"""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+import pyoracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(REPO, "rtlsdr-airband_amd", "csrc")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"  # csrc/demod.hip uses clang's ext_vector_type
+
+pkg = importlib.import_module("rtlsdr-airband_amd")
+capi = pkg.capi
+sg = pkg.siggen
+
+
+@pytest.fixture(scope="module")
+def hostdemod(tmp_path_factory):
+    if not os.path.exists(CLANG):
+        pytest.skip("no host clang++ in this image")
+    out = str(tmp_path_factory.mktemp("hostdemod") / "libhostdemod.so")
+    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-I" + os.path.join(HERE, "hostshim"),
+           "-I" + os.path.join(REPO, "include"), "-o", out, os.path.join(HERE, "host_demod_harness.cpp"), os.path.join(CSRC, "params.cpp")]
+    subprocess.run(cmd, check=True)
+    lib = C.CDLL(out)
+    vp = C.c_void_p
+    lib.hostdemod_create.argtypes = [C.POINTER(capi.Config), C.c_int, C.POINTER(vp)]
+    lib.hostdemod_destroy.argtypes = [vp]
+    lib.hostdemod_destroy.restype = None
+    lib.hostdemod_wave_batch.argtypes = [vp]
+    lib.hostdemod_process_bins.argtypes = [vp, vp, vp]
+    lib.hostdemod_collect.argtypes = [vp, vp, vp, vp]
+    lib.hostdemod_collect.restype = None
+    lib.hostdemod_stats.argtypes = [vp, vp]
+    lib.hostdemod_stats.restype = None
+    return lib
+
+
+class HostDemod:
+    def __init__(self, lib, devices, wave_rate, fm_demod=0):
+        self.lib = lib
+        cfg, self._keep = pkg.make_config(devices, wave_rate=wave_rate, fm_demod=fm_demod)
+        self.h = C.c_void_p()
+        rc = lib.hostdemod_create(C.byref(cfg), 1, C.byref(self.h))
+        assert rc == 0, rc
+        self.B = lib.hostdemod_wave_batch(self.h)
+        self.n = sum(len(d["channels"]) for d in devices)
+
+    def process_bins(self, wavein, iqin):
+        wavein = np.ascontiguousarray(wavein, np.float32)
+        iqin = np.ascontiguousarray(iqin, np.float32)
+        assert wavein.shape == (self.n, self.B) and iqin.shape == (self.n, 2 * self.B)
+        assert self.lib.hostdemod_process_bins(self.h, wavein.ctypes.data, iqin.ctypes.data) == 0
+
+    def collect(self):
+        wave = np.zeros((self.n, self.B), np.float32)
+        axc = np.zeros((self.n,), np.uint8)
+        trace = np.zeros((self.n, self.B), np.uint8)
+        self.lib.hostdemod_collect(self.h, wave.ctypes.data, axc.ctypes.data, trace.ctypes.data)
+        return wave, axc, trace
+
+    def stats(self):
+        st = (capi.ChannelStats * self.n)()
+        self.lib.hostdemod_stats(self.h, C.cast(st, C.c_void_p))
+        return [{f[0]: getattr(s, f[0]) for f in capi.ChannelStats._fields_} for s in st]
+
+    def close(self):
+        if self.h:
+            self.lib.hostdemod_destroy(self.h)
+            self.h = None
+
+
+def _plan(variant):
+    """(devices, carriers, wave_rate, fm_demod): plans of the kinds the harness can run."""
+    if variant == "am":
+        chans, carriers = sg.baseline_plan(mixed=False)
+        chans[1]["notch_freq"], chans[1]["notch_q"] = 1000.0, 5.0
+        chans[2]["squelch_threshold_dbfs"] = -40
+        chans[3]["squelch_snr_threshold_db"] = 6.0
+        chans[5]["ampfactor"] = 2.5
+        return chans, carriers, 8000, 0
+    chans, carriers = sg.baseline_plan(mixed=True)
+    for c, ch in enumerate(chans):  # the CTCSS channels of the mixed plan become plain NFM ones: the tone kernel is not a lane-per-channel kernel
+        if ch["ctcss_freq"]:
+            ch["ctcss_freq"] = 0.0
+            ch["notch_freq"] = 0.0
+    chans[1]["tau_us"] = 0 if variant == "nfm_quadri" else 100  # NFM, de-emphasis off / on
+    chans[5]["notch_freq"], chans[5]["notch_q"] = 150.0, 8.0     # NFM + notch
+    chans[7]["bandwidth_hz"] = 6250                              # a second lowpass gain
+    chans[0]["squelch_threshold_dbfs"] = -35                     # AM, manual squelch
+    return chans, carriers, 16000, (1 if variant == "nfm_quadri" else 0)
+
+
+def _bursty(carriers):
+    out = []
+    for k, c in enumerate(carriers):
+        period, on = [(0.11, 0.045), (0.31, 0.02), (0.26, 0.19), (0.07, 0.05)][k % 4]
+        amp = [0.08, 0.03, 0.05, 0.012][(k // 2) % 4]
+        out.append(sg.make_carrier(sg.PLAN_OFFSETS_HZ[k], sg.SAMPLE_RATE, amplitude=amp, kind=c.kind, key_slot=k, key_period_s=period, key_on_s=on, key_slot_s=0.013))
+    return out
+
+
+@pytest.mark.parametrize("style", ["keyed", "bursty"])
+@pytest.mark.parametrize("variant", ["am", "nfm_atan2", "nfm_quadri"])
+def test_kernel_source_on_the_host_equals_the_oracle(hostdemod, variant, style):
+    chans, carriers, wave_rate, fm_demod = _plan(variant)
+    if style == "bursty":
+        carriers = _bursty(carriers)
+    n_dev, n_batches = 2, 7
+    devices = [dict(channels=[dict(c) for c in chans]) for _ in range(n_dev)]
+    nbytes = helpers.stream_bytes(n_batches, wave_rate)
+    src = pyoracle.Oracle(devices, wave_rate=wave_rate, fm_demod=fm_demod)
+    raw = [src.run_device(d, sg.generate_u8(d, 0, nbytes // 2, carriers), n_batches) for d in range(n_dev)]
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fm_demod=fm_demod)
+    hd = HostDemod(hostdemod, devices, wave_rate, fm_demod)
+    try:
+        opened = 0
+        for b in range(n_batches):
+            wavein = np.concatenate([r["raw_wavein"][b] for r in raw])
+            iqin = np.concatenate([r["raw_iq"][b] for r in raw])
+            want = [orc.run_bins(d, raw[d]["raw_wavein"][b], raw[d]["raw_iq"][b]) for d in range(n_dev)]
+            hd.process_bins(wavein, iqin)
+            wave, axc, trace = hd.collect()
+            assert np.array_equal(trace, np.concatenate([w["trace"] for w in want])), "batch %d: squelch trace" % b
+            assert np.array_equal(axc, np.concatenate([w["axc"] for w in want])), "batch %d: axc" % b
+            ww = np.concatenate([w["waveout"] for w in want])
+            assert np.array_equal(wave.view(np.uint32), ww.view(np.uint32)), "batch %d: waveout, max diff %g" % (b, np.abs(wave - ww).max())
+            opened += int((axc != ord(" ")).sum())
+        assert opened > 0
+        st = hd.stats()
+        k = 0
+        for d in range(n_dev):
+            for j in range(len(chans)):
+                o = orc.stats(d, j)
+                for f in ("noise_level", "signal_level", "squelch_level", "agcavgfast", "open_count", "flappy_count", "active_counter", "squelch_state"):
+                    assert o[f] == st[k][f], (d, j, f, o[f], st[k][f])
+                k += 1
+    finally:
+        hd.close()
+        src.close()
+        orc.close()
+
+
+def test_harness_refuses_the_kinds_it_cannot_run(hostdemod):
+    chans, _ = sg.baseline_plan(mixed=True)  # has CTCSS channels
+    cfg, keep = pkg.make_config([dict(channels=chans)], wave_rate=16000)
+    h = C.c_void_p()
+    assert hostdemod.hostdemod_create(C.byref(cfg), 0, C.byref(h)) == -100
