@@ -25,8 +25,8 @@ struct ChannelizerArgs {
     const int* ext_to_slot; /* channel (device-major external index) -> demod slot */
     const float* window;    /* fft_size */
     const float2* twiddle;  /* fft_size: exp(-2 pi i k / fft_size) */
-    float* mag;             /* [ring_rows][stride] */
-    float2* iq_bins;        /* [ring_rows][stride] */
+    float* mag;             /* |bin| ring, blocked by 64 slots and transposed in tiles of AB_TILE_ROWS rows (common.h: ab_tile_base / ab_tile_off) */
+    float2* iq_bins;        /* raw bin I/Q ring, same layout */
     float* last_spectrum;   /* [n_dev][2*fft_size] full FFT of the batch's last hop (AFC), or null */
     int n_dev, fft_log;
     int hop_samples, bytes_per_sample, sfmt;
@@ -71,11 +71,11 @@ struct DemodArgs {
     const int* slot_to_ext;
     int wave_stride;
     int tail_copy;          /* 0 for the very first batch: nothing has been consumed yet */
-    float2* iq_out;         /* [wave_batch][stride] */
-    float* sqbuf;           /* [AB_SQ_BUF][stride] */
+    float2* iq_out;         /* [slot blocks][wave_batch][64] raw I/Q of open samples (channels with has_iq_outputs), emit_iq_kernel turns it channel-major */
+    float* sqbuf;           /* [slot blocks][AB_SQ_BUF][64] the squelch's pre-filter delay line (ab_ring_base); only the generic kind still stores it -- the NFM + lowpass kind recomputes its entries (SqShadow) */
     const float* ct_coeff;  /* [n_ctcss][2 detectors][AB_MAX_TONES] */
     float* ct_q;            /* [n_ctcss][2 detectors][q1|q2][AB_MAX_TONES] */
-    uint8_t* trace;         /* [wave_batch][stride] or null */
+    uint8_t* trace;         /* [slot blocks][wave_batch][64] per-sample squelch trace, or null */
     /* split (CTCSS-capable) kinds: front -> tone -> back hand-off */
     /* hand-off rows, channel-major (the tone kernel reads a channel's samples across its lanes):
      *   generic kind  [slots of the generic blocks][wave_batch] (pre-notch audio, flag word) pairs
