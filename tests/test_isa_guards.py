@@ -174,3 +174,18 @@ def test_specialised_demod_kinds_do_not_spill(demod_asm):
         meta = text[at:at + 1500]
         assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1)) == 0, name
         assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1)) == 0, name
+
+
+def test_nfm_kinds_take_the_short_square_root(demod_asm):
+    """csrc/exact_math.h: every correctly rounded sqrtf() of the NFM kinds is the short sequence with the compiler's general one (which first scales a
+    small argument by 2^32, `v_mul_f32 .., 0x4f800000`) behind a seldom-taken branch -- so exactly half of a kernel's `v_sqrt_f32` sit next to such a
+    scaling.  A plain sqrtf() slipping back in (every one scaled) costs 6 vector instructions per square root and shows in no parity test."""
+    for k, ct in ((1, 0), (2, 0), (3, 1)):
+        body = _function(demod_asm, "demod_kernelILi%dELb%dEEE" % (k, ct))
+        n_sqrt = sum(1 for l in body if re.match(r"^\s*v_sqrt_f32", l))
+        n_scaled = sum(1 for l in body if re.match(r"^\s*v_mul_f32\w*\s+v\d+, 0x4f800000,", l))
+        assert n_sqrt >= 8 and n_scaled * 2 == n_sqrt, (k, n_sqrt, n_scaled)
+    # and the two divisions by the lowpass gain are packed corrected products: FMAs exist in this -ffp-contract=off file only where exact_math.h
+    # (or the compiler's own division / square root) asks for one
+    body = _function(demod_asm, "demod_kernelILi2ELb0EEE")
+    assert sum(1 for l in body if re.match(r"^\s*v_pk_fma_f32", l)) >= 16
