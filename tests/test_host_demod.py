@@ -158,3 +158,80 @@ def test_harness_refuses_the_kinds_it_cannot_run(hostdemod):
     cfg, keep = pkg.make_config([dict(channels=chans)], wave_rate=16000)
     h = C.c_void_p()
     assert hostdemod.hostdemod_create(C.byref(cfg), 0, C.byref(h)) == -100
+
+
+def _fuzz_streams(rng, n_ch, B, n_batches, nfm):
+    """Stage-1 outputs made up directly (no channelizer): per channel a noise floor, keyed bursts of random strength and length, stretches of exact
+    zeros, of values whose squares underflow, and of large values -- the seams of the kernels' short sqrt / division sequences and of the squelch."""
+    n = B * n_batches
+    wave = np.zeros((n_ch, n), np.float32)
+    iq = np.zeros((n_ch, 2 * n), np.float32)
+    for c in range(n_ch):
+        floor = float(10.0 ** rng.uniform(-3.5, -1.0))
+        env = np.full(n, floor, np.float64) * (1.0 + 0.3 * rng.standard_normal(n))
+        t = 0
+        while t < n:
+            gap, on = int(rng.integers(50, 3000)), int(rng.integers(5, 2500))
+            t += gap
+            env[t:t + on] += floor * float(10.0 ** rng.uniform(-0.3, 1.8)) * (1.0 + 0.15 * rng.standard_normal(min(on, max(0, n - t))))
+            t += on
+        for _ in range(3):  # the odd stretches
+            a, ln = int(rng.integers(0, n - 400)), int(rng.integers(1, 400))
+            env[a:a + ln] = [0.0, 1e-25, 3e5, floor * 1e-6][int(rng.integers(0, 4))]
+        env = np.abs(env)
+        if nfm[c]:
+            ph = np.cumsum(rng.normal(0.0, 0.4, n)) + 2 * np.pi * rng.uniform(-0.2, 0.2) * np.arange(n)
+            re = (env * np.cos(ph)).astype(np.float32)
+            im = (env * np.sin(ph)).astype(np.float32)
+            iq[c, 0::2], iq[c, 1::2] = re, im
+            wave[c] = np.sqrt(re * re + im * im)  # float32 throughout: what stage 1 hands over (src/rtl_airband.cpp:484-487)
+        else:
+            wave[c] = env.astype(np.float32)
+    return wave, iq
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS", "12"))))
+def test_random_plans_and_made_up_stage1_output(hostdemod, seed):
+    """Random channel settings (squelch mode and thresholds, notch, lowpass bandwidth, de-emphasis, amplification, discriminator) on made-up stage-1
+    output with awkward values; the host-compiled kernel source against the oracle, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    nfm_build = bool(seed % 3)  # WAVE_RATE 16000 builds carry NFM channels
+    wave_rate = 16000 if nfm_build else 8000
+    fm_demod = int(rng.integers(0, 2)) if nfm_build else 0
+    chans = []
+    for k, off in enumerate(sg.PLAN_OFFSETS_HZ):
+        c = dict(frequency=sg.CENTERFREQ + off, modulation=0, afc=0, squelch_threshold_dbfs=0, squelch_snr_threshold_db=-1.0, notch_freq=0.0, notch_q=0.0, ctcss_freq=0.0,
+                 bandwidth_hz=0, ampfactor=1.0, tau_us=-1, has_iq_outputs=0)
+        if nfm_build and rng.random() < 0.6:
+            c["modulation"] = 1
+            if rng.random() < 0.5:
+                c["bandwidth_hz"] = int(rng.choice([5000, 6250, 12500, 25000]))
+            c["tau_us"] = int(rng.choice([-1, 0, 50, 200, 750]))
+        mode = rng.random()
+        if mode < 0.3:
+            c["squelch_threshold_dbfs"] = int(rng.integers(-60, -10))
+        elif mode < 0.6:
+            c["squelch_snr_threshold_db"] = float(rng.choice([3.0, 6.0, 9.5, 14.0]))
+        if rng.random() < 0.3:
+            c["notch_freq"], c["notch_q"] = float(rng.choice([100.0, 150.0, 1000.0])), float(rng.choice([0.0, 4.0, 10.0]))
+        if rng.random() < 0.3:
+            c["ampfactor"] = float(rng.choice([0.25, 2.0, 8.0]))
+        chans.append(c)
+    devices = [dict(channels=chans)]
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fm_demod=fm_demod)
+    hd = HostDemod(hostdemod, devices, wave_rate, fm_demod)
+    try:
+        B, n_batches = hd.B, 4
+        wave, iq = _fuzz_streams(rng, len(chans), B, n_batches, [c["modulation"] == 1 for c in chans])
+        for b in range(n_batches):
+            w, q = wave[:, b * B:(b + 1) * B], iq[:, 2 * b * B:2 * (b + 1) * B]
+            want = orc.run_bins(0, w, q)
+            hd.process_bins(w, q)
+            got_w, got_a, got_t = hd.collect()
+            assert np.array_equal(got_t, want["trace"]), "seed %d batch %d: squelch trace (channels %s)" % (seed, b, np.nonzero((got_t != want["trace"]).any(axis=1))[0])
+            assert np.array_equal(got_a, want["axc"]), "seed %d batch %d: axc" % (seed, b)
+            same = (got_w.view(np.uint32) == want["waveout"].view(np.uint32)) | (np.isnan(got_w) & np.isnan(want["waveout"]))
+            assert same.all(), "seed %d batch %d: waveout (channels %s)" % (seed, b, np.nonzero((~same).any(axis=1))[0])
+    finally:
+        hd.close()
+        orc.close()
