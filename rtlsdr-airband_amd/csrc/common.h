@@ -71,7 +71,7 @@ struct ChanState {
     uint32_t open_count, flappy_count, recent_open, closed_count;
     /* NotchFilter / LowpassFilter delay lines */
     float nx[3], ny[3];
-    float lxr[3], lxi[3], lyr[3], lyi[3];
+    float lxr[3], lxi[3], lyr[3], lyi[3]; /* ([0] of each is not kept: LowpassFilter::apply overwrites it before reading it) */
     /* CTCSS detectors: [0] fast, [1] slow (src/ctcss.h:84-95) */
     int32_t ct_enough[2], ct_count[2], ct_has_tone[2];
     uint32_t ct_found[2], ct_not_found[2];

@@ -271,8 +271,10 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     OutRegs o;
     o.nx0 = sp->nx[0]; o.nx1 = sp->nx[1]; o.nx2 = sp->nx[2]; o.ny0 = sp->ny[0]; o.ny1 = sp->ny[1]; o.ny2 = sp->ny[2];
     o.axc = ' ';
-    float lxr0 = sp->lxr[0], lxr1 = sp->lxr[1], lxr2 = sp->lxr[2], lxi0 = sp->lxi[0], lxi1 = sp->lxi[1], lxi2 = sp->lxi[2];
-    float lyr0 = sp->lyr[0], lyr1 = sp->lyr[1], lyr2 = sp->lyr[2], lyi0 = sp->lyi[0], lyi1 = sp->lyi[1], lyi2 = sp->lyi[2];
+    /* LowpassFilter's delay lines: only [1] and [2] carry over -- apply() shifts [1] into [0] before it reads [0] (src/filters.cpp:146-163), so [0] is a
+     * temporary of the step (four exec-masked moves per sample less than keeping it as state) */
+    float lxr1 = sp->lxr[1], lxr2 = sp->lxr[2], lxi1 = sp->lxi[1], lxi2 = sp->lxi[2];
+    float lyr1 = sp->lyr[1], lyr2 = sp->lyr[2], lyi1 = sp->lyi[1], lyi2 = sp->lyi[2];
 
     const float one_minus_alpha = 1.0f - cc.alpha;
     const float div_lo = cc.lp_rgain != 0.0f ? AB_DIV_CONST_LO : __builtin_inff(); /* exact_math.h: the range in which x / lp_gain is three instructions */
@@ -419,10 +421,10 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                 float ti = im * cwf + re * nswf;
                 dm_phi = (dm_phi + cc.dm_dphi) & 0xffffffu;
                 if (lowpass) { /* LowpassFilter::apply (src/filters.cpp:146-163) */
-                    lxr0 = lxr1; lxi0 = lxi1;
+                    const float lxr0 = lxr1, lxi0 = lxi1;
                     lxr1 = lxr2; lxi1 = lxi2;
                     ab_div_const2(tr, ti, cc.lp_gain, cc.lp_rgain, div_lo, lxr2, lxi2); /* tr / gain, ti / gain */
-                    lyr0 = lyr1; lyi0 = lyi1;
+                    const float lyr0 = lyr1, lyi0 = lyi1;
                     lyr1 = lyr2; lyi1 = lyi2;
                     lyr2 = (lxr0 + lxr2) + (2.0f * lxr1) + (cc.lp_yc0 * lyr0) + (cc.lp_yc1 * lyr1);
                     lyi2 = (lxi0 + lxi2) + (2.0f * lxi1) + (cc.lp_yc0 * lyi0) + (cc.lp_yc1 * lyi1);
@@ -694,8 +696,8 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     sp->agcavgfast = agc; sp->pr = pr; sp->pj = pj; sp->prev_waveout = prev_out; sp->dm_phi = dm_phi;
     if (KIND == AB_KIND_NFM_LOWPASS) { sp->sh_nf = sh.nf; sp->sh_cap = sh.cap; sp->sh_capped = sh.capped; }
     sq_store(s, L, sp, B);
-    sp->lxr[0] = lxr0; sp->lxr[1] = lxr1; sp->lxr[2] = lxr2; sp->lxi[0] = lxi0; sp->lxi[1] = lxi1; sp->lxi[2] = lxi2;
-    sp->lyr[0] = lyr0; sp->lyr[1] = lyr1; sp->lyr[2] = lyr2; sp->lyi[0] = lyi0; sp->lyi[1] = lyi1; sp->lyi[2] = lyi2;
+    sp->lxr[1] = lxr1; sp->lxr[2] = lxr2; sp->lxi[1] = lxi1; sp->lxi[2] = lxi2;
+    sp->lyr[1] = lyr1; sp->lyr[2] = lyr2; sp->lyi[1] = lyi1; sp->lyi[2] = lyi2;
 }
 
 constexpr int TONE_GROUP = 50; /* samples per tone-kernel step; divides WAVE_BATCH = 1000 and 2000, fits one wavefront's lanes */
