@@ -719,22 +719,14 @@ int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const air
     }
     for (int m = 0; m < mixer_count; m++) first[m + 1] += first[m];
     std::vector<int> cur(first.begin(), first.end() - 1);
-    h->mix_pos.assign(n_in, 0);
+    std::vector<int> pos(n_in, 0);
     for (int i = 0; i < n_in; i++) { /* stable: connection order inside a mixer is kept (summation order) */
         const int k = cur[in[i].mixer]++;
-        h->mix_pos[i] = k;
+        pos[i] = k;
         chan[k] = p.chan_base[in[i].device] + in[i].channel;
         ml[k] = in[i].ampfactor * fminf(1.0f, 1.0f - in[i].balance); /* src/mixer.cpp:82-83,203-208 */
         mr[k] = in[i].ampfactor * fminf(1.0f, 1.0f + in[i].balance);
     }
-    order_behind_last_batch(h);
-    HIP_TRY(h, hipStreamSynchronize(h->stream), AIRBAND_HIP_ERUNTIME); /* a batch under way still sums the old wiring */
-    h->n_mixers = 0; /* until the new wiring is complete: a failure below leaves a handle without mixers, not one with freed tables */
-    h->n_mix_runs = 0;
-    h->d_mix_chan.release(); h->d_mix_first.release(); h->d_mix_ml.release(); h->d_mix_mr.release();
-    h->d_mix_left.release(); h->d_mix_right.release(); h->d_mix_stereo.release(); h->d_mix_signal.release();
-    h->d_mix_run_first.release(); h->d_mix_run_mixer.release(); h->d_mix_first_run.release();
-    h->d_mix_run_left.release(); h->d_mix_run_right.release(); h->d_mix_run_signal.release();
     std::vector<int> run_first, run_mixer, first_run(mixer_count + 1, 0);
     for (int m = 0; m < mixer_count; m++) {
         first_run[m] = (int)run_mixer.size();
@@ -746,6 +738,16 @@ int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const air
     first_run[mixer_count] = (int)run_mixer.size();
     run_first.push_back(n_in);
     const int n_runs = (int)run_mixer.size();
+    /* the mixer kernels index runs / mixers with blockIdx.y: say so here rather than fail at the first launch */
+    if (n_runs > 65535 || mixer_count > 65535) return fail(h, AIRBAND_HIP_EBADSIZE, "more than 65 535 mixers (or runs of 64 mixer inputs) on one handle");
+    order_behind_last_batch(h);
+    HIP_TRY(h, hipStreamSynchronize(h->stream), AIRBAND_HIP_ERUNTIME); /* a batch under way still sums the old wiring */
+    h->n_mixers = 0; /* until the new wiring is complete: a failure below leaves a handle without mixers, not one with freed tables */
+    h->n_mix_runs = 0;
+    h->d_mix_chan.release(); h->d_mix_first.release(); h->d_mix_ml.release(); h->d_mix_mr.release();
+    h->d_mix_left.release(); h->d_mix_right.release(); h->d_mix_stereo.release(); h->d_mix_signal.release();
+    h->d_mix_run_first.release(); h->d_mix_run_mixer.release(); h->d_mix_first_run.release();
+    h->d_mix_run_left.release(); h->d_mix_run_right.release(); h->d_mix_run_signal.release();
     HIP_TRY(h, upload(h->d_mix_run_first, run_first), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, upload(h->d_mix_run_mixer, run_mixer), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, upload(h->d_mix_first_run, first_run), AIRBAND_HIP_ENOMEM);
@@ -760,6 +762,7 @@ int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const air
     HIP_TRY(h, h->d_mix_left.alloc((size_t)mixer_count * h->B), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, h->d_mix_right.alloc((size_t)mixer_count * h->B), AIRBAND_HIP_ENOMEM);
     HIP_TRY(h, h->d_mix_signal.alloc((size_t)mixer_count), AIRBAND_HIP_ENOMEM);
+    h->mix_pos = pos;
     h->mix_chan_host = chan;
     h->mix_user_on.assign(n_in, 1);
     for (int k = 0; k < n_in; k++) /* inputs of dongles that are already switched off stay out */
