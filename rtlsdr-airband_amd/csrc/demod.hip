@@ -38,12 +38,24 @@ namespace {
 /* "These vector registers are needed now": an empty asm statement that names them, so that the compiler's wait for the loads that fill them lands
  * HERE (see demod_wave: before the next group's loads are issued).  The file also compiles as plain C++ for tests/host_demod_harness.cpp, where there
  * is nothing to wait for. */
+#if !defined(AB_NEEDED_NOW)
 #if defined(__HIPCC__)
 #define AB_NEEDED_NOW(...) asm volatile("" ::__VA_ARGS__)
 #define AB_V(x) "v"(x)
 #else
 #define AB_NEEDED_NOW(...) ((void)0)
 #define AB_V(x) 0
+#endif
+#endif
+/* The 64 lanes of a wavefront execute in lockstep, and LDS operations of one wavefront complete in order: where lanes exchange data through LDS
+ * WITHOUT a barrier (the cooperative row stores, the tone kernel's power sum) the code relies on that.  AB_LOCKSTEP() marks those places; it is
+ * nothing on the GPU.  tests/hostshim_wave64 runs the lanes as fibers and makes them meet there. */
+#if !defined(AB_LOCKSTEP)
+#define AB_LOCKSTEP() ((void)0)
+#endif
+/* the kernel's dynamic LDS array */
+#if !defined(AB_DYNAMIC_LDS)
+#define AB_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 #endif
 
 /* per-sample flag word parked in LDS between the phases */
@@ -147,7 +159,9 @@ __device__ __forceinline__ void wave_flush(const WaveRow& w, RowZero& z, int n =
     row_run_done(z);
     if (w.coop) { /* wave-uniform */
         const int lane = threadIdx.x & 63, q = lane & 7;
+        AB_LOCKSTEP(); /* every lane has staged its run */
         w.skip_of[lane] = skip ? 1 : 0; /* (LDS operations of one wave complete in order: the lanes that store this channel's line read it below) */
+        AB_LOCKSTEP();
         if (4 * q < n) {
 #pragma unroll
             for (int i = 0; i < 8; i++) {
@@ -158,6 +172,7 @@ __device__ __forceinline__ void wave_flush(const WaveRow& w, RowZero& z, int n =
                 *dst = make_float4(src[0], src[OSTRIDE], src[2 * OSTRIDE], src[3 * OSTRIDE]);
             }
         }
+        AB_LOCKSTEP(); /* ... before any lane stages its next run over it */
         return;
     }
     if (skip) return;
@@ -316,6 +331,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         if (PACKED) {
             if (full_block) { /* wave-uniform */
                 const int q = lane & 7; /* samples 4q .. 4q + 3 */
+                AB_LOCKSTEP(); /* every lane has parked its words */
                 if (4 * q < n) {
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
@@ -324,6 +340,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                         *reinterpret_cast<uint4*>(ct_blockw + (long)c * a.ct_pk_pitch + jstart + 4 * q) = make_uint4(src[0], src[OSTRIDE], src[2 * OSTRIDE], src[3 * OSTRIDE]);
                     }
                 }
+                AB_LOCKSTEP();
             } else {
                 for (int i = 0; i < n; i += 4)
                     *reinterpret_cast<uint4*>(ct_ap + jstart + i) = make_uint4(handw[i * OSTRIDE], handw[(i + 1) * OSTRIDE], handw[(i + 2) * OSTRIDE], handw[(i + 3) * OSTRIDE]);
@@ -332,6 +349,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         }
         if (full_block) { /* wave-uniform */
             const int q = lane & 7; /* samples 2q, 2q + 1 */
+            AB_LOCKSTEP();
             if (2 * q < n) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
@@ -340,6 +358,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                     *reinterpret_cast<float4*>(ct_block + (long)c * B + jstart + 2 * q) = make_float4(p0.x, p0.y, p1.x, p1.y);
                 }
             }
+            AB_LOCKSTEP();
         } else {
             for (int i = 0; i < n; i += 2) {
                 const float2 p0 = hand[i * OSTRIDE], p1 = hand[(i + 1) * OSTRIDE];
@@ -734,7 +753,7 @@ template <int KIND, bool WAVE_HAS_CTCSS>
  * eight cycles whatever shares its SIMD (VALU -> SGPR -> SALU -> VALU hops of the lane-mask state machine), so throughput
  * rises with residency until the vector pipe saturates: the AM kind, light on registers, is built for four (2.12 -> 1.63 ms alone). */
 __global__ __launch_bounds__(64, KIND == AB_KIND_AM ? AB_AM_WAVES : KIND == AB_KIND_NFM_CTCSS ? AB_FRONT_WAVES : AB_DEMOD_WAVES) void demod_kernel(DemodArgs a, int first_block) {
-    extern __shared__ __attribute__((aligned(16))) float lds_demod[];
+    AB_DYNAMIC_LDS(float, lds_demod);
     demod_block<KIND, WAVE_HAS_CTCSS>(a, first_block + blockIdx.x, lds_demod);
 }
 
@@ -856,6 +875,7 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a, int first_block,
                         q1 = q0;
                         if (++count >= win) { /* CTCSS::process_audio_sample window end (src/ctcss.cpp:141-162) */
                             scratch[lane] = q1 * q1 + q2 * q2 - q1 * q2 * co;
+                            AB_LOCKSTEP(); /* every tone's power is in LDS (the readfirstlane below keeps the next window's writes behind these reads) */
                             float total = 0.0f, best = 0.0f;
                             for (int i = 0; i < n; i++) { /* index-order float sum, as ToneDetectorSet::sorted_powers does */
                                 const float m = scratch[i];

@@ -5,6 +5,10 @@
 // so that the per-sample arithmetic of the kernels (squelch, derotation, lowpass, discriminator, AGC, notch, clamp, fade-out, tail copy, zero-row skipping,
 // the short sqrt / division sequences) can be compared bit for bit with the oracle WITHOUT a GPU.  The CTCSS kinds (wavefront-per-channel tone kernel)
 // and the channelizer (matrix cores, cross-lane exchange) are not reachable this way; the GPU parity tests cover those.
+//
+// Second mode (-DAB_WAVE64_EMU, through tests/hostshim_wave64/ instead): the 64 lanes of a wavefront run as fibers that meet at every cross-lane
+// operation, kernels are "launched" by the library's own launch_demod() -- so ALL stage-2 kinds run, the CTCSS chain (front, tone, back kernels) and the
+// cooperative stores of full 64-channel blocks included, with real lane masks.
 #include <cstdlib>
 #include <new>
 #include <vector>
@@ -49,11 +53,19 @@ struct HostDemod {
     uint8_t* out_axc = nullptr;
     uint8_t* trace = nullptr;
     float* lds = nullptr;
+    /* split kinds (wave64 mode) */
+    float* ct_coeff = nullptr;
+    float* ct_q = nullptr;
+    float2* ct_af = nullptr;
+    unsigned long long* ct_mask = nullptr;
+    int ct_first_block = 0, ct_n_blocks = 0, ct_pk_pitch = 0, ct_stride = 0;
     ~HostDemod() {
         free(mag); free(iq); free(iq_out); free(sqbuf); free(out_wave); free(out_axc); free(trace); free(lds);
+        free(ct_coeff); free(ct_q); free(ct_af); free(ct_mask);
     }
 };
 
+#ifndef AB_WAVE64_EMU
 template <int KIND>
 void run_kind(HostDemod* h, const DemodArgs& a) {
     for (int b = 0; b < h->kind_blocks[KIND]; b++) {
@@ -66,8 +78,15 @@ void run_kind(HostDemod* h, const DemodArgs& a) {
     }
     threadIdx.x = 0;
 }
+#endif
 
 }  // namespace
+
+#ifdef AB_WAVE64_EMU
+namespace airband {
+alignas(16) float lds_demod[258 * 2 + RUN * OSTRIDE + 2 * 64]; /* demod_kernel's dynamic LDS (one block runs at a time) */
+}
+#endif
 
 extern "C" {
 
@@ -94,10 +113,12 @@ int hostdemod_create(const airband_hip_config* cfg, int trace, void** out) {
         bool any = false;
         for (int e = 0; e < p.total_ch; e++) {
             if (kind_of(p.cc[e]) != k) continue;
+#ifndef AB_WAVE64_EMU
             if (k == AB_KIND_NFM_CTCSS || k == AB_KIND_GENERIC) {
                 delete h;
                 return -100;
             }
+#endif
             any = true;
             h->ext_to_slot[e] = (int)h->cc.size();
             h->slot_to_ext.push_back(e);
@@ -127,6 +148,23 @@ int hostdemod_create(const airband_hip_config* cfg, int trace, void** out) {
     h->out_axc = aligned_array<uint8_t>((size_t)p.total_ch, (uint8_t)' ');
     if (trace) h->trace = aligned_array<uint8_t>((size_t)h->B * h->n_slots, 0);
     h->lds = aligned_array<float>(258 * 2 + (size_t)RUN * OSTRIDE + 2 * 64, 0.0f);
+    { /* CTCSS tables and the hand-off buffers of the split kinds, as airband_hip_prepare() lays them out */
+        const int n_ct = (int)p.tones.size();
+        h->ct_stride = n_ct;
+        h->ct_coeff = aligned_array<float>((size_t)(n_ct > 0 ? n_ct : 1) * 2 * AB_MAX_TONES, 0.0f);
+        for (int s = 0; s < n_ct; s++)
+            for (int k = 0; k < 2; k++)
+                for (int t = 0; t < p.tones[s].n[k]; t++) h->ct_coeff[((size_t)s * 2 + k) * AB_MAX_TONES + t] = p.tones[s].coeff[k][t];
+        h->ct_q = aligned_array<float>((size_t)(n_ct > 0 ? n_ct : 1) * 4 * AB_MAX_TONES, 0.0f);
+        h->ct_n_blocks = h->kind_blocks[AB_KIND_NFM_CTCSS] + h->kind_blocks[AB_KIND_GENERIC];
+        h->ct_first_block = h->kind_blocks[AB_KIND_NFM_CTCSS] ? h->kind_first[AB_KIND_NFM_CTCSS] : h->kind_first[AB_KIND_GENERIC];
+        h->ct_pk_pitch = (h->B + 31) / 32 * 32;
+        if (h->ct_n_blocks > 0) {
+            h->ct_af = aligned_array<float2>((size_t)h->kind_blocks[AB_KIND_NFM_CTCSS] * AB_SLOT_BLOCK * h->ct_pk_pitch / 2 + (size_t)h->kind_blocks[AB_KIND_GENERIC] * AB_SLOT_BLOCK * h->B,
+                                             make_float2(0.0f, 0.0f));
+            h->ct_mask = aligned_array<unsigned long long>((size_t)h->ct_n_blocks * (h->B / 50) * AB_SLOT_BLOCK, 0ull);
+        }
+    }
     *out = h;
     return 0;
 }
@@ -171,9 +209,26 @@ int hostdemod_process_bins(void* hv, const float* wavein, const float* iq_in) {
     a.wave_batch = B;
     a.row0 = h->row0;
     a.ring_rows = R;
+#ifdef AB_WAVE64_EMU
+    a.ct_coeff = h->ct_coeff;
+    a.ct_q = h->ct_q;
+    a.ct_pk_first_block = h->kind_first[AB_KIND_NFM_CTCSS];
+    a.ct_pk_n_blocks = h->kind_blocks[AB_KIND_NFM_CTCSS];
+    a.ct_gen_first_block = h->kind_first[AB_KIND_GENERIC];
+    a.ct_gen_n_blocks = h->kind_blocks[AB_KIND_GENERIC];
+    a.ct_pk_pitch = h->ct_pk_pitch;
+    a.ct_ap = reinterpret_cast<unsigned*>(h->ct_af);
+    a.ct_af = h->ct_af + (size_t)a.ct_pk_n_blocks * AB_SLOT_BLOCK * h->ct_pk_pitch / 2;
+    a.ct_mask = h->ct_mask;
+    a.ct_first_block = h->ct_first_block;
+    a.ct_n_blocks = h->ct_n_blocks;
+    a.ct_stride = h->ct_stride;
+    launch_demod(a, h->kind_first, h->kind_blocks, nullptr, nullptr, nullptr); /* the library's own launch sequence; every launch runs to completion */
+#else
     run_kind<AB_KIND_NFM_LOWPASS>(h, a);
     run_kind<AB_KIND_NFM>(h, a);
     run_kind<AB_KIND_AM>(h, a);
+#endif
     h->row0 = (h->row0 + B) % R;
     h->batches++;
     return 0;

@@ -1,0 +1,108 @@
+"""Stage 2 with its wavefront semantics, on the CPU: csrc/demod.hip compiled for the host with tests/hostshim_wave64/ -- every work-item a fiber, the
+cross-lane operations (ballots, v_readlane, barriers, the lockstep LDS exchanges) rendezvous points of a wavefront's fibers -- and driven by the
+library's own launch_demod().  All kinds run: the CTCSS chain (front -> tone -> back kernels), the cooperative stores of full 64-channel blocks, real
+64-bit lane masks with lanes in different squelch states.  Squelch trace (tone bit included), axcindicate, audio and statistics (CTCSS counters
+included) must equal the oracle's bit for bit.  A cross-lane operation reached by only part of a wavefront would hang the emulation and is reported
+as a deadlock -- the kernels' rule "lane masks are only assigned in wave-uniform control flow" is checked on the way.
+Test infrastructure: it tests the logic of the code the GPU runs; the GPU parity tests test the kernels.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers
+import pyoracle
+from test_host_demod import CLANG, CSRC, HERE, REPO, HostDemod, _bursty, capi, pkg, sg
+
+
+@pytest.fixture(scope="module")
+def wave64(tmp_path_factory):
+    if not os.path.exists(CLANG):
+        pytest.skip("no host clang++ in this image")
+    out = str(tmp_path_factory.mktemp("hostwave64") / "libhostwave64.so")
+    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-DAB_WAVE64_EMU",
+           "-I" + os.path.join(HERE, "hostshim_wave64"), "-I" + os.path.join(REPO, "include"), "-o", out, os.path.join(HERE, "host_demod_harness.cpp"),
+           os.path.join(CSRC, "params.cpp")]
+    subprocess.run(cmd, check=True)
+    lib = C.CDLL(out)
+    vp = C.c_void_p
+    lib.hostdemod_create.argtypes = [C.POINTER(capi.Config), C.c_int, C.POINTER(vp)]
+    lib.hostdemod_destroy.argtypes = [vp]
+    lib.hostdemod_destroy.restype = None
+    lib.hostdemod_wave_batch.argtypes = [vp]
+    lib.hostdemod_process_bins.argtypes = [vp, vp, vp]
+    lib.hostdemod_collect.argtypes = [vp, vp, vp, vp]
+    lib.hostdemod_collect.restype = None
+    lib.hostdemod_stats.argtypes = [vp, vp]
+    lib.hostdemod_stats.restype = None
+    return lib
+
+
+def _tweak(d, ch):
+    """Different dongles, different settings: the lanes of one wavefront then sit in different squelch states and take different per-lane paths."""
+    if d % 2:
+        ch[2]["squelch_snr_threshold_db"] = 6.0
+        ch[3]["bandwidth_hz"] = 6250
+    if d % 3 == 1:
+        ch[0]["notch_freq"], ch[0]["notch_q"] = 1000.0, 5.0
+        ch[5]["ctcss_freq"] = 88.5  # a CTCSS tone nobody sends: the gate stays shut
+    if d % 4 == 2:
+        ch[4]["squelch_threshold_dbfs"] = -38
+        ch[7]["ctcss_freq"] = 100.0   # lowpass + CTCSS: the generic kind (pairs hand-off)
+        ch[6]["bandwidth_hz"] = 8000  # an AM channel with a lowpass filter: raw I/Q on an AM lane (the generic kind again)
+        ch[1]["has_iq_outputs"] = 1   # raw-I/Q output rows
+
+
+@pytest.mark.parametrize("style,n_dev,mixed,wave_rate,n_batches", [("keyed", 3, True, 16000, 6), ("long", 3, True, 16000, 16), ("bursty", 3, True, 16000, 4), ("keyed", 8, False, 8000, 3),
+                                                                    ("keyed", 32, True, 16000, 2)])
+def test_all_kinds_with_wavefront_semantics(wave64, style, n_dev, mixed, wave_rate, n_batches):
+    """3 dongles: partial blocks (lane-private stores).  8 AM dongles: one full 64-channel block (cooperative stores).  32 mixed dongles: full blocks of
+    the AM, NFM + lowpass and NFM + CTCSS kinds -- cooperative stores in the fused kinds, the front's hand-off rows, the back kernel."""
+    devices, carriers = helpers.plan_devices(n_dev, mixed, _tweak if mixed else None)
+    if style == "bursty":
+        carriers = _bursty(carriers) if not mixed else [sg.make_carrier(sg.PLAN_OFFSETS_HZ[k], sg.SAMPLE_RATE, amplitude=[0.08, 0.03, 0.05, 0.012][(k // 2) % 4], kind=c.kind,
+                                                                        ctcss_hz=100.0 if c.step_ctcss else 0.0, key_slot=k,
+                                                                        key_period_s=[0.11, 0.31, 0.26, 0.07][k % 4], key_on_s=[0.045, 0.02, 0.19, 0.05][k % 4], key_slot_s=0.013)
+                                                        for k, c in enumerate(carriers)]
+    if style == "long":  # keyed for 1.7 of 2 s: the slow CTCSS detector (0.4 s windows) completes several windows, the tone kernel's slow-only steady path decides
+        carriers = [sg.make_carrier(sg.PLAN_OFFSETS_HZ[k], sg.SAMPLE_RATE, kind=c.kind, ctcss_hz=100.0 if c.step_ctcss else 0.0, key_slot=k, key_period_s=2.0, key_on_s=1.7)
+                    for k, c in enumerate(carriers)]
+    nbytes = helpers.stream_bytes(n_batches, wave_rate)
+    src = pyoracle.Oracle(devices, wave_rate=wave_rate)
+    raw = [src.run_device(d, sg.generate_u8(d, 0, nbytes // 2, carriers), n_batches) for d in range(n_dev)]
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate)
+    hd = HostDemod(wave64, devices, wave_rate)
+    try:
+        tone_seen = 0
+        for b in range(n_batches):
+            wavein = np.concatenate([r["raw_wavein"][b] for r in raw])
+            iqin = np.concatenate([r["raw_iq"][b] for r in raw])
+            want = [orc.run_bins(d, raw[d]["raw_wavein"][b], raw[d]["raw_iq"][b]) for d in range(n_dev)]
+            hd.process_bins(wavein, iqin)
+            wave, axc, trace = hd.collect()
+            wt = np.concatenate([w["trace"] for w in want])
+            assert np.array_equal(trace, wt), "batch %d: squelch trace (channels %s)" % (b, np.nonzero((trace != wt).any(axis=1))[0])
+            assert np.array_equal(axc, np.concatenate([w["axc"] for w in want])), "batch %d: axc" % b
+            ww = np.concatenate([w["waveout"] for w in want])
+            assert np.array_equal(wave.view(np.uint32), ww.view(np.uint32)), "batch %d: waveout (channels %s)" % (b, np.nonzero((wave.view(np.uint32) != ww.view(np.uint32)).any(axis=1))[0])
+            tone_seen += int(((wt >> 5) & 1).sum())
+        if mixed and style != "bursty":
+            assert tone_seen > 0  # the CTCSS gate did open somewhere (the short bursts of the other style never fill a detector window)
+        st = hd.stats()
+        k = 0
+        for d in range(n_dev):
+            for j in range(len(devices[d]["channels"])):
+                o = orc.stats(d, j)
+                for f in ("noise_level", "signal_level", "squelch_level", "agcavgfast", "open_count", "flappy_count", "ctcss_count", "no_ctcss_count", "active_counter",
+                          "squelch_state"):
+                    assert o[f] == st[k][f], (d, j, f, o[f], st[k][f])
+                k += 1
+        if style == "long":
+            assert max(s["ctcss_count"] for s in st) >= 3
+    finally:
+        hd.close()
+        src.close()
+        orc.close()
