@@ -29,6 +29,11 @@ namespace airband {
 
 namespace {
 
+/* the workgroup's dynamic LDS (tests/hostshim_wave64 gives the host build a static array instead) */
+#if !defined(AB_DYNAMIC_LDS_BYTES)
+#define AB_DYNAMIC_LDS_BYTES(name) extern __shared__ __attribute__((aligned(16))) uint8_t name[]
+#endif
+
 constexpr int HOPS_PER_TILE = 16;
 constexpr float kPi = 3.14159265358979323846f;
 
@@ -38,7 +43,7 @@ template <int LOGP>
 __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a) {
     constexpr int P = 1 << LOGP;
     constexpr int N = P * 64;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    AB_DYNAMIC_LDS_BYTES(lds_raw);
 
     const int tiles = (a.n_hops + HOPS_PER_TILE - 1) / HOPS_PER_TILE;
     const int d = blockIdx.x / tiles, tile = blockIdx.x - d * tiles;

@@ -209,4 +209,25 @@ static inline bool ab_emu_inverse_ballot(unsigned long long m) { return (m >> ab
 #define __builtin_amdgcn_readlane(v, l) ab_emu::readlane((unsigned)(v), (l))
 #define __builtin_amdgcn_sqrtf(x) sqrtf(x) /* v_sqrt_f32 is within 1 ulp; tests/test_exact_math.py covers what exact_math.h makes of either neighbour */
 
+/* ---- what csrc/channelizer_fft.hip needs on top (tests/host_fft_harness.cpp): shuffles as rendezvous points, a block's dynamic LDS, two vector types */
+struct char2 { signed char x, y; };
+struct short2 { short x, y; };
+static inline unsigned __brev(unsigned v) {
+    unsigned r = 0;
+    for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i);
+    return r;
+}
+static inline float ab_emu_shfl(float v, int src) { /* ds_bpermute: every live lane deposits, then reads its source lane's deposit */
+    ab_emu::Group& g = ab_emu::my_wave();
+    const unsigned my = ab_emu::rendezvous(g, ab_emu::my_lane(), __float_as_uint(v));
+    src &= 63;
+    return g.put[my & 1][src] ? __uint_as_float(g.slot[my & 1][src]) : v;
+}
+static inline float __shfl(float v, int src) { return ab_emu_shfl(v, src); }
+static inline float __shfl_xor(float v, int mask) { return ab_emu_shfl(v, ab_emu::my_lane() ^ mask); }
+#define AB_WAVE_SYNC() ab_emu::lockstep() /* csrc/channelizer_fft.hip: lanes of one wavefront exchange data through LDS */
+#define AB_DYNAMIC_LDS_BYTES(name) alignas(16) static uint8_t name[160 * 1024] /* one block runs at a time */
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
+
 #endif
