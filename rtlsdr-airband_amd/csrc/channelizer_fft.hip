@@ -4,21 +4,28 @@
  *   sample -> float (LUT / scale) x window      (:402-455, NEON twin src/rtl_airband_neon.s:28-83)
  *   forward complex FFT of fft_size points      (:460 fftwf_execute, VideoCore twin gpu_fft_execute :458)
  *   per-channel bin magnitude (+ raw bin I/Q)   (:483-489)
+ * for what the matrix-core channelizer (channelizer_dft.hip) does not take: f32 samples, hops that are not a multiple of four bytes,
+ * AIRBAND_HIP_FLAG_FORCE_FFT, and the whole spectrum of a batch's last hop that AFC looks at.
  *
- * Mapping (wave64, CDNA4):
+ * Mapping (wave64, CDNA4), both kernels:
  *   * a 256-thread workgroup owns one dongle and a tile of HOPS_PER_TILE consecutive hops; the raw bytes those
  *     hops cover ((T-1)*hop + N samples; consecutive windows overlap by N-hop samples) are fetched from HBM once,
  *     16 bytes per lane, into LDS;
  *   * each wavefront then transforms whole hops: lane l holds the P = N/64 samples n = r*64 + l, converts and
- *     windows them in registers, runs a P-point radix-2 FFT inside the lane (constant twiddles), multiplies by the
- *     per-lane twiddles W_N^(l*k1) and finishes with six radix-2 butterfly stages ACROSS lanes, exchanging
- *     partners with __shfl_xor (ds_bpermute; no LDS storage).  Bin k = k1 + P*k2 ends up in register
- *     bitrev(k1) of lane bitrev6(k2);
- *   * the (at most 64) channels of the dongle pull their bin with one more shuffle round and lanes 0..n_ch-1
- *     write |bin| (and re/im for raw-I/Q channels) time-major into the stage-2 rings.
+ *     windows them in registers, runs a P-point radix-2 FFT inside the lane (constant twiddles) and multiplies by the
+ *     per-lane twiddles W_N^(l*k1); what is left is a 64-point FFT ACROSS the lanes for each of the P values k1.
+ * channelizer_fft8_kernel (fft_size 256 / 512 / 1024): the 64-point FFT as 8 x 8 -- two radix-8 passes inside the lanes with two 8 x 8
+ *     transposes through a per-wavefront LDS buffer between them (l = 8a + b, k2 = c + 8e: DFT over a, twiddle W_64^(bc), DFT over b); the bins
+ *     land in the same buffer and the dongle's channel lanes pick theirs up.  40 eight-byte LDS operations and ~190 vector instructions per
+ *     512-point hop, where the shuffle kernel below issues 112 ds_bpermute and ~450.
+ * channelizer_fft_kernel (fft_size 2048 ... 8192): six radix-2 butterfly stages across lanes, exchanging partners with __shfl_xor
+ *     (ds_bpermute; no LDS storage).  Bin k = k1 + P*k2 ends up in register bitrev(k1) of lane bitrev6(k2); the (at most 64) channels of the
+ *     dongle pull their bin with one more shuffle round.
+ * Lanes 0..n_ch-1 write |bin| (and re/im for raw-I/Q channels) time-major into the stage-2 rings.
  *
  * Arithmetic: float32, FMA contraction allowed (stage 1 agrees with FFTW's float FFT to ~1e-7 relative, not
  * bit-wise -- no FFT does; see DESIGN.md "parity definition").
+ * tests/test_host_fft.py runs this file on the CPU (lanes as fibers) against a float64 FFT.
  */
 #include <hip/hip_runtime.h>
 
@@ -34,7 +41,31 @@ namespace {
 #define AB_DYNAMIC_LDS_BYTES(name) extern __shared__ __attribute__((aligned(16))) uint8_t name[]
 #endif
 
+/* Lanes of ONE wavefront exchange data through LDS: a wavefront's LDS operations execute in order, so all that is needed is that the compiler keeps
+ * them in program order across the exchange (no instruction is emitted).  tests/hostshim_wave64 makes the lanes, which it runs as fibers, meet here. */
+#if !defined(AB_WAVE_SYNC)
+#define AB_WAVE_SYNC()                                           \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
+#endif
+
 constexpr int HOPS_PER_TILE = 16;
+constexpr int FFT8_MAX_LOGP = 4;          /* fft_size <= 1024 runs on channelizer_fft8_kernel */
+constexpr int XS = 72;                    /* complex values per row of a wavefront's exchange buffer: 64 + 8, so that two rows land in different banks */
+constexpr int XBUF_BYTES = 8 * XS * 8;    /* eight rows */
+
+/* bytes of a tile's raw samples in LDS (+ alignment slack), a multiple of 16 */
+__host__ __device__ inline long fft_raw_bytes(int fft_log, int hop_samples, int bytes_per_sample) {
+    return ((((long)(HOPS_PER_TILE - 1) * hop_samples + (1L << fft_log)) * 2 * bytes_per_sample + 32) + 15) & ~15L;
+}
+/* the exchange kernel: fft_size <= 1024, and the four exchange buffers fit a CU's LDS beside the tile's raw samples (wide samples at very high
+ * sample rates leave no room: those configurations stay on the shuffle kernel, which needs none) */
+inline bool fft_uses_exchange(int fft_log, int hop_samples, int bytes_per_sample) {
+    return fft_log - 6 <= FFT8_MAX_LOGP && fft_raw_bytes(fft_log, hop_samples, bytes_per_sample) + 4 * XBUF_BYTES <= 160 * 1024;
+}
 constexpr float kPi = 3.14159265358979323846f;
 
 __device__ __forceinline__ int bitrev(int v, int bits) { return (int)(__brev((unsigned)v) >> (32 - bits)); }
@@ -231,23 +262,230 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
     }
 }
 
+typedef float v2f __attribute__((ext_vector_type(2))); /* (re, im): the compiler turns arithmetic on these into v_pk_*_f32 */
+
+/* x * w with the twiddle as the pair w = (c, s), wr = i w = (-s, c): (x.re, x.re) * w + (x.im, x.im) * wr -- one packed multiply and one packed FMA
+ * (left to itself the compiler spends five instructions on a complex product: it does not negate one half of a packed operand) */
+__device__ __forceinline__ v2f cmul(const v2f x, const v2f w, const v2f wr) { return __builtin_elementwise_fma(x.xx, w, x.yy * wr); }
+__device__ __forceinline__ v2f rot_i(const v2f w) { return v2f{-w.y, w.x}; }
+
+/* P-point radix-2 decimation-in-frequency FFT in registers, constant twiddles; output in bit-reversed register order */
+template <int P>
+__device__ __forceinline__ void fft_dif(v2f (&x)[P]) {
+#pragma unroll
+    for (int half = P / 2; half >= 1; half >>= 1) {
+#pragma unroll
+        for (int base = 0; base < P; base += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                const int i0 = base + j, i1 = i0 + half;
+                const v2f u = x[i0], v = x[i1];
+                x[i0] = u + v;
+                const v2f d = u - v;
+                const float ang = -kPi * (float)j / (float)half; /* W_(2 half)^j: a compile-time constant after unrolling */
+                const float wc = __builtin_cosf(ang), ws = __builtin_sinf(ang);
+                if (j == 0) x[i1] = d;
+                else if (2 * j == half) x[i1] = d.yx * v2f{1.0f, -1.0f}; /* -i: (im, -re), a packed multiply that contracts into the next butterfly's add */
+                else x[i1] = cmul(d, v2f{wc, ws}, v2f{-ws, wc});
+            }
+        }
+    }
+}
+
+template <int LOGP>
+__global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a) {
+    constexpr int P = 1 << LOGP;
+    constexpr int N = P * 64;
+    constexpr int JN = P < 8 ? P : 8;   /* values k1 per exchange round: a round is JN 64-point FFTs, eight lanes each */
+    constexpr int NQ = P / JN;          /* exchange rounds per hop */
+    AB_DYNAMIC_LDS_BYTES(lds_raw);
+
+    const int tiles = (a.n_hops + HOPS_PER_TILE - 1) / HOPS_PER_TILE;
+    const int d = blockIdx.x / tiles, tile = blockIdx.x - d * tiles;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); /* the same number on every lane: hop counters and addresses stay scalar */
+    const int hop0 = tile * HOPS_PER_TILE;
+    const int hops_here = min(HOPS_PER_TILE, a.n_hops - hop0);
+    const int bps2 = 2 * a.bytes_per_sample; /* bytes per complex sample */
+    const DevConst dev = a.dev[d];
+    if (dev.disabled) return; /* a failed / disabled dongle (airband_hip_device_enable): block-uniform, in front of every barrier */
+    if (a.spectrum_only && !dev.any_afc) return; /* AFC's look at the batch's last hop: only dongles with an AFC channel need it */
+
+    /* ---- stage the tile's raw bytes: coalesced 16 B per lane, HBM -> LDS (as in the shuffle kernel below) ---- */
+    const long span_begin = (long)hop0 * a.hop_samples * bps2;
+    const long span_bytes = ((long)(hops_here - 1) * a.hop_samples + N) * bps2;
+    const uint8_t* src = a.iq + (long)d * a.iq_stride + span_begin;
+    const long mis = (long)((uintptr_t)src & 15);
+    const uint8_t* src_al = src - mis;
+    const long n16 = (span_bytes + mis + 15) >> 4;
+    const long avail_end = ((long)(a.n_hops - 1) * a.hop_samples + N) * bps2 - span_begin + mis; /* relative to src_al */
+    const long avail_begin = span_begin == 0 ? mis : 0;
+    for (long i = threadIdx.x; i < n16; i += blockDim.x) {
+        const long o = i << 4;
+        if (o >= avail_begin && o + 16 <= avail_end) {
+            *reinterpret_cast<uint4*>(lds_raw + o) = *reinterpret_cast<const uint4*>(src_al + o);
+        } else { /* nothing outside the span the API promises is touched */
+            for (int b = 0; b < 16; b++) lds_raw[o + b] = (o + b >= avail_begin && o + b < avail_end) ? src_al[o + b] : (uint8_t)0;
+        }
+    }
+
+    /* ---- per-lane constants ---- */
+    float win[P]; /* window x sample scale (u8 (b - 127.5)/127.5, s8 i/128, s16 / f32 x/fullscale of THIS dongle: src/rtl_airband.cpp:316-324,403,421) */
+    const float pre = a.sfmt == AIRBAND_SFMT_U8 ? (1.0f / 127.5f) : a.sfmt == AIRBAND_SFMT_S8 ? (1.0f / 128.0f) : dev.scale;
+#pragma unroll
+    for (int r = 0; r < P; r++) win[r] = a.window[r * 64 + lane] * pre;
+    v2f tw[P], twr[P]; /* W_N^(lane k1) for the k1 = bitrev(rho) register rho holds after the in-lane FFT; from the table the host evaluated in double */
+#pragma unroll
+    for (int rho = 0; rho < P; rho++) {
+        const float2 w = a.twiddle[(lane * bitrev(rho, LOGP)) & (N - 1)];
+        tw[rho] = v2f{w.x, w.y};
+        twr[rho] = rot_i(tw[rho]);
+    }
+    const int b8 = lane & 7;                /* b in the first radix-8 pass, c in the second */
+    const int jj = (lane >> 3) & (JN - 1);  /* the round's k1 this lane works on (fft_size 256: lanes 32 .. 63 repeat the work of lanes 0 .. 31) */
+    v2f cw[8], cwr[8]; /* W_64^(b c) for the c = bitrev3(t) register t holds after the first pass */
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const float2 w = a.twiddle[(b8 * bitrev(t, 3) * P) & (N - 1)];
+        cw[t] = v2f{w.x, w.y};
+        cwr[t] = rot_i(cw[t]);
+    }
+    /* the round and the buffer position in which this lane's channel finds its bin k = k1 + P k2: row = position of k1 in its round, column k2 */
+    int my_slot = -1, my_q = -1, my_idx = 0;
+    bool my_raw = false, my_mag = true; /* NFM channels: stage 2 recomputes |bin| from the raw I/Q */
+    float* my_mag_ring = a.mag;
+    float2* my_iq_ring = a.iq_bins;
+    if (lane < dev.n_ch) {
+        my_slot = a.ext_to_slot[dev.chan_base + lane];
+        const int bin = a.cs[my_slot].bin;
+        const int rho = bitrev(bin & (P - 1), LOGP);
+        my_q = rho / JN;
+        my_idx = (rho % JN) * XS + (bin >> LOGP);
+        my_raw = (a.cc[my_slot].flags & AB_F_RAW_IQ) != 0;
+        my_mag = (a.cc[my_slot].flags & AB_F_NFM) == 0;
+        const long base = ab_tile_base(my_slot, a.ring_rows / AB_TILE_ROWS);
+        my_mag_ring += base;
+        my_iq_ring += base;
+    }
+    v2f* xb = reinterpret_cast<v2f*>(lds_raw + fft_raw_bytes(a.fft_log, a.hop_samples, a.bytes_per_sample) + (long)wave * XBUF_BYTES);
+    v2f* x_w1 = xb + lane;                     /* [j][lane]: value k1_j of lane l                     */
+    v2f* x_r1 = xb + jj * XS + b8;             /* [jj][8 a + b], a = 0 .. 7                           */
+    v2f* x_w2 = xb + jj * XS + b8 * 9;         /* [jj][9 b + c]: rows of nine, a transpose without bank conflicts */
+    v2f* x_r2 = xb + jj * XS + b8;             /* [jj][9 b + c], b = 0 .. 7 (this lane's c = lane & 7) */
+    v2f* x_w3 = xb + jj * XS + b8;             /* [jj][k2 = c + 8 e]                                  */
+    __syncthreads();
+
+    const uint8_t* lds = lds_raw + mis;
+    for (int h = wave; h < hops_here; h += (int)(blockDim.x >> 6)) {
+        v2f x[P];
+        const uint8_t* hp = lds + (long)h * a.hop_samples * bps2;
+        /* convert + window (src/rtl_airband.cpp:402-455) */
+        if (a.sfmt == AIRBAND_SFMT_U8) {
+#pragma unroll
+            for (int r = 0; r < P; r++) {
+                const unsigned v = *reinterpret_cast<const unsigned short*>(hp + 2 * (r * 64 + lane));
+                x[r] = (v2f{(float)(v & 0xffu), (float)(v >> 8)} - 127.5f) * win[r];
+            }
+        } else if (a.sfmt == AIRBAND_SFMT_S8) {
+#pragma unroll
+            for (int r = 0; r < P; r++) {
+                const char2 v = *reinterpret_cast<const char2*>(hp + 2 * (r * 64 + lane));
+                /* i / 128 for every byte: the reference never initialises its table entry for -128 (src/rtl_airband.cpp:322-324); -1.0
+                 * continues the table's own rule (oracle/airband_oracle.c says the same) */
+                x[r] = v2f{(float)v.x, (float)v.y} * win[r];
+            }
+        } else if (a.sfmt == AIRBAND_SFMT_S16) {
+#pragma unroll
+            for (int r = 0; r < P; r++) {
+                const short2 v = *reinterpret_cast<const short2*>(hp + 4 * (r * 64 + lane));
+                x[r] = v2f{(float)v.x, (float)v.y} * win[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < P; r++) {
+                const float2 v = *reinterpret_cast<const float2*>(hp + 8 * (r * 64 + lane));
+                x[r] = v2f{v.x, v.y} * win[r];
+            }
+        }
+        fft_dif<P>(x); /* over r: register rho now holds k1 = bitrev(rho) */
+#pragma unroll
+        for (int rho = 1; rho < P; rho++) x[rho] = cmul(x[rho], tw[rho], twr[rho]);
+
+        v2f mine = v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            /* 64-point FFT over the lanes for the JN values k1 of this round, l = 8 a + b, k2 = c + 8 e */
+#pragma unroll
+            for (int j = 0; j < JN; j++) x_w1[j * XS] = x[q * JN + j];
+            AB_WAVE_SYNC();
+            v2f z[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) z[i] = x_r1[8 * i];
+            AB_WAVE_SYNC(); /* every lane has its eight values: the buffer may be written again */
+            fft_dif<8>(z); /* over a: register t holds c = bitrev3(t) */
+#pragma unroll
+            for (int t = 1; t < 8; t++) z[t] = cmul(z[t], cw[t], cwr[t]);
+#pragma unroll
+            for (int t = 0; t < 8; t++) x_w2[bitrev(t, 3)] = z[t];
+            AB_WAVE_SYNC();
+#pragma unroll
+            for (int i = 0; i < 8; i++) z[i] = x_r2[9 * i];
+            AB_WAVE_SYNC();
+            fft_dif<8>(z); /* over b: register t holds e = bitrev3(t); the lane is (k1 = round's jj-th, c = lane & 7) */
+#pragma unroll
+            for (int t = 0; t < 8; t++) x_w3[8 * bitrev(t, 3)] = z[t];
+            AB_WAVE_SYNC();
+            /* the buffer now holds bins k1 + P k2 of the round's k1 values as [row of k1][k2]: the channel lanes pick theirs up (src/rtl_airband.cpp:483-489) */
+            if (my_q == q) mine = xb[my_idx];
+            /* AFC looks at the whole spectrum of the batch's last hop (afc.finalize(dev, i, fftout), src/rtl_airband.cpp:626-630) */
+            if (a.last_spectrum && hop0 + h == a.n_hops - 1) {
+                float2* sp = reinterpret_cast<float2*>(a.last_spectrum) + (long)d * N;
+#pragma unroll
+                for (int j = 0; j < JN; j++) {
+                    const v2f v = xb[j * XS + lane];
+                    sp[bitrev(q * JN + j, LOGP) + P * lane] = make_float2(v.x, v.y);
+                }
+            }
+            AB_WAVE_SYNC(); /* ... before the next round (or hop) overwrites it */
+        }
+        if (my_slot >= 0 && !a.spectrum_only) {
+            int row = a.row0 + a.first_row + hop0 + h;
+            if (row >= a.ring_rows) row -= a.ring_rows;
+            const int off = ab_tile_off(row);
+            if (my_mag) my_mag_ring[off] = sqrtf(mine.x * mine.x + mine.y * mine.y);
+            if (my_raw) my_iq_ring[off] = make_float2(mine.x, mine.y);
+        }
+    }
+}
+
 template <int LOGP>
 void launch_one(const ChannelizerArgs& a, hipStream_t stream) {
     const int tiles = (a.n_hops + HOPS_PER_TILE - 1) / HOPS_PER_TILE;
     const size_t lds = fft_lds_bytes(a.fft_log, a.hop_samples, a.bytes_per_sample);
     const long blocks = (long)tiles * a.n_dev;
+    /* a spectrum-only launch transforms ONE hop per dongle: one wavefront */
+    const dim3 block(a.spectrum_only ? 64 : 256);
     /* wide formats at high sample rates: opt in to the CU's full 160 KiB (prepare() has checked the upper bound) */
     /* (should the runtime refuse, the launch below fails with hipErrorInvalidValue and the batch driver reports it: airband_hip.cpp checks hipGetLastError) */
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_fft_kernel<LOGP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    /* a spectrum-only launch transforms ONE hop per dongle: one wavefront */
-    hipLaunchKernelGGL(channelizer_fft_kernel<LOGP>, dim3((unsigned)blocks), dim3(a.spectrum_only ? 64 : 256), lds, stream, a);
+    if constexpr (LOGP <= FFT8_MAX_LOGP) {
+        if (!fft_uses_exchange(a.fft_log, a.hop_samples, a.bytes_per_sample)) {
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_fft_kernel<LOGP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(channelizer_fft_kernel<LOGP>, dim3((unsigned)blocks), block, lds, stream, a);
+            return;
+        }
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_fft8_kernel<LOGP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(channelizer_fft8_kernel<LOGP>, dim3((unsigned)blocks), block, lds, stream, a);
+    } else {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_fft_kernel<LOGP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(channelizer_fft_kernel<LOGP>, dim3((unsigned)blocks), block, lds, stream, a);
+    }
 }
 
 }  // namespace
 
-/* dynamic LDS of one workgroup: the raw bytes of HOPS_PER_TILE consecutive hops (+ alignment slack) */
+/* dynamic LDS of one workgroup: the raw bytes of HOPS_PER_TILE consecutive hops (+ alignment slack), and for fft_size <= 1024 the four wavefronts' exchange buffers */
 size_t fft_lds_bytes(int fft_log, int hop_samples, int bytes_per_sample) {
-    return (size_t)(((long)(HOPS_PER_TILE - 1) * hop_samples + (1L << fft_log)) * 2 * bytes_per_sample + 32);
+    return (size_t)fft_raw_bytes(fft_log, hop_samples, bytes_per_sample) + (fft_uses_exchange(fft_log, hop_samples, bytes_per_sample) ? 4 * XBUF_BYTES : 0);
 }
 
 void launch_channelizer_fft(const ChannelizerArgs& a, hipStream_t stream) {
