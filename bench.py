@@ -269,7 +269,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("AIRBAND_BENCH_WORKLOAD", "cfg3"), choices=sorted(WORKLOADS))
     ap.add_argument("--dongles", type=int, default=0, help="override dongles per GPU")
-    ap.add_argument("--sample-format", default="u8", choices=["u8", "s16"], help="u8 = RTL-SDR bytes (BASELINE configs); s16 = CS16 as SoapySDR devices deliver it "
+    ap.add_argument("--sample-format", default="u8", choices=["u8", "s16", "s8", "f32"], help="u8 = RTL-SDR bytes (BASELINE configs); s16 = CS16 as SoapySDR devices deliver it; s8 (mirisdr), f32 (SoapySDR CF32: the wavefront-FFT channelizer; 8 bytes per sample, so use --ring 1 --dongles 32768) "
                     "(the same synthetic signal re-expressed at 16 bits, full scale 25 500)")
     ap.add_argument("--sample-rate", type=int, default=2_560_000, help="dongle sample rate (BASELINE: 2 560 000; 2 400 000 is the other common RTL-SDR rate: hops of "
                     "300 / 600 bytes, not multiples of 16)")
@@ -341,10 +341,12 @@ def main():
     if args.afc:
         chans = [dict(c) for c in chans]
         chans[0]["afc"] = args.afc
-    s16 = args.sample_format == "s16"
+    s16 = args.sample_format != "u8"  # (name kept from when CS16 was the only other format: "not the BASELINE's u8")
+    bpc = {"u8": 1, "s8": 1, "s16": 2, "f32": 4}[args.sample_format]  # bytes per sample component
     sr = args.sample_rate
     samples_per_batch = sr // 8
-    devices = [dict(channels=chans, sample_rate=sr, sfmt=pkg.capi.SFMT_S16, fullscale=25500.0) if s16 else dict(channels=chans, sample_rate=sr) for _ in range(D)]
+    other = {"s16": dict(sfmt=pkg.capi.SFMT_S16, fullscale=25500.0), "s8": dict(sfmt=pkg.capi.SFMT_S8), "f32": dict(sfmt=pkg.capi.SFMT_F32)}
+    devices = [dict(channels=chans, sample_rate=sr, **other[args.sample_format]) if s16 else dict(channels=chans, sample_rate=sr) for _ in range(D)]
     # AIRBAND_BENCH_FLAGS adds AIRBAND_HIP_FLAG_* bits for experiments (e.g. 8 = demod kinds one after the other, for per-kernel profiles)
     flags = int(os.environ.get("AIRBAND_BENCH_FLAGS", "0"), 0) | (pkg.capi.FLAG_PIPELINE if args.pipelined else 0)
     hip = pkg.AirbandHip(devices, wave_rate=wave_rate, hip_device=local_rank, flags=flags, fft_log=args.fft_log)
@@ -362,17 +364,22 @@ def main():
     if not s16:
         hip.generate_iq(iq.data_ptr(), stride, 0, span, seed=0x5EED, device_index_offset=rank * D)
     else:
-        # the generator emits u8; CS16 dongles get the same signal as (b - 127.5) * 200, converted slab by slab
+        # the generator emits u8; CS16 dongles get the same signal as (b - 127.5) * 200, s8 ones b - 128, f32 ones (b - 127.5) / 127.5, converted slab by slab
         slab = min(D, 2048)
         gen = pkg.AirbandHip([dict(channels=chans, sample_rate=sr) for _ in range(slab)], wave_rate=wave_rate, hip_device=local_rank)
         gen.set_signal_plan(carriers)
-        tmp = torch.empty((slab, span // 2), dtype=torch.uint8, device="cuda")
-        iq16 = iq.view(torch.int16)
+        tmp = torch.empty((slab, span // bpc), dtype=torch.uint8, device="cuda")
+        iqv = iq.view({1: torch.int8, 2: torch.int16, 4: torch.float32}[bpc])
         for d0 in range(0, D, slab):
             n = min(slab, D - d0)
-            gen.generate_iq(tmp.data_ptr(), span // 2, 0, span // 2, seed=0x5EED, device_index_offset=rank * D + d0)
+            gen.generate_iq(tmp.data_ptr(), span // bpc, 0, span // bpc, seed=0x5EED, device_index_offset=rank * D + d0)
             gen.synchronize()
-            iq16[d0:d0 + n, :span // 2] = tmp[:n].to(torch.int16) * 200 - 25500
+            if bpc == 2:
+                iqv[d0:d0 + n, :span // 2] = tmp[:n].to(torch.int16) * 200 - 25500
+            elif bpc == 1:
+                iqv[d0:d0 + n, :span] = (tmp[:n].to(torch.int16) - 128).clamp_(-127, 127).to(torch.int8)
+            else:
+                iqv[d0:d0 + n, :span // 4] = (tmp[:n].to(torch.float32) - 127.5) / 127.5
         gen.close()
         del tmp
     hip.synchronize()
@@ -430,12 +437,12 @@ def main():
 
     total_samples = float(D) * world * samples_per_batch * args.steps
     value = total_samples / elapsed / 1e6
-    hop = g.batch_bytes // ((4 if s16 else 2) * hip.B)
-    alg_bytes_per_sample = (4.0 if s16 else 2.0) + 8 * 4.0 / hop   # u8 (cs16) I/Q in, 8 channels of float audio out per hop
+    hop = g.batch_bytes // (2 * bpc * hip.B)
+    alg_bytes_per_sample = 2.0 * bpc + 8 * 4.0 / hop   # u8 (cs16) I/Q in, 8 channels of float audio out per hop
     name = hip.channelizer_name()
     build = hip.build_info()
     achieved = alg_bytes_per_sample * D * samples_per_batch / (ch_ms * 1e-3) / 1e9
-    read_only = (4.0 if s16 else 2.0) * D * samples_per_batch / (ch_ms * 1e-3) / 1e9
+    read_only = 2.0 * bpc * D * samples_per_batch / (ch_ms * 1e-3) / 1e9
     roofline = dict(bound="hbm", kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                     avg_launch_ms=round(ch_ms, 4), algorithmic_bytes_per_launch=alg_bytes_per_sample * D * samples_per_batch,
                     frac_read_only=round(read_only / HBM_PEAK_GBS, 4),
@@ -448,7 +455,7 @@ def main():
         n_fft = g.fft_size
         pieces = max(1, n_fft // 512)
         ksteps = min(n_fft, 512) // 32
-        per_tile = (3 * ksteps - (ksteps // 4 if pieces == 1 else 0)) * pieces * (2 if s16 else 1)
+        per_tile = (3 * ksteps - (ksteps // 4 if pieces == 1 else 0)) * pieces * bpc
         tiles = -(-(hip.B) // 16) + 1
         tops = per_tile * tiles * D * 32768.0 / (ch_ms * 1e-3) / 1e12
         roofline["mfma_int8_tops"] = round(tops, 1)

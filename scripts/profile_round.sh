@@ -1,8 +1,8 @@
 # Regenerates the round's measurements on a GPU box:  rm -rf gpurun_out/final; gpurun --timeout 2400 -- 'bash scripts/profile_round.sh'
-# (gpurun MERGES into the local gpurun_out/, so remove the old copy first), then `python scripts/collect_profiles.py r03` copies the summaries into profiles/.
+# (gpurun MERGES into the local gpurun_out/, so remove the old copy first), then `python scripts/collect_profiles.py r04` copies the summaries into profiles/.
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=r03
+R=${R:-r04}
 O=gpurun_out/final; rm -rf $O; mkdir -p $O
 nproc > $O/host.txt; grep -m1 "model name" /proc/cpuinfo >> $O/host.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -n 1 $O/smoke.log
@@ -24,6 +24,7 @@ timeout 300 python bench.py $N --fft-log 11 2>/dev/null | tail -n 1 > $O/${R}_be
 timeout 300 python bench.py $N --fft-log 12 --steps 12 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg3_fft4096.json
 timeout 300 python bench.py $N --fft-log 13 --steps 8 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg3_fft8192.json
 AIRBAND_BENCH_FLAGS=4 timeout 300 python bench.py --no-cpu-baseline --no-traffic --no-verify-all --verify 4 --steps 6 --warmup 2 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg3_force_fft.json
+timeout 300 python bench.py --no-cpu-baseline --no-traffic --no-verify-all --verify 4 --steps 6 --warmup 2 --sample-format f32 --ring 1 --dongles 32768 2>/dev/null | tail -n 1 > $O/${R}_bench_f32_32768.json
 K="--no-cpu-baseline --no-traffic --no-verify-all --verify 0 --steps 8 --warmup 2"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg3 -- python bench.py $K > $O/kt_cfg3.log 2>&1
 AIRBAND_BENCH_FLAGS=8 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg3_serial -- python bench.py $K > $O/kt_serial.log 2>&1
