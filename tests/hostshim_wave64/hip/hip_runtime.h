@@ -177,20 +177,34 @@ static inline void run_block(int n, const std::function<void()>& body) {
     M.cur = -1;
 }
 
+/* a block's dynamic LDS (kernels that declare it with AB_DYNAMIC_LDS_BYTES): the bytes the launch asked for, then a guard zone that must come back untouched */
+constexpr size_t LDS_MAX = 160 * 1024, LDS_GUARD = 4096;
+alignas(16) static uint8_t dynamic_lds[LDS_MAX + LDS_GUARD];
+
 template <class K, class... A>
-static inline void launch(K kernel, dim3 grid, dim3 block, A... args) {
+static inline void launch(K kernel, dim3 grid, dim3 block, size_t lds_bytes, A... args) {
     gridDim = grid;
     blockDim = block;
+    if (lds_bytes > LDS_MAX) {
+        std::fprintf(stderr, "ab_emu: launch asks for %zu bytes of LDS\n", lds_bytes);
+        std::abort();
+    }
     for (unsigned by = 0; by < grid.y; by++)
         for (unsigned bx = 0; bx < grid.x; bx++) {
             blockIdx = dim3(bx, by, 0);
+            std::memset(dynamic_lds + lds_bytes, 0xA5, LDS_GUARD);
             run_block((int)block.x, [&]() { kernel(args...); });
+            for (size_t i = 0; i < LDS_GUARD; i++)
+                if (dynamic_lds[lds_bytes + i] != 0xA5) {
+                    std::fprintf(stderr, "ab_emu: block %u wrote LDS byte %zu of a launch with %zu bytes of dynamic LDS\n", bx, lds_bytes + i, lds_bytes);
+                    std::abort();
+                }
         }
 }
 
 }  // namespace ab_emu
 
-#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) ab_emu::launch(kernel, dim3(grid), dim3(block), __VA_ARGS__)
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) ab_emu::launch(kernel, dim3(grid), dim3(block), (size_t)(lds), __VA_ARGS__)
 #define AB_LOCKSTEP() ab_emu::lockstep()
 
 static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
@@ -226,7 +240,7 @@ static inline float ab_emu_shfl(float v, int src) { /* ds_bpermute: every live l
 static inline float __shfl(float v, int src) { return ab_emu_shfl(v, src); }
 static inline float __shfl_xor(float v, int mask) { return ab_emu_shfl(v, ab_emu::my_lane() ^ mask); }
 #define AB_WAVE_SYNC() ab_emu::lockstep() /* csrc/channelizer_fft.hip: lanes of one wavefront exchange data through LDS */
-#define AB_DYNAMIC_LDS_BYTES(name) alignas(16) static uint8_t name[160 * 1024] /* one block runs at a time */
+#define AB_DYNAMIC_LDS_BYTES(name) uint8_t* const name = ab_emu::dynamic_lds /* one block runs at a time; writes past the launch's size are caught (ab_emu::launch) */
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
 
