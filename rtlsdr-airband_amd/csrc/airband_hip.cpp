@@ -92,6 +92,7 @@ struct airband_hip_handle {
     DevBuf<int> d_slot_to_ext, d_ext_to_slot;
     DevBuf<uint8_t> d_block_kind;
     DevBuf<float> d_window, d_sin, d_cos, d_twiddle;
+    DevBuf<float> d_window_dec; /* fft_size >= 2048: the window de-interleaved by sample index mod (fft_size / 512), for the decimated wavefront FFT (channelizer_fft.hip) */
     DevBuf<float> d_mag, d_sqbuf, d_ct_coeff, d_ct_q;
     DevBuf<float2> d_iq, d_iq_out, d_ct_af;
     DevBuf<unsigned long long> d_ct_mask;
@@ -186,7 +187,7 @@ void destroy(airband_hip_handle* h) {
         if (st) (void)hipStreamSynchronize(st);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_dev.release(); h->d_cc.release(); h->d_cs.release(); h->d_slot_to_ext.release(); h->d_ext_to_slot.release(); h->d_block_kind.release();
-    h->d_window.release(); h->d_sin.release(); h->d_cos.release(); h->d_twiddle.release();
+    h->d_window.release(); h->d_sin.release(); h->d_cos.release(); h->d_twiddle.release(); h->d_window_dec.release();
     h->d_mag.release(); h->d_sqbuf.release(); h->d_ct_coeff.release(); h->d_ct_q.release();
     h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release(); h->d_ct_af.release(); h->d_ct_mask.release();
     h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
@@ -297,6 +298,7 @@ void launch_last_hop_spectrum(airband_hip_handle* h, hipStream_t s) {
     ca.cc = h->d_cc.p;
     ca.ext_to_slot = h->d_ext_to_slot.p;
     ca.window = h->d_window.p;
+    ca.window_dec = h->d_window_dec.p;
     ca.twiddle = reinterpret_cast<const float2*>(h->d_twiddle.p);
     ca.mag = h->d_mag.p;
     ca.iq_bins = h->d_iq.p;
@@ -559,6 +561,12 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     PREP_TRY(upload(h->d_ext_to_slot, h->ext_to_slot), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_block_kind, block_kind), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_window, p.window), AIRBAND_HIP_ENOMEM);
+    if (p.fft_size >= 2048) { /* row n2 = the window at samples n2, n2 + M, n2 + 2 M, ... (M = fft_size / 512): what transform n2 of a decimated FFT multiplies by, contiguous */
+        const int M = p.fft_size / 512;
+        std::vector<float> dec((size_t)p.fft_size);
+        for (int n = 0; n < p.fft_size; n++) dec[(size_t)(n % M) * 512 + n / M] = p.window[n];
+        PREP_TRY(upload(h->d_window_dec, dec), AIRBAND_HIP_ENOMEM);
+    }
     PREP_TRY(upload(h->d_sin, p.sin_lut), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_twiddle, p.twiddle), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_cos, p.cos_lut), AIRBAND_HIP_ENOMEM);
@@ -894,6 +902,7 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         ca.cc = h->d_cc.p;
         ca.ext_to_slot = h->d_ext_to_slot.p;
         ca.window = h->d_window.p;
+        ca.window_dec = h->d_window_dec.p;
         ca.twiddle = reinterpret_cast<const float2*>(h->d_twiddle.p);
         ca.mag = h->d_mag.p;
         ca.iq_bins = h->d_iq.p;

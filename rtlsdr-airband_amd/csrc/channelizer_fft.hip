@@ -14,13 +14,14 @@
  *   * each wavefront then transforms whole hops: lane l holds the P = N/64 samples n = r*64 + l, converts and
  *     windows them in registers, runs a P-point radix-2 FFT inside the lane (constant twiddles) and multiplies by the
  *     per-lane twiddles W_N^(l*k1); what is left is a 64-point FFT ACROSS the lanes for each of the P values k1.
- * channelizer_fft8_kernel (fft_size 256 / 512 / 1024): the 64-point FFT as 8 x 8 -- two radix-8 passes inside the lanes with two 8 x 8
+ * channelizer_fft8_kernel (every fft_size): the 64-point FFT as 8 x 8 -- two radix-8 passes inside the lanes with two 8 x 8
  *     transposes through a per-wavefront LDS buffer between them (l = 8a + b, k2 = c + 8e: DFT over a, twiddle W_64^(bc), DFT over b); the bins
  *     land in the same buffer and the dongle's channel lanes pick theirs up.  40 eight-byte LDS operations and ~190 vector instructions per
- *     512-point hop, where the shuffle kernel below issues 112 ds_bpermute and ~450.
- * channelizer_fft_kernel (fft_size 2048 ... 8192): six radix-2 butterfly stages across lanes, exchanging partners with __shfl_xor
- *     (ds_bpermute; no LDS storage).  Bin k = k1 + P*k2 ends up in register bitrev(k1) of lane bitrev6(k2); the (at most 64) channels of the
- *     dongle pull their bin with one more shuffle round.
+ *     512-point hop, where the shuffle kernel below issues 112 ds_bpermute and ~450.  fft_size 2048 ... 8192 run as 4 / 8 / 16 DECIMATED 512-point
+ *     transforms per hop, combined for the channels' bins only (see the kernel).
+ * channelizer_fft_kernel (AFC's whole-spectrum launch at fft_size >= 2048; tiles whose raw samples leave no LDS for the exchange buffers): six
+ *     radix-2 butterfly stages across lanes, exchanging partners with __shfl_xor (ds_bpermute; no LDS storage).  Bin k = k1 + P*k2 ends up in
+ *     register bitrev(k1) of lane bitrev6(k2); the (at most 64) channels of the dongle pull their bin with one more shuffle round.
  * Lanes 0..n_ch-1 write |bin| (and re/im for raw-I/Q channels) time-major into the stage-2 rings.
  *
  * Arithmetic: float32, FMA contraction allowed (stage 1 agrees with FFTW's float FFT to ~1e-7 relative, not
@@ -53,7 +54,6 @@ namespace {
 #endif
 
 constexpr int HOPS_PER_TILE = 16;
-constexpr int FFT8_MAX_LOGP = 4;          /* fft_size <= 1024 runs on channelizer_fft8_kernel */
 constexpr int XS = 72;                    /* complex values per row of a wavefront's exchange buffer: 64 + 8, so that two rows land in different banks */
 constexpr int XBUF_BYTES = 8 * XS * 8;    /* eight rows */
 
@@ -61,10 +61,10 @@ constexpr int XBUF_BYTES = 8 * XS * 8;    /* eight rows */
 __host__ __device__ inline long fft_raw_bytes(int fft_log, int hop_samples, int bytes_per_sample) {
     return ((((long)(HOPS_PER_TILE - 1) * hop_samples + (1L << fft_log)) * 2 * bytes_per_sample + 32) + 15) & ~15L;
 }
-/* the exchange kernel: fft_size <= 1024, and the four exchange buffers fit a CU's LDS beside the tile's raw samples (wide samples at very high
- * sample rates leave no room: those configurations stay on the shuffle kernel, which needs none) */
+/* the exchange kernel runs where its four exchange buffers fit a CU's LDS beside the tile's raw samples (wide samples at very high sample rates
+ * leave no room: those configurations stay on the shuffle kernel, which needs none) */
 inline bool fft_uses_exchange(int fft_log, int hop_samples, int bytes_per_sample) {
-    return fft_log - 6 <= FFT8_MAX_LOGP && fft_raw_bytes(fft_log, hop_samples, bytes_per_sample) + 4 * XBUF_BYTES <= 160 * 1024;
+    return fft_raw_bytes(fft_log, hop_samples, bytes_per_sample) + 4 * XBUF_BYTES <= 160 * 1024;
 }
 constexpr float kPi = 3.14159265358979323846f;
 
@@ -292,12 +292,20 @@ __device__ __forceinline__ void fft_dif(v2f (&x)[P]) {
     }
 }
 
-template <int LOGP>
+/* LOGM > 0: fft_size = M x 512 (2048 ... 8192).  With n = M n1 + n2 the transform is M transforms of 512 points over the DECIMATED samples,
+ *      X[k] = sum over n2 of  W_N^(n2 k) * F_n2[k mod 512],      F_n2[kk] = sum over n1 of x[M n1 + n2] w[M n1 + n2] W_512^(n1 kk),
+ * and since only the dongle's channels' bins are wanted, the outer sum is one complex multiply-add per channel lane and n2: a wavefront runs the M
+ * 512-point transforms of its hop one after the other with the register footprint of ONE (the shuffle kernel keeps all fft_size / 64 values per lane in
+ * registers: 298 VGPRs at 2048 points, scratch memory beyond).  The window is read per transform from a de-interleaved copy of its table (row n2 = the window at samples n2 + M n1: 256 contiguous bytes per
+ * load instruction) instead of held in registers. */
+template <int LOGP, int LOGM>
 __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a) {
-    constexpr int P = 1 << LOGP;
-    constexpr int N = P * 64;
+    constexpr int P = 1 << LOGP, M = 1 << LOGM;
+    constexpr int NS = P * 64;          /* points per transform */
+    constexpr int N = NS * M;           /* fft_size */
+    static_assert(LOGM == 0 || LOGP == 3, "decimated transforms are 512 points long");
     constexpr int JN = P < 8 ? P : 8;   /* values k1 per exchange round: a round is JN 64-point FFTs, eight lanes each */
-    constexpr int NQ = P / JN;          /* exchange rounds per hop */
+    constexpr int NQ = P / JN;          /* exchange rounds per transform */
     AB_DYNAMIC_LDS_BYTES(lds_raw);
 
     const int tiles = (a.n_hops + HOPS_PER_TILE - 1) / HOPS_PER_TILE;
@@ -330,37 +338,40 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
     }
 
     /* ---- per-lane constants ---- */
-    float win[P]; /* window x sample scale (u8 (b - 127.5)/127.5, s8 i/128, s16 / f32 x/fullscale of THIS dongle: src/rtl_airband.cpp:316-324,403,421) */
+    /* window x sample scale (u8 (b - 127.5)/127.5, s8 i/128, s16 / f32 x/fullscale of THIS dongle: src/rtl_airband.cpp:316-324,403,421) */
     const float pre = a.sfmt == AIRBAND_SFMT_U8 ? (1.0f / 127.5f) : a.sfmt == AIRBAND_SFMT_S8 ? (1.0f / 128.0f) : dev.scale;
+    float win[P]; /* (M > 1: re-read per transform from the de-interleaved table) */
 #pragma unroll
-    for (int r = 0; r < P; r++) win[r] = a.window[r * 64 + lane] * pre;
-    v2f tw[P], twr[P]; /* W_N^(lane k1) for the k1 = bitrev(rho) register rho holds after the in-lane FFT; from the table the host evaluated in double */
+    for (int r = 0; r < P; r++) win[r] = M > 1 ? 0.0f : a.window[r * 64 + lane] * pre;
+    /* W_NS^(lane k1) for the k1 = bitrev(rho) register rho holds after the in-lane FFT; from the table of W_N the host evaluated in double (W_NS = W_N^M) */
+    v2f tw[P], twr[P];
 #pragma unroll
     for (int rho = 0; rho < P; rho++) {
-        const float2 w = a.twiddle[(lane * bitrev(rho, LOGP)) & (N - 1)];
+        const float2 w = a.twiddle[((lane * bitrev(rho, LOGP)) & (NS - 1)) * M];
         tw[rho] = v2f{w.x, w.y};
         twr[rho] = rot_i(tw[rho]);
     }
     const int b8 = lane & 7;                /* b in the first radix-8 pass, c in the second */
-    const int jj = (lane >> 3) & (JN - 1);  /* the round's k1 this lane works on (fft_size 256: lanes 32 .. 63 repeat the work of lanes 0 .. 31) */
+    const int jj = (lane >> 3) & (JN - 1);  /* the round's k1 this lane works on (256-point transforms: lanes 32 .. 63 repeat the work of lanes 0 .. 31) */
     v2f cw[8], cwr[8]; /* W_64^(b c) for the c = bitrev3(t) register t holds after the first pass */
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-        const float2 w = a.twiddle[(b8 * bitrev(t, 3) * P) & (N - 1)];
+        const float2 w = a.twiddle[(b8 * bitrev(t, 3) * P * M) & (N - 1)];
         cw[t] = v2f{w.x, w.y};
         cwr[t] = rot_i(cw[t]);
     }
-    /* the round and the buffer position in which this lane's channel finds its bin k = k1 + P k2: row = position of k1 in its round, column k2 */
-    int my_slot = -1, my_q = -1, my_idx = 0;
+    /* the round and the buffer position in which this lane's channel finds bin kk = k mod NS of a transform: row = position of kk mod P in its round, column kk / P */
+    int my_slot = -1, my_q = -1, my_idx = 0, my_bin = 0;
     bool my_raw = false, my_mag = true; /* NFM channels: stage 2 recomputes |bin| from the raw I/Q */
     float* my_mag_ring = a.mag;
     float2* my_iq_ring = a.iq_bins;
     if (lane < dev.n_ch) {
         my_slot = a.ext_to_slot[dev.chan_base + lane];
-        const int bin = a.cs[my_slot].bin;
-        const int rho = bitrev(bin & (P - 1), LOGP);
+        my_bin = a.cs[my_slot].bin;
+        const int kk = my_bin & (NS - 1);
+        const int rho = bitrev(kk & (P - 1), LOGP);
         my_q = rho / JN;
-        my_idx = (rho % JN) * XS + (bin >> LOGP);
+        my_idx = (rho % JN) * XS + (kk >> LOGP);
         my_raw = (a.cc[my_slot].flags & AB_F_RAW_IQ) != 0;
         my_mag = (a.cc[my_slot].flags & AB_F_NFM) == 0;
         const long base = ab_tile_base(my_slot, a.ring_rows / AB_TILE_ROWS);
@@ -377,125 +388,149 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
 
     const uint8_t* lds = lds_raw + mis;
     for (int h = wave; h < hops_here; h += (int)(blockDim.x >> 6)) {
-        v2f x[P];
         const uint8_t* hp = lds + (long)h * a.hop_samples * bps2;
-        /* convert + window (src/rtl_airband.cpp:402-455) */
-        if (a.sfmt == AIRBAND_SFMT_U8) {
+        v2f bin_sum = v2f{0.0f, 0.0f};
+#pragma unroll 1
+        for (int n2 = 0; n2 < M; n2++) { /* one pass unless the transform is decimated */
+            v2f x[P];
+            if (M > 1) {
 #pragma unroll
-            for (int r = 0; r < P; r++) {
-                const unsigned v = *reinterpret_cast<const unsigned short*>(hp + 2 * (r * 64 + lane));
-                x[r] = (v2f{(float)(v & 0xffu), (float)(v >> 8)} - 127.5f) * win[r];
+                for (int r = 0; r < P; r++) win[r] = a.window_dec[n2 * NS + r * 64 + lane] * pre; /* = window[M (r 64 + lane) + n2], coalesced */
             }
-        } else if (a.sfmt == AIRBAND_SFMT_S8) {
+            /* convert + window (src/rtl_airband.cpp:402-455): this lane's samples n = M (r 64 + lane) + n2 */
+            if (a.sfmt == AIRBAND_SFMT_U8) {
 #pragma unroll
-            for (int r = 0; r < P; r++) {
-                const char2 v = *reinterpret_cast<const char2*>(hp + 2 * (r * 64 + lane));
-                /* i / 128 for every byte: the reference never initialises its table entry for -128 (src/rtl_airband.cpp:322-324); -1.0
-                 * continues the table's own rule (oracle/airband_oracle.c says the same) */
-                x[r] = v2f{(float)v.x, (float)v.y} * win[r];
-            }
-        } else if (a.sfmt == AIRBAND_SFMT_S16) {
+                for (int r = 0; r < P; r++) {
+                    const unsigned v = *reinterpret_cast<const unsigned short*>(hp + 2 * (M * (r * 64 + lane) + n2));
+                    x[r] = (v2f{(float)(v & 0xffu), (float)(v >> 8)} - 127.5f) * win[r];
+                }
+            } else if (a.sfmt == AIRBAND_SFMT_S8) {
 #pragma unroll
-            for (int r = 0; r < P; r++) {
-                const short2 v = *reinterpret_cast<const short2*>(hp + 4 * (r * 64 + lane));
-                x[r] = v2f{(float)v.x, (float)v.y} * win[r];
-            }
-        } else {
+                for (int r = 0; r < P; r++) {
+                    const char2 v = *reinterpret_cast<const char2*>(hp + 2 * (M * (r * 64 + lane) + n2));
+                    /* i / 128 for every byte: the reference never initialises its table entry for -128 (src/rtl_airband.cpp:322-324); -1.0
+                     * continues the table's own rule (oracle/airband_oracle.c says the same) */
+                    x[r] = v2f{(float)v.x, (float)v.y} * win[r];
+                }
+            } else if (a.sfmt == AIRBAND_SFMT_S16) {
 #pragma unroll
-            for (int r = 0; r < P; r++) {
-                const float2 v = *reinterpret_cast<const float2*>(hp + 8 * (r * 64 + lane));
-                x[r] = v2f{v.x, v.y} * win[r];
-            }
-        }
-        fft_dif<P>(x); /* over r: register rho now holds k1 = bitrev(rho) */
+                for (int r = 0; r < P; r++) {
+                    const short2 v = *reinterpret_cast<const short2*>(hp + 4 * (M * (r * 64 + lane) + n2));
+                    x[r] = v2f{(float)v.x, (float)v.y} * win[r];
+                }
+            } else {
 #pragma unroll
-        for (int rho = 1; rho < P; rho++) x[rho] = cmul(x[rho], tw[rho], twr[rho]);
-
-        v2f mine = v2f{0.0f, 0.0f};
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            /* 64-point FFT over the lanes for the JN values k1 of this round, l = 8 a + b, k2 = c + 8 e */
-#pragma unroll
-            for (int j = 0; j < JN; j++) x_w1[j * XS] = x[q * JN + j];
-            AB_WAVE_SYNC();
-            v2f z[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) z[i] = x_r1[8 * i];
-            AB_WAVE_SYNC(); /* every lane has its eight values: the buffer may be written again */
-            fft_dif<8>(z); /* over a: register t holds c = bitrev3(t) */
-#pragma unroll
-            for (int t = 1; t < 8; t++) z[t] = cmul(z[t], cw[t], cwr[t]);
-#pragma unroll
-            for (int t = 0; t < 8; t++) x_w2[bitrev(t, 3)] = z[t];
-            AB_WAVE_SYNC();
-#pragma unroll
-            for (int i = 0; i < 8; i++) z[i] = x_r2[9 * i];
-            AB_WAVE_SYNC();
-            fft_dif<8>(z); /* over b: register t holds e = bitrev3(t); the lane is (k1 = round's jj-th, c = lane & 7) */
-#pragma unroll
-            for (int t = 0; t < 8; t++) x_w3[8 * bitrev(t, 3)] = z[t];
-            AB_WAVE_SYNC();
-            /* the buffer now holds bins k1 + P k2 of the round's k1 values as [row of k1][k2]: the channel lanes pick theirs up (src/rtl_airband.cpp:483-489) */
-            if (my_q == q) mine = xb[my_idx];
-            /* AFC looks at the whole spectrum of the batch's last hop (afc.finalize(dev, i, fftout), src/rtl_airband.cpp:626-630) */
-            if (a.last_spectrum && hop0 + h == a.n_hops - 1) {
-                float2* sp = reinterpret_cast<float2*>(a.last_spectrum) + (long)d * N;
-#pragma unroll
-                for (int j = 0; j < JN; j++) {
-                    const v2f v = xb[j * XS + lane];
-                    sp[bitrev(q * JN + j, LOGP) + P * lane] = make_float2(v.x, v.y);
+                for (int r = 0; r < P; r++) {
+                    const float2 v = *reinterpret_cast<const float2*>(hp + 8 * (M * (r * 64 + lane) + n2));
+                    x[r] = v2f{v.x, v.y} * win[r];
                 }
             }
-            AB_WAVE_SYNC(); /* ... before the next round (or hop) overwrites it */
+            fft_dif<P>(x); /* over r: register rho now holds k1 = bitrev(rho) */
+#pragma unroll
+            for (int rho = 1; rho < P; rho++) x[rho] = cmul(x[rho], tw[rho], twr[rho]);
+
+            v2f mine = v2f{0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                /* 64-point FFT over the lanes for the JN values k1 of this round, l = 8 a + b, k2 = c + 8 e */
+#pragma unroll
+                for (int j = 0; j < JN; j++) x_w1[j * XS] = x[q * JN + j];
+                AB_WAVE_SYNC();
+                v2f z[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) z[i] = x_r1[8 * i];
+                AB_WAVE_SYNC(); /* every lane has its eight values: the buffer may be written again */
+                fft_dif<8>(z); /* over a: register t holds c = bitrev3(t) */
+#pragma unroll
+                for (int t = 1; t < 8; t++) z[t] = cmul(z[t], cw[t], cwr[t]);
+#pragma unroll
+                for (int t = 0; t < 8; t++) x_w2[bitrev(t, 3)] = z[t];
+                AB_WAVE_SYNC();
+#pragma unroll
+                for (int i = 0; i < 8; i++) z[i] = x_r2[9 * i];
+                AB_WAVE_SYNC();
+                fft_dif<8>(z); /* over b: register t holds e = bitrev3(t); the lane is (k1 = round's jj-th, c = lane & 7) */
+#pragma unroll
+                for (int t = 0; t < 8; t++) x_w3[8 * bitrev(t, 3)] = z[t];
+                AB_WAVE_SYNC();
+                /* the buffer now holds bins k1 + P k2 of the round's k1 values as [row of k1][k2]: the channel lanes pick theirs up (src/rtl_airband.cpp:483-489) */
+                if (my_q == q) mine = xb[my_idx];
+                /* AFC looks at the whole spectrum of the batch's last hop (afc.finalize(dev, i, fftout), src/rtl_airband.cpp:626-630); decimated transforms
+                 * leave that to a one-hop launch of the shuffle kernel (launch_channelizer_fft) */
+                if (M == 1 && a.last_spectrum && hop0 + h == a.n_hops - 1) {
+                    float2* sp = reinterpret_cast<float2*>(a.last_spectrum) + (long)d * N;
+#pragma unroll
+                    for (int j = 0; j < JN; j++) {
+                        const v2f v = xb[j * XS + lane];
+                        sp[bitrev(q * JN + j, LOGP) + P * lane] = make_float2(v.x, v.y);
+                    }
+                }
+                AB_WAVE_SYNC(); /* ... before the next round (or transform, or hop) overwrites it */
+            }
+            if (M == 1) {
+                bin_sum = mine;
+            } else { /* X[k] += W_N^(n2 k) F_n2[k mod 512], n2 in ascending order */
+                const float2 w = a.twiddle[(n2 * my_bin) & (N - 1)];
+                const v2f wv = v2f{w.x, w.y};
+                bin_sum += cmul(mine, wv, rot_i(wv));
+            }
         }
         if (my_slot >= 0 && !a.spectrum_only) {
             int row = a.row0 + a.first_row + hop0 + h;
             if (row >= a.ring_rows) row -= a.ring_rows;
             const int off = ab_tile_off(row);
-            if (my_mag) my_mag_ring[off] = sqrtf(mine.x * mine.x + mine.y * mine.y);
-            if (my_raw) my_iq_ring[off] = make_float2(mine.x, mine.y);
+            if (my_mag) my_mag_ring[off] = sqrtf(bin_sum.x * bin_sum.x + bin_sum.y * bin_sum.y);
+            if (my_raw) my_iq_ring[off] = make_float2(bin_sum.x, bin_sum.y);
         }
     }
 }
 
-template <int LOGP>
+template <int LOGP, int LOGM, int LOGP_SHUFFLE>
 void launch_one(const ChannelizerArgs& a, hipStream_t stream) {
     const int tiles = (a.n_hops + HOPS_PER_TILE - 1) / HOPS_PER_TILE;
     const size_t lds = fft_lds_bytes(a.fft_log, a.hop_samples, a.bytes_per_sample);
     const long blocks = (long)tiles * a.n_dev;
-    /* a spectrum-only launch transforms ONE hop per dongle: one wavefront */
-    const dim3 block(a.spectrum_only ? 64 : 256);
     /* wide formats at high sample rates: opt in to the CU's full 160 KiB (prepare() has checked the upper bound) */
     /* (should the runtime refuse, the launch below fails with hipErrorInvalidValue and the batch driver reports it: airband_hip.cpp checks hipGetLastError) */
-    if constexpr (LOGP <= FFT8_MAX_LOGP) {
-        if (!fft_uses_exchange(a.fft_log, a.hop_samples, a.bytes_per_sample)) {
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_fft_kernel<LOGP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipLaunchKernelGGL(channelizer_fft_kernel<LOGP>, dim3((unsigned)blocks), block, lds, stream, a);
-            return;
-        }
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_fft8_kernel<LOGP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(channelizer_fft8_kernel<LOGP>, dim3((unsigned)blocks), block, lds, stream, a);
-    } else {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_fft_kernel<LOGP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(channelizer_fft_kernel<LOGP>, dim3((unsigned)blocks), block, lds, stream, a);
+    auto shuffle = [&](const ChannelizerArgs& b, long n_blocks) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_fft_kernel<LOGP_SHUFFLE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        /* a spectrum-only launch transforms ONE hop per dongle: one wavefront */
+        hipLaunchKernelGGL(channelizer_fft_kernel<LOGP_SHUFFLE>, dim3((unsigned)n_blocks), dim3(b.spectrum_only ? 64 : 256), lds, stream, b);
+    };
+    if (!fft_uses_exchange(a.fft_log, a.hop_samples, a.bytes_per_sample) || (LOGM > 0 && a.spectrum_only)) {
+        shuffle(a, blocks);
+        return;
+    }
+    ChannelizerArgs b = a;
+    if (LOGM > 0) b.last_spectrum = nullptr; /* decimated transforms produce the channels' bins only */
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_fft8_kernel<LOGP, LOGM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((channelizer_fft8_kernel<LOGP, LOGM>), dim3((unsigned)blocks), dim3(a.spectrum_only ? 64 : 256), lds, stream, b);
+    if (LOGM > 0 && a.last_spectrum) { /* ... and AFC's spectrum of the batch's last hop comes from a one-hop, one-wavefront launch of the shuffle kernel */
+        ChannelizerArgs c = a;
+        c.iq = a.iq + (long)(a.n_hops - 1) * a.hop_samples * 2 * a.bytes_per_sample;
+        c.n_hops = 1;
+        c.first_row = 0;
+        c.row0 = 0;
+        c.spectrum_only = 1;
+        shuffle(c, a.n_dev);
     }
 }
 
 }  // namespace
 
-/* dynamic LDS of one workgroup: the raw bytes of HOPS_PER_TILE consecutive hops (+ alignment slack), and for fft_size <= 1024 the four wavefronts' exchange buffers */
+/* dynamic LDS of one workgroup: the raw bytes of HOPS_PER_TILE consecutive hops (+ alignment slack), and the four wavefronts' exchange buffers where they fit */
 size_t fft_lds_bytes(int fft_log, int hop_samples, int bytes_per_sample) {
     return (size_t)fft_raw_bytes(fft_log, hop_samples, bytes_per_sample) + (fft_uses_exchange(fft_log, hop_samples, bytes_per_sample) ? 4 * XBUF_BYTES : 0);
 }
 
 void launch_channelizer_fft(const ChannelizerArgs& a, hipStream_t stream) {
-    switch (a.fft_log - 6) {
-        case 2: launch_one<2>(a, stream); break;
-        case 3: launch_one<3>(a, stream); break;
-        case 4: launch_one<4>(a, stream); break;
-        case 5: launch_one<5>(a, stream); break;
-        case 6: launch_one<6>(a, stream); break;
-        case 7: launch_one<7>(a, stream); break;
+    switch (a.fft_log - 6) { /* <points per transform / 64, decimation, the shuffle kernel's values per lane> */
+        case 2: launch_one<2, 0, 2>(a, stream); break;
+        case 3: launch_one<3, 0, 3>(a, stream); break;
+        case 4: launch_one<4, 0, 4>(a, stream); break;
+        case 5: launch_one<3, 2, 5>(a, stream); break;
+        case 6: launch_one<3, 3, 6>(a, stream); break;
+        case 7: launch_one<3, 4, 7>(a, stream); break;
         default: break;
     }
 }

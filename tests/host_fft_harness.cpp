@@ -36,8 +36,7 @@ int hostfft_run(const airband_hip_config* cfg, const uint8_t* iq, long iq_stride
     }
     std::vector<DevConst> dev = p.dev;
     for (int d = 0; d < p.n_dev; d++) dev[d].chan_base = p.chan_base[d];
-    if (spectrum_only)
-        for (auto& d : dev) d.any_afc = 1;
+    for (auto& d : dev) d.any_afc = 1; /* every dongle's last-hop spectrum is wanted here (the library asks for it only where a channel has AFC) */
     const int R = (n_hops + 15) / 16 * 16;
     std::vector<float> mag((size_t)R * n_slots, 0.0f);
     std::vector<float2> bins((size_t)R * n_slots, make_float2(0.0f, 0.0f));
@@ -50,6 +49,13 @@ int hostfft_run(const airband_hip_config* cfg, const uint8_t* iq, long iq_stride
     a.cc = cc.data();
     a.ext_to_slot = ext_to_slot.data();
     a.window = p.window.data();
+    std::vector<float> wdec; /* as airband_hip_prepare() builds it */
+    if (p.fft_size >= 2048) {
+        const int M = p.fft_size / 512;
+        wdec.resize(p.fft_size);
+        for (int n = 0; n < p.fft_size; n++) wdec[(size_t)(n % M) * 512 + n / M] = p.window[n];
+    }
+    a.window_dec = wdec.empty() ? nullptr : wdec.data();
     a.twiddle = reinterpret_cast<const float2*>(p.twiddle.data());
     a.mag = mag.data();
     a.iq_bins = bins.data();

@@ -67,6 +67,8 @@ CASES = [
     (capi.SFMT_U8, 11, 2_560_000, 8000, 1, 6),
     (capi.SFMT_S16, 12, 2_560_000, 8000, 1, 5),
     (capi.SFMT_U8, 13, 2_560_000, 8000, 1, 4),
+    (capi.SFMT_F32, 11, 2_560_000, 16000, 2, 19),
+    (capi.SFMT_S8, 12, 2_400_000, 16000, 1, 5),
     (capi.SFMT_U8, 9, 20_000_000, 8000, 1, 17),    # hops of 5 000 bytes: 94 KiB of dynamic LDS (the launch opts in above 64 KiB)
     (capi.SFMT_F32, 9, 9_600_000, 8000, 1, 17),   # 150 KiB of raw samples per tile: no room for the exchange buffers, the shuffle kernel at fft 512
 ]

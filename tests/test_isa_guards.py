@@ -205,21 +205,21 @@ def fft_asm(tmp_path_factory):
 def test_exchange_fft_kernel_is_packed_and_shuffle_free(fft_asm):
     """channelizer_fft8_kernel (fft_size 256 / 512 / 1024): the 64-point FFT across the lanes goes through the wavefront's LDS buffer -- no ds_bpermute --,
     a complex product is one packed multiply and one packed FMA (the compiler's own form is five instructions: cmul() in channelizer_fft.hip), nothing
-    spills, and the 512-point kernel keeps four wavefronts per SIMD (<= 128 vector registers)."""
+    spills, and the 512-point kernel -- also as the transform of the decimated fft 2048 ... 8192 variants -- keeps four wavefronts per SIMD (<= 128 vector registers)."""
     text = "\n".join(fft_asm)
-    for logp, max_vgpr in ((2, 128), (3, 128), (4, 256)):
-        body = _function(fft_asm, "channelizer_fft8_kernelILi%dE" % logp)
+    for logp, logm, max_vgpr in ((2, 0, 128), (3, 0, 128), (4, 0, 256), (3, 2, 128), (3, 3, 128), (3, 4, 128)):  # fft 256 ... 1024; 2048 ... 8192 as 4 / 8 / 16 decimated 512-point transforms
+        body = _function(fft_asm, "channelizer_fft8_kernelILi%dELi%dE" % (logp, logm))
         assert not any("ds_bpermute" in l for l in body), logp
         n_mul = sum(1 for l in body if re.match(r"^\s*v_pk_mul_f32", l))
         n_fma = sum(1 for l in body if re.match(r"^\s*v_pk_fma_f32", l))
         n_add = sum(1 for l in body if re.match(r"^\s*v_pk_add_f32", l))
         assert n_add >= 48 and n_fma >= 14, (logp, n_add, n_fma, n_mul)
         assert not any(re.match(r"^\s*v_pk_add_f32 .*, 0 neg_lo", l) for l in body), logp  # the compiler's way of negating one half of a pair
-        at = text.index(".name:           _ZN7airband12_GLOBAL__N_123channelizer_fft8_kernelILi%dE" % logp)
+        at = text.index(".name:           _ZN7airband12_GLOBAL__N_123channelizer_fft8_kernelILi%dELi%dE" % (logp, logm))
         meta = text[at:at + 1500]
         assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1)) == 0, logp
         assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1)) == 0, logp
         assert int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)) <= max_vgpr, logp
     # the exchange itself: per 512-point hop five rounds of eight 8-byte LDS operations (paired by the compiler into ds_read2 / ds_write2)
-    body = _function(fft_asm, "channelizer_fft8_kernelILi3E")
+    body = _function(fft_asm, "channelizer_fft8_kernelILi3ELi0E")
     assert sum(1 for l in body if re.match(r"^\s*ds_write2?_b64", l)) >= 12
