@@ -1,0 +1,67 @@
+"""The wavefront-FFT channelizer (csrc/channelizer_fft.hip) on the GPU beyond the cases tests/test_gpu_parity.py holds: its decimated variants
+(fft_size 2048 / 4096: 4 / 8 transforms of 512 points per hop), f32 at a hop that is not a power of two, and u8 at 2.0 MS/s -- hops of 250 bytes, which the
+matrix-core path does not take.  Same bars as everywhere: squelch trace and axcindicate equal to the oracle's, audio within 1e-4 RMS.
+(tests/test_host_fft.py runs the same kernel source on the CPU against a float64 FFT; this file is what a GPU says.)"""
+import importlib
+
+import numpy as np
+import pytest
+
+import helpers
+import pyoracle
+
+CASES = [
+    # sfmt, fft_log, sample_rate, wave_rate, force the FFT path
+    ("SFMT_U8", 9, 2_000_000, 16000, False),
+    ("SFMT_F32", 10, 2_400_000, 8000, False),
+    ("SFMT_F32", 11, 2_560_000, 16000, False),
+    ("SFMT_U8", 12, 2_560_000, 8000, True),
+]
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module("rtlsdr-airband_amd")
+
+
+def _case(pkg, sfmt_name, fft_log, sample_rate, wave_rate, n_dev=2, n_batches=5):
+    sfmt = getattr(pkg.capi, sfmt_name)
+    devices, iq = helpers.format_case(pkg, sfmt, fft_log, sample_rate, wave_rate, n_dev, n_batches)
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fft_log=fft_log)
+    ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
+    orc.close()
+    assert all(r["n_batches"] == n_batches for r in ref)
+    return devices, iq, ref
+
+
+@pytest.mark.parametrize("sfmt_name,fft_log,sample_rate,wave_rate,force", CASES)
+def test_the_cases_open_a_squelch_on_the_oracle(pkg, sfmt_name, fft_log, sample_rate, wave_rate, force):
+    """CPU half: the synthetic streams of the GPU cases below do open squelches (so the GPU comparison is not vacuous)."""
+    _, _, ref = _case(pkg, sfmt_name, fft_log, sample_rate, wave_rate, n_dev=1, n_batches=5)
+    assert sum(int((a == ord("*")).sum()) for a in ref[0]["axc"]) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sfmt_name,fft_log,sample_rate,wave_rate,force", CASES)
+def test_wavefront_fft_variants(pkg, sfmt_name, fft_log, sample_rate, wave_rate, force):
+    capi = pkg.capi
+    n_dev, n_batches = 2, 5
+    devices, iq, ref = _case(pkg, sfmt_name, fft_log, sample_rate, wave_rate, n_dev, n_batches)
+    opened = 0
+    with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=capi.FLAG_TRACE_SQUELCH | (capi.FLAG_FORCE_FFT if force else 0)) as hip:
+        assert hip.channelizer_name() == "fft_wave64"
+        pos = [0] * n_dev
+        for b in range(n_batches):
+            for d in range(n_dev):
+                raw = iq[d].view(np.uint8)
+                pos[d] += hip.submit(d, raw[pos[d]:])
+            assert hip.process(), "batch %d: not enough input queued" % b
+            out = hip.collect()
+            tr = hip.read_trace()
+            want_t = np.concatenate([r["trace"][b] for r in ref])
+            assert np.array_equal(out["axc"], np.concatenate([r["axc"][b] for r in ref])), "batch %d axc" % b
+            assert np.array_equal(tr, want_t), "batch %d: %d squelch-state mismatches" % (b, int((tr != want_t).sum()))
+            ww = np.concatenate([r["waveout"][b] for r in ref])
+            assert helpers.rms(out["waveout"] - ww) <= 1e-4
+            opened += int((out["axc"] == ord("*")).sum())
+    assert opened > 0
