@@ -66,7 +66,7 @@ SAMPLES_PER_BATCH = 320_000  # complex samples per dongle per batch (2.56 MS/s /
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_I8_PEAK_TOPS = 5000.0   # MI355X_MICROARCH.md: int8 MFMA at 2x the dense bf16 rate (~2.5 PF); micro-benchmark ceiling >= 3 944 TOPS
 METRIC = "IQ Msamples/sec channelized+demodulated per node; % HBM roofline"
-CHANNELIZER_KERNEL = {"dft_mfma_i8": "channelizer_dft_kernel", "fft_wave64": "channelizer_fft"}  # channelizer_fft8_kernel (fft <= 1024) / channelizer_fft_kernel
+CHANNELIZER_KERNEL = {"dft_mfma_i8": "channelizer_dft_kernel", "fft_wave64": "channelizer_fft8_kernel"}  # (channelizer_fft_kernel, the shuffle variant, only runs AFC spectrum launches at fft >= 2048 and tiles without LDS room)
 
 
 def cpu_model() -> str:
