@@ -106,3 +106,83 @@ def test_all_kinds_with_wavefront_semantics(wave64, style, n_dev, mixed, wave_ra
         hd.close()
         src.close()
         orc.close()
+
+
+def _fuzz_streams_ct(rng, chans, wave_rate, B, n_batches):
+    """test_host_demod._fuzz_streams with a CTCSS sub-tone on the FM channels that ask for one: the right tone, a neighbouring standard tone, or none."""
+    from test_host_demod import _fuzz_streams
+    nfm = [c["modulation"] == 1 for c in chans]
+    wave, iq = _fuzz_streams(rng, len(chans), B, n_batches, nfm)
+    n = B * n_batches
+    t = np.arange(n) / wave_rate
+    for c, ch in enumerate(chans):
+        if not (nfm[c] and ch["ctcss_freq"]):
+            continue
+        kind = rng.random()
+        f = ch["ctcss_freq"] if kind < 0.6 else (ch["ctcss_freq"] * 1.035 if kind < 0.8 else 0.0)
+        if f:
+            beta = float(rng.uniform(0.5, 4.0))
+            rot = np.exp(1j * beta * np.sin(2 * np.pi * f * t))
+            z = (iq[c, 0::2] + 1j * iq[c, 1::2]) * rot
+            iq[c, 0::2], iq[c, 1::2] = z.real.astype(np.float32), z.imag.astype(np.float32)
+            re, im = iq[c, 0::2], iq[c, 1::2]
+            wave[c] = np.sqrt(re * re + im * im)
+    return wave, iq
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_WAVE64", "6"))))
+def test_random_plans_with_wavefront_semantics(wave64, seed):
+    """Random plans over EVERY kind -- CTCSS on FM and AM channels, lowpass + CTCSS, raw-I/Q outputs, notch, manual squelch -- on made-up stage-1 output
+    with awkward values, several dongles (so that a wavefront's lanes sit in different squelch states and blocks are partly filled): the kernels with
+    their wavefront semantics against the oracle, bit for bit, squelch trace (tone bit included), axcindicate, audio."""
+    rng = np.random.default_rng(5000 + seed)
+    nfm_build = bool(seed % 4)
+    wave_rate = 16000 if nfm_build else 8000
+    fm_demod = int(rng.integers(0, 2)) if nfm_build else 0
+    n_dev = int(rng.integers(1, 10))
+    devices = []
+    for d in range(n_dev):
+        chans = []
+        for k, off in enumerate(sg.PLAN_OFFSETS_HZ):
+            c = dict(frequency=sg.CENTERFREQ + off, modulation=0, afc=0, squelch_threshold_dbfs=0, squelch_snr_threshold_db=-1.0, notch_freq=0.0, notch_q=0.0, ctcss_freq=0.0,
+                     bandwidth_hz=0, ampfactor=1.0, tau_us=-1, has_iq_outputs=0)
+            if nfm_build and rng.random() < 0.6:
+                c["modulation"] = 1
+                c["tau_us"] = int(rng.choice([-1, 0, 50, 200, 750]))
+            if rng.random() < 0.3:
+                c["bandwidth_hz"] = int(rng.choice([5000, 6250, 12500, 25000]))  # on an AM channel too: raw I/Q on an AM lane (generic kind)
+            if rng.random() < 0.4:
+                c["ctcss_freq"] = float(rng.choice([67.0, 100.0, 123.0, 254.1]))
+            mode = rng.random()
+            if mode < 0.3:
+                c["squelch_threshold_dbfs"] = int(rng.integers(-60, -10))
+            elif mode < 0.6:
+                c["squelch_snr_threshold_db"] = float(rng.choice([3.0, 6.0, 9.5, 14.0]))
+            if rng.random() < 0.3:
+                c["notch_freq"], c["notch_q"] = float(rng.choice([100.0, 150.0, 1000.0])), float(rng.choice([0.0, 4.0, 10.0]))
+            if rng.random() < 0.3:
+                c["ampfactor"] = float(rng.choice([0.25, 2.0, 8.0]))
+            if rng.random() < 0.15:
+                c["has_iq_outputs"] = 1
+            chans.append(c)
+        devices.append(dict(channels=chans))
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fm_demod=fm_demod)
+    hd = HostDemod(wave64, devices, wave_rate, fm_demod)
+    try:
+        B, n_batches = hd.B, 3
+        streams = [_fuzz_streams_ct(rng, devices[d]["channels"], wave_rate, B, n_batches) for d in range(n_dev)]
+        for b in range(n_batches):
+            w = np.concatenate([s[0][:, b * B:(b + 1) * B] for s in streams])
+            q = np.concatenate([s[1][:, 2 * b * B:2 * (b + 1) * B] for s in streams])
+            want = [orc.run_bins(d, streams[d][0][:, b * B:(b + 1) * B], streams[d][1][:, 2 * b * B:2 * (b + 1) * B]) for d in range(n_dev)]
+            hd.process_bins(w, q)
+            got_w, got_a, got_t = hd.collect()
+            wt = np.concatenate([x["trace"] for x in want])
+            assert np.array_equal(got_t, wt), "seed %d batch %d: squelch trace (channels %s)" % (seed, b, np.nonzero((got_t != wt).any(axis=1))[0])
+            assert np.array_equal(got_a, np.concatenate([x["axc"] for x in want])), "seed %d batch %d: axc" % (seed, b)
+            ww = np.concatenate([x["waveout"] for x in want])
+            same = (got_w.view(np.uint32) == ww.view(np.uint32)) | (np.isnan(got_w) & np.isnan(ww))
+            assert same.all(), "seed %d batch %d: waveout (channels %s)" % (seed, b, np.nonzero((~same).any(axis=1))[0])
+    finally:
+        hd.close()
+        orc.close()
