@@ -223,5 +223,3 @@ def test_exchange_fft_kernel_is_packed_and_shuffle_free(fft_asm):
     # the exchange itself: per 512-point hop five rounds of eight 8-byte LDS operations (paired by the compiler into ds_read2 / ds_write2)
     body = _function(fft_asm, "channelizer_fft8_kernelILi3ELi0E")
     assert sum(1 for l in body if re.match(r"^\s*ds_write2?_b64", l)) >= 12
-    # ... and the two rounds of exchange reads (and the f32 samples) stay single ds_read_b64: paired into ds_read2_b64 they would move half the bytes per LDS cycle
-    assert sum(1 for l in body if re.match(r"^\s*ds_read_b64 ", l)) >= 24
