@@ -426,8 +426,18 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
                 }
             }
             fft_dif<P>(x); /* over r: register rho now holds k1 = bitrev(rho) */
+            { /* (all the products, then all the FMAs: a packed-f32 instruction wants a wait state before a dependent one, and written pair by pair the
+               * compiler fills it with a no-op) */
 #pragma unroll
-            for (int rho = 1; rho < P; rho++) x[rho] = cmul(x[rho], tw[rho], twr[rho]);
+                for (int g = 0; g < P; g += 4) { /* four at a time: enough independent work for the wait states, few enough registers for four waves per SIMD */
+                    v2f t[4];
+#pragma unroll
+                    for (int rho = g; rho < g + 4; rho++) t[rho - g] = x[rho].yy * twr[rho];
+#pragma unroll
+                    for (int rho = g; rho < g + 4; rho++)
+                        if (rho > 0) x[rho] = __builtin_elementwise_fma(x[rho].xx, tw[rho], t[rho - g]);
+                }
+            }
 
             v2f mine = v2f{0.0f, 0.0f};
 #pragma unroll
@@ -441,8 +451,17 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
                 for (int i = 0; i < 8; i++) z[i] = x_r1[8 * i];
                 AB_WAVE_SYNC(); /* every lane has its eight values: the buffer may be written again */
                 fft_dif<8>(z); /* over a: register t holds c = bitrev3(t) */
+                {
 #pragma unroll
-                for (int t = 1; t < 8; t++) z[t] = cmul(z[t], cw[t], cwr[t]);
+                    for (int g = 0; g < 8; g += 4) {
+                        v2f u[4];
+#pragma unroll
+                        for (int t = g; t < g + 4; t++) u[t - g] = z[t].yy * cwr[t];
+#pragma unroll
+                        for (int t = g; t < g + 4; t++)
+                            if (t > 0) z[t] = __builtin_elementwise_fma(z[t].xx, cw[t], u[t - g]);
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < 8; t++) x_w2[bitrev(t, 3)] = z[t];
                 AB_WAVE_SYNC();
@@ -479,7 +498,8 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
             int row = a.row0 + a.first_row + hop0 + h;
             if (row >= a.ring_rows) row -= a.ring_rows;
             const int off = ab_tile_off(row);
-            if (my_mag) my_mag_ring[off] = sqrtf(bin_sum.x * bin_sum.x + bin_sum.y * bin_sum.y);
+            /* (v_sqrt_f32, within one ulp, as the matrix-core channelizer takes it: stage 1 is held to 1e-5 of the bins' RMS, and the correctly rounded sqrtf() is sixteen instructions) */
+            if (my_mag) my_mag_ring[off] = __builtin_amdgcn_sqrtf(bin_sum.x * bin_sum.x + bin_sum.y * bin_sum.y);
             if (my_raw) my_iq_ring[off] = make_float2(bin_sum.x, bin_sum.y);
         }
     }
