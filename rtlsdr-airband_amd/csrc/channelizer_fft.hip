@@ -30,6 +30,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -387,6 +389,9 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
     __syncthreads();
 
     const uint8_t* lds = lds_raw + mis;
+    /* the hop loop once per sample format (the format is the launch's, not the hop's: chosen once, below, instead of by three scalar branches per transform) */
+    auto hops = [&](auto fmt_tag) {
+    constexpr int FMT = decltype(fmt_tag)::value;
     for (int h = wave; h < hops_here; h += (int)(blockDim.x >> 6)) {
         const uint8_t* hp = lds + (long)h * a.hop_samples * bps2;
         v2f bin_sum = v2f{0.0f, 0.0f};
@@ -398,13 +403,13 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
                 for (int r = 0; r < P; r++) win[r] = a.window_dec[n2 * NS + r * 64 + lane] * pre; /* = window[M (r 64 + lane) + n2], coalesced */
             }
             /* convert + window (src/rtl_airband.cpp:402-455): this lane's samples n = M (r 64 + lane) + n2 */
-            if (a.sfmt == AIRBAND_SFMT_U8) {
+            if (FMT == AIRBAND_SFMT_U8) {
 #pragma unroll
                 for (int r = 0; r < P; r++) {
                     const unsigned v = *reinterpret_cast<const unsigned short*>(hp + 2 * (M * (r * 64 + lane) + n2));
                     x[r] = (v2f{(float)(v & 0xffu), (float)(v >> 8)} - 127.5f) * win[r];
                 }
-            } else if (a.sfmt == AIRBAND_SFMT_S8) {
+            } else if (FMT == AIRBAND_SFMT_S8) {
 #pragma unroll
                 for (int r = 0; r < P; r++) {
                     const char2 v = *reinterpret_cast<const char2*>(hp + 2 * (M * (r * 64 + lane) + n2));
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
                      * continues the table's own rule (oracle/airband_oracle.c says the same) */
                     x[r] = v2f{(float)v.x, (float)v.y} * win[r];
                 }
-            } else if (a.sfmt == AIRBAND_SFMT_S16) {
+            } else if (FMT == AIRBAND_SFMT_S16) {
 #pragma unroll
                 for (int r = 0; r < P; r++) {
                     const short2 v = *reinterpret_cast<const short2*>(hp + 4 * (M * (r * 64 + lane) + n2));
@@ -502,6 +507,13 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
             if (my_mag) my_mag_ring[off] = __builtin_amdgcn_sqrtf(bin_sum.x * bin_sum.x + bin_sum.y * bin_sum.y);
             if (my_raw) my_iq_ring[off] = make_float2(bin_sum.x, bin_sum.y);
         }
+    }
+    };
+    switch (a.sfmt) {
+        case AIRBAND_SFMT_U8: hops(std::integral_constant<int, AIRBAND_SFMT_U8>{}); break;
+        case AIRBAND_SFMT_S8: hops(std::integral_constant<int, AIRBAND_SFMT_S8>{}); break;
+        case AIRBAND_SFMT_S16: hops(std::integral_constant<int, AIRBAND_SFMT_S16>{}); break;
+        default: hops(std::integral_constant<int, AIRBAND_SFMT_F32>{}); break;
     }
 }
 
