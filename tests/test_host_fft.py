@@ -27,7 +27,7 @@ def hostfft(tmp_path_factory):
     if not os.path.exists(CLANG):
         pytest.skip("no host clang++ in this image")
     out = str(tmp_path_factory.mktemp("hostfft") / "libhostfft.so")
-    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DAB_WAVE64_EMU", "-I" + os.path.join(HERE, "hostshim_wave64"),
+    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-DAB_WAVE64_EMU", "-I" + os.path.join(HERE, "hostshim_wave64"),
            "-I" + os.path.join(REPO, "include"), "-o", out, os.path.join(HERE, "host_fft_harness.cpp"), os.path.join(CSRC, "params.cpp")]
     subprocess.run(cmd, check=True)
     lib = C.CDLL(out)
