@@ -7,7 +7,7 @@
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/first; rm -rf $O; mkdir -p $O
-timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_golden.py -m gpu -x -q -k "fft_wave64 or other_formats or afc or odd or golden" > $O/parity_fft.log 2>&1; tail -3 $O/parity_fft.log
+timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_gpu_wavefront_fft.py -m gpu -q -k "fft_wave64 or other_formats or afc or golden or wavefront_fft_variants" > $O/parity_fft.log 2>&1; tail -5 $O/parity_fft.log
 N="--no-cpu-baseline --no-traffic --no-verify-all --verify 4"
 AIRBAND_BENCH_FLAGS=4 timeout 200 python bench.py $N --steps 6 --warmup 2 2>/dev/null | tail -n 1 > $O/bench_cfg3_force_fft.json; cut -c1-400 $O/bench_cfg3_force_fft.json
 timeout 200 python bench.py $N --steps 6 --warmup 2 --sample-format f32 --ring 1 --dongles 32768 2>/dev/null | tail -n 1 > $O/bench_f32_32768.json; cut -c1-400 $O/bench_f32_32768.json
