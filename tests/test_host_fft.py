@@ -148,3 +148,59 @@ def test_last_hop_spectrum_launch(hostfft, sfmt, fft_log):
         F = np.fft.fft(vals[d] * win.astype(np.float64))
         got = spec[d, 0::2] + 1j * spec[d, 1::2]
         assert np.sqrt(np.mean(np.abs(got - F) ** 2)) / np.sqrt(np.mean(np.abs(F) ** 2)) < 2e-6
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_FFT", "8"))))
+def test_random_geometries(hostfft, seed):
+    """Random sample format, fft size, hop (odd ones too), number of hops, dongles, channels per dongle (1 .. 64) and alignment of the dongles' spans
+    (any whole sample: the staging loop fetches the 16-byte pieces that straddle a span's ends byte by byte)."""
+    rng = np.random.default_rng(9000 + seed)
+    sfmt = int(rng.choice([capi.SFMT_U8, capi.SFMT_S8, capi.SFMT_S16, capi.SFMT_F32]))
+    fft_log = int(rng.choice([8, 9, 9, 9, 10, 11, 12, 13]))
+    wave_rate = int(rng.choice([8000, 16000]))
+    hop = int(rng.integers(40, 700))
+    sample_rate = hop * wave_rate
+    N = 1 << fft_log
+    n_dev = int(rng.integers(1, 4))
+    n_ch = int(rng.integers(1, 65))
+    n_hops = int(rng.integers(1, 40 if fft_log <= 10 else 8))
+    base_ch, _ = sg.baseline_plan(mixed=wave_rate == 16000)
+    chans = [dict(base_ch[i % 8], frequency=120_000_000 + 1000 * i) for i in range(n_ch)]
+    fullscale = 32768.0 if sfmt == capi.SFMT_S16 else 0.0
+    devices = [dict(channels=[dict(c) for c in chans], sample_rate=sample_rate, sfmt=sfmt, fullscale=fullscale) for _ in range(n_dev)]
+    cfg, keep = pkg.make_config(devices, wave_rate=wave_rate, fft_log=fft_log)
+    assert hostfft.hostfft_hop_samples(C.byref(cfg)) == hop
+    n_samp = (n_hops - 1) * hop + N
+    bins = rng.integers(0, N, n_dev * n_ch).astype(np.int32)
+    raws, vals = zip(*[_samples(rng, sfmt, n_samp) for _ in range(n_dev)])
+    bpc2 = 2 * capi.BYTES_PER_SAMPLE[sfmt]
+    stride = ((raws[0].nbytes + 15) // 16 * 16 + 16 + bpc2 * int(rng.integers(0, 8)))
+    buf = np.full(n_dev * stride + 128, 0xEE, np.uint8)  # whatever lies outside a span must not matter
+    base = (-buf.ctypes.data) % 16 + bpc2 * int(rng.integers(0, 16 // bpc2 + 1))
+    for d in range(n_dev):
+        buf[base + d * stride: base + d * stride + raws[d].nbytes] = raws[d].view(np.uint8)
+    mag = np.zeros((n_dev * n_ch, n_hops), np.float32)
+    iqb = np.zeros((n_dev * n_ch, n_hops, 2), np.float32)
+    spec = np.zeros((n_dev, 2 * N), np.float32)
+    win = np.zeros(N, np.float32)
+    rc = hostfft.hostfft_run(C.byref(cfg), buf.ctypes.data + base, stride, n_hops, 0, bins.ctypes.data, mag.ctypes.data, iqb.ctypes.data, spec.ctypes.data, win.ctypes.data)
+    if rc == -200:
+        pytest.skip("a tile of this geometry does not fit a CU's LDS (the library refuses it too)")
+    assert rc == 0, rc
+    nfm = [c["modulation"] == 1 for c in chans]
+    worst = 0.0
+    for d in range(n_dev):
+        frames = np.stack([vals[d][t * hop: t * hop + N] * win.astype(np.float64) for t in range(n_hops)])
+        F = np.fft.fft(frames, axis=1)
+        ref_rms = np.sqrt(np.mean(np.abs(F) ** 2))
+        for j in range(n_ch):
+            want = F[:, bins[d * n_ch + j]]
+            if nfm[j]:
+                got = iqb[d * n_ch + j, :, 0] + 1j * iqb[d * n_ch + j, :, 1]
+                err = np.sqrt(np.mean(np.abs(got - want) ** 2)) / ref_rms
+            else:
+                err = np.sqrt(np.mean((mag[d * n_ch + j] - np.abs(want)) ** 2)) / ref_rms
+            worst = max(worst, err)
+        got = spec[d, 0::2] + 1j * spec[d, 1::2]
+        worst = max(worst, np.sqrt(np.mean(np.abs(got - F[-1]) ** 2)) / ref_rms)
+    assert worst < 2e-6, (seed, sfmt, fft_log, hop, n_hops, n_dev, n_ch, worst)
