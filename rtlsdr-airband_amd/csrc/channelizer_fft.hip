@@ -520,7 +520,11 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
 template <int LOGP, int LOGM, int LOGP_SHUFFLE>
 void launch_one(const ChannelizerArgs& a, hipStream_t stream) {
     const int tiles = (a.n_hops + HOPS_PER_TILE - 1) / HOPS_PER_TILE;
-    const size_t lds = fft_lds_bytes(a.fft_log, a.hop_samples, a.bytes_per_sample);
+    const bool exchange = fft_uses_exchange(a.fft_log, a.hop_samples, a.bytes_per_sample);
+    /* a spectrum-only launch is ONE wavefront per dongle: one exchange buffer, so that its workgroups (10 KiB at fft 512) still fit beside the matrix-core
+     * channelizer's 144 KiB per CU when it runs on the side stream next to stage 1 (airband_hip.cpp, launch_last_hop_spectrum) */
+    const size_t lds = a.spectrum_only ? (size_t)fft_raw_bytes(a.fft_log, a.hop_samples, a.bytes_per_sample) + (exchange ? XBUF_BYTES : 0)
+                                       : fft_lds_bytes(a.fft_log, a.hop_samples, a.bytes_per_sample);
     const long blocks = (long)tiles * a.n_dev;
     /* wide formats at high sample rates: opt in to the CU's full 160 KiB (prepare() has checked the upper bound) */
     /* (should the runtime refuse, the launch below fails with hipErrorInvalidValue and the batch driver reports it: airband_hip.cpp checks hipGetLastError) */
@@ -529,7 +533,7 @@ void launch_one(const ChannelizerArgs& a, hipStream_t stream) {
         /* a spectrum-only launch transforms ONE hop per dongle: one wavefront */
         hipLaunchKernelGGL(channelizer_fft_kernel<LOGP_SHUFFLE>, dim3((unsigned)n_blocks), dim3(b.spectrum_only ? 64 : 256), lds, stream, b);
     };
-    if (!fft_uses_exchange(a.fft_log, a.hop_samples, a.bytes_per_sample) || (LOGM > 0 && a.spectrum_only)) {
+    if (!exchange || (LOGM > 0 && a.spectrum_only)) {
         shuffle(a, blocks);
         return;
     }
