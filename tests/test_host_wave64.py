@@ -130,7 +130,7 @@ def _fuzz_streams_ct(rng, chans, wave_rate, B, n_batches):
     return wave, iq
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_WAVE64", "6"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_WAVE64", "4"))))
 def test_random_plans_with_wavefront_semantics(wave64, seed):
     """Random plans over EVERY kind -- CTCSS on FM and AM channels, lowpass + CTCSS, raw-I/Q outputs, notch, manual squelch -- on made-up stage-1 output
     with awkward values, several dongles (so that a wavefront's lanes sit in different squelch states and blocks are partly filled): the kernels with
