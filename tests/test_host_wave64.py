@@ -118,6 +118,18 @@ def _fuzz_streams_ct(rng, chans, wave_rate, B, n_batches):
     for c, ch in enumerate(chans):
         if not (nfm[c] and ch["ctcss_freq"]):
             continue
+        if rng.random() < 0.5:  # transmissions long enough for several windows of the fast detector and one or two of the slow one (0.4 s)
+            floor = float(10.0 ** rng.uniform(-3.0, -1.5))
+            env = np.full(n, floor) * (1.0 + 0.2 * rng.standard_normal(n))
+            pos = int(rng.integers(0, 2000))
+            while pos < n:
+                on = int(rng.integers(2000, 12000))
+                env[pos:pos + on] += floor * float(10.0 ** rng.uniform(0.6, 1.6))
+                pos += on + int(rng.integers(300, 4000))
+            ph = np.cumsum(rng.normal(0.0, 0.3, n)) + 2 * np.pi * rng.uniform(-0.1, 0.1) * np.arange(n)
+            z = np.abs(env) * np.exp(1j * ph)
+            iq[c, 0::2], iq[c, 1::2] = z.real.astype(np.float32), z.imag.astype(np.float32)
+            wave[c] = np.sqrt(iq[c, 0::2] * iq[c, 0::2] + iq[c, 1::2] * iq[c, 1::2])
         kind = rng.random()
         f = ch["ctcss_freq"] if kind < 0.6 else (ch["ctcss_freq"] * 1.035 if kind < 0.8 else 0.0)
         if f:
@@ -169,7 +181,7 @@ def test_random_plans_with_wavefront_semantics(wave64, seed):
     orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fm_demod=fm_demod)
     hd = HostDemod(wave64, devices, wave_rate, fm_demod)
     try:
-        B, n_batches = hd.B, 3
+        B, n_batches = hd.B, (6 if seed % 3 == 0 else 3)  # six batches: the slow CTCSS detector (0.4 s) completes windows
         streams = [_fuzz_streams_ct(rng, devices[d]["channels"], wave_rate, B, n_batches) for d in range(n_dev)]
         for b in range(n_batches):
             w = np.concatenate([s[0][:, b * B:(b + 1) * B] for s in streams])
