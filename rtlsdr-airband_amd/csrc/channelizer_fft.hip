@@ -30,6 +30,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -66,7 +67,9 @@ __host__ __device__ inline long fft_raw_bytes(int fft_log, int hop_samples, int 
 /* the exchange kernel runs where its four exchange buffers fit a CU's LDS beside the tile's raw samples (wide samples at very high sample rates
  * leave no room: those configurations stay on the shuffle kernel, which needs none) */
 inline bool fft_uses_exchange(int fft_log, int hop_samples, int bytes_per_sample) {
-    return fft_raw_bytes(fft_log, hop_samples, bytes_per_sample) + 4 * XBUF_BYTES <= 160 * 1024;
+    /* AIRBAND_HIP_FFT_SHUFFLE=1 in the environment keeps every launch on the shuffle kernel: the A/B partner of the exchange kernel (scripts/next_round_first.sh) */
+    static const bool shuffle_only = std::getenv("AIRBAND_HIP_FFT_SHUFFLE") != nullptr;
+    return !shuffle_only && fft_raw_bytes(fft_log, hop_samples, bytes_per_sample) + 4 * XBUF_BYTES <= 160 * 1024;
 }
 constexpr float kPi = 3.14159265358979323846f;
 

@@ -11,6 +11,9 @@ timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests
 N="--no-cpu-baseline --no-traffic --no-verify-all --verify 4"
 AIRBAND_BENCH_FLAGS=4 timeout 200 python bench.py $N --steps 6 --warmup 2 2>/dev/null | tail -n 1 > $O/bench_cfg3_force_fft.json; cut -c1-400 $O/bench_cfg3_force_fft.json
 timeout 200 python bench.py $N --steps 6 --warmup 2 --sample-format f32 --ring 1 --dongles 32768 2>/dev/null | tail -n 1 > $O/bench_f32_32768.json; cut -c1-400 $O/bench_f32_32768.json
+# the same two lines on the shuffle kernel the exchange kernel replaced (A/B on one box)
+AIRBAND_HIP_FFT_SHUFFLE=1 AIRBAND_BENCH_FLAGS=4 timeout 300 python bench.py $N --steps 4 --warmup 1 2>/dev/null | tail -n 1 > $O/bench_cfg3_force_fft_shuffle.json; cut -c1-400 $O/bench_cfg3_force_fft_shuffle.json
+AIRBAND_HIP_FFT_SHUFFLE=1 timeout 300 python bench.py $N --steps 4 --warmup 1 --sample-format f32 --ring 1 --dongles 32768 2>/dev/null | tail -n 1 > $O/bench_f32_32768_shuffle.json; cut -c1-400 $O/bench_f32_32768_shuffle.json
 timeout 200 python bench.py $N --steps 40 2>/dev/null | tail -n 1 > $O/bench_cfg3.json; cut -c1-400 $O/bench_cfg3.json
 K="--no-cpu-baseline --no-traffic --no-verify-all --verify 0 --steps 3 --warmup 1"
 AIRBAND_BENCH_FLAGS=4 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_force_fft -- python bench.py $K > $O/kt_fft.log 2>&1
