@@ -19,7 +19,7 @@
  *     land in the same buffer and the dongle's channel lanes pick theirs up.  40 eight-byte LDS operations and ~190 vector instructions per
  *     512-point hop, where the shuffle kernel below issues 112 ds_bpermute and ~450.  fft_size 2048 ... 8192 run as 4 / 8 / 16 DECIMATED 512-point
  *     transforms per hop, combined for the channels' bins only (see the kernel).
- * channelizer_fft_kernel (AFC's whole-spectrum launch at fft_size >= 2048; tiles whose raw samples leave no LDS for the exchange buffers): six
+ * channelizer_fft_kernel (AFC's one-hop spectrum launches; tiles whose raw samples leave no LDS for the exchange buffers): six
  *     radix-2 butterfly stages across lanes, exchanging partners with __shfl_xor (ds_bpermute; no LDS storage).  Bin k = k1 + P*k2 ends up in
  *     register bitrev(k1) of lane bitrev6(k2); the (at most 64) channels of the dongle pull their bin with one more shuffle round.
  * Lanes 0..n_ch-1 write |bin| (and re/im for raw-I/Q channels) time-major into the stage-2 rings.
@@ -524,10 +524,10 @@ template <int LOGP, int LOGM, int LOGP_SHUFFLE>
 void launch_one(const ChannelizerArgs& a, hipStream_t stream) {
     const int tiles = (a.n_hops + HOPS_PER_TILE - 1) / HOPS_PER_TILE;
     const bool exchange = fft_uses_exchange(a.fft_log, a.hop_samples, a.bytes_per_sample);
-    /* a spectrum-only launch is ONE wavefront per dongle: one exchange buffer, so that its workgroups (10 KiB at fft 512) still fit beside the matrix-core
-     * channelizer's 144 KiB per CU when it runs on the side stream next to stage 1 (airband_hip.cpp, launch_last_hop_spectrum) */
-    const size_t lds = a.spectrum_only ? (size_t)fft_raw_bytes(a.fft_log, a.hop_samples, a.bytes_per_sample) + (exchange ? XBUF_BYTES : 0)
-                                       : fft_lds_bytes(a.fft_log, a.hop_samples, a.bytes_per_sample);
+    /* a spectrum-only launch (ONE hop and one wavefront per dongle, on a side stream beside the matrix-core channelizer: airband_hip.cpp,
+     * launch_last_hop_spectrum) stays on the shuffle kernel at every size: it needs no exchange buffer, so its 6 KiB workgroups fit beside the channelizer's
+     * 144 KiB per CU, and one transform per dongle and batch is no time either way */
+    const size_t lds = a.spectrum_only ? (size_t)fft_raw_bytes(a.fft_log, a.hop_samples, a.bytes_per_sample) : fft_lds_bytes(a.fft_log, a.hop_samples, a.bytes_per_sample);
     const long blocks = (long)tiles * a.n_dev;
     /* wide formats at high sample rates: opt in to the CU's full 160 KiB (prepare() has checked the upper bound) */
     /* (should the runtime refuse, the launch below fails with hipErrorInvalidValue and the batch driver reports it: airband_hip.cpp checks hipGetLastError) */
@@ -536,14 +536,14 @@ void launch_one(const ChannelizerArgs& a, hipStream_t stream) {
         /* a spectrum-only launch transforms ONE hop per dongle: one wavefront */
         hipLaunchKernelGGL(channelizer_fft_kernel<LOGP_SHUFFLE>, dim3((unsigned)n_blocks), dim3(b.spectrum_only ? 64 : 256), lds, stream, b);
     };
-    if (!exchange || (LOGM > 0 && a.spectrum_only)) {
+    if (!exchange || a.spectrum_only) {
         shuffle(a, blocks);
         return;
     }
     ChannelizerArgs b = a;
     if (LOGM > 0) b.last_spectrum = nullptr; /* decimated transforms produce the channels' bins only */
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_fft8_kernel<LOGP, LOGM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((channelizer_fft8_kernel<LOGP, LOGM>), dim3((unsigned)blocks), dim3(a.spectrum_only ? 64 : 256), lds, stream, b);
+    hipLaunchKernelGGL((channelizer_fft8_kernel<LOGP, LOGM>), dim3((unsigned)blocks), dim3(256), lds, stream, b);
     if (LOGM > 0 && a.last_spectrum) { /* ... and AFC's spectrum of the batch's last hop comes from a one-hop, one-wavefront launch of the shuffle kernel */
         ChannelizerArgs c = a;
         c.iq = a.iq + (long)(a.n_hops - 1) * a.hop_samples * 2 * a.bytes_per_sample;

@@ -18,7 +18,7 @@ def pytest_configure(config):
 # without a GPU (checked on the host emulation only), and the driver runs the GPU suite with `-x`: ordered like this, the run first says
 # everything about the path the benchmark measures, and then what the GPU makes of the rewritten kernel -- instead of stopping at the first FFT case and
 # saying nothing about the rest.
-_FFT_PATH = ("fft_wave64", "SFMT_F32", "test_afc", "test_fft_channelizer_lds_budget", "test_gpu_wavefront_fft")
+_FFT_PATH = ("fft_wave64", "SFMT_F32", "test_fft_channelizer_lds_budget", "test_gpu_wavefront_fft")  # (AFC on the matrix-core path: its one-hop spectrum launch stays on the shuffle kernel)
 
 
 def pytest_collection_modifyitems(config, items):
