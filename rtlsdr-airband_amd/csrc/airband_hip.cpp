@@ -92,7 +92,7 @@ struct airband_hip_handle {
     DevBuf<int> d_slot_to_ext, d_ext_to_slot;
     DevBuf<uint8_t> d_block_kind;
     DevBuf<float> d_window, d_sin, d_cos, d_twiddle;
-    DevBuf<float> d_window_dec; /* fft_size >= 2048: the window de-interleaved by sample index mod (fft_size / 512), for the decimated wavefront FFT (channelizer_fft.hip) */
+    DevBuf<float> d_window_dec; /* fft_size >= 1024: the window de-interleaved by sample index mod (fft_size / 512), for the decimated wavefront FFT (channelizer_fft.hip) */
     DevBuf<float> d_mag, d_sqbuf, d_ct_coeff, d_ct_q;
     DevBuf<float2> d_iq, d_iq_out, d_ct_af;
     DevBuf<unsigned long long> d_ct_mask;
@@ -561,7 +561,7 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     PREP_TRY(upload(h->d_ext_to_slot, h->ext_to_slot), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_block_kind, block_kind), AIRBAND_HIP_ENOMEM);
     PREP_TRY(upload(h->d_window, p.window), AIRBAND_HIP_ENOMEM);
-    if (p.fft_size >= 2048) { /* row n2 = the window at samples n2, n2 + M, n2 + 2 M, ... (M = fft_size / 512): what transform n2 of a decimated FFT multiplies by, contiguous */
+    if (p.fft_size >= 1024) { /* row n2 = the window at samples n2, n2 + M, n2 + 2 M, ... (M = fft_size / 512): what transform n2 of a decimated FFT multiplies by, contiguous */
         const int M = p.fft_size / 512;
         std::vector<float> dec((size_t)p.fft_size);
         for (int n = 0; n < p.fft_size; n++) dec[(size_t)(n % M) * 512 + n / M] = p.window[n];

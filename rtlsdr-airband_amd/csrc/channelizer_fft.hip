@@ -17,7 +17,7 @@
  * channelizer_fft8_kernel (every fft_size): the 64-point FFT as 8 x 8 -- two radix-8 passes inside the lanes with two 8 x 8
  *     transposes through a per-wavefront LDS buffer between them (l = 8a + b, k2 = c + 8e: DFT over a, twiddle W_64^(bc), DFT over b); the bins
  *     land in the same buffer and the dongle's channel lanes pick theirs up.  40 eight-byte LDS operations and ~190 vector instructions per
- *     512-point hop, where the shuffle kernel below issues 112 ds_bpermute and ~450.  fft_size 2048 ... 8192 run as 4 / 8 / 16 DECIMATED 512-point
+ *     512-point hop, where the shuffle kernel below issues 112 ds_bpermute and ~450.  fft_size 1024 ... 8192 run as 2 ... 16 DECIMATED 512-point
  *     transforms per hop, combined for the channels' bins only (see the kernel).
  * channelizer_fft_kernel (AFC's one-hop spectrum launches; tiles whose raw samples leave no LDS for the exchange buffers): six
  *     radix-2 butterfly stages across lanes, exchanging partners with __shfl_xor (ds_bpermute; no LDS storage).  Bin k = k1 + P*k2 ends up in
@@ -297,7 +297,7 @@ __device__ __forceinline__ void fft_dif(v2f (&x)[P]) {
     }
 }
 
-/* LOGM > 0: fft_size = M x 512 (2048 ... 8192).  With n = M n1 + n2 the transform is M transforms of 512 points over the DECIMATED samples,
+/* LOGM > 0: fft_size = M x 512 (1024 ... 8192).  With n = M n1 + n2 the transform is M transforms of 512 points over the DECIMATED samples,
  *      X[k] = sum over n2 of  W_N^(n2 k) * F_n2[k mod 512],      F_n2[kk] = sum over n1 of x[M n1 + n2] w[M n1 + n2] W_512^(n1 kk),
  * and since only the dongle's channels' bins are wanted, the outer sum is one complex multiply-add per channel lane and n2: a wavefront runs the M
  * 512-point transforms of its hop one after the other with the register footprint of ONE (the shuffle kernel keeps all fft_size / 64 values per lane in
@@ -308,9 +308,8 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
     constexpr int P = 1 << LOGP, M = 1 << LOGM;
     constexpr int NS = P * 64;          /* points per transform */
     constexpr int N = NS * M;           /* fft_size */
+    static_assert(LOGP == 2 || LOGP == 3, "transforms of 256 or 512 points: four or eight values per lane, ONE exchange round of P 64-point FFTs, eight lanes each");
     static_assert(LOGM == 0 || LOGP == 3, "decimated transforms are 512 points long");
-    constexpr int JN = P < 8 ? P : 8;   /* values k1 per exchange round: a round is JN 64-point FFTs, eight lanes each */
-    constexpr int NQ = P / JN;          /* exchange rounds per transform */
     AB_DYNAMIC_LDS_BYTES(lds_raw);
 
     const int tiles = (a.n_hops + HOPS_PER_TILE - 1) / HOPS_PER_TILE;
@@ -357,7 +356,7 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
         twr[rho] = rot_i(tw[rho]);
     }
     const int b8 = lane & 7;                /* b in the first radix-8 pass, c in the second */
-    const int jj = (lane >> 3) & (JN - 1);  /* the round's k1 this lane works on (256-point transforms: lanes 32 .. 63 repeat the work of lanes 0 .. 31) */
+    const int jj = (lane >> 3) & (P - 1);   /* the k1 (as its register index) this lane works on after the first transpose (256-point transforms: lanes 32 .. 63 repeat the work of lanes 0 .. 31) */
     v2f cw[8], cwr[8]; /* W_64^(b c) for the c = bitrev3(t) register t holds after the first pass */
 #pragma unroll
     for (int t = 0; t < 8; t++) {
@@ -365,8 +364,8 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
         cw[t] = v2f{w.x, w.y};
         cwr[t] = rot_i(cw[t]);
     }
-    /* the round and the buffer position in which this lane's channel finds bin kk = k mod NS of a transform: row = position of kk mod P in its round, column kk / P */
-    int my_slot = -1, my_q = -1, my_idx = 0, my_bin = 0;
+    /* the buffer position in which this lane's channel finds bin kk = k mod NS of a transform: row = the register index of kk mod P, column kk / P */
+    int my_slot = -1, my_idx = 0, my_bin = 0;
     bool my_raw = false, my_mag = true; /* NFM channels: stage 2 recomputes |bin| from the raw I/Q */
     float* my_mag_ring = a.mag;
     float2* my_iq_ring = a.iq_bins;
@@ -374,9 +373,7 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
         my_slot = a.ext_to_slot[dev.chan_base + lane];
         my_bin = a.cs[my_slot].bin;
         const int kk = my_bin & (NS - 1);
-        const int rho = bitrev(kk & (P - 1), LOGP);
-        my_q = rho / JN;
-        my_idx = (rho % JN) * XS + (kk >> LOGP);
+        my_idx = bitrev(kk & (P - 1), LOGP) * XS + (kk >> LOGP);
         my_raw = (a.cc[my_slot].flags & AB_F_RAW_IQ) != 0;
         my_mag = (a.cc[my_slot].flags & AB_F_NFM) == 0;
         const long base = ab_tile_base(my_slot, a.ring_rows / AB_TILE_ROWS);
@@ -448,11 +445,10 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
             }
 
             v2f mine = v2f{0.0f, 0.0f};
+            {
+                /* 64-point FFT over the lanes for each of the P values k1, l = 8 a + b, k2 = c + 8 e */
 #pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                /* 64-point FFT over the lanes for the JN values k1 of this round, l = 8 a + b, k2 = c + 8 e */
-#pragma unroll
-                for (int j = 0; j < JN; j++) x_w1[j * XS] = x[q * JN + j];
+                for (int j = 0; j < P; j++) x_w1[j * XS] = x[j];
                 AB_WAVE_SYNC();
                 v2f z[8];
 #pragma unroll
@@ -476,23 +472,23 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
 #pragma unroll
                 for (int i = 0; i < 8; i++) z[i] = x_r2[9 * i];
                 AB_WAVE_SYNC();
-                fft_dif<8>(z); /* over b: register t holds e = bitrev3(t); the lane is (k1 = round's jj-th, c = lane & 7) */
+                fft_dif<8>(z); /* over b: register t holds e = bitrev3(t); the lane is (k1 of register jj, c = lane & 7) */
 #pragma unroll
                 for (int t = 0; t < 8; t++) x_w3[8 * bitrev(t, 3)] = z[t];
                 AB_WAVE_SYNC();
-                /* the buffer now holds bins k1 + P k2 of the round's k1 values as [row of k1][k2]: the channel lanes pick theirs up (src/rtl_airband.cpp:483-489) */
-                if (my_q == q) mine = xb[my_idx];
+                /* the buffer now holds the transform's bins k1 + P k2 as [register index of k1][k2]: the channel lanes pick theirs up (src/rtl_airband.cpp:483-489) */
+                mine = xb[my_idx];
                 /* AFC looks at the whole spectrum of the batch's last hop (afc.finalize(dev, i, fftout), src/rtl_airband.cpp:626-630); decimated transforms
                  * leave that to a one-hop launch of the shuffle kernel (launch_channelizer_fft) */
                 if (M == 1 && a.last_spectrum && hop0 + h == a.n_hops - 1) {
                     float2* sp = reinterpret_cast<float2*>(a.last_spectrum) + (long)d * N;
 #pragma unroll
-                    for (int j = 0; j < JN; j++) {
+                    for (int j = 0; j < P; j++) {
                         const v2f v = xb[j * XS + lane];
-                        sp[bitrev(q * JN + j, LOGP) + P * lane] = make_float2(v.x, v.y);
+                        sp[bitrev(j, LOGP) + P * lane] = make_float2(v.x, v.y);
                     }
                 }
-                AB_WAVE_SYNC(); /* ... before the next round (or transform, or hop) overwrites it */
+                AB_WAVE_SYNC(); /* ... before the next transform (or hop) overwrites it */
             }
             if (M == 1) {
                 bin_sum = mine;
@@ -566,7 +562,7 @@ void launch_channelizer_fft(const ChannelizerArgs& a, hipStream_t stream) {
     switch (a.fft_log - 6) { /* <points per transform / 64, decimation, the shuffle kernel's values per lane> */
         case 2: launch_one<2, 0, 2>(a, stream); break;
         case 3: launch_one<3, 0, 3>(a, stream); break;
-        case 4: launch_one<4, 0, 4>(a, stream); break;
+        case 4: launch_one<3, 1, 4>(a, stream); break;
         case 5: launch_one<3, 2, 5>(a, stream); break;
         case 6: launch_one<3, 3, 6>(a, stream); break;
         case 7: launch_one<3, 4, 7>(a, stream); break;

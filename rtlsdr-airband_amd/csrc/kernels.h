@@ -24,7 +24,7 @@ struct ChannelizerArgs {
     const ChanConst* cc;
     const int* ext_to_slot; /* channel (device-major external index) -> demod slot */
     const float* window;    /* fft_size */
-    const float* window_dec;/* fft_size >= 2048: [fft_size / 512][512] the window at samples n2 + (fft_size / 512) n1, row n2 (decimated wavefront FFT); else unused */
+    const float* window_dec;/* fft_size >= 1024: [fft_size / 512][512] the window at samples n2 + (fft_size / 512) n1, row n2 (decimated wavefront FFT); else unused */
     const float2* twiddle;  /* fft_size: exp(-2 pi i k / fft_size) */
     float* mag;             /* |bin| ring, blocked by 64 slots and transposed in tiles of AB_TILE_ROWS rows (common.h: ab_tile_base / ab_tile_off) */
     float2* iq_bins;        /* raw bin I/Q ring, same layout */

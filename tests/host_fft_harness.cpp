@@ -50,7 +50,7 @@ int hostfft_run(const airband_hip_config* cfg, const uint8_t* iq, long iq_stride
     a.ext_to_slot = ext_to_slot.data();
     a.window = p.window.data();
     std::vector<float> wdec; /* as airband_hip_prepare() builds it */
-    if (p.fft_size >= 2048) {
+    if (p.fft_size >= 1024) {
         const int M = p.fft_size / 512;
         wdec.resize(p.fft_size);
         for (int n = 0; n < p.fft_size; n++) wdec[(size_t)(n % M) * 512 + n / M] = p.window[n];
