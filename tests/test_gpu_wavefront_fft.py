@@ -1,5 +1,5 @@
 """The wavefront-FFT channelizer (csrc/channelizer_fft.hip) on the GPU beyond the cases tests/test_gpu_parity.py holds: its decimated variants
-(fft_size 2048 / 4096: 4 / 8 transforms of 512 points per hop), f32 at a hop that is not a power of two, and u8 at 2.0 MS/s -- hops of 250 bytes, which the
+(fft_size 1024 / 2048 / 4096: 2 / 4 / 8 transforms of 512 points per hop), f32 at a hop that is not a power of two, and u8 at 2.0 MS/s -- hops of 250 bytes, which the
 matrix-core path does not take.  Same bars as everywhere: squelch trace and axcindicate equal to the oracle's, audio within 1e-4 RMS.
 (tests/test_host_fft.py runs the same kernel source on the CPU against a float64 FFT; this file is what a GPU says.)"""
 import importlib

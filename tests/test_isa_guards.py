@@ -205,7 +205,7 @@ def fft_asm(tmp_path_factory):
 def test_exchange_fft_kernel_is_packed_and_shuffle_free(fft_asm):
     """channelizer_fft8_kernel (fft_size 256 / 512 / 1024): the 64-point FFT across the lanes goes through the wavefront's LDS buffer -- no ds_bpermute --,
     a complex product is one packed multiply and one packed FMA (the compiler's own form is five instructions: cmul() in channelizer_fft.hip), nothing
-    spills, and the 512-point kernel -- also as the transform of the decimated fft 2048 ... 8192 variants -- keeps four wavefronts per SIMD (<= 128 vector registers)."""
+    spills, and the 512-point kernel -- also as the transform of the decimated fft 1024 ... 8192 variants -- keeps four wavefronts per SIMD (<= 128 vector registers)."""
     text = "\n".join(fft_asm)
     for logp, logm, max_vgpr in ((2, 0, 128), (3, 0, 128), (3, 1, 128), (3, 2, 128), (3, 3, 128), (3, 4, 128)):  # fft 256, 512; 1024 ... 8192 as 2 ... 16 decimated 512-point transforms
         body = _function(fft_asm, "channelizer_fft8_kernelILi%dELi%dE" % (logp, logm))
