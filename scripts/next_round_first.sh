@@ -8,6 +8,8 @@ set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/first; rm -rf $O; mkdir -p $O
 timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_gpu_wavefront_fft.py -m gpu -q -k "fft_wave64 or other_formats or afc or golden or wavefront_fft_variants" > $O/parity_fft.log 2>&1; tail -5 $O/parity_fft.log
+# the same cases on the shuffle kernel: tells a fault of the exchange kernel from a fault of a case (2.0 MS/s and f32 at these sizes are new on the GPU either way)
+AIRBAND_HIP_FFT_SHUFFLE=1 timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_wavefront_fft.py -m gpu -q -k "fft_wave64 or SFMT_F32 or wavefront_fft_variants" > $O/parity_fft_shuffle.log 2>&1; tail -5 $O/parity_fft_shuffle.log
 N="--no-cpu-baseline --no-traffic --no-verify-all --verify 4"
 AIRBAND_BENCH_FLAGS=4 timeout 200 python bench.py $N --steps 6 --warmup 2 2>/dev/null | tail -n 1 > $O/bench_cfg3_force_fft.json; cut -c1-400 $O/bench_cfg3_force_fft.json
 timeout 200 python bench.py $N --steps 6 --warmup 2 --sample-format f32 --ring 1 --dongles 32768 2>/dev/null | tail -n 1 > $O/bench_f32_32768.json; cut -c1-400 $O/bench_f32_32768.json
