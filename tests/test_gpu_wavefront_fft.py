@@ -2,8 +2,6 @@
 (fft_size 1024 / 2048 / 4096: 2 / 4 / 8 transforms of 512 points per hop), f32 at a hop that is not a power of two, and u8 at 2.0 MS/s -- hops of 250 bytes, which the
 matrix-core path does not take.  Same bars as everywhere: squelch trace and axcindicate equal to the oracle's, audio within 1e-4 RMS.
 (tests/test_host_fft.py runs the same kernel source on the CPU against a float64 FFT; this file is what a GPU says.)"""
-import importlib
-
 import numpy as np
 import pytest
 
@@ -19,11 +17,6 @@ CASES = [
 ]
 
 
-@pytest.fixture(scope="module")
-def pkg():
-    return importlib.import_module("rtlsdr-airband_amd")
-
-
 def _case(pkg, sfmt_name, fft_log, sample_rate, wave_rate, n_dev=2, n_batches=5):
     sfmt = getattr(pkg.capi, sfmt_name)
     devices, iq = helpers.format_case(pkg, sfmt, fft_log, sample_rate, wave_rate, n_dev, n_batches)
@@ -35,7 +28,7 @@ def _case(pkg, sfmt_name, fft_log, sample_rate, wave_rate, n_dev=2, n_batches=5)
 
 
 @pytest.mark.parametrize("sfmt_name,fft_log,sample_rate,wave_rate,force", CASES)
-def test_the_cases_open_a_squelch_on_the_oracle(pkg, sfmt_name, fft_log, sample_rate, wave_rate, force):
+def test_the_cases_open_a_squelch_on_the_oracle(pkg, built, sfmt_name, fft_log, sample_rate, wave_rate, force):
     """CPU half: the synthetic streams of the GPU cases below do open squelches (so the GPU comparison is not vacuous)."""
     _, _, ref = _case(pkg, sfmt_name, fft_log, sample_rate, wave_rate, n_dev=1, n_batches=5)
     assert sum(int((a == ord("*")).sum()) for a in ref[0]["axc"]) > 0
@@ -43,7 +36,7 @@ def test_the_cases_open_a_squelch_on_the_oracle(pkg, sfmt_name, fft_log, sample_
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("sfmt_name,fft_log,sample_rate,wave_rate,force", CASES)
-def test_wavefront_fft_variants(pkg, sfmt_name, fft_log, sample_rate, wave_rate, force):
+def test_wavefront_fft_variants(pkg, built, sfmt_name, fft_log, sample_rate, wave_rate, force):
     capi = pkg.capi
     n_dev, n_batches = 2, 5
     devices, iq, ref = _case(pkg, sfmt_name, fft_log, sample_rate, wave_rate, n_dev, n_batches)
