@@ -79,6 +79,22 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def physical_cores() -> int:
+    """Distinct (socket, core) pairs of /proc/cpuinfo; os.cpu_count() where that cannot be read (SMT siblings then count as cores)."""
+    try:
+        seen, phys = set(), "0"
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                seen.add((phys, line.split(":", 1)[1].strip()))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(pkg, devices, wave_rate, mixed, seconds):
     """The reference's own demodulate() (oracle/_ref, compiled in place) timed on this box's host cores, on a bounded sample:
     T = nproc dongles of the same workload, one pthread per dongle (the reference's multiple_demod_threads model,
@@ -119,23 +135,31 @@ def cpu_baseline(pkg, devices, wave_rate, mixed, seconds):
                     sample="oracle C restatement, 1 dongle x 8 ch for %.1f s wall (%d batches)" % (el, batches))
 
     def run(variant, n, secs):
-        b, e = pyref.reference_throughput(devices[:n], [host[d] for d in range(n)], secs, n, nfm=nfm, fast=variant)
-        return round(b * SAMPLES_PER_BATCH / e / 1e6, 3), b, e
+        b, e, taken, overran = pyref.reference_throughput(devices[:n], [host[d] for d in range(n)], secs, n, nfm=nfm, fast=variant)
+        return round(b * SAMPLES_PER_BATCH / e / 1e6, 3), b, e, overran
 
     have32 = os.path.exists(pyref.ref_lib_path(nfm, "fast32"))
     have_fast = os.path.exists(pyref.ref_lib_path(nfm, "fast"))
     main_variant = "fast32" if have32 else ("fast" if have_fast else False)
-    share = seconds / (2.0 if have32 and have_fast else 1.0)
-    value, batches, el = run(main_variant, threads, max(3.0, 0.7 * share))
-    one_thread, _, _ = run(main_variant, 1, max(2.0, 0.3 * share))
-    out = dict(value=value, unit="Msamples/s", cores=threads, nproc=nproc, cpu_model=cpu_model(), kind="reference", value_1_thread=one_thread,
+    cores = min(physical_cores(), threads)
+    # T = nproc (every hardware thread), T = physical cores, T = 1: the same per-thread work each time (one dongle per demodulate() thread), so
+    # value(T) / (T x value(1)) is the scaling of the host, consumer threads included (one per 8 dongles, oracle/ref_harness.cpp)
+    share = seconds / (1.35 if have32 and have_fast else 1.0)
+    value, batches, el, overran = run(main_variant, threads, max(3.0, 0.45 * share))
+    at_cores, _, _, over_cores = run(main_variant, cores, max(3.0, 0.35 * share)) if cores != threads else (value, batches, el, overran)
+    one_thread, _, _, over_one = run(main_variant, 1, max(2.0, 0.2 * share))
+    best = max(value, at_cores)
+    out = dict(value=best, unit="Msamples/s", cores=threads if value >= at_cores else cores, nproc=nproc, physical_cores=cores, cpu_model=cpu_model(), kind="reference",
+               value_nproc_threads=value, value_physical_cores=at_cores, value_1_thread=one_thread,
+               scaling_vs_linear=dict(nproc=round(value / (threads * one_thread), 3), physical_cores=round(at_cores / (cores * one_thread), 3)),
+               batches_overrun=dict(nproc=overran, physical_cores=over_cores, one_thread=over_one),
                fft="f32 radix-4 Stockham (oracle_fft32.c)" if have32 else "f64 radix-2 (oracle_fft.c)",
-               sample="oracle/_ref = the reference's demodulate() compiled in place (%s), %d dongles x 8 ch of the same workload, one pthread each, "
-                      "%.1f s wall (%d batches); FFTW3 is not installed: see `fft`" %
-                      ("-O3 -march=native -ffast-math" if main_variant else "-O2 strict", n_dev, el, batches))
+               sample="oracle/_ref = the reference's demodulate() compiled in place (%s), T dongles x 8 ch of the same workload on T pthreads (its multiple_demod_threads "
+                      "model) for T = %d / %d / 1, one consumer thread per 8 dongles, %.1f s wall at T = %d (%d batches, of which %d finished before the consumer had "
+                      "taken the previous one: output_overrun_count, counted as work done); FFTW3 is not installed: see `fft`" %
+                      ("-O3 -march=native -ffast-math" if main_variant else "-O2 strict", threads, cores, el, threads, batches, overran))
     if have32 and have_fast:
-        out["value_f64_fft"], _, _ = run("fast", threads, max(3.0, 0.7 * share))
-        out["value_f64_fft_1_thread"], _, _ = run("fast", 1, max(2.0, 0.3 * share))
+        out["value_f64_fft"], _, _, _ = run("fast", out["cores"], max(3.0, 0.25 * share))
     return out
 
 
@@ -197,7 +221,8 @@ def measure_traffic(args, kernel_substr):
     for counter, mult in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
         out_dir = tempfile.mkdtemp(prefix="airband_pmc_", dir="/tmp")
         cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
-               "--child", "--no-verify-all", "--workload", args.workload, "--steps", "3", "--warmup", "1", "--ring", "1"]
+               "--child", "--no-verify-all", "--workload", args.workload, "--steps", str(max(3, args.ring)), "--warmup", "1", "--ring", str(args.ring),
+               "--signal-start-batch", str(args.signal_start_batch)]  # first launch dropped: the average is over the resident ring, like the timed region
         if args.dongles:
             cmd += ["--dongles", str(args.dongles)]
         if args.sample_format != "u8":
@@ -240,7 +265,7 @@ def measure_traffic(args, kernel_substr):
     out_dir = tempfile.mkdtemp(prefix="airband_kt_", dir="/tmp")
     try:
         cmd = [rocprof, "--kernel-trace", "--stats", "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
-               "--child", "--no-verify-all", "--workload", args.workload, "--steps", "10", "--warmup", "2", "--ring", "1"]
+               "--child", "--no-verify-all", "--workload", args.workload, "--steps", "10", "--warmup", "2", "--ring", str(args.ring), "--signal-start-batch", str(args.signal_start_batch)]
         if args.dongles:
             cmd += ["--dongles", str(args.dongles)]
         if args.sample_format != "u8":
@@ -269,6 +294,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("AIRBAND_BENCH_WORKLOAD", "cfg3"), choices=sorted(WORKLOADS))
     ap.add_argument("--dongles", type=int, default=0, help="override dongles per GPU")
+    ap.add_argument("--signal-start-batch", type=int, default=1, help="signal time (in batches of 1/8 s) of the first resident batch.  The synthetic transmitters key "
+                    "0.75 s on / 0.75 s off in eight phase slots (SURVEY 8d): the ring of 3 resident batches that follows the first one then covers batches 2..4 of "
+                    "the 12-batch keying period, in which 3, 4 and 5 of the 8 slots are keyed -- 50 %, the period's own average (0 = the stream's start: 2, 3, 4 of 8 slots "
+                    "minus the squelch's opening delay, what rounds 1-3 timed); the measured share of open channels is printed as `open_fraction`")
     ap.add_argument("--sample-format", default="u8", choices=["u8", "s16", "s8", "f32"], help="u8 = RTL-SDR bytes (BASELINE configs); s16 = CS16 as SoapySDR devices deliver it; s8 (mirisdr), f32 (SoapySDR CF32: the wavefront-FFT channelizer; 8 bytes per sample, so use --ring 1 --dongles 32768) "
                     "(the same synthetic signal re-expressed at 16 bits, full scale 25 500)")
     ap.add_argument("--sample-rate", type=int, default=2_560_000, help="dongle sample rate (BASELINE: 2 560 000; 2 400 000 is the other common RTL-SDR rate: hops of "
@@ -362,7 +391,7 @@ def main():
     stride = (span + 255) // 256 * 256
     iq = torch.empty((D, stride), dtype=torch.uint8, device="cuda")
     if not s16:
-        hip.generate_iq(iq.data_ptr(), stride, 0, span, seed=0x5EED, device_index_offset=rank * D)
+        hip.generate_iq(iq.data_ptr(), stride, args.signal_start_batch * g.batch_bytes, span, seed=0x5EED, device_index_offset=rank * D)
     else:
         # the generator emits u8; CS16 dongles get the same signal as (b - 127.5) * 200, s8 ones b - 128, f32 ones (b - 127.5) / 127.5, converted slab by slab
         slab = min(D, 2048)
@@ -372,7 +401,7 @@ def main():
         iqv = iq.view({1: torch.int8, 2: torch.int16, 4: torch.float32}[bpc])
         for d0 in range(0, D, slab):
             n = min(slab, D - d0)
-            gen.generate_iq(tmp.data_ptr(), span // bpc, 0, span // bpc, seed=0x5EED, device_index_offset=rank * D + d0)
+            gen.generate_iq(tmp.data_ptr(), span // bpc, args.signal_start_batch * (g.batch_bytes // bpc), span // bpc, seed=0x5EED, device_index_offset=rank * D + d0)
             gen.synchronize()
             if bpc == 2:
                 iqv[d0:d0 + n, :span // 2] = tmp[:n].to(torch.int16) * 200 - 25500
@@ -504,6 +533,20 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["verified_dongles"] = 0
             out["verify"] = dict(error="spot check could not run: %r" % (e,))
+    if rank == 0 and not args.pipelined:
+        # how busy the benchmarked signal keeps the squelches: one more pass over the resident ring (untimed), share of channels whose batch had signal
+        try:
+            total_ch = hip.geometry.total_channels
+            axc_view = torch.as_tensor(mg._DevicePtr(hip.device_results()["axc"], (total_ch,), "|u1"), device="cuda")
+            fr = []
+            for i in range(total_steps, total_steps + args.ring):
+                step(i)
+                hip.synchronize()
+                fr.append(float((axc_view == ord("*")).float().mean().item()))
+            out["open_fraction"] = dict(per_ring_batch=[round(x, 4) for x in fr], mean=round(sum(fr) / len(fr), 4),
+                                        note="share of channels with axcindicate == SIGNAL per resident batch; the keying period's own average is 0.5")
+        except Exception as e:  # noqa: BLE001
+            out["open_fraction"] = dict(error=repr(e)[:200])
     if rank == 0 and world == 1 and args.host_path:
         # host-buffer path: what the shim of INTEGRATION.md does -- pageable host memory through submit() (one feeder thread per group of
         # dongles, like the reference's per-device rx threads) and process(); PCIe-inclusive, reported separately, never as `value`

@@ -34,7 +34,7 @@ def _load(nfm: bool, fast=False) -> C.CDLL:
     lib.refh_channel_stats.argtypes = [C.c_int, C.c_int, C.POINTER(capi.ChannelStats)]
     lib.refh_channel_constants.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
     lib.refh_set_trace_dir.argtypes = [C.c_char_p]
-    lib.refh_throughput.argtypes = [C.POINTER(C.c_void_p), C.c_double, C.POINTER(C.c_double)]
+    lib.refh_throughput.argtypes = [C.POINTER(C.c_void_p), C.c_double, C.c_int, C.POINTER(C.c_double)]
     lib.refh_throughput.restype = C.c_long
     return lib
 
@@ -143,10 +143,10 @@ def _tp_worker(q, nfm, fast, fft_log, devices, iq_list, seconds, threads):
         lib.refh_start(threads)
         bufs = [np.ascontiguousarray(x) for x in iq_list]
         ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
-        el = C.c_double(0)
-        nb = lib.refh_throughput(ptrs, float(seconds), C.byref(el))
+        out = (C.c_double * 3)()
+        nb = lib.refh_throughput(ptrs, float(seconds), 8, out)  # one consumer thread per 8 devices
         lib.refh_stop()
-        q.put(("ok", (int(nb), float(el.value))))
+        q.put(("ok", (int(nb), float(out[2]), int(out[0]), int(out[1]))))
     except BaseException as e:  # noqa: BLE001
         q.put(("err", repr(e)))
 
@@ -158,7 +158,8 @@ def ring_bytes(fft_size: int = 512, bytes_per_sample: int = 1) -> int:
 
 def reference_throughput(devices, iq_list, seconds: float, threads: int, *, nfm: bool, fast=True, fft_log: int = 9):
     """CPU baseline: the real reference demodulate() in `threads` pthreads over contiguous device shards, rings
-    pre-filled and kept full by cursor rewind.  Returns (batches completed over all devices, elapsed seconds)."""
+    pre-filled and kept full by cursor rewind, one consumer thread per 8 devices.  Returns (batches completed over all devices, elapsed
+    seconds, batches the consumers took, batches counted in output_overrun_count): completed = taken + overrun."""
     ctx = mp.get_context("fork")
     q = ctx.Queue()
     p = ctx.Process(target=_tp_worker, args=(q, nfm, fast, fft_log, devices, iq_list, seconds, threads))

@@ -618,10 +618,39 @@ float refh_fm_quadri_demod(float ar, float aj, float br, float bj) { return fm_q
 #endif
 
 /* ---- throughput mode (CPU baseline) ------------------------------------------------
- * Ring of device d is pre-filled once with `iq` (buf_size bytes + tail) and kept "full" by moving the
- * write cursor, so the timed region contains no memcpy: only demodulate() and the drain. Returns the
- * number of batches completed over all devices in `seconds` of wall time. */
-long refh_throughput(const unsigned char* const* iq_per_device, double seconds, double* elapsed_out) {
+ * Ring of device d is pre-filled once with `iq` (buf_size bytes + tail) and kept "full" by moving the write cursor, so the timed region
+ * contains no memcpy: only demodulate() and the consumers.  The consumer side imitates output_thread (src/output.cpp:903-923) with ONE
+ * DRAIN THREAD PER `devices_per_drain` DEVICES (round 4; before: one thread walked every device's buffer_lock in a sched_yield() spin and
+ * became the bottleneck at 256 demodulate() threads): it takes a batch when waveavail is up, refills the ring cursor and sleeps 250 us
+ * between rounds.  demodulate() never waits for its consumer -- a batch finished while the previous one is still flagged is counted in
+ * output_overrun_count (src/rtl_airband.cpp:649-654) and is work done all the same: out[0] = batches drained, out[1] = batches that
+ * overran, both over all devices; their sum is what the demodulate() threads completed in out[2] seconds of wall time. */
+struct tp_drain_t {
+    int d0, d1;
+    volatile int stop;
+    long drained;
+    pthread_t thread;
+};
+static void* tp_drain_main(void* p) {
+    tp_drain_t* a = (tp_drain_t*)p;
+    while (!a->stop) {
+        for (int d = a->d0; d < a->d1; d++) {
+            input_t* in = devices[d].input;
+            if (devices[d].waveavail) {
+                refh_drain(d, NULL, NULL, NULL);
+                a->drained++;
+            }
+            /* keep the ring full: write cursor trails the read cursor by one hop */
+            pthread_mutex_lock(&in->buffer_lock);
+            in->bufe = (in->bufs + in->buf_size - refh_bps(in)) % in->buf_size;
+            pthread_mutex_unlock(&in->buffer_lock);
+        }
+        usleep(250);
+    }
+    return NULL;
+}
+long refh_throughput(const unsigned char* const* iq_per_device, double seconds, int devices_per_drain, double* out3) {
+    if (devices_per_drain < 1) devices_per_drain = 1;
     for (int d = 0; d < device_count; d++) {
         input_t* in = devices[d].input;
         memcpy(in->buffer, iq_per_device[d], in->buf_size + 2 * in->bytes_per_sample * fft_size);
@@ -630,29 +659,40 @@ long refh_throughput(const unsigned char* const* iq_per_device, double seconds, 
         in->bufe = in->buf_size - refh_bps(in);
         pthread_mutex_unlock(&in->buffer_lock);
     }
+    const int n_drain = (device_count + devices_per_drain - 1) / devices_per_drain;
+    std::vector<tp_drain_t> drains(n_drain);
     struct timeval t0, t1;
+    /* the demodulate() threads have been running since refh_start() (spinning on empty rings in 10 ms sleeps): what they finished before t0 is taken off */
+    std::vector<long> over0(device_count);
+    for (int d = 0; d < device_count; d++) over0[d] = (long)devices[d].output_overrun_count;
     gettimeofday(&t0, NULL);
-    long batches = 0;
-    double el = 0;
-    for (;;) {
-        for (int d = 0; d < device_count; d++) {
-            input_t* in = devices[d].input;
-            if (devices[d].waveavail) {
-                refh_drain(d, NULL, NULL, NULL);
-                batches++;
-            }
-            /* keep the ring full: write cursor trails the read cursor by one hop */
-            pthread_mutex_lock(&in->buffer_lock);
-            in->bufe = (in->bufs + in->buf_size - refh_bps(in)) % in->buf_size;
-            pthread_mutex_unlock(&in->buffer_lock);
-        }
-        gettimeofday(&t1, NULL);
-        el = (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);
-        if (el >= seconds) break;
-        sched_yield();
+    for (int k = 0; k < n_drain; k++) {
+        drains[k].d0 = k * devices_per_drain;
+        drains[k].d1 = std::min(device_count, (k + 1) * devices_per_drain);
+        drains[k].stop = 0;
+        drains[k].drained = 0;
+        pthread_create(&drains[k].thread, NULL, tp_drain_main, &drains[k]);
     }
-    if (elapsed_out) *elapsed_out = el;
-    return batches;
+    struct timespec nap;
+    nap.tv_sec = (time_t)seconds;
+    nap.tv_nsec = (long)((seconds - (double)nap.tv_sec) * 1e9);
+    nanosleep(&nap, NULL);
+    long overruns = 0;
+    for (int d = 0; d < device_count; d++) overruns += (long)devices[d].output_overrun_count - over0[d];
+    gettimeofday(&t1, NULL);
+    long drained = 0;
+    for (int k = 0; k < n_drain; k++) drains[k].stop = 1;
+    for (int k = 0; k < n_drain; k++) {
+        pthread_join(drains[k].thread, NULL);
+        drained += drains[k].drained;
+    }
+    const double el = (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);
+    if (out3) {
+        out3[0] = (double)drained;
+        out3[1] = (double)overruns;
+        out3[2] = el;
+    }
+    return drained + overruns;
 }
 
 } /* extern "C" */

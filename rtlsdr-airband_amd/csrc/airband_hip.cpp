@@ -20,6 +20,11 @@
 #include "kernels.h"
 #include "params.h"
 
+/* upper bound for the private (per AFC group) coefficient tables of a handle; past it prepare() picks the wavefront-FFT channelizer (override for tests) */
+#ifndef AB_PRIVATE_TABLE_BUDGET
+#define AB_PRIVATE_TABLE_BUDGET ((size_t)8 << 30)
+#endif
+
 using namespace airband;
 
 namespace {
@@ -643,7 +648,11 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     h->use_dft = !(h->flags & AIRBAND_HIP_FLAG_FORCE_FFT) && dft_supported(p.fft_size, (int)h->hop_bytes, p.dev[0].sfmt, p.max_ch);
     if (h->use_dft) {
         build_dft_tables(h->plan, false);
-        if (p.n_shared_bsets > 4096) {
+        /* private tables (one per group with an AFC channel) are only bounded by the fleet: 65 536 AFC dongles are 3.2 GB of them at fft 512 and ~51 GB at
+         * fft 8192.  Past a budget the handle runs on the wavefront FFT, which is what AFC configurations ran on before the matrix-core path took them */
+        const size_t tab_bytes_each = (size_t)3 * (p.fft_size > 512 ? 16 : p.fft_size / 32) * 64 * 16 * (p.fft_size > 512 ? p.fft_size / 512 : 1);
+        const size_t private_bytes = (size_t)(p.n_bsets - p.n_shared_bsets) * tab_bytes_each;
+        if (p.n_shared_bsets > 4096 || private_bytes > AB_PRIVATE_TABLE_BUDGET) {
             h->use_dft = false; /* that many different shared tables would not stay cache resident; fall back */
         } else {
             PREP_TRY(upload(h->d_item_dev, p.item_dev), AIRBAND_HIP_ENOMEM);
@@ -814,14 +823,15 @@ int airband_hip_device_enable(airband_hip_handle* h, int32_t dev, int32_t enable
     }
     /* channel->axcindicate of a device that is not demodulated any more: NO_SIGNAL */
     if (!on) HIP_TRY(h, hipMemcpyAsync(h->d_out_axc.p + c0, blank.data(), (size_t)nc, hipMemcpyHostToDevice, s), AIRBAND_HIP_ERUNTIME);
-    h->dev_enabled[dev].store(on);
+    /* host-ring path: a dongle that comes back joins the others at the common stream position with an empty queue -- its write cursor is put there
+     * BEFORE the dongle is published as enabled (release / acquire with submit()'s load): a feeder thread that sees it enabled never sees the stale cursor */
+    if (on && h->ring_wr) h->ring_wr[dev].store(h->ring_rd, std::memory_order_release);
+    h->dev_enabled[dev].store(on, std::memory_order_release);
     h->n_enabled += on ? 1 : -1;
     /* its mixer connections: mixer_disable_input() for every output of the device, as disable_device_outputs() does (src/output.cpp, src/mixer.cpp:96-110) */
     for (size_t k = 0; k < h->mix_chan_host.size(); k++)
         if (p.cc[h->mix_chan_host[k]].dev == dev) HIP_TRY(h, write_mix_input(h, (int)k), AIRBAND_HIP_ERUNTIME);
     HIP_TRY(h, hipStreamSynchronize(s), AIRBAND_HIP_ERUNTIME); /* the host buffers above go out of scope */
-    /* host-ring path: a dongle that comes back joins the others at the common stream position with an empty queue */
-    if (on && h->ring_wr) h->ring_wr[dev].store(h->ring_rd, std::memory_order_release);
     return AIRBAND_HIP_OK;
 }
 

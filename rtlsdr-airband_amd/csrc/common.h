@@ -82,7 +82,10 @@ struct ChanState {
     /* what the channel's result row holds: bit 0 = its AGC_EXTRA carry is all zeros, bit 1 = its batch area is -- a channel that stays closed
      * leaves both alone instead of rewriting 8 KiB of zeros per batch (demod.hip, RowZero) */
     int32_t row_zero;
-    int32_t pad[2];
+    /* the delay-line entry the batch's LAST sample saw (SqRegs::dly): update_current_state() tests the post-filter gate against buffer_[buffer_tail_]
+     * before the tail moves (src/squelch.cpp:390,407,467), so the first sample of the next batch needs it once more -- the shadow itself has stepped on */
+    float sh_dly;
+    int32_t pad[1];
 };
 
 /* Per-dongle constants for the channelizer. */

@@ -280,7 +280,9 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     const bool aligned4 = ((s.sample_count + 1u) & 3u) == 0u;
     SqShadow sh = {sp->sh_nf, sp->sh_cap, sp->sh_capped};
     const bool first_batch = a.tail_copy == 0; /* the stream's first 101 samples read the zeros the reference's delay line starts with (src/squelch.cpp:69) */
-    s.dly = (KIND == AB_KIND_NFM_LOWPASS && !first_batch) ? sq_shadow_value(sh) : 0.0f;
+    /* buffer_[buffer_tail_] as the previous batch's last sample left it (0 in a fresh buffer): NOT sq_shadow_value(sh), which is already the entry under the
+     * tail's next position -- the OPENING / CLOSING timers that run out on a batch's first sample gate on this one (tests/test_host_demod.py, ..._first_sample_of_a_batch...) */
+    s.dly = KIND == AB_KIND_NFM_LOWPASS ? sp->sh_dly : 0.0f;
     float agc = sp->agcavgfast, pr = sp->pr, pj = sp->pj, prev_out = sp->prev_waveout;
     unsigned dm_phi = sp->dm_phi;
     OutRegs o;
@@ -713,7 +715,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         sp->row_zero = rz.batch_open ? 0 : ((rz.held & 1) | 2); /* an open batch may also have faded into the carry */
     }
     sp->agcavgfast = agc; sp->pr = pr; sp->pj = pj; sp->prev_waveout = prev_out; sp->dm_phi = dm_phi;
-    if (KIND == AB_KIND_NFM_LOWPASS) { sp->sh_nf = sh.nf; sp->sh_cap = sh.cap; sp->sh_capped = sh.capped; }
+    if (KIND == AB_KIND_NFM_LOWPASS) { sp->sh_nf = sh.nf; sp->sh_cap = sh.cap; sp->sh_capped = sh.capped; sp->sh_dly = s.dly; }
     sq_store(s, L, sp, B);
     sp->lxr[1] = lxr1; sp->lxr[2] = lxr2; sp->lxi[1] = lxi1; sp->lxi[2] = lxi2;
     sp->lyr[1] = lyr1; sp->lyr[2] = lyr2; sp->lyi[1] = lyi1; sp->lyi[2] = lyi2;

@@ -114,3 +114,45 @@ def wait_for_gpu_memory(nbytes: int, timeout_s: float = 60.0) -> None:
         if free >= nbytes:
             return
         time.sleep(0.5)
+
+
+def boundary_devices(n_dev):
+    """NFM + lowpass channels with a manual squelch level and frequencies at which dm_dphi is 0 (src/config.cpp:679-712): what boundary_streams() feeds."""
+    chans = [dict(frequency=sg.CENTERFREQ + 16000 * (k + 3), modulation=1, afc=0, squelch_threshold_dbfs=-40, squelch_snr_threshold_db=-1.0, notch_freq=0.0, notch_q=0.0,
+                  ctcss_freq=0.0, bandwidth_hz=5000 if k % 2 == 0 else 6250, ampfactor=1.0, tau_us=-1, has_iq_outputs=0) for k in range(8)]
+    return [dict(channels=[dict(c) for c in chans]) for _ in range(n_dev)], 0.17666475474834442  # Squelch::squelch_level() of -40 dBFS (the tests assert it)
+
+
+def boundary_streams(orc_factory, n_dev, B, level):
+    """Per channel: quiet, then a steady level just above the squelch level from an onset chosen (with the oracle, two passes) so that the OPENING
+    delay runs out on sample 0 of batch 2; 101 samples before that boundary the level steps up by a height swept over the channels."""
+    n_ch, n_batches, n0 = n_dev * 8, 3, 2 * B
+    steady = 3.5 / 3.0 * level
+    onset = np.full(n_ch, n0 - 420)
+    step = level * np.geomspace(4.0, 120.0, n_ch)
+
+    def streams(with_step):
+        env = np.full((n_ch, n_batches * B), 0.1 * level, np.float64)
+        for c in range(n_ch):
+            env[c, onset[c]:] = steady
+            if with_step:
+                env[c, n0 - 101:] += step[c]
+        iq = np.zeros((n_ch, 2 * n_batches * B), np.float32)
+        iq[:, 0::2] = env.astype(np.float32)  # dm_dphi is 0 at these frequencies: the derotation leaves the samples alone, the lowpass passes their level
+        return np.abs(iq[:, 0::2]), iq
+
+    for _ in range(2):  # pass 1 finds where the delay runs out, pass 2 confirms the shifted onsets
+        wave, iq = streams(False)
+        orc = orc_factory()
+        first = np.zeros(n_ch, int)
+        for b in range(n_batches):
+            for d in range(n_dev):
+                r = orc.run_bins(d, wave[8 * d:8 * d + 8, b * B:(b + 1) * B], iq[8 * d:8 * d + 8, 2 * b * B:2 * (b + 1) * B])
+                if b == 2:
+                    for c in range(8):
+                        assert r["trace"][c, 0] & 7 == 1 or _ == 1, "the onset guess leaves no OPENING delay across the boundary"
+                        first[8 * d + c] = int(np.argmax((r["trace"][c] & 7) != 1))
+        orc.close()
+        onset -= first - 1
+    assert (first == 1).all(), first
+    return streams(True)

@@ -76,6 +76,33 @@ def test_stage2_bit_exact_on_oracle_bins(pkg, built, mixed, wave_rate, style):
             assert opens > 50 and flappy > 10, (opens, flappy)  # the signal did exercise re-opening and flap detection
 
 
+def test_opening_timer_expires_on_the_first_sample_of_a_batch(pkg, built):
+    """The GPU twin of tests/test_host_demod.py::test_opening_timer_expires_on_the_first_sample_of_a_batch_with_the_post_filter_in_use: 64 NFM + lowpass
+    channels whose OPENING delay runs out on sample 0 of batch 2 with the post-filter gate deciding against the delay-line entry the kernel has to carry
+    across the batch boundary (src/squelch.cpp:381-398,467-475)."""
+    wave_rate, B, n_dev = 16000, 2000, 8
+    devices, level = helpers.boundary_devices(n_dev)
+    wave, iq = helpers.boundary_streams(lambda: pyoracle.Oracle(devices, wave_rate=wave_rate), n_dev, B, level)
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate)
+    outcomes = set()
+    with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=pkg.capi.FLAG_TRACE_SQUELCH) as hip:
+        for b in range(3):
+            w, q = wave[:, b * B:(b + 1) * B], iq[:, 2 * b * B:2 * (b + 1) * B]
+            want = [orc.run_bins(d, w[8 * d:8 * d + 8], q[8 * d:8 * d + 8]) for d in range(n_dev)]
+            hip.process_bins(np.ascontiguousarray(w), np.ascontiguousarray(q))
+            out = hip.collect()
+            tr = hip.read_trace()
+            want_t = np.concatenate([r["trace"] for r in want])
+            if b == 2:
+                outcomes = {int(t[1]) & 7 for t in want_t}
+            assert np.array_equal(tr, want_t), "batch %d: squelch trace (channels %s)" % (b, np.nonzero((tr != want_t).any(axis=1))[0])
+            assert np.array_equal(out["axc"], np.concatenate([r["axc"] for r in want]))
+            ww = np.concatenate([r["waveout"] for r in want])
+            assert np.array_equal(out["waveout"].view(np.uint32), ww.view(np.uint32))
+    assert orc.stats(0, 0)["squelch_level"] == level and 4 in outcomes
+    orc.close()
+
+
 @pytest.mark.parametrize("force_fft", [False, True], ids=["dft_mfma", "fft_wave64"])
 @pytest.mark.parametrize("mixed,wave_rate", [(False, 8000), (True, 16000)])
 def test_end_to_end_stream(pkg, built, mixed, wave_rate, force_fft):

@@ -49,20 +49,23 @@ def _tweak(d, ch):
 
 
 CASES = [
-    # n_dev, mixed, wave_rate, sampled dongles, pipelined, tweak
-    pytest.param(1024, False, 8000, 40, False, False, id="configs1_1024_am"),
-    pytest.param(200, True, 16000, 24, False, True, id="200_mixed_partial_group"),
-    pytest.param(1000, True, 16000, 32, False, False, id="1000_mixed_partial_group"),
-    pytest.param(4096, True, 16000, 40, False, True, id="4096_mixed_splits2"),
-    pytest.param(4096, True, 16000, 24, True, False, id="4096_mixed_pipelined"),
-    pytest.param(65536, True, 16000, 48, False, False, id="configs2_65536_mixed"),
-    pytest.param(65536, False, 8000, 32, False, False, id="65536_am"),
+    # n_dev, mixed, wave_rate, sampled dongles, pipelined, tweak, path ("" = u8 on the matrix-core channelizer, "force_fft" = u8 with
+    # AIRBAND_HIP_FLAG_FORCE_FFT, "f32" = SoapySDR CF32 samples: both on the wavefront FFT, multi-workgroup placement and ragged last groups included)
+    pytest.param(1024, False, 8000, 40, False, False, "", id="configs1_1024_am"),
+    pytest.param(200, True, 16000, 24, False, True, "", id="200_mixed_partial_group"),
+    pytest.param(1000, True, 16000, 32, False, False, "", id="1000_mixed_partial_group"),
+    pytest.param(4096, True, 16000, 40, False, True, "", id="4096_mixed_splits2"),
+    pytest.param(4096, True, 16000, 24, True, False, "", id="4096_mixed_pipelined"),
+    pytest.param(65536, True, 16000, 48, False, False, "", id="configs2_65536_mixed"),
+    pytest.param(65536, False, 8000, 32, False, False, "", id="65536_am"),
+    pytest.param(4096, True, 16000, 32, False, True, "force_fft", id="4096_mixed_fft_wave64"),
+    pytest.param(4099, True, 16000, 32, False, False, "f32", id="4099_mixed_SFMT_F32"),
 ]
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("n_dev,mixed,wave_rate,k,pipelined,tweak", CASES)
-def test_sampled_dongles_of_large_handles(pkg, built, n_dev, mixed, wave_rate, k, pipelined, tweak):
+@pytest.mark.parametrize("n_dev,mixed,wave_rate,k,pipelined,tweak,path", CASES)
+def test_sampled_dongles_of_large_handles(pkg, built, n_dev, mixed, wave_rate, k, pipelined, tweak, path):
     torch = pytest.importorskip("torch")
     n_batches = 7
     chans, carriers = pkg.siggen.baseline_plan(mixed=mixed)
@@ -71,15 +74,15 @@ def test_sampled_dongles_of_large_handles(pkg, built, n_dev, mixed, wave_rate, k
         ch = [dict(c) for c in chans]
         if tweak:
             _tweak(d, ch)
-        return dict(channels=ch)
+        return dict(channels=ch, sfmt=pkg.capi.SFMT_F32) if path == "f32" else dict(channels=ch)
 
     devices = [device(d) for d in range(n_dev)]
-    flags = pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_PIPELINE if pipelined else 0)
+    flags = pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_PIPELINE if pipelined else 0) | (pkg.capi.FLAG_FORCE_FFT if path == "force_fft" else 0)
     dongles = pyverify.sample_dongles(n_dev, k)
     hip = pkg.AirbandHip(devices, wave_rate=wave_rate, flags=flags)
     iq = spot = None
     try:
-        assert hip.channelizer_name() == "dft_mfma_i8"
+        assert hip.channelizer_name() == ("fft_wave64" if path else "dft_mfma_i8")
         g = hip.geometry
         lead = g.first_batch_bytes - g.batch_bytes
         span = lead + (RING + 1) * g.batch_bytes + g.lookahead_bytes
@@ -92,7 +95,8 @@ def test_sampled_dongles_of_large_handles(pkg, built, n_dev, mixed, wave_rate, k
         # the on-device generator is the host generator, also at the far end of the handle
         last = dongles[-1]
         assert last == n_dev - 1
-        assert np.array_equal(host[last][:65536], pkg.siggen.generate_u8(last, 0, 32768, carriers))
+        if path != "f32":
+            assert np.array_equal(host[last][:65536], pkg.siggen.generate_u8(last, 0, 32768, carriers))
 
         spot = pyverify.SpotCheck(device, dongles, wave_rate=wave_rate)
 

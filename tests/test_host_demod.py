@@ -235,3 +235,35 @@ def test_random_plans_and_made_up_stage1_output(hostdemod, seed):
     finally:
         hd.close()
         orc.close()
+
+
+def test_opening_timer_expires_on_the_first_sample_of_a_batch_with_the_post_filter_in_use(hostdemod):
+    """NFM + lowpass channels whose OPENING delay runs out on sample 0 of a batch while the post-filter gate is what decides
+    (src/squelch.cpp:381-398,467-475): update_current_state() tests post_filter_.capped_ against buffer_[buffer_tail_] BEFORE the tail moves --
+    the entry pushed 102 samples earlier -- and the kernel, which recomputes the delay line (SqShadow), has to carry that very value across the
+    batch boundary.  The entry one sample later is made much larger (a step in the level 101 samples before the boundary); with the later entry
+    the gate closes channels that the reference opens."""
+    wave_rate, B, n_dev = 16000, 2000, 8
+    devices, level = helpers.boundary_devices(n_dev)
+    wave, iq = helpers.boundary_streams(lambda: pyoracle.Oracle(devices, wave_rate=wave_rate), n_dev, B, level)
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate)
+    hd = HostDemod(hostdemod, devices, wave_rate, 0)
+    try:
+        assert hd.B == B
+        outcomes = set()
+        for b in range(3):
+            w, q = wave[:, b * B:(b + 1) * B], iq[:, 2 * b * B:2 * (b + 1) * B]
+            want = [orc.run_bins(d, w[8 * d:8 * d + 8], q[8 * d:8 * d + 8]) for d in range(n_dev)]
+            want_t, want_a, want_w = (np.concatenate([r[k] for r in want]) for k in ("trace", "axc", "waveout"))
+            hd.process_bins(w, q)
+            got_w, got_a, got_t = hd.collect()
+            if b == 2:
+                outcomes = {int(t[1]) & 7 for t in want_t}
+            assert np.array_equal(got_t, want_t), "batch %d: squelch trace (channels %s)" % (b, np.nonzero((got_t != want_t).any(axis=1))[0])
+            assert np.array_equal(got_a, want_a)
+            assert np.array_equal(got_w.view(np.uint32), want_w.view(np.uint32))
+        assert orc.stats(0, 0)["squelch_level"] == level
+        assert 4 in outcomes, "no channel went OPEN at the boundary: the streams no longer exercise the case (%s)" % outcomes
+    finally:
+        hd.close()
+        orc.close()
