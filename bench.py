@@ -95,6 +95,29 @@ def physical_cores() -> int:
     return os.cpu_count() or 1
 
 
+def usable_cpus():
+    """(hardware threads this process may run on, CPU quota in cores or None): the container's affinity mask and its cgroup CPU limit
+    (cpu.max of cgroup v2, cpu.cfs_quota_us / cpu.cfs_period_us of v1) -- os.cpu_count() is the machine's, not the container's."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return aff, quota
+
+
 def cpu_baseline(pkg, devices, wave_rate, mixed, seconds):
     """The reference's own demodulate() (oracle/_ref, compiled in place) timed on this box's host cores, on a bounded sample:
     T = nproc dongles of the same workload, one pthread per dongle (the reference's multiple_demod_threads model,
@@ -109,7 +132,8 @@ def cpu_baseline(pkg, devices, wave_rate, mixed, seconds):
         return dict(value=None, unit="Msamples/s", cores=0, kind="reference", sample="unavailable: %r" % (e,))
     nfm = wave_rate == 16000
     nproc = os.cpu_count() or 1
-    threads = nproc
+    aff, quota = usable_cpus()
+    threads = min(nproc, aff)
     n_dev = threads
     rb = pyref.ring_bytes()
     buf = torch.zeros((n_dev, rb), dtype=torch.uint8, device="cuda")
@@ -141,25 +165,30 @@ def cpu_baseline(pkg, devices, wave_rate, mixed, seconds):
     have32 = os.path.exists(pyref.ref_lib_path(nfm, "fast32"))
     have_fast = os.path.exists(pyref.ref_lib_path(nfm, "fast"))
     main_variant = "fast32" if have32 else ("fast" if have_fast else False)
+    # How many threads: the box's GPU containers carry a cgroup CPU quota far below the machine's core count (16 of 256 hardware threads on the
+    # round-4 boxes: 256 demodulate() threads then share 16 cores' worth of time and are throttled together -- the "5.6x on 128 cores" of round 3).
+    # T = what the container may actually use (quota, else affinity, capped at the physical cores), next to T = 1 and to an oversubscribed 2T.
     cores = min(physical_cores(), threads)
-    # T = nproc (every hardware thread), T = physical cores, T = 1: the same per-thread work each time (one dongle per demodulate() thread), so
-    # value(T) / (T x value(1)) is the scaling of the host, consumer threads included (one per 8 dongles, oracle/ref_harness.cpp)
-    share = seconds / (1.35 if have32 and have_fast else 1.0)
-    value, batches, el, overran = run(main_variant, threads, max(3.0, 0.45 * share))
-    at_cores, _, _, over_cores = run(main_variant, cores, max(3.0, 0.35 * share)) if cores != threads else (value, batches, el, overran)
+    if quota:
+        cores = max(1, min(cores, int(quota + 0.5)))
+    share = seconds / (1.3 if have32 and have_fast else 1.0)
+    value, batches, el, overran = run(main_variant, cores, max(3.0, 0.45 * share))
+    over2, _, _, over_over2 = run(main_variant, min(threads, 2 * cores), max(3.0, 0.3 * share)) if threads > cores else (value, batches, el, overran)
     one_thread, _, _, over_one = run(main_variant, 1, max(2.0, 0.2 * share))
-    best = max(value, at_cores)
-    out = dict(value=best, unit="Msamples/s", cores=threads if value >= at_cores else cores, nproc=nproc, physical_cores=cores, cpu_model=cpu_model(), kind="reference",
-               value_nproc_threads=value, value_physical_cores=at_cores, value_1_thread=one_thread,
-               scaling_vs_linear=dict(nproc=round(value / (threads * one_thread), 3), physical_cores=round(at_cores / (cores * one_thread), 3)),
-               batches_overrun=dict(nproc=overran, physical_cores=over_cores, one_thread=over_one),
+    best = max(value, over2)
+    out = dict(value=best, unit="Msamples/s", cores=cores, threads=cores if value >= over2 else min(threads, 2 * cores), nproc=nproc, physical_cores=physical_cores(), affinity_cpus=aff,
+               cgroup_cpu_quota_cores=quota, cpu_model=cpu_model(), kind="reference",
+               value_at_cores=value, value_at_2x_cores_threads=over2, value_1_thread=one_thread,
+               scaling_vs_linear=round(value / (cores * one_thread), 3),
+               batches_overrun=dict(at_cores=overran, at_2x=over_over2, one_thread=over_one),
                fft="f32 radix-4 Stockham (oracle_fft32.c)" if have32 else "f64 radix-2 (oracle_fft.c)",
                sample="oracle/_ref = the reference's demodulate() compiled in place (%s), T dongles x 8 ch of the same workload on T pthreads (its multiple_demod_threads "
-                      "model) for T = %d / %d / 1, one consumer thread per 8 dongles, %.1f s wall at T = %d (%d batches, of which %d finished before the consumer had "
-                      "taken the previous one: output_overrun_count, counted as work done); FFTW3 is not installed: see `fft`" %
-                      ("-O3 -march=native -ffast-math" if main_variant else "-O2 strict", threads, cores, el, threads, batches, overran))
+                      "model) for T = %d (the cores this container may use: cgroup quota %s, affinity %d, %d physical), 2T and 1; one consumer thread per 8 dongles; "
+                      "%.1f s wall at T = %d (%d batches, of which %d finished before the consumer had taken the previous one: output_overrun_count, counted as work "
+                      "done); FFTW3 is not installed: see `fft`" %
+                      ("-O3 -march=native -ffast-math" if main_variant else "-O2 strict", cores, ("%.1f" % quota) if quota else "none", aff, physical_cores(), el, cores, batches, overran))
     if have32 and have_fast:
-        out["value_f64_fft"], _, _, _ = run("fast", out["cores"], max(3.0, 0.25 * share))
+        out["value_f64_fft"], _, _, _ = run("fast", cores, max(3.0, 0.25 * share))
     return out
 
 
@@ -232,7 +261,9 @@ def measure_traffic(args, kernel_substr):
         if args.fft_log != 9:
             cmd += ["--fft-log", str(args.fft_log)]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=args.traffic_timeout, check=False)
+            child = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=args.traffic_timeout, check=False)
+            if child.returncode != 0:
+                detail[counter + "_child"] = dict(returncode=child.returncode, stderr_tail=child.stderr.decode(errors="replace")[-400:])
             vals = []
             others = {}
             for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
@@ -294,10 +325,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("AIRBAND_BENCH_WORKLOAD", "cfg3"), choices=sorted(WORKLOADS))
     ap.add_argument("--dongles", type=int, default=0, help="override dongles per GPU")
-    ap.add_argument("--signal-start-batch", type=int, default=1, help="signal time (in batches of 1/8 s) of the first resident batch.  The synthetic transmitters key "
-                    "0.75 s on / 0.75 s off in eight phase slots (SURVEY 8d): the ring of 3 resident batches that follows the first one then covers batches 2..4 of "
-                    "the 12-batch keying period, in which 3, 4 and 5 of the 8 slots are keyed -- 50 %, the period's own average (0 = the stream's start: 2, 3, 4 of 8 slots "
-                    "minus the squelch's opening delay, what rounds 1-3 timed); the measured share of open channels is printed as `open_fraction`")
+    ap.add_argument("--signal-start-batch", type=int, default=4, help="signal time (in batches of 1/8 s) of the first resident batch.  The synthetic transmitters key "
+                    "0.75 s on / 0.75 s off in eight phase slots (SURVEY 8d): over the 12-batch keying period 2 ... 6 of the 8 slots are keyed, 50 %% on "
+                    "average.  A ring of 3 resident batches cannot hold a period, and the squelches lag the keying (opening delay, CTCSS detection), so the start is chosen by "
+                    "what it MEASURES: 4 (ring = batches 5..7) keeps 0.44 of the channels open per batch, the closest to the period's 0.5 (profiles/r04_summary.md: 0 -> 0.33, "
+                    "1 / 2 -> 0.30, 3 -> 0.39, 4 -> 0.44, 5 -> 0.35); rounds 1-3 timed 0.  The measured share is printed as `open_fraction`")
     ap.add_argument("--sample-format", default="u8", choices=["u8", "s16", "s8", "f32"], help="u8 = RTL-SDR bytes (BASELINE configs); s16 = CS16 as SoapySDR devices deliver it; s8 (mirisdr), f32 (SoapySDR CF32: the wavefront-FFT channelizer; 8 bytes per sample, so use --ring 1 --dongles 32768) "
                     "(the same synthetic signal re-expressed at 16 bits, full scale 25 500)")
     ap.add_argument("--sample-rate", type=int, default=2_560_000, help="dongle sample rate (BASELINE: 2 560 000; 2 400 000 is the other common RTL-SDR rate: hops of "
@@ -414,25 +446,24 @@ def main():
     hip.synchronize()
     torch.cuda.synchronize()
 
-    mix_t = right_t = sig_t = None
+    # configs[4]: the mixer exchange is the library's own entry (include/airband_hip.h: airband_hip_allreduce_mixers, librccl called directly, enqueued
+    # on the handle's stream behind the batch's mixer sums -- no host synchronisation inside a step, no torch tensor in between).  torch.distributed only
+    # carries rank 0's 128-byte communicator id to the other ranks.
+    exchange = False
     if n_mixers and use_dist:
-        # torch views over the library's device-side mixer sums, for the RCCL all-reduce (the baseline wiring is mono: no right channel)
-        mix_t, right_t, sig_t = mg.device_mixer_views(hip, n_mixers, stereo=False)
-
-    # the RCCL all-reduce is issued on torch's stream: that stream waits (on the GPU) for the batch's mixer sums, and the next
-    # process call orders its overwrite of them behind the all-reduce -- no host synchronisation inside a step
-    cstream = torch.cuda.Stream() if mix_t is not None else None   # a real stream: torch's default one is the NULL handle
-    consumer = cstream.cuda_stream if cstream is not None else 0
+        box = [pkg.AirbandHip.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        hip.comm_init_rank(box[0], world, rank)
+        exchange = True
+    consumer = 0
 
     def offset(i):
         return 0 if i == 0 else g.first_batch_bytes + ((i - 1) % args.ring) * g.batch_bytes
 
     def step(i):
         hip.process_device(iq.data_ptr() + offset(i), stride, consumer)
-        if mix_t is not None:
-            hip.stream_wait_results(consumer)
-            with torch.cuda.stream(cstream):
-                mg.allreduce_mixers(mix_t, right_t, sig_t, force=True)  # SUM of the mixer waveforms over xGMI, MAX of the signal flags (src/mixer.cpp:133-140,209)
+        if exchange:
+            hip.allreduce_mixers()  # SUM of the mixer waveforms over xGMI, MAX of the signal flags (src/mixer.cpp:133-140,209)
 
     def sync():
         hip.synchronize()
@@ -500,7 +531,7 @@ def main():
                config=dict(workload=_describe(wl["desc"], D, wl["dongles"], g.fft_size, sr, args.sample_format), dongles_per_gpu=D, channels_per_dongle=8, fft_size=g.fft_size, wave_rate=wave_rate, sample_rate=sr,
                            sample_format=args.sample_format, iq_resident="HBM", ring_batches=args.ring, mixers=n_mixers, afc=args.afc,
                            schedule="pipelined: stage 1 of batch k beside stage 2 of batch k-1" if args.pipelined else "one batch at a time",
-                           parallelism="dongle-sharded x%d, %s" % (world, "RCCL all-reduce of mixer sums" if mix_t is not None else "no collective"),
+                           parallelism="dongle-sharded x%d, %s" % (world, "mixer sums all-reduced over RCCL by airband_hip_allreduce_mixers" if exchange else "no collective"),
                            channelizer=name,
                            arithmetic="stage 1: u8 x 24-bit window*twiddle as 3 int8 digits -> exact int32 MFMA sums -> 3 f32 FMAs -> f32 bins; stage 2: f32, reference operation order"
                            if name == "dft_mfma_i8" else "stage 1: f32 radix-2 FFT; stage 2: f32, reference operation order",
@@ -623,6 +654,7 @@ def main():
             out["value"] = None
         except Exception as e:  # noqa: BLE001
             out["verify_all"] = dict(error="whole-handle check could not run: %r" % (e,))
+    need_free = int(iq.numel()) + (24 << 30)  # what a child run of the same workload allocates: the resident I/Q and a handle
     del iq
     torch.cuda.empty_cache()
     if use_dist:
@@ -630,6 +662,14 @@ def main():
         dist.destroy_process_group()
     want_traffic = args.traffic if args.traffic is not None else (world == 1)
     if rank == 0 and world == 1 and want_traffic:
+        # the driver hands a freed allocation of > 100 GiB back with a delay: the child runs below need the room the resident I/Q just left
+        t_wait = time.time()
+        while time.time() - t_wait < 90.0:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            if torch.cuda.mem_get_info()[0] >= need_free:
+                break
+            time.sleep(0.5)
         traffic, detail = measure_traffic(args, CHANNELIZER_KERNEL.get(name, name))
         out["roofline"]["traffic"] = traffic
         out["roofline"]["traffic_detail"] = detail

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AIRBAND_HIP_ABI_VERSION 1u
+#define AIRBAND_HIP_ABI_VERSION 2u /* 2: airband_hip_channel_stats carries signal_outside_filter (the TUI's '~') */
 
 /* error codes (negative ints; 0 = success).  -1/-2/-3 keep gpu_fft_prepare()'s meaning
  * (reference: src/rtl_airband.cpp:297-310). */
@@ -55,8 +55,7 @@ extern "C" {
 #define AIRBAND_HIP_FLAG_TRACE_SQUELCH 0x1u /* record per-sample squelch state (parity debugging;       \
                                                mirrors the reference's DEBUG_SQUELCH dump,               \
                                                src/squelch.cpp:593-633)                                 */
-#define AIRBAND_HIP_FLAG_KEEP_BINS 0x2u     /* accepted for ABI compatibility, not needed: the stage-1 rings always hold \
-                                               the last batch (see airband_hip_read_bins)                                 */
+#define AIRBAND_HIP_FLAG_RESERVED_2 0x2u    /* (was KEEP_BINS: the stage-1 rings always hold the last batch's bins, airband_hip_read_bins) */
 #define AIRBAND_HIP_FLAG_FORCE_FFT 0x4u     /* always use the full wavefront-FFT channelizer             */
 #define AIRBAND_HIP_FLAG_SERIAL_DEMOD 0x8u  /* run the per-kind demod kernels one after another instead   \
                                                of side by side on forked streams (profiling aid)          */
@@ -150,6 +149,8 @@ typedef struct airband_hip_channel_stats {
     uint64_t active_counter; /* freq_t.active_counter                                                 */
     int32_t bin;             /* dev->bins[i] (moves only with AFC)                                    */
     int32_t squelch_state;   /* Squelch::State after the batch                                        */
+    int32_t signal_outside_filter; /* Squelch::signal_outside_filter() after the batch (src/squelch.cpp:152-154): the TUI prints '~' for it (src/rtl_airband.cpp:633) */
+    int32_t reserved;
 } airband_hip_channel_stats;
 
 typedef struct airband_hip_handle airband_hip_handle;
@@ -165,6 +166,34 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
 /* Optional: wire channels into mixers before the first batch (reference: src/config.cpp mixer outputs,
  * src/mixer.cpp:57-94).  mixer_count mixers, n_inputs connections. */
 int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const airband_hip_mixer_input* inputs, int32_t n_inputs);
+
+/* Forces the right channel of one mixer on (or back to what its local inputs say): a mixer is stereo as soon as ANY of its inputs has a
+ * balance (mixer->channel.mode = MM_STEREO, src/mixer.cpp:84-85), and when its inputs are spread over several handles (GPUs) the handles
+ * without such an input must produce a right-channel partial sum all the same.  Call after airband_hip_set_mixers. */
+int airband_hip_mixer_set_stereo(airband_hip_handle* h, int32_t mixer, int32_t stereo);
+
+/* ---- the mixer exchange: the one step of the path where dongles on different GPUs meet (src/mixer.cpp:133-140,201-214) ----------------
+ * Every handle holds PARTIAL sums of the mixers over its own dongles (airband_hip_set_mixers with the same mixer_count on each).  The
+ * exchange is an in-place all-reduce of those buffers -- SUM of left and right, MAX of the signal flags -- over RCCL (xGMI between the
+ * GPUs of a node), enqueued on the GPU behind the batch's results: no host synchronisation.  librccl.so is loaded on first use.
+ *   one process per GPU (bench.py --gpus N):  rank 0 calls airband_hip_comm_unique_id and hands the 128 bytes to the others (any
+ *       transport), every rank calls airband_hip_comm_init_rank(h, id, nranks, rank);
+ *   one process, one handle per GPU (the reference-side shim, integration/demod_hip.cpp):  airband_hip_comm_init_all(handles, n) --
+ *       the handles must sit on n DIFFERENT GPUs;
+ * then, per batch and per handle (from n threads or one after the other inside airband_hip_comm_group_begin / _end):
+ *       airband_hip_allreduce_mixers(h, stream)   -- stream NULL = the handle's own; airband_hip_collect_mixers() then returns the node's sums.
+ * Handles of one process that share a GPU need no fabric: airband_hip_add_mixers(dst, src) adds src's partial sums to dst's with a kernel
+ * on dst's stream, ordered behind src's batch (summation order: dst, then src -- deterministic).
+ * Float summation order differs from a single handle's connection order, so mixer parity across handles is tolerance parity (1e-4 RMS). */
+#define AIRBAND_HIP_COMM_ID_BYTES 128
+int airband_hip_comm_unique_id(uint8_t id[AIRBAND_HIP_COMM_ID_BYTES]);
+int airband_hip_comm_init_rank(airband_hip_handle* h, const uint8_t id[AIRBAND_HIP_COMM_ID_BYTES], int32_t nranks, int32_t rank);
+int airband_hip_comm_init_all(airband_hip_handle** handles, int32_t n);
+int airband_hip_comm_group_begin(void);
+int airband_hip_comm_group_end(void);
+int airband_hip_allreduce_mixers(airband_hip_handle* h, void* stream);
+int airband_hip_add_mixers(airband_hip_handle* dst, airband_hip_handle* src);
+int airband_hip_comm_destroy(airband_hip_handle* h);
 
 /* Masks one mixer connection out (enabled = 0) or back in, by its index in the `inputs` array handed to airband_hip_set_mixers:
  * a masked input adds nothing and does not raise the mixer's signal flag -- mixer_disable_input(), which the reference
@@ -215,6 +244,11 @@ int64_t airband_hip_submit(airband_hip_handle* h, int32_t dev, const void* iq, s
  * Replaces: one WAVE_BATCH worth of demodulate() iterations for all devices
  * (reference: src/rtl_airband.cpp:402-492 stage 1 and :494-655 stage 2). */
 int airband_hip_process(airband_hip_handle* h);
+
+/* Would airband_hip_process() run a batch now (OK) or not yet (EAGAIN)?  The availability rule alone; nothing is enqueued.  A caller that
+ * drives several handles in lockstep -- the shards of one device class on the GPUs of a node, whose mixer sums belong to the same batch --
+ * asks every one of them first (integration/demod_hip.cpp). */
+int airband_hip_batch_ready(airband_hip_handle* h);
 
 /* Zero-copy path for HBM-resident I/Q.  `d_iq` is a DEVICE pointer; device `d`'s span for this batch
  * starts at d_iq + d*stride_bytes and holds at least (first_)batch_bytes + lookahead_bytes bytes:

@@ -960,6 +960,9 @@ int orc_channel_stats(orc_t* o, int d, int j, airband_hip_channel_stats* out) {
     out->active_counter = c->active_counter;
     out->bin = c->bin;
     out->squelch_state = c->sq.cur;
+    /* Squelch::signal_outside_filter (src/squelch.cpp:152-154) */
+    out->signal_outside_filter = (c->sq.using_post && c->sq.pre_capped >= sq_level(&c->sq) && !(c->sq.post_capped >= c->sq.buf[c->sq.tail])) ? 1 : 0;
+    out->reserved = 0;
     return 0;
 }
 

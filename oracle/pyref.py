@@ -171,8 +171,11 @@ def reference_throughput(devices, iq_list, seconds: float, threads: int, *, nfm:
     return res
 
 
-def _all_worker(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib, fail_after, end_of_streams):
+def _all_worker(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib, fail_after, end_of_streams, extra=None):
     try:
+        extra = extra or {}
+        for k, v in (extra.get("env") or {}).items():
+            os.environ[k] = v
         lib = _load(nfm, "patched" if hip_lib else False)
         lib.refh_run_all.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.POINTER(C.c_int), C.c_double]
@@ -186,9 +189,37 @@ def _all_worker(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib,
             dc, arr = capi.device_cfg(**dev)
             keep.append(arr)
             assert lib.refh_add_device(d, C.byref(dc)) == 0
+        nd, nch = len(devices), len(devices[0]["channels"])
+        # mixers: (n_mixers, [(device, channel, mixer, ampfactor, balance), ...]) -- wired like parse_outputs() / mixer_connect_input() do it
+        n_mix, conns = extra.get("mixers") or (0, [])
+        if n_mix:
+            lib.refh_connect.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+            lib.refh_set_mixer_outputs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            lib.refh_mixer_counters.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
+            lib.refh_mixer_counters.restype = None
+            assert lib.refh_add_mixers(n_mix) == 0
+            for (d, j, m, amp, bal) in conns:
+                assert lib.refh_connect(d, j, m, amp, bal) >= 0
+        # file inputs: {device: (path, speedup_factor)} -- the reference's own input-file.cpp driver instead of the harness's rx role
+        files = extra.get("file_inputs") or {}
+        lib.refh_use_file_input.argtypes = [C.c_int, C.c_char_p, C.c_float]
+        for d, (path, speedup) in files.items():
+            assert lib.refh_use_file_input(int(d), path.encode(), float(speedup)) == 0
+        if extra.get("tui_path"):
+            lib.refh_tui_begin.argtypes = [C.c_char_p]
+            assert lib.refh_tui_begin(extra["tui_path"].encode()) == 0
+        mix_l = mix_r = mix_a = mix_got = None
+        if n_mix:
+            mix_l = np.zeros((n_mix, n_batches, wb), np.float32)
+            mix_r = np.zeros((n_mix, n_batches, wb), np.float32)
+            mix_a = np.zeros((n_mix, n_batches), np.uint8)
+            mix_got = (C.c_int * n_mix)()
+            lib.refh_set_mixer_outputs(mix_l.ctypes.data, mix_r.ctypes.data, mix_a.ctypes.data, C.cast(mix_got, C.c_void_p))
+            assert lib.refh_start_mixer_thread() == 0
         rc = lib.refh_start_hip(hip_lib.encode()) if hip_lib else lib.refh_start(1)
         assert rc == 0, rc
-        nd, nch = len(devices), len(devices[0]["channels"])
+        if files:
+            assert lib.refh_start_inputs() == 0
         wave = np.zeros((nd, n_batches, nch, wb), np.float32)
         iqo = np.zeros((nd, n_batches, nch, 2 * wb), np.float32)
         axc = np.zeros((nd, n_batches, nch), np.uint8)
@@ -197,7 +228,9 @@ def _all_worker(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib,
         sizes = (C.c_size_t * nd)(*[b.nbytes for b in bufs])
         fa = (C.c_int * nd)(*[(-1 if fail_after is None or fail_after[d] is None else int(fail_after[d])) for d in range(nd)])
         got = (C.c_int * nd)()
-        short = lib.refh_run_all(ptrs, sizes, fa, n_batches, wave.ctypes.data, iqo.ctypes.data, axc.ctypes.data, got, 120.0)
+        short = lib.refh_run_all(ptrs, sizes, fa, n_batches, wave.ctypes.data, iqo.ctypes.data, axc.ctypes.data, got, float(extra.get("timeout_s", 120.0)))
+        if extra.get("tui_path"):
+            lib.refh_tui_end()
         stats = []
         for d in range(nd):
             row = []
@@ -209,6 +242,19 @@ def _all_worker(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib,
         res = dict(n_batches=n_batches + short, batches=[int(g) for g in got], waveout=wave, iq_out=iqo, axc=axc, stats=stats,
                    outputs_disabled=[lib.refh_outputs_disabled(d) for d in range(nd)], devices_running=lib.refh_devices_running(),
                    input_state=[lib.refh_input_state(d) for d in range(nd)], output_overruns=[lib.refh_output_overruns(d) for d in range(nd)])
+        if n_mix:
+            res["mix_left"], res["mix_right"], res["mix_axc"], res["mix_batches"] = mix_l, mix_r, mix_a, [int(x) for x in mix_got]
+            cnt = []
+            for m in range(n_mix):
+                c4 = (C.c_uint64 * 4)()
+                lib.refh_mixer_counters(m, c4)
+                cnt.append(dict(output_overruns=int(c4[0]), enabled=int(c4[1]), inputs=int(c4[2]), gpu_served=int(c4[3])))
+            res["mixers"] = cnt
+        if extra.get("wait_exit_s"):  # file inputs end on their own (INPUT_FAILED at end of file): the demodulator must then set do_exit and return
+            lib.refh_wait_exit.argtypes = [C.c_double]
+            res["exited_on_its_own"] = bool(lib.refh_wait_exit(float(extra["wait_exit_s"])))
+            res["devices_running_at_exit"] = lib.refh_devices_running()
+            res["input_state_at_exit"] = [lib.refh_input_state(d) for d in range(nd)]
         if end_of_streams:
             res["exited_on_its_own"] = bool(lib.refh_fail_all_and_wait_exit(20.0))
             res["devices_running_at_exit"] = lib.refh_devices_running()
@@ -220,16 +266,20 @@ def _all_worker(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib,
 
 
 def run_reference_all(devices, iq_list, n_batches, *, nfm: bool, fft_log: int = 9, fm_demod: int = 0, hip_lib: str | None = None, fail_after=None,
-                      end_of_streams: bool = False):
+                      end_of_streams: bool = False, mixers=None, file_inputs=None, tui_path=None, env=None, timeout_s: float = 120.0, wait_exit_s: float = 0.0):
     """All devices fed concurrently through the reference's own rings.  hip_lib=None: the reference's demodulate();
     hip_lib=path to libairband_hip.so: the harness built from the PATCHED reference (integration/airband_hip.patch applied to a
     scratch copy, integration/demod_hip.cpp compiled verbatim): demodulate_hip() instead of demodulate(), statistics read back
     through the reference's own Squelch getters.
     fail_after[d] = k: device d's input reports INPUT_FAILED (a file input at end of file) after it has delivered k batches.
-    end_of_streams: afterwards every input fails; `exited_on_its_own` tells whether the demodulator then set do_exit and returned."""
+    end_of_streams: afterwards every input fails; `exited_on_its_own` tells whether the demodulator then set do_exit and returned.
+    mixers=(n, [(device, channel, mixer, ampfactor, balance), ...]): the reference's mixer_t objects and O_MIXER outputs, its mixer_thread() started
+    (with the HIP backend the shim serves them on the GPU); file_inputs={device: (path, speedup_factor)}: the reference's own file input driver
+    (src/input-file.cpp) feeds that device; tui_path: the waterfall (`tui` = 1) written to that file; env: environment for the child (AIRBAND_HIP_GPUS)."""
     ctx = mp.get_context("spawn" if hip_lib else "fork")
     q = ctx.Queue()
-    p = ctx.Process(target=_all_worker, args=(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib, fail_after, end_of_streams))
+    extra = dict(mixers=mixers, file_inputs=file_inputs, tui_path=tui_path, env=env, timeout_s=timeout_s, wait_exit_s=wait_exit_s)
+    p = ctx.Process(target=_all_worker, args=(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib, fail_after, end_of_streams, extra))
     p.start()
     status, res = q.get()
     p.join()

@@ -30,6 +30,8 @@
 #include <vector>
 
 #include "../include/airband_hip.h"
+#include "input-file.h" /* file_dev_data_t: the reference's file input (src/input-file.cpp) is compiled in */
+MODULE_EXPORT input_t* file_input_new(); /* src/input-file.cpp:162-181; input_new() finds it with dlsym in the real binary (src/input-common.cpp:35-54) */
 #include "input-helpers.h"
 
 /* ---- symbols main()/demodulate() reference but the oracle never reaches ---------------------- */
@@ -50,9 +52,7 @@ void disable_device_outputs(device_t* dev) {
 void disable_channel_outputs(channel_t*) {}
 void* output_check_thread(void*) { refh_unreachable("output_check_thread"); return NULL; }
 void* output_thread(void*) { refh_unreachable("output_thread"); return NULL; }
-void* mixer_thread(void*) { refh_unreachable("mixer_thread"); return NULL; }
-mixer_t* getmixerbyname(const char*) { return NULL; }
-const char* mixer_get_error() { return ""; }
+/* (mixer_thread, getmixerbyname, mixer_get_error: the reference's own src/mixer.cpp is compiled in) */
 
 /* ---- harness state --------------------------------------------------------------------------- */
 #define REFH_MAX_THREADS 256
@@ -272,6 +272,15 @@ struct HipApi {
     int (*collect)(airband_hip_handle*, float*, float*, char*, airband_hip_channel_stats*);
     int (*device_enable)(airband_hip_handle*, int32_t, int32_t);
     int (*gpu_count)(void);
+    int (*batch_ready)(airband_hip_handle*);
+    int (*set_mixers)(airband_hip_handle*, int32_t, const airband_hip_mixer_input*, int32_t);
+    int (*mixer_set_stereo)(airband_hip_handle*, int32_t, int32_t);
+    int (*collect_mixers)(airband_hip_handle*, float*, float*, uint8_t*);
+    int (*comm_init_all)(airband_hip_handle**, int32_t);
+    int (*comm_group_begin)(void);
+    int (*comm_group_end)(void);
+    int (*allreduce_mixers)(airband_hip_handle*, void*);
+    int (*add_mixers)(airband_hip_handle*, airband_hip_handle*);
 };
 static HipApi g_hip;
 
@@ -285,6 +294,15 @@ int airband_hip_process(airband_hip_handle* h) { return g_hip.process(h); }
 int airband_hip_collect(airband_hip_handle* h, float* w, float* q, char* a, airband_hip_channel_stats* st) { return g_hip.collect(h, w, q, a, st); }
 int airband_hip_device_enable(airband_hip_handle* h, int32_t dev, int32_t on) { return g_hip.device_enable(h, dev, on); }
 int airband_hip_gpu_count(void) { return g_hip.gpu_count(); }
+int airband_hip_batch_ready(airband_hip_handle* h) { return g_hip.batch_ready(h); }
+int airband_hip_set_mixers(airband_hip_handle* h, int32_t n, const airband_hip_mixer_input* in, int32_t k) { return g_hip.set_mixers(h, n, in, k); }
+int airband_hip_mixer_set_stereo(airband_hip_handle* h, int32_t m, int32_t on) { return g_hip.mixer_set_stereo(h, m, on); }
+int airband_hip_collect_mixers(airband_hip_handle* h, float* l, float* r, uint8_t* s) { return g_hip.collect_mixers(h, l, r, s); }
+int airband_hip_comm_init_all(airband_hip_handle** hs, int32_t n) { return g_hip.comm_init_all(hs, n); }
+int airband_hip_comm_group_begin(void) { return g_hip.comm_group_begin(); }
+int airband_hip_comm_group_end(void) { return g_hip.comm_group_end(); }
+int airband_hip_allreduce_mixers(airband_hip_handle* h, void* s) { return g_hip.allreduce_mixers(h, s); }
+int airband_hip_add_mixers(airband_hip_handle* a, airband_hip_handle* b) { return g_hip.add_mixers(a, b); }
 }
 
 /* statistics exactly as the stats file / TUI would read them with the HIP backend: through the reference's own Squelch getters
@@ -303,6 +321,7 @@ int refh_hip_channel_stats(int d, int j, airband_hip_channel_stats* out) {
     out->no_ctcss_count = f->squelch.no_ctcss_count();
     out->active_counter = f->active_counter;
     out->bin = (int32_t)devices[d].bins[j];
+    out->signal_outside_filter = f->squelch.signal_outside_filter() ? 1 : 0; /* through the patch's mirror */
     return 0;
 }
 
@@ -318,6 +337,9 @@ int refh_start_hip(const char* lib_path) {
     if (!g_hip.field) return -2;
     REFH_SYM(prepare, "prepare") REFH_SYM(release, "release") REFH_SYM(get_geometry, "get_geometry") REFH_SYM(last_error, "last_error")
     REFH_SYM(submit, "submit") REFH_SYM(process, "process") REFH_SYM(collect, "collect") REFH_SYM(device_enable, "device_enable") REFH_SYM(gpu_count, "gpu_count")
+    REFH_SYM(batch_ready, "batch_ready") REFH_SYM(set_mixers, "set_mixers") REFH_SYM(mixer_set_stereo, "mixer_set_stereo") REFH_SYM(collect_mixers, "collect_mixers")
+    REFH_SYM(comm_init_all, "comm_init_all") REFH_SYM(comm_group_begin, "comm_group_begin") REFH_SYM(comm_group_end, "comm_group_end")
+    REFH_SYM(allreduce_mixers, "allreduce_mixers") REFH_SYM(add_mixers, "add_mixers")
 #undef REFH_SYM
     devices_running = device_count;
     g_demod_params[0].mp3_signal = &g_signal;
@@ -331,6 +353,121 @@ int refh_start_hip(const char* lib_path) {
 int refh_hip_channel_stats(int, int, airband_hip_channel_stats*) { return -1; }
 int refh_start_hip(const char*) { return -3; } /* only the *_patched builds carry the HIP backend */
 #endif /* REFH_PATCHED */
+
+/* ---- mixers: what parse_mixers() / parse_outputs() build (src/config.cpp:835-880, the "mixer" output type :160-190), by hand -------- */
+static char g_rx_started[4096]; /* devices whose input driver's own rx thread runs (file inputs) */
+static Signal g_mixer_signal; /* the Signal of the output thread that serves the mixers (src/rtl_airband.cpp:1097-1100) */
+static pthread_t g_mixer_thread;
+static int g_mixer_thread_running = 0;
+
+int refh_add_mixers(int n) {
+    mixers = (mixer_t*)XCALLOC(n, sizeof(mixer_t));
+    mixer_count = n;
+    for (int m = 0; m < n; m++) {
+        mixer_t* mixer = mixers + m;
+        char name[32];
+        snprintf(name, sizeof(name), "mixer%d", m);
+        mixer->name = strdup(name);
+        mixer->enabled = false;
+        mixer->interval = MIX_DIVISOR;
+        mixer->channel.highpass = 100;
+        mixer->channel.lowpass = 2500;
+        mixer->channel.mode = MM_MONO;
+        mixer->channel.state = CH_DIRTY;
+        mixer->channel.axcindicate = NO_SIGNAL;
+    }
+    return 0;
+}
+
+/* channel (d, j) feeds mixer m: one more output of type O_MIXER on the channel, one more input on the mixer (mixer_connect_input,
+ * src/mixer.cpp:57-94).  Returns the mixer's input index. */
+int refh_connect(int d, int j, int m, float ampfactor, float balance) {
+    if (d < 0 || d >= device_count || j < 0 || j >= devices[d].channel_count || m < 0 || m >= mixer_count) return -1;
+    channel_t* channel = devices[d].channels + j;
+    const int input = mixer_connect_input(mixers + m, ampfactor, balance);
+    if (input < 0) return -2;
+    channel->outputs = (output_t*)XREALLOC(channel->outputs, (channel->output_count + 1) * sizeof(output_t));
+    output_t* o = channel->outputs + channel->output_count++;
+    memset(o, 0, sizeof(*o));
+    o->type = O_MIXER;
+    o->enabled = true;
+    mixer_data* md = (mixer_data*)XCALLOC(1, sizeof(mixer_data));
+    md->mixer = mixers + m;
+    md->input = input;
+    o->data = md;
+    return input;
+}
+
+int refh_start_mixer_thread(void) {
+    if (mixer_count <= 0 || g_mixer_thread_running) return 0;
+    if (pthread_create(&g_mixer_thread, NULL, &mixer_thread, &g_mixer_signal) != 0) return -1;
+    g_mixer_thread_running = 1;
+    return 0;
+}
+
+void refh_mixer_counters(int m, uint64_t* out4) {
+    out4[0] = mixers[m].output_overrun_count;
+    out4[1] = mixers[m].enabled ? 1 : 0;
+    out4[2] = (uint64_t)mixers[m].input_count;
+#ifdef WITH_AIRBAND_HIP
+    out4[3] = mixers[m].gpu_served ? 1 : 0;
+#else
+    out4[3] = 0;
+#endif
+}
+
+/* ---- the reference's own file input (src/input-file.cpp:82-181) in place of the hand-built input of refh_add_device(): file_input_new(),
+ * the two values file_parse_config() reads from the config, the ring as parse_devices() sizes it (src/config.cpp:796-806), then input_init() and
+ * input_start() (src/input-common.cpp:56-87) -- the rx thread replays the file paced by speedup_factor and sets INPUT_FAILED at end of file. */
+int refh_use_file_input(int d, const char* path, float speedup_factor) {
+    if (d < 0 || d >= device_count) return -1;
+    device_t* dev = devices + d;
+    input_t* old = dev->input;
+    input_t* in = file_input_new();
+    file_dev_data_t* dd = (file_dev_data_t*)in->dev_data;
+    dd->filepath = strdup(path);
+    dd->speedup_factor = speedup_factor;
+    in->sample_rate = old->sample_rate;
+    in->centerfreq = old->centerfreq;
+    in->buf_size = old->buf_size;
+    in->buffer = old->buffer;
+    in->bufs = in->bufe = 0;
+    in->overflow_count = 0;
+    dev->input = in;
+    free(old);
+    if (input_init(in) != 0) return -2;
+    return 0;
+}
+int refh_start_inputs(void) {
+    for (int d = 0; d < device_count; d++)
+        if (devices[d].input->state == INPUT_INITIALIZED) {
+            if (input_start(devices[d].input) != 0) return -1;
+            if (d < 4096) g_rx_started[d] = 1;
+        }
+    return 0;
+}
+
+/* ---- the waterfall (src/rtl_airband.cpp:632-643): `tui` on, stdout into a file for the duration ------------------------------------ */
+static int g_saved_stdout = -1;
+int refh_tui_begin(const char* path) {
+    fflush(stdout);
+    g_saved_stdout = dup(1);
+    FILE* f = fopen(path, "w");
+    if (!f) return -1;
+    dup2(fileno(f), 1);
+    fclose(f);
+    tui = 1;
+    return 0;
+}
+void refh_tui_end(void) {
+    tui = 0;
+    fflush(stdout);
+    if (g_saved_stdout >= 0) {
+        dup2(g_saved_stdout, 1);
+        close(g_saved_stdout);
+        g_saved_stdout = -1;
+    }
+}
 
 /* n_threads demodulate() instances over contiguous device shards: the reference's own
  * multiple_demod_threads model (src/rtl_airband.cpp:1052-1086,1110-1112), 1 = its default. */
@@ -348,11 +485,23 @@ int refh_start(int n_threads) {
     return 0;
 }
 
+static void refh_join_inputs(void) {
+    for (int d = 0; d < device_count && d < 4096; d++)
+        if (g_rx_started[d]) {
+            pthread_join(devices[d].input->rx_thread, NULL);
+            g_rx_started[d] = 0;
+        }
+}
 void refh_stop(void) {
-    if (!g_threads_running) return;
     do_exit = 1;
+    refh_join_inputs();
+    if (!g_threads_running && !g_mixer_thread_running) return;
     for (int t = 0; t < g_threads_running; t++) pthread_join(g_demod_thread[t], NULL);
     g_threads_running = 0;
+    if (g_mixer_thread_running) {
+        pthread_join(g_mixer_thread, NULL);
+        g_mixer_thread_running = 0;
+    }
 #ifdef DEBUG_SQUELCH
     for (int d = 0; d < device_count; d++)
         for (int j = 0; j < devices[d].channel_count; j++) devices[d].channels[j].freqlist[0].squelch.~Squelch(); /* flush traces */
@@ -376,6 +525,11 @@ static void refh_drain(int d, float* waveout, float* iq_out, char* axc) {
         if (waveout) memcpy(waveout + (size_t)j * WAVE_BATCH, channel->waveout, sizeof(float) * WAVE_BATCH);
         if (iq_out) memcpy(iq_out + (size_t)j * 2 * WAVE_BATCH, channel->iq_out, sizeof(float) * 2 * WAVE_BATCH);
         if (axc) axc[j] = (char)channel->axcindicate;
+        for (int k = 0; k < channel->output_count; k++) /* process_outputs(), src/output.cpp:533-535 */
+            if (channel->outputs[k].type == O_MIXER && channel->outputs[k].enabled) {
+                mixer_data* mdata = (mixer_data*)(channel->outputs[k].data);
+                mixer_put_samples(mdata->mixer, mdata->input, channel->waveout, channel->axcindicate != NO_SIGNAL, WAVE_BATCH);
+            }
         memcpy(channel->waveout, channel->waveout + WAVE_BATCH, AGC_EXTRA * 4); /* src/output.cpp:920 */
     }
     dev->waveavail = 0;
@@ -421,6 +575,19 @@ int refh_run_device(int d, const unsigned char* iq, size_t nbytes, int max_batch
  * sets input->state = INPUT_FAILED; its target is then fail_after[d] batches instead of n_batches.  fail_after may be NULL.
  * waveout [device][n_batches][C][WAVE_BATCH] with C = the (common) channel count, etc.; got[d] = batches device d produced.
  * Returns the minimum over the devices of (batches produced - target), i.e. 0 when every device reached its target. */
+/* where refh_run_all() puts what the mixers emit (the output thread's role for mixer channels, src/output.cpp:887-896): left / right
+ * [mixer][n_batches][WAVE_BATCH], axc [mixer][n_batches], got [mixer]; NULL = mixers are not collected */
+static float* g_mix_left = NULL;
+static float* g_mix_right = NULL;
+static char* g_mix_axc = NULL;
+static int* g_mix_got = NULL;
+void refh_set_mixer_outputs(float* left, float* right, char* axc, int* got) {
+    g_mix_left = left;
+    g_mix_right = right;
+    g_mix_axc = axc;
+    g_mix_got = got;
+}
+
 int refh_run_all(const unsigned char* const* iq, const size_t* nbytes, const int* fail_after, int n_batches, float* waveout, float* iq_out, char* axc, int* got,
                  double timeout_s) {
     std::vector<size_t> off(device_count, 0);
@@ -430,11 +597,46 @@ int refh_run_all(const unsigned char* const* iq, const size_t* nbytes, const int
     struct timeval t0, t1;
     gettimeofday(&t0, NULL);
     const int C = devices[0].channel_count;
+    std::vector<int> mb(mixer_count, 0);
     for (;;) {
         bool done = true;
+        /* mixers first: a mixer channel that is CH_READY is taken like output_thread() takes it; devices are not fed beyond the batch the slowest
+         * enabled mixer still has to emit (mixer_thread() looks at its inputs every 1/16 s: a device that ran ahead would overrun them) */
+        int mixers_at = n_batches;
+        for (int m = 0; m < mixer_count; m++) {
+            mixer_t* mixer = mixers + m;
+            if (!mixer->enabled) continue;
+            channel_t* channel = &mixer->channel;
+            if (channel->state == CH_READY) {
+                if (g_mix_left && mb[m] < n_batches) {
+                    const size_t o = (size_t)m * n_batches + mb[m];
+                    memcpy(g_mix_left + o * WAVE_BATCH, channel->waveout, sizeof(float) * WAVE_BATCH);
+                    if (g_mix_right) {
+                        if (channel->mode == MM_STEREO) memcpy(g_mix_right + o * WAVE_BATCH, channel->waveout_r, sizeof(float) * WAVE_BATCH);
+                        else memset(g_mix_right + o * WAVE_BATCH, 0, sizeof(float) * WAVE_BATCH);
+                    }
+                    if (g_mix_axc) g_mix_axc[o] = (char)channel->axcindicate;
+                }
+                mb[m]++;
+                channel->state = CH_DIRTY;
+            }
+            if (g_mix_left) {
+                mixers_at = std::min(mixers_at, mb[m]);
+                if (mb[m] < n_batches) {
+                    bool feeders_left = false; /* a mixer all of whose devices have reached their target emits nothing more */
+                    for (int d = 0; d < device_count; d++)
+                        if (nb[d] < target[d] || nb[d] > mb[m]) feeders_left = true;
+                    if (feeders_left) done = false;
+                }
+            }
+        }
         for (int d = 0; d < device_count; d++) {
             device_t* dev = devices + d;
             input_t* in = dev->input;
+            if (g_mix_left && mixer_count > 0 && nb[d] > mixers_at) { /* wait for the mixers to emit this device's last batch */
+                if (nb[d] < target[d]) done = false;
+                continue;
+            }
             if (dev->waveavail && nb[d] < target[d]) {
                 const size_t o = ((size_t)d * n_batches + nb[d]) * C;
                 refh_drain(d, waveout ? waveout + o * WAVE_BATCH : NULL, iq_out ? iq_out + o * 2 * WAVE_BATCH : NULL, axc ? axc + o : NULL);
@@ -453,6 +655,11 @@ int refh_run_all(const unsigned char* const* iq, const size_t* nbytes, const int
                     off[d] += n;
                 }
             }
+            /* an input driver of the reference's own that has ended (file input at end of file -> INPUT_FAILED -> demodulate() disables the device):
+             * what it delivered is all there will be */
+            if (nb[d] < target[d] && g_rx_started[d < 4096 ? d : 0] && d < 4096 && in->state != INPUT_RUNNING && in->state != INPUT_INITIALIZED && !dev->waveavail &&
+                refh_available(in) < refh_bps(in) * (size_t)WAVE_BATCH)
+                target[d] = nb[d];
             if (nb[d] < target[d]) done = false;
         }
         if (done) break;
@@ -465,6 +672,8 @@ int refh_run_all(const unsigned char* const* iq, const size_t* nbytes, const int
         if (got) got[d] = nb[d];
         mn = std::min(mn, nb[d] - target[d]);
     }
+    if (g_mix_got)
+        for (int m = 0; m < mixer_count; m++) g_mix_got[m] = mb[m];
     return mn;
 }
 
@@ -483,6 +692,28 @@ int refh_fail_all_and_wait_exit(double timeout_s) {
     }
     for (int t = 0; t < g_threads_running; t++) pthread_join(g_demod_thread[t], NULL);
     g_threads_running = 0;
+    if (g_mixer_thread_running) {
+        pthread_join(g_mixer_thread, NULL);
+        g_mixer_thread_running = 0;
+    }
+    return 1;
+}
+
+/* inputs that end on their own (file inputs at end of file): waits for the demodulator to notice that every receiver has failed */
+int refh_wait_exit(double timeout_s) {
+    struct timeval t0, t1;
+    gettimeofday(&t0, NULL);
+    while (!do_exit) {
+        gettimeofday(&t1, NULL);
+        if ((t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec) > timeout_s) return 0;
+        usleep(1000);
+    }
+    for (int t = 0; t < g_threads_running; t++) pthread_join(g_demod_thread[t], NULL);
+    g_threads_running = 0;
+    if (g_mixer_thread_running) {
+        pthread_join(g_mixer_thread, NULL);
+        g_mixer_thread_running = 0;
+    }
     return 1;
 }
 
@@ -507,6 +738,8 @@ int refh_channel_stats(int d, int j, airband_hip_channel_stats* out) {
     out->active_counter = f->active_counter;
     out->bin = (int32_t)dev->bins[j];
     out->squelch_state = -1; /* private in the reference */
+    out->signal_outside_filter = f->squelch.signal_outside_filter() ? 1 : 0;
+    out->reserved = 0;
     return 0;
 }
 

@@ -30,6 +30,8 @@ EXPORTS = [
     "airband_hip_derive_constants", "airband_hip_last_timings", "airband_hip_channelizer_name", "airband_hip_set_signal_plan", "airband_hip_generate_iq",
     "airband_hip_flush", "airband_hip_timing_totals", "airband_hip_stream_wait_results", "airband_hip_mixer_enable_input",
     "airband_hip_device_enable", "airband_hip_gpu_count", "airband_hip_build_info", "airband_hip_dft_selftest", "airband_hip_collect_channels", "airband_hip_read_bins_channels", "airband_hip_read_trace_channels",
+    "airband_hip_batch_ready", "airband_hip_mixer_set_stereo", "airband_hip_comm_unique_id", "airband_hip_comm_init_rank", "airband_hip_comm_init_all",
+    "airband_hip_comm_group_begin", "airband_hip_comm_group_end", "airband_hip_allreduce_mixers", "airband_hip_add_mixers", "airband_hip_comm_destroy",
 ]
 
 _lib = None
@@ -67,6 +69,14 @@ def load_library() -> C.CDLL:
     L.airband_hip_submit.argtypes = [vp, i32, vp, sz]
     L.airband_hip_submit.restype = i64
     L.airband_hip_process.argtypes = [vp]
+    L.airband_hip_batch_ready.argtypes = [vp]
+    L.airband_hip_mixer_set_stereo.argtypes = [vp, i32, i32]
+    L.airband_hip_comm_unique_id.argtypes = [vp]
+    L.airband_hip_comm_init_rank.argtypes = [vp, vp, i32, i32]
+    L.airband_hip_comm_init_all.argtypes = [C.POINTER(vp), i32]
+    L.airband_hip_allreduce_mixers.argtypes = [vp, vp]
+    L.airband_hip_add_mixers.argtypes = [vp, vp]
+    L.airband_hip_comm_destroy.argtypes = [vp]
     L.airband_hip_process_device.argtypes = [vp, vp, sz, vp]
     L.airband_hip_collect.argtypes = [vp, vp, vp, vp, vp]
     L.airband_hip_collect_channels.argtypes = [vp, i64, i64, vp, vp, vp, vp]
@@ -274,6 +284,35 @@ class AirbandHip:
 
     def mixer_enable_input(self, input_index: int, enabled: bool):
         self._check(self.L.airband_hip_mixer_enable_input(self.h, input_index, 1 if enabled else 0))
+
+    def mixer_set_stereo(self, mixer: int, stereo: bool):
+        self._check(self.L.airband_hip_mixer_set_stereo(self.h, int(mixer), 1 if stereo else 0))
+
+    # ---- the mixer exchange over RCCL (include/airband_hip.h): one handle per GPU, in one process or in one process each -----------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        rc = load_library().airband_hip_comm_unique_id(buf)
+        if rc < 0:
+            raise AirbandError(rc, (load_library().airband_hip_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    def comm_init_rank(self, unique_id: bytes, nranks: int, rank: int):
+        assert len(unique_id) == 128
+        self._check(self.L.airband_hip_comm_init_rank(self.h, (C.c_uint8 * 128).from_buffer_copy(unique_id), int(nranks), int(rank)))
+
+    def allreduce_mixers(self, stream: int = 0):
+        self._check(self.L.airband_hip_allreduce_mixers(self.h, C.c_void_p(stream)))
+
+    def add_mixers(self, src: "AirbandHip"):
+        self._check(self.L.airband_hip_add_mixers(self.h, src.h))
+
+    def batch_ready(self) -> bool:
+        rc = self.L.airband_hip_batch_ready(self.h)
+        if rc == capi.EAGAIN:
+            return False
+        self._check(rc)
+        return True
 
     def device_enable(self, dev: int, enabled: bool):
         """Switch a dongle off / on: the reference's handling of a failed input (src/rtl_airband.cpp:383-391)."""

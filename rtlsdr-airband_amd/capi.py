@@ -3,13 +3,13 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, ENODEV, EBADSIZE, ENOMEM, EINVAL, EAGAIN, ERUNTIME = 0, -1, -2, -3, -4, -5, -6
 SFMT_U8, SFMT_S8, SFMT_S16, SFMT_F32 = 1, 2, 3, 4
 MOD_AM, MOD_NFM = 0, 1
 FM_FAST_ATAN2, FM_QUADRI_DEMOD = 0, 1
 AGC_EXTRA = 100
-FLAG_TRACE_SQUELCH, FLAG_KEEP_BINS, FLAG_FORCE_FFT, FLAG_SERIAL_DEMOD, FLAG_PIPELINE = 0x1, 0x2, 0x4, 0x8, 0x10
+FLAG_TRACE_SQUELCH, FLAG_RESERVED_2, FLAG_FORCE_FFT, FLAG_SERIAL_DEMOD, FLAG_PIPELINE = 0x1, 0x2, 0x4, 0x8, 0x10
 
 BYTES_PER_SAMPLE = {SFMT_U8: 1, SFMT_S8: 1, SFMT_S16: 2, SFMT_F32: 4}
 
@@ -43,7 +43,7 @@ class Geometry(C.Structure):
 class ChannelStats(C.Structure):
     _fields_ = [("noise_level", C.c_float), ("signal_level", C.c_float), ("squelch_level", C.c_float), ("agcavgfast", C.c_float),
                 ("open_count", C.c_uint64), ("flappy_count", C.c_uint64), ("ctcss_count", C.c_uint64), ("no_ctcss_count", C.c_uint64),
-                ("active_counter", C.c_uint64), ("bin", C.c_int32), ("squelch_state", C.c_int32)]
+                ("active_counter", C.c_uint64), ("bin", C.c_int32), ("squelch_state", C.c_int32), ("signal_outside_filter", C.c_int32), ("reserved", C.c_int32)]
 
 
 def channel_cfg(frequency, modulation=MOD_AM, afc=0, squelch_threshold_dbfs=0, squelch_snr_threshold_db=-1.0, notch_freq=0.0, notch_q=0.0, ctcss_freq=0.0,

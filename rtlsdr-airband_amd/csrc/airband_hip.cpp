@@ -6,6 +6,8 @@
  * prepared on and fails with AIRBAND_HIP_ENODEV / AIRBAND_HIP_ERUNTIME otherwise.
  */
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h> /* types and prototypes only: librccl.so is loaded on first use (airband_hip_comm_*) */
 
 #include <atomic>
 #include <cstdio>
@@ -154,6 +156,10 @@ struct airband_hip_handle {
     DevBuf<float> d_mix_ml, d_mix_mr, d_mix_left, d_mix_right;
     DevBuf<uint8_t> d_mix_stereo, d_mix_signal;
 
+    /* the mixer exchange (airband_hip_comm_*): this handle's rank in an RCCL communicator over the GPUs that hold the other dongles */
+    ncclComm_t comm = nullptr;
+    hipEvent_t ev_peer = nullptr; /* airband_hip_add_mixers: "src's batch is done" for dst's stream */
+
     /* synthetic dongles */
     DevBuf<int16_t> d_sin_tab;
     DevBuf<long long> d_carriers;
@@ -185,6 +191,8 @@ hipError_t upload(DevBuf<T>& b, const std::vector<T>& v) {
 void destroy(airband_hip_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->hip_device);
+    (void)airband_hip_comm_destroy(h);
+    if (h->ev_peer) (void)hipEventDestroy(h->ev_peer);
     /* everything in flight must be done before its memory goes away: the front stream of a pipelined handle, the forked demod streams */
     if (h->ev_last && h->ev_last_pending) (void)hipEventSynchronize(h->ev_last); /* a batch enqueued on a caller's stream */
     if (h->front) (void)hipStreamSynchronize(h->front);
@@ -721,7 +729,8 @@ int airband_hip_get_geometry(const airband_hip_handle* h, airband_hip_geometry* 
 }
 
 int airband_hip_set_mixers(airband_hip_handle* h, int32_t mixer_count, const airband_hip_mixer_input* in, int32_t n_in) {
-    if (!h || mixer_count < 1 || !in || n_in < 1) return fail(h, AIRBAND_HIP_EINVAL, "bad mixer arguments");
+    if (!h || mixer_count < 1 || n_in < 0 || (!in && n_in > 0)) return fail(h, AIRBAND_HIP_EINVAL, "bad mixer arguments");
+    /* n_in == 0: a handle whose dongles feed no mixer still takes part in the exchange with all-zero partial sums */
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
     const Plan& p = h->plan;
     std::vector<int> first(mixer_count + 1, 0), chan(n_in);
@@ -1047,6 +1056,18 @@ int64_t airband_hip_submit(airband_hip_handle* h, int32_t dev, const void* iq, s
     return (int64_t)take;
 }
 
+/* would airband_hip_process() run a batch now?  The availability rule alone, nothing is enqueued.  -2 from airband_hip_process's own codes is not
+ * used: OK = yes, EAGAIN = not yet (or every dongle is switched off). */
+int airband_hip_batch_ready(airband_hip_handle* h) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    if (h->n_enabled == 0) return AIRBAND_HIP_EAGAIN;
+    if (!h->h_ring.load(std::memory_order_acquire)) return AIRBAND_HIP_EAGAIN; /* nothing has been submitted yet */
+    const int64_t need = (h->front_batches == 0 ? h->first_batch_bytes : h->batch_bytes) + h->lookahead_bytes;
+    for (int d = 0; d < h->plan.n_dev; d++)
+        if (h->dev_enabled[d] && (int64_t)(h->ring_wr[d].load(std::memory_order_acquire) - h->ring_rd) < need) return AIRBAND_HIP_EAGAIN;
+    return AIRBAND_HIP_OK;
+}
+
 int airband_hip_process(airband_hip_handle* h) {
     if (!h) return AIRBAND_HIP_EINVAL;
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
@@ -1316,6 +1337,185 @@ int airband_hip_generate_iq(airband_hip_handle* h, void* d_iq, size_t stride_byt
     launch_siggen(a, stream ? (hipStream_t)stream : h->stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, AIRBAND_HIP_ERUNTIME, std::string("siggen launch: ") + hipGetErrorString(e));
+    return AIRBAND_HIP_OK;
+}
+
+/* ---- the mixer exchange (include/airband_hip.h) ------------------------------------------------------------------------------------ */
+namespace {
+struct Rccl {
+    void* dl = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+Rccl g_rccl;
+std::mutex g_rccl_lock;
+
+/* librccl.so on first use: a process that never exchanges mixer sums never loads it */
+Rccl* rccl() {
+    std::lock_guard<std::mutex> guard(g_rccl_lock);
+    if (g_rccl.dl) return &g_rccl;
+    if (!g_rccl.why.empty()) return nullptr;
+    void* dl = nullptr;
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        dl = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (dl) break;
+    }
+    if (!dl) {
+        g_rccl.why = std::string("librccl.so: ") + (dlerror() ? dlerror() : "not found");
+        return nullptr;
+    }
+#define AB_RCCL_SYM(field, name)                              \
+    *(void**)(&g_rccl.field) = dlsym(dl, name);               \
+    if (!g_rccl.field) {                                      \
+        g_rccl.why = std::string("librccl.so lacks ") + name; \
+        dlclose(dl);                                          \
+        return nullptr;                                       \
+    }
+    AB_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") AB_RCCL_SYM(CommInitRank, "ncclCommInitRank") AB_RCCL_SYM(CommInitAll, "ncclCommInitAll")
+    AB_RCCL_SYM(AllReduce, "ncclAllReduce") AB_RCCL_SYM(CommDestroy, "ncclCommDestroy") AB_RCCL_SYM(GroupStart, "ncclGroupStart")
+    AB_RCCL_SYM(GroupEnd, "ncclGroupEnd") AB_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef AB_RCCL_SYM
+    g_rccl.dl = dl;
+    return &g_rccl;
+}
+
+#define RCCL_TRY(h, R, expr)                                                                                        \
+    do {                                                                                                            \
+        ncclResult_t r_ = (expr);                                                                                   \
+        if (r_ != ncclSuccess) return fail(h, AIRBAND_HIP_ERUNTIME, std::string(#expr ": ") + (R)->GetErrorString(r_)); \
+    } while (0)
+
+/* the stream on which the last batch's mixer sums become final */
+hipStream_t results_stream(airband_hip_handle* h) { return h->pipeline ? h->stream : (h->last_stream ? h->last_stream : h->stream); }
+}  // namespace
+
+int airband_hip_mixer_set_stereo(airband_hip_handle* h, int32_t mixer, int32_t stereo) {
+    if (!h || h->n_mixers <= 0 || mixer < 0 || mixer >= h->n_mixers) return fail(h, AIRBAND_HIP_EINVAL, "mixer index out of range");
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    order_behind_last_batch(h);
+    const uint8_t v = stereo ? 1 : 0;
+    HIP_TRY(h, hipMemcpyAsync(h->d_mix_stereo.p + mixer, &v, 1, hipMemcpyHostToDevice, h->stream), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipStreamSynchronize(h->stream), AIRBAND_HIP_ERUNTIME);
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_comm_unique_id(uint8_t id[AIRBAND_HIP_COMM_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) == AIRBAND_HIP_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    Rccl* R = rccl();
+    if (!R) return fail(nullptr, AIRBAND_HIP_ENODEV, g_rccl.why);
+    ncclUniqueId u;
+    RCCL_TRY(nullptr, R, R->GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_comm_init_rank(airband_hip_handle* h, const uint8_t id[AIRBAND_HIP_COMM_ID_BYTES], int32_t nranks, int32_t rank) {
+    if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, AIRBAND_HIP_EINVAL, "bad communicator arguments");
+    if (h->comm) return fail(h, AIRBAND_HIP_EINVAL, "the handle already has a communicator");
+    Rccl* R = rccl();
+    if (!R) return fail(h, AIRBAND_HIP_ENODEV, g_rccl.why);
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    RCCL_TRY(h, R, R->CommInitRank(&h->comm, nranks, u, rank));
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_comm_init_all(airband_hip_handle** hs, int32_t n) {
+    if (!hs || n < 1) return fail(nullptr, AIRBAND_HIP_EINVAL, "bad communicator arguments");
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; i++) {
+        if (!hs[i] || hs[i]->comm) return fail(hs[i], AIRBAND_HIP_EINVAL, "NULL handle, or a handle that already has a communicator");
+        devs[i] = hs[i]->hip_device;
+        for (int k = 0; k < i; k++)
+            if (devs[k] == devs[i]) return fail(hs[i], AIRBAND_HIP_EINVAL, "two handles of the clique share a GPU: use airband_hip_add_mixers between them");
+        if (hs[i]->n_mixers != hs[0]->n_mixers || hs[i]->B != hs[0]->B) return fail(hs[i], AIRBAND_HIP_EINVAL, "the handles of a clique need the same mixer_count and WAVE_BATCH");
+    }
+    Rccl* R = rccl();
+    if (!R) return fail(hs[0], AIRBAND_HIP_ENODEV, g_rccl.why);
+    std::vector<ncclComm_t> comms(n, nullptr);
+    RCCL_TRY(hs[0], R, R->CommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; i++) hs[i]->comm = comms[i];
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_comm_group_begin(void) {
+    Rccl* R = rccl();
+    if (!R) return fail(nullptr, AIRBAND_HIP_ENODEV, g_rccl.why);
+    RCCL_TRY(nullptr, R, R->GroupStart());
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_comm_group_end(void) {
+    Rccl* R = rccl();
+    if (!R) return fail(nullptr, AIRBAND_HIP_ENODEV, g_rccl.why);
+    RCCL_TRY(nullptr, R, R->GroupEnd());
+    return AIRBAND_HIP_OK;
+}
+
+/* SUM of the mixer waveforms (src/mixer.cpp:133-140), MAX of the signal flags (channel->axcindicate = SIGNAL if any input had signal, :209), in place */
+int airband_hip_allreduce_mixers(airband_hip_handle* h, void* stream) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    if (h->n_mixers <= 0) return fail(h, AIRBAND_HIP_EINVAL, "no mixers configured");
+    if (!h->comm) return fail(h, AIRBAND_HIP_EINVAL, "no communicator: airband_hip_comm_init_rank / _init_all first");
+    Rccl* R = rccl();
+    if (!R) return fail(h, AIRBAND_HIP_ENODEV, g_rccl.why);
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    hipStream_t s = stream ? (hipStream_t)stream : results_stream(h);
+    if (stream) {
+        const int rc = airband_hip_stream_wait_results(h, stream);
+        if (rc != AIRBAND_HIP_OK) return rc;
+    }
+    const size_t n = (size_t)h->n_mixers * h->B;
+    RCCL_TRY(h, R, R->GroupStart());
+    RCCL_TRY(h, R, R->AllReduce(h->d_mix_left.p, h->d_mix_left.p, n, ncclFloat, ncclSum, h->comm, s));
+    RCCL_TRY(h, R, R->AllReduce(h->d_mix_right.p, h->d_mix_right.p, n, ncclFloat, ncclSum, h->comm, s));
+    RCCL_TRY(h, R, R->AllReduce(h->d_mix_signal.p, h->d_mix_signal.p, (size_t)h->n_mixers, ncclUint8, ncclMax, h->comm, s));
+    RCCL_TRY(h, R, R->GroupEnd());
+    if (stream && (hipStream_t)stream != h->stream) { /* whatever the handle does next to these buffers (the next batch's sums, collect_mixers) comes behind the exchange */
+        if (!h->ev_last) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
+        HIP_TRY(h, hipEventRecord(h->ev_last, s), AIRBAND_HIP_ERUNTIME);
+        h->ev_last_pending = true;
+    }
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_add_mixers(airband_hip_handle* dst, airband_hip_handle* src) {
+    if (!dst || !src || dst == src) return fail(dst, AIRBAND_HIP_EINVAL, "two different handles needed");
+    if (dst->n_mixers <= 0 || dst->n_mixers != src->n_mixers || dst->B != src->B) return fail(dst, AIRBAND_HIP_EINVAL, "the handles need the same mixer_count and WAVE_BATCH");
+    if (dst->hip_device != src->hip_device) return fail(dst, AIRBAND_HIP_EINVAL, "handles on different GPUs exchange through airband_hip_allreduce_mixers");
+    HIP_TRY(dst, hipSetDevice(dst->hip_device), AIRBAND_HIP_ENODEV);
+    if (!dst->ev_peer) HIP_TRY(dst, hipEventCreateWithFlags(&dst->ev_peer, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
+    hipStream_t s = results_stream(dst);
+    HIP_TRY(dst, hipEventRecord(dst->ev_peer, results_stream(src)), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(dst, hipStreamWaitEvent(s, dst->ev_peer, 0), AIRBAND_HIP_ERUNTIME);
+    launch_mix_add(dst->d_mix_left.p, dst->d_mix_right.p, dst->d_mix_signal.p, src->d_mix_left.p, src->d_mix_right.p, src->d_mix_signal.p, dst->n_mixers, dst->B, s);
+    /* src's next batch must not overwrite its sums before they have been read */
+    if (!src->ev_last) HIP_TRY(src, hipEventCreateWithFlags(&src->ev_last, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
+    HIP_TRY(src, hipEventRecord(src->ev_last, s), AIRBAND_HIP_ERUNTIME);
+    src->ev_last_pending = true;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(dst, AIRBAND_HIP_ERUNTIME, std::string("mixer add launch: ") + hipGetErrorString(e));
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_comm_destroy(airband_hip_handle* h) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    if (!h->comm) return AIRBAND_HIP_OK;
+    Rccl* R = rccl();
+    if (R) {
+        (void)hipSetDevice(h->hip_device);
+        (void)hipStreamSynchronize(h->stream);
+        (void)R->CommDestroy(h->comm);
+    }
+    h->comm = nullptr;
     return AIRBAND_HIP_OK;
 }
 

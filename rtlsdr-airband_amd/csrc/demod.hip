@@ -716,6 +716,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     }
     sp->agcavgfast = agc; sp->pr = pr; sp->pj = pj; sp->prev_waveout = prev_out; sp->dm_phi = dm_phi;
     if (KIND == AB_KIND_NFM_LOWPASS) { sp->sh_nf = sh.nf; sp->sh_cap = sh.cap; sp->sh_capped = sh.capped; sp->sh_dly = s.dly; }
+    if (KIND == AB_KIND_GENERIC) sp->sh_dly = sq_delayed(s, L); /* buffer_[buffer_tail_] for the stats mirror (signal_outside_filter); this kind keeps the delay line in memory */
     sq_store(s, L, sp, B);
     sp->lxr[1] = lxr1; sp->lxr[2] = lxr2; sp->lxi[1] = lxi1; sp->lxi[2] = lxi2;
     sp->lyr[1] = lyr1; sp->lyr[2] = lyr2; sp->lyi[1] = lyi1; sp->lyi[2] = lyi2;
@@ -1167,6 +1168,10 @@ __global__ void stats_kernel(const ChanConst* cc, const ChanState* cs, const int
     o.active_counter = s.active_counter;
     o.bin = s.bin;
     o.squelch_state = s.cur;
+    /* Squelch::signal_outside_filter() (src/squelch.cpp:152-154): using_post_filter_ && has_pre_filter_signal() && !has_post_filter_signal(), the latter
+     * against buffer_[buffer_tail_] as the batch's last sample left it (ChanState::sh_dly) */
+    o.signal_outside_filter = (s.using_post && s.pre_capped >= lvl && !(s.post_capped >= s.sh_dly)) ? 1 : 0;
+    o.reserved = 0;
     out[ext] = o;
 }
 

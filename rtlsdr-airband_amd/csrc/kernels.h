@@ -147,6 +147,8 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
 void launch_emit_iq(const EmitArgs& a, hipStream_t stream);
 void launch_axc(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, uint8_t* out_axc, int n_slots, hipStream_t stream);
 void launch_mix(const MixArgs& a, hipStream_t stream);
+/* dst += src for the mixer sums of two handles on one GPU (airband_hip_add_mixers): left, right [n_mixers][wave_batch], signal flags OR-ed */
+void launch_mix_add(float* dl, float* dr, uint8_t* ds, const float* sl, const float* sr, const uint8_t* ss, int n_mixers, int wave_batch, hipStream_t stream);
 void launch_stats(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, int n_slots, airband_hip_channel_stats* out, hipStream_t stream);
 void launch_siggen(const SiggenArgs& a, hipStream_t stream);
 void launch_afc(const ChanConst* cc, ChanState* cs, const float* spectrum, int fft_size, int n_slots, int* moved_epoch, int epoch, hipStream_t stream);

@@ -172,6 +172,20 @@ __global__ __launch_bounds__(256) void mix_final_kernel(MixArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0) a.has_signal[m] = any ? 1 : 0;
 }
 
+__global__ __launch_bounds__(256) void mix_add_kernel(float* dl, float* dr, uint8_t* ds, const float* sl, const float* sr, const uint8_t* ss, long n, int n_mixers) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        dl[i] += sl[i];
+        dr[i] += sr[i];
+    }
+    if (i < n_mixers) ds[i] = (ds[i] | ss[i]) ? 1 : 0;
+}
+
+void launch_mix_add(float* dl, float* dr, uint8_t* ds, const float* sl, const float* sr, const uint8_t* ss, int n_mixers, int wave_batch, hipStream_t stream) {
+    const long n = (long)n_mixers * wave_batch;
+    hipLaunchKernelGGL(mix_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dl, dr, ds, sl, sr, ss, n, n_mixers);
+}
+
 void launch_mix(const MixArgs& a, hipStream_t stream) {
     const int bx = (a.wave_batch + 255) / 256;
     hipLaunchKernelGGL(mix_runs_kernel, dim3((a.wave_batch / 4 + 255) / 256, a.n_runs), dim3(256), 0, stream, a);

@@ -156,3 +156,38 @@ def boundary_streams(orc_factory, n_dev, B, level):
         onset -= first - 1
     assert (first == 1).all(), first
     return streams(True)
+
+
+def mixer_reference_sum(conns, n_mixers, waveout, axc):
+    """What mixer_thread() leaves in mixer->channel for ONE batch when every input was ready (src/mixer.cpp:189-214): inputs in input-index order
+    (= connection order per mixer), sum[s] += in[s] * (ampfactor * ampl) in float32, only inputs with signal; right channel for stereo mixers
+    (any input with a balance, src/mixer.cpp:84-85); axcindicate = SIGNAL as soon as one input had signal.
+    conns: [(device, channel, mixer, ampfactor, balance)]; waveout [device][channel][B] float32, axc [device][channel]."""
+    B = waveout.shape[-1]
+    left = np.zeros((n_mixers, B), np.float32)
+    right = np.zeros((n_mixers, B), np.float32)
+    sig = np.zeros((n_mixers,), np.uint8)
+    stereo = [any(c[2] == m and c[4] != 0.0 for c in conns) for m in range(n_mixers)]
+    for (d, j, m, amp, bal) in conns:
+        if axc[d][j] == ord(" "):
+            continue
+        sig[m] = 1
+        ampl = np.float32(min(1.0, 1.0 - np.float32(bal)))
+        ampr = np.float32(min(1.0, 1.0 + np.float32(bal)))
+        ml, mr = np.float32(amp) * ampl, np.float32(amp) * ampr
+        if ml != 0.0:
+            left[m] = left[m] + waveout[d][j] * ml
+        if stereo[m] and mr != 0.0:
+            right[m] = right[m] + waveout[d][j] * mr
+    return left, right, sig
+
+
+def parse_waterfall(text: str):
+    """The TUI lines demodulate() prints per channel and batch (src/rtl_airband.cpp:632-643): ESC [ y ; x f, then "%4.0f/%3.0f%c ".
+    Returns [(y, x, signal_dBFS, noise_dBFS, symbol)] in print order."""
+    import re
+
+    out = []
+    for m in re.finditer(r"\x1b\[(\d+);(\d+)f\s*(-?\d+)/\s*(-?\d+)(.) ", text):
+        out.append((int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), m.group(5)))
+    return out

@@ -31,7 +31,7 @@ def test_struct_layouts_match_header(pkg):
     assert C.sizeof(capi.Config) == 40
     assert C.sizeof(capi.MixerInput) == 20
     assert C.sizeof(capi.Geometry) == 56
-    assert C.sizeof(capi.ChannelStats) == 64
+    assert C.sizeof(capi.ChannelStats) == 72  # ABI 2: + signal_outside_filter, reserved
 
 
 def _tweak(d, ch):

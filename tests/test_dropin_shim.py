@@ -99,3 +99,110 @@ def test_shard_with_two_device_classes(pkg, built):
             a, b = ref["stats"][d][j], hip["stats"][d][j]
             for k in ("open_count", "flappy_count", "ctcss_count", "no_ctcss_count", "active_counter", "bin"):
                 assert a[k] == b[k], (d, j, k, a[k], b[k])
+
+
+need_patched_am = pytest.mark.skipif(not (pyref.have_ref(False) and os.path.exists(pyref.ref_lib_path(False, "patched"))), reason="oracle/_ref not built")
+need_patched_nfm = pytest.mark.skipif(not (pyref.have_ref(True) and os.path.exists(pyref.ref_lib_path(True, "patched"))), reason="oracle/_ref not built")
+
+
+def _mixer_scenario(pkg, n_dev, n_batches, nfm):
+    wave_rate = 16000 if nfm else 8000
+    devices, carriers = helpers.plan_devices(n_dev, nfm, None)
+    nbytes = helpers.stream_bytes(n_batches, wave_rate) + 4 * 640
+    iq = [pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)]
+    return devices, iq
+
+
+@need_patched_am
+def test_mixers_served_on_the_gpu(pkg, built):
+    """The reference's mixers (mixer_t, O_MIXER outputs, mixer_thread(), src/mixer.cpp) with demodulate(), then with the HIP backend: the shim wires the
+    mixers into the library (airband_hip_set_mixers from the reference's own mixinput_t values), marks them gpu_served -- mixer_put_samples() and
+    mixer_thread() then leave them alone -- and publishes the sums where mixer_thread() would have.  Stereo, ampfactors, a mixer with one input."""
+    from test_reference_plumbing import MIXER_CONNS
+    n_dev, n_batches = 3, 6
+    devices, iq = _mixer_scenario(pkg, n_dev, n_batches, False)
+    ref = pyref.run_reference_all(devices, iq, n_batches, nfm=False, mixers=(3, MIXER_CONNS))
+    hip = pyref.run_reference_all(devices, iq, n_batches, nfm=False, mixers=(3, MIXER_CONNS), hip_lib=pkg.LIB_PATH)
+    assert hip["batches"] == [n_batches] * n_dev and hip["mix_batches"] == [n_batches] * 3
+    assert [m["gpu_served"] for m in hip["mixers"]] == [1, 1, 1] and [m["gpu_served"] for m in ref["mixers"]] == [0, 0, 0]
+    assert np.array_equal(ref["axc"], hip["axc"]) and np.array_equal(ref["mix_axc"], hip["mix_axc"])
+    assert (hip["mix_axc"] != ord(" ")).any()
+    for m in range(3):
+        assert helpers.rms(ref["mix_left"][m] - hip["mix_left"][m]) <= 1e-4 * max(1.0, helpers.rms(ref["mix_left"][m]))
+    assert helpers.rms(ref["mix_right"][1] - hip["mix_right"][1]) <= 1e-4 and np.abs(hip["mix_right"][1]).max() > 0
+    # ... and bit for bit the reference's own summation order over the HIP backend's channel audio
+    for b in range(n_batches):
+        left, right, sig = helpers.mixer_reference_sum(MIXER_CONNS, 3, hip["waveout"][:, b], hip["axc"][:, b])
+        assert np.array_equal(hip["mix_left"][:, b].view(np.uint32), left.view(np.uint32)), b
+        assert np.array_equal(hip["mix_right"][1, b].view(np.uint32), right[1].view(np.uint32)), b
+
+
+@need_patched_nfm
+def test_a_shard_spread_over_two_parts(pkg, built):
+    """AIRBAND_HIP_GPUS = "0,0": the shim cuts the shard's five devices into two contiguous parts (2 + 3), one library handle each -- on a node with
+    several GPUs one per GPU, here both on GPU 0 -- and the mixer sums of the parts meet on the GPU (airband_hip_add_mixers; airband_hip_allreduce_mixers
+    over RCCL between different GPUs).  Everything a device produces must be bit-identical to the one-handle run; mixers whose inputs lie in both parts
+    too where the association order is the same, within float tolerance otherwise."""
+    n_dev, n_batches = 5, 6
+    devices, iq = _mixer_scenario(pkg, n_dev, n_batches, True)
+    conns = [(d, 0, 0, 1.0, 0.0) for d in range(5)] + [(0, 2, 1, 2.0, -0.25), (4, 2, 1, 1.0, 0.5)] + [(3, 4, 2, 1.0, 0.0), (4, 6, 2, 0.5, 0.0)]
+    one = pyref.run_reference_all(devices, iq, n_batches, nfm=True, mixers=(3, conns), hip_lib=pkg.LIB_PATH, env={"AIRBAND_HIP_GPUS": "0"})
+    two = pyref.run_reference_all(devices, iq, n_batches, nfm=True, mixers=(3, conns), hip_lib=pkg.LIB_PATH, env={"AIRBAND_HIP_GPUS": "0,0"})
+    for r in (one, two):
+        assert r["batches"] == [n_batches] * n_dev and r["mix_batches"] == [n_batches] * 3 and [m["gpu_served"] for m in r["mixers"]] == [1, 1, 1]
+    assert np.array_equal(one["axc"], two["axc"]) and (one["axc"] == ord("*")).any()
+    assert np.array_equal(one["waveout"].view(np.uint32), two["waveout"].view(np.uint32))
+    assert np.array_equal(one["iq_out"].view(np.uint32), two["iq_out"].view(np.uint32))
+    assert one["stats"] == two["stats"]
+    assert np.array_equal(one["mix_axc"], two["mix_axc"]) and (one["mix_axc"] != ord(" ")).any()
+    # mixer 1: one input per part, mixer 2: both inputs in the second part -> the same additions in the same order
+    for m in (1, 2):
+        assert np.array_equal(one["mix_left"][m].view(np.uint32), two["mix_left"][m].view(np.uint32)), m
+    assert np.array_equal(one["mix_right"][1].view(np.uint32), two["mix_right"][1].view(np.uint32))
+    # mixer 0: (d0 + d1) + ((d2 + d3) + d4) against (((d0 + d1) + d2) + d3) + d4
+    assert helpers.rms(one["mix_left"][0] - two["mix_left"][0]) <= 1e-6 * max(1.0, helpers.rms(one["mix_left"][0]))
+
+
+@need_patched_am
+def test_waterfall_with_the_hip_backend(pkg, built, tmp_path):
+    """`tui` = 1: the shim prints the reference's waterfall cells (src/rtl_airband.cpp:632-643) from the mirrored statistics, '~' for
+    Squelch::signal_outside_filter() included, and scrolls dev->row like demodulate() (:663-667)."""
+    n_dev, n_batches, wave_rate = 2, 14, 8000
+    devices, carriers = helpers.plan_devices(n_dev, False, None)
+    nbytes = helpers.stream_bytes(n_batches, wave_rate) + 4 * 640
+    iq = [pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)]
+    ref = pyref.run_reference_all(devices, iq, n_batches, nfm=False, tui_path=str(tmp_path / "ref.txt"))
+    hip = pyref.run_reference_all(devices, iq, n_batches, nfm=False, tui_path=str(tmp_path / "hip.txt"), hip_lib=pkg.LIB_PATH)
+    a = helpers.parse_waterfall((tmp_path / "ref.txt").read_text(errors="replace"))
+    b = helpers.parse_waterfall((tmp_path / "hip.txt").read_text(errors="replace"))
+    assert len(a) == len(b) == n_dev * n_batches * 8
+    key = lambda c: (c[0], c[1])  # the two runs interleave their devices differently (one thread walks the devices; the shim publishes a class at a time)
+    for d in range(n_dev):
+        ra = [c for c in a if (c[0] - 3) // 17 == d]
+        rb = [c for c in b if (c[0] - 3) // 17 == d]
+        assert [key(c) for c in ra] == [key(c) for c in rb]
+        for x, y in zip(ra, rb):
+            assert x[4] == y[4] and abs(x[2] - y[2]) <= 1 and abs(x[3] - y[3]) <= 1, (x, y)
+    assert any(c[4] == "*" for c in b)
+    assert np.array_equal(ref["axc"], hip["axc"])
+
+
+@need_patched_am
+def test_configs0_file_input_with_the_hip_backend(pkg, built, tmp_path):
+    """BASELINE configs[0] with the backend switched: the reference's file input driver (src/input-file.cpp) replays generated I/Q into the device's ring,
+    demodulate_hip() instead of demodulate(); end of file -> INPUT_FAILED -> the shim disables the device and, with no receiver left, exits."""
+    from test_reference_plumbing import configs0_devices
+    devices, carriers = configs0_devices()
+    n_batches, wave_rate = 6, 8000
+    iq = pkg.siggen.generate_u8(0, 0, helpers.stream_bytes(n_batches + 2, wave_rate) // 2, carriers)
+    path = tmp_path / "dongle0.u8"
+    iq.tofile(path)
+    kw = dict(nfm=False, file_inputs={0: (str(path), 8.0)}, wait_exit_s=20.0, timeout_s=60.0)
+    ref = pyref.run_reference_all(devices, [np.zeros(0, np.uint8)], n_batches, **kw)
+    hip = pyref.run_reference_all(devices, [np.zeros(0, np.uint8)], n_batches, hip_lib=pkg.LIB_PATH, **kw)
+    assert ref["batches"] == hip["batches"] == [n_batches] and hip["output_overruns"] == [0]
+    assert np.array_equal(ref["axc"], hip["axc"]) and (hip["axc"] == ord("*")).any()
+    assert helpers.rms(ref["waveout"] - hip["waveout"]) <= 1e-4
+    assert hip["stats"][0][0]["bin"] == 411 and hip["stats"][0][5]["bin"] == 44
+    for r in (ref, hip):
+        assert r["exited_on_its_own"] and r["devices_running_at_exit"] == 0 and r["input_state_at_exit"] == [5]

@@ -1,6 +1,7 @@
 """N > 1 on real GPUs (skipped below two visible devices -- the driver's lease has one; runs the day a bigger node appears): two ranks,
 one HIP handle each on its own GPU, BASELINE configs[4] wiring (channel (d, c) -> mixer (d * 8 + c) mod M), per-rank mixer partials
-all-reduced with RCCL through the SAME host logic bench.py uses (rtlsdr-airband_amd/multigpu.py) == the sums of ONE handle holding
+all-reduced with RCCL through the SAME entry bench.py and the reference-side shim use (airband_hip_allreduce_mixers, include/airband_hip.h; the
+communicator id travels over torch.distributed) == the sums of ONE handle holding
 all dongles, within 1e-4 RMS (float summation order differs); signal flags equal.  At a size the oracle finishes in
 seconds the single-handle sums are tied to the oracle's ordered sum as well (src/mixer.cpp:133-140,201-214)."""
 import importlib
@@ -22,8 +23,8 @@ def _paths():
             sys.path.insert(0, p)
 
 
-def _run_handle(pkg, torch, gpu, d_start, d_end, reduce_fn=None):
-    """Handle with the global dongles [d_start, d_end) on GPU `gpu`; returns per batch (left, has_signal) after reduce_fn (if any)."""
+def _run_handle(pkg, torch, gpu, d_start, d_end, comm=None):
+    """Handle with the global dongles [d_start, d_end) on GPU `gpu`; returns per batch (left, has_signal), all-reduced over comm = (id, nranks, rank) if given."""
     mg = importlib.import_module("rtlsdr-airband_amd.multigpu")
     chans, carriers = pkg.siggen.baseline_plan(mixed=True)
     n = d_end - d_start
@@ -38,15 +39,15 @@ def _run_handle(pkg, torch, gpu, d_start, d_end, reduce_fn=None):
         iq = torch.empty((n, stride), dtype=torch.uint8, device="cuda:%d" % gpu)
         hip.generate_iq(iq.data_ptr(), stride, 0, span, seed=0x5EED, device_index_offset=d_start)
         hip.synchronize()
-        left_t, right_t, sig_t = mg.device_mixer_views(hip, N_MIXERS)
+        if comm is not None:
+            hip.comm_init_rank(*comm)
         for b in range(N_BATCHES):
             off = 0 if b == 0 else g.first_batch_bytes + (b - 1) * g.batch_bytes
             hip.process_device(iq.data_ptr() + off, stride)
-            hip.synchronize()
-            if reduce_fn is not None:
-                reduce_fn(left_t, right_t, sig_t)
-                torch.cuda.synchronize()
-            out.append((left_t.cpu().numpy().copy(), sig_t.cpu().numpy().copy()))
+            if comm is not None:
+                hip.allreduce_mixers()  # enqueued behind the batch on the handle's stream; collect_mixers() orders itself behind it
+            left, _, sig = hip.collect_mixers()
+            out.append((left.copy(), sig.copy()))
         del iq
     return out
 
@@ -62,7 +63,9 @@ def _rank_main(rank, world, port, per_rank, q):
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     d0, d1 = mg.shard_range(per_rank * world, rank, world)
-    res = _run_handle(pkg, torch, rank, d0, d1, reduce_fn=mg.allreduce_mixers)
+    box = [pkg.AirbandHip.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    res = _run_handle(pkg, torch, rank, d0, d1, comm=(box[0], world, rank))
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:

@@ -66,7 +66,7 @@ def test_stage2_bit_exact_on_oracle_bins(pkg, built, mixed, wave_rate, style):
             for j in range(8):
                 o, g = orc.stats(d, j), out["stats"][k]
                 for f in ("noise_level", "signal_level", "squelch_level", "agcavgfast", "open_count", "flappy_count", "ctcss_count", "no_ctcss_count",
-                          "active_counter", "bin", "squelch_state"):
+                          "active_counter", "bin", "squelch_state", "signal_outside_filter"):
                     assert o[f] == g[f], (d, j, f, o[f], g[f])
                 opens += int(g["open_count"])
                 flappy += int(g["flappy_count"])
@@ -272,7 +272,7 @@ def test_pipelined_mode_is_the_sequential_mode_one_batch_late(pkg, built, mixed,
                 assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8)), "%s batch %d mixers" % (what, k)
             for x, y in zip(got["stats"], w["stats"]):
                 for f in ("noise_level", "signal_level", "squelch_level", "agcavgfast", "open_count", "flappy_count", "ctcss_count", "no_ctcss_count",
-                          "active_counter", "bin", "squelch_state"):
+                          "active_counter", "bin", "squelch_state", "signal_outside_filter"):
                     assert x[f] == y[f], (what, k, f)
 
         def grab(h):
@@ -391,6 +391,53 @@ def test_mixers_match_reference_order_sum(pkg, built):
         hip.mixer_enable_input(masked[0], True)  # and back in
         with pytest.raises(pkg.AirbandError):
             hip.mixer_enable_input(len(inputs), False)
+
+
+def test_mixer_exchange_between_handles(pkg, built):
+    """The mixer exchange of include/airband_hip.h at the library boundary, on one GPU: the dongles of a 12-dongle fleet on two handles (5 + 7, the way the
+    shim or `bench.py --gpus 2` shards them), every handle summing its own inputs of the three mixers -- one handle has NO input of mixer 2, and none with a
+    balance for the stereo mixer 1 (airband_hip_mixer_set_stereo) -- then (a) airband_hip_add_mixers, the same-GPU transport, against the one-handle sums,
+    (b) the RCCL entry points (librccl loaded on first use, communicator of one rank from a unique id, airband_hip_allreduce_mixers on the handle's stream
+    and on a caller's): with one rank the all-reduce must leave the sums as they are."""
+    import torch
+    n_dev, n_batches, wave_rate, split = 12, 5, 8000, 5
+    devices, carriers = helpers.plan_devices(n_dev, False)
+    nbytes = helpers.stream_bytes(n_batches, wave_rate)
+    iq = [pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)]
+    conns = [(d, 0, 0, 1.0, 0.0) for d in range(n_dev)] + [(8, 2, 1, 1.5, -0.5), (2, 3, 1, 1.0, 0.0), (10, 2, 1, 0.5, 0.25)] + [(1, 5, 2, 2.0, 0.0), (3, 6, 2, 1.0, 0.0)]
+    parts = [(0, split), (split, n_dev)]
+    with pkg.AirbandHip(devices, wave_rate=wave_rate) as whole, pkg.AirbandHip(devices[:split], wave_rate=wave_rate) as a, pkg.AirbandHip(devices[split:], wave_rate=wave_rate) as b:
+        whole.set_mixers(3, conns)
+        for h, (lo, hi) in zip((a, b), parts):
+            h.set_mixers(3, [(d - lo, c, m, amp, bal) for (d, c, m, amp, bal) in conns if lo <= d < hi])
+            h.mixer_set_stereo(1, True)   # part a holds only the mono input of the stereo mixer
+        uid = pkg.AirbandHip.comm_unique_id()
+        whole.comm_init_rank(uid, 1, 0)
+        side = torch.cuda.Stream()
+        pos = [0] * n_dev
+        opened = 0
+        for k in range(n_batches):
+            for d in range(n_dev):
+                h, lo = (a, 0) if d < split else (b, split)
+                n = whole.submit(d, iq[d][pos[d]:])
+                assert h.submit(d - lo, iq[d][pos[d]:pos[d] + n]) == n
+                pos[d] += n
+            assert a.batch_ready() and b.batch_ready()
+            assert whole.process() and a.process() and b.process()
+            want_l, want_r, want_s = whole.collect_mixers()
+            whole.allreduce_mixers(side.cuda_stream if k % 2 else 0)   # one rank: identity, on either stream
+            got = whole.collect_mixers()
+            assert np.array_equal(got[0].view(np.uint32), want_l.view(np.uint32)) and np.array_equal(got[1].view(np.uint32), want_r.view(np.uint32)) and np.array_equal(got[2], want_s)
+            a.add_mixers(b)
+            l, r, s = a.collect_mixers()
+            assert np.array_equal(s, want_s)
+            assert np.array_equal(l[2].view(np.uint32), want_l[2].view(np.uint32))          # both inputs in part a: the same additions
+            assert np.array_equal(l[1].view(np.uint32), want_l[1].view(np.uint32)) or helpers.rms(l[1] - want_l[1]) <= 1e-6   # connection order (8, 2, 10) vs part order (2 | 8, 10)
+            assert helpers.rms(l[0] - want_l[0]) <= 1e-6 * max(1.0, helpers.rms(want_l[0])) and helpers.rms(r[1] - want_r[1]) <= 1e-6
+            assert np.abs(want_r[1]).max() > 0 or not want_s[1]
+            opened += int(want_s.sum())
+        assert opened > 0
+        assert not a.batch_ready()
 
 
 @pytest.mark.parametrize("mixed,wave_rate,n_dev", [(True, 16000, 36), (False, 8000, 20)], ids=["nfm_build", "am_build"])

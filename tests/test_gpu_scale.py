@@ -88,9 +88,24 @@ def test_sampled_dongles_of_large_handles(pkg, built, n_dev, mixed, wave_rate, k
         span = lead + (RING + 1) * g.batch_bytes + g.lookahead_bytes
         stride = (span + 255) // 256 * 256
         iq = _resident_iq(torch, n_dev * stride)[:n_dev * stride].view(n_dev, stride)
-        hip.set_signal_plan(carriers)
-        hip.generate_iq(iq.data_ptr(), stride, 0, span, seed=0x5EED)
-        hip.synchronize()
+        if path != "f32":
+            hip.set_signal_plan(carriers)
+            hip.generate_iq(iq.data_ptr(), stride, 0, span, seed=0x5EED)
+            hip.synchronize()
+        else:  # the generator emits u8: a u8 handle generates slab by slab, (b - 127.5) / 127.5 makes CF32 of it (what bench.py --sample-format f32 does)
+            slab = 512
+            gen = pkg.AirbandHip([dict(channels=chans)] * slab, wave_rate=wave_rate)
+            gen.set_signal_plan(carriers)
+            tmp = torch.empty((slab, span // 4), dtype=torch.uint8, device="cuda")
+            iqf = iq.view(torch.float32)
+            for d0 in range(0, n_dev, slab):
+                n = min(slab, n_dev - d0)
+                gen.generate_iq(tmp.data_ptr(), span // 4, 0, span // 4, seed=0x5EED, device_index_offset=d0)
+                gen.synchronize()
+                iqf[d0:d0 + n, :span // 4] = (tmp[:n].to(torch.float32) - 127.5) / 127.5
+            gen.close()
+            del tmp
+            torch.cuda.synchronize()
         host = {d: iq[d].cpu().numpy() for d in dongles}
         # the on-device generator is the host generator, also at the far end of the handle
         last = dongles[-1]

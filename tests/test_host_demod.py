@@ -144,7 +144,7 @@ def test_kernel_source_on_the_host_equals_the_oracle(hostdemod, variant, style):
         for d in range(n_dev):
             for j in range(len(chans)):
                 o = orc.stats(d, j)
-                for f in ("noise_level", "signal_level", "squelch_level", "agcavgfast", "open_count", "flappy_count", "active_counter", "squelch_state"):
+                for f in ("noise_level", "signal_level", "squelch_level", "agcavgfast", "open_count", "flappy_count", "active_counter", "squelch_state", "signal_outside_filter"):
                     assert o[f] == st[k][f], (d, j, f, o[f], st[k][f])
                 k += 1
     finally:
@@ -262,6 +262,10 @@ def test_opening_timer_expires_on_the_first_sample_of_a_batch_with_the_post_filt
             assert np.array_equal(got_t, want_t), "batch %d: squelch trace (channels %s)" % (b, np.nonzero((got_t != want_t).any(axis=1))[0])
             assert np.array_equal(got_a, want_a)
             assert np.array_equal(got_w.view(np.uint32), want_w.view(np.uint32))
+            st = hd.stats()
+            for q in range(n_dev * 8):  # the TUI's '~' (Squelch::signal_outside_filter) reads the same delay-line entry
+                o = orc.stats(q // 8, q % 8)
+                assert (st[q]["signal_outside_filter"], st[q]["squelch_state"]) == (o["signal_outside_filter"], o["squelch_state"]), (b, q)
         assert orc.stats(0, 0)["squelch_level"] == level
         assert 4 in outcomes, "no channel went OPEN at the boundary: the streams no longer exercise the case (%s)" % outcomes
     finally:

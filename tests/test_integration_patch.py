@@ -22,7 +22,7 @@ def test_patch_applies_cleanly_to_the_reference(tmp_path):
     body = open(os.path.join(ROOT, "integration", "airband_hip.patch")).read()
     added = [ln for ln in body.splitlines() if ln.startswith("+") and not ln.startswith("+++")]
     touched = sorted(set(re.findall(r"^\+\+\+ b/src/(\S+)", body, re.M)))
-    assert touched == ["CMakeLists.txt", "config.cpp", "config.h.in", "rtl_airband.cpp", "rtl_airband.h", "squelch.cpp", "squelch.h"]
+    assert touched == ["CMakeLists.txt", "config.cpp", "config.h.in", "mixer.cpp", "rtl_airband.cpp", "rtl_airband.h", "squelch.cpp", "squelch.h"]
     assert len(added) <= 100, len(added)
 
 
