@@ -281,7 +281,9 @@ def measure_traffic(args, kernel_substr):
                 if len(v) >= 2:
                     per_kernel.setdefault(short, {})[counter.lower() + "_bytes"] = sum(v[1:]) / (len(v) - 1) * mult
             if len(vals) < 2:
-                return None, dict(error="%s: %d launches of %s seen" % (counter, len(vals), kernel_substr))
+                detail["error"] = "%s: %d launches of %s seen" % (counter, len(vals), kernel_substr)
+                detail.setdefault(counter + "_child", dict(returncode=child.returncode, stderr_tail=child.stderr.decode(errors="replace")[-600:]))
+                return None, detail
             per = sum(vals[1:]) / (len(vals) - 1) * mult
             detail[counter.lower() + "_bytes"] = per
             total += per
@@ -670,7 +672,11 @@ def main():
             if torch.cuda.mem_get_info()[0] >= need_free:
                 break
             time.sleep(0.5)
+        waited = round(time.time() - t_wait, 1)
         traffic, detail = measure_traffic(args, CHANNELIZER_KERNEL.get(name, name))
+        if isinstance(detail, dict):
+            detail["waited_for_free_memory_s"] = waited
+            detail["free_bytes_before_children"] = int(torch.cuda.mem_get_info()[0])
         out["roofline"]["traffic"] = traffic
         out["roofline"]["traffic_detail"] = detail
         kt = detail.pop("rocprof_kernel_trace", None) if isinstance(detail, dict) else None

@@ -205,8 +205,9 @@ static void hip_check(airband_hip_handle* h, int rc, const char* what) {
 // Mixers whose inputs ALL come from channels of this class are served on the GPUs (mixer_connect_input(), mixer.cpp:57-94, has
 // recorded ampfactor / ampl / ampr per input; the connection order inside a mixer is its input index, which is also the order
 // mix_waveforms() adds them in, mixer.cpp:189-214).  Any other mixer stays with mixer_thread().
-static void wire_mixers(hip_class& c, int device_start, int device_end) {
-    struct conn { int part, dev_in_part, chan, input; };
+struct mixer_conn { int part, dev_in_part, chan, input; };
+typedef mixer_conn conn;
+static void wire_mixers(hip_class& c, int device_start, int device_end, bool mark_only) {
     std::vector<std::vector<conn> > per_mixer(mixer_count);
     std::vector<char> foreign(mixer_count, 0);
     std::vector<int> part_of(device_count, -1), idx_in_part(device_count, -1);
@@ -233,10 +234,16 @@ static void wire_mixers(hip_class& c, int device_start, int device_end) {
             }
         }
     }
-    for (int m = 0; m < mixer_count; m++) {
-        if (!mixers[m].enabled || foreign[m] || per_mixer[m].empty() || (int)per_mixer[m].size() != mixers[m].input_count) continue;
-        served_mixer s = {m};
-        c.served.push_back(s);
+    if (mark_only) {
+        // first thing, before the handles are built (which takes a while): from here on mixer_thread() and mixer_put_samples() leave these mixers
+        // alone -- a mixer_thread() that still saw them would emit an (empty) batch every third interval (mixer.cpp:225-248)
+        for (int m = 0; m < mixer_count; m++) {
+            if (!mixers[m].enabled || foreign[m] || per_mixer[m].empty() || (int)per_mixer[m].size() != mixers[m].input_count) continue;
+            served_mixer s = {m};
+            c.served.push_back(s);
+            mixers[m].gpu_served = true;
+        }
+        return;
     }
     if (c.served.empty()) return;
     const int S = (int)c.served.size();
@@ -263,7 +270,6 @@ static void wire_mixers(hip_class& c, int device_start, int device_end) {
         for (int s = 0; s < S; s++)
             if (mixers[c.served[s].mixer].channel.mode == MM_STEREO) hip_check(c.parts[p].h, airband_hip_mixer_set_stereo(c.parts[p].h, s, 1), "mixer_set_stereo");
     }
-    for (int s = 0; s < S; s++) mixers[c.served[s].mixer].gpu_served = true;
     c.mix_left.resize((size_t)S * WAVE_BATCH);
     c.mix_right.resize((size_t)S * WAVE_BATCH);
     c.mix_signal.resize(S);
@@ -446,8 +452,9 @@ void* demodulate_hip(void* params) {
             part.devs.assign(cls.devs.begin() + first[g], cls.devs.begin() + first[g + 1]);
             cls.parts.push_back(part);
         }
+        wire_mixers(cls, dp->device_start, dp->device_end, true);
         for (size_t p = 0; p < cls.parts.size(); p++) prepare_part(cls.parts[p]);
-        wire_mixers(cls, dp->device_start, dp->device_end);
+        wire_mixers(cls, dp->device_start, dp->device_end, false);
         if (cls.parts.size() > max_parts) max_parts = cls.parts.size();
     }
     hip_pool pool;

@@ -105,10 +105,10 @@ class SpotCheck:
         return worst
 
 
-# airband_hip_channel_stats as a numpy record (include/airband_hip.h:141-153): 4 floats, 5 uint64, 2 int32 = 64 bytes
+# airband_hip_channel_stats as a numpy record (include/airband_hip.h): 4 floats, 5 uint64, 4 int32 = 72 bytes (ABI 2)
 STATS_DT = np.dtype([("noise_level", "<f4"), ("signal_level", "<f4"), ("squelch_level", "<f4"), ("agcavgfast", "<f4"), ("open_count", "<u8"),
-                     ("flappy_count", "<u8"), ("ctcss_count", "<u8"), ("no_ctcss_count", "<u8"), ("active_counter", "<u8"), ("bin", "<i4"), ("squelch_state", "<i4")])
-assert STATS_DT.itemsize == 64
+                     ("flappy_count", "<u8"), ("ctcss_count", "<u8"), ("no_ctcss_count", "<u8"), ("active_counter", "<u8"), ("bin", "<i4"), ("squelch_state", "<i4"), ("signal_outside_filter", "<i4"), ("reserved", "<i4")])
+assert STATS_DT.itemsize == 72
 
 
 def replica_check(hip, n_dev: int, n_ch: int, *, trace: bool = True, chunk: int = 2048) -> Dict[str, int]:
@@ -134,12 +134,12 @@ def replica_check(hip, n_dev: int, n_ch: int, *, trace: bool = True, chunk: int 
             rc = L.airband_hip_read_trace_channels(hip.h, d0 * n_ch, n * n_ch, tr.ctypes.data)
             assert rc == 0, rc
         if ref is None:
-            ref = dict(wave=wave[:n_ch].view(np.uint32).copy(), axc=axc[:n_ch].copy(), st=st[:n_ch].copy().view(np.uint8).reshape(n_ch, 64),
+            ref = dict(wave=wave[:n_ch].view(np.uint32).copy(), axc=axc[:n_ch].copy(), st=st[:n_ch].copy().view(np.uint8).reshape(n_ch, STATS_DT.itemsize),
                        tr=tr[:n_ch].copy() if trace else None)
         diff = {
             "waveout": (wave[:n * n_ch].view(np.uint32).reshape(n, n_ch, B) != ref["wave"]).any(axis=(1, 2)),
             "axc": (axc[:n * n_ch].reshape(n, n_ch) != ref["axc"]).any(axis=1),
-            "stats": (st[:n * n_ch].view(np.uint8).reshape(n, n_ch, 64) != ref["st"]).any(axis=(1, 2)),
+            "stats": (st[:n * n_ch].view(np.uint8).reshape(n, n_ch, STATS_DT.itemsize) != ref["st"]).any(axis=(1, 2)),
         }
         if trace:
             diff["trace"] = (tr[:n * n_ch].reshape(n, n_ch, B) != ref["tr"]).any(axis=(1, 2))

@@ -10,7 +10,7 @@
  *
  * Exactness: bytes enter as int8 (b - 128, one XOR); the coefficient table is quantised to a 24-bit fixed point
  * number split into three balanced base-256 digits, so each v_mfma_i32_16x16x64_i8 accumulates EXACT integers
- * (|acc| <= 2^24); the three partial sums are recombined in float64 and the (b-127.5) offset of the reference's
+ * (|acc| <= 2^24, exact as floats); the three partial sums are recombined with three f32 FMAs and the (b-127.5) offset of the reference's
  * LUT is restored with a per-column constant.  Result = the exact DFT with coefficients rounded at 2^-24 of full
  * scale -- the same class of error as a float FFT (~1e-7 relative), no accumulation round-off at all.
  *
@@ -22,7 +22,7 @@
  *   A (16 hops x 64 bytes per MFMA): lane l reads the 16 consecutive stream bytes at hop (l&15), k-chunk (l>>4)
  *     of the current 64-byte step straight from an LDS copy of the raw stream (ds_read_b128); consecutive
  *     hops overlap, so every HBM byte is fetched once (16 B/lane coalesced) and re-used N/hop times from LDS.
- *   B (64 x 16 per MFMA, 3 digits x 16 steps): 192 VGPRs, loaded once per wave from a per-bin-set table.
+ *   B (64 x 16 per MFMA, 3 digits x 16 steps, all-zero edge digits dropped: 44 fragments): 176 VGPRs, loaded once per wave from a per-bin-set table.
  *   D: lane l holds column (l&15) = (channel, re|im) of hops (l>>4)*4 + {0..3}; |bin| needs the neighbour lane.
  */
 #include <hip/hip_runtime.h>
@@ -109,8 +109,18 @@ __device__ __forceinline__ v4i lds_read16(const uint8_t* p) {
         const v2i lo = *reinterpret_cast<const v2i*>(p), hi = *reinterpret_cast<const v2i*>(p + 8);
         return (v4i){lo.x, lo.y, hi.x, hi.y};
     }
-    const int* q = reinterpret_cast<const int*>(p);
-    return (v4i){q[0], q[1], q[2], q[3]};
+    if (AL == 4) {
+        const int* q = reinterpret_cast<const int*>(p);
+        return (v4i){q[0], q[1], q[2], q[3]};
+    }
+    /* AL == 2: any even address (u8 / s8 hops of an odd number of samples: 2.0 MS/s at WAVE_RATE 16000 is 125 samples = 250 bytes).  The five
+     * aligned dwords that hold the 16 bytes, funnelled through v_alignbyte_b32 with the lane's own byte offset (0 or 2): 5 LDS reads + 4 vector
+     * instructions per fragment where the aligned variants need one read.  The last dword's upper bytes lie past the fragment and are shifted out. */
+    const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);
+    const int* q = reinterpret_cast<const int*>(p - sh); /* (pointer arithmetic, not an integer round trip: the compiler must keep seeing an LDS address -- a flat load would also count in vmcnt) */
+    const unsigned d0 = (unsigned)q[0], d1 = (unsigned)q[1], d2 = (unsigned)q[2], d3 = (unsigned)q[3], d4 = (unsigned)q[4];
+    return (v4i){(int)__builtin_amdgcn_alignbyte(d1, d0, sh), (int)__builtin_amdgcn_alignbyte(d2, d1, sh), (int)__builtin_amdgcn_alignbyte(d3, d2, sh),
+                 (int)__builtin_amdgcn_alignbyte(d4, d3, sh)};
 }
 
 /* NP: window pieces of FFT_N samples = wavefronts per workgroup.  fft_size 1024 / 2048:
@@ -164,7 +174,13 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
     const int shift = (a.row0 + a.first_row) & 15;
     /* hops that are not multiples of 16 bytes: a step's first byte sits `delta` bytes into its (16-byte aligned) LDS image; a step
      * advances by 16 hops, so delta is the same for every step of the wave */
-    const int delta = AL >= 16 ? 0 : (int)((-(long)shift * (HOPB ? HOPB : a.hop_bytes)) & 15);
+    const uint8_t* src = a.iq + (long)d * a.iq_stride + (long)a.piece0 * WIN_BYTES;    /* first byte this pass reads of the batch's first hop */
+    /* Hops that are not multiples of 16 bytes: a batch of such hops need not START on a 16-byte boundary either (250-byte hops: the second batch of a
+     * stream begins 2 100 hops = 525 000 bytes in).  The transfers move aligned 16-byte pieces, so the stream is addressed from the aligned byte at or
+     * in front of its first one and every position below carries the `mis` bytes in between. */
+    const int mis = AL >= 16 ? 0 : (int)(reinterpret_cast<uintptr_t>(src) & 15u);
+    src -= mis;
+    const int delta = AL >= 16 ? 0 : (int)((-(long)shift * (HOPB ? HOPB : a.hop_bytes) + mis) & 15);
     const int ring_tiles = a.ring_rows / AB_TILE_ROWS;
     const int ring_tiles16 = a.ring_rows / TILE_HOPS; /* the ring length is a whole number of 16-hop MFMA tiles */
     const int ptile0 = (a.row0 + a.first_row) >> 4;
@@ -175,11 +191,11 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
     const int st_end = min(steps_total, st_begin + steps_per_split);
     if (st_begin >= st_end) return;
 
-    const uint8_t* src = a.iq + (long)d * a.iq_stride + (long)a.piece0 * WIN_BYTES;    /* first byte this pass reads of the batch's first hop */
+
     /* bytes of the batch span that may be read, rounded up to whole 16-byte pieces (geometry.lookahead_bytes includes the round-up).
      * fft_size 8192 runs as two passes of 8 window pieces (a.piece0 = 0, 8): a pass streams the part of every window that starts
      * piece0 pieces in, so its addresses are relative to that byte and the readable span is what is left of the window behind it */
-    const long span_end = ((long)(a.n_hops - 1) * hop_bytes + (long)(a.np_total - a.piece0) * WIN_BYTES + 15) & ~15L;
+    const long span_end = ((long)(a.n_hops - 1) * hop_bytes + (long)(a.np_total - a.piece0) * WIN_BYTES + mis + 15) & ~15L;
 
     /* ---- B fragments: 3 digits x 16 k-steps, resident for the whole wave ---------------------------------- */
     /* fft_size > 512: each window piece has its own coefficient table */
@@ -216,7 +232,7 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int n_dma = (buf_bytes + 1023) >> 10;
     auto stage = [&](int step, uint8_t* buf) {
-        const long base = ((long)step * step_hops - shift) * hop_bytes;
+        const long base = ((long)step * step_hops - shift) * hop_bytes + mis;
         if (HOPB && base >= 0 && base + (long)n_dma * 1024 <= span_end) {
             /* interior step (wave-uniform test): every piece lies inside the batch span, so no lane needs its address clamped -- one
              * 64-bit add per step, the pieces differ only in the instruction's immediate offset, which moves the global source and
@@ -426,11 +442,11 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
         /* steps whose transfer lies wholly inside the batch span (no lane's address needs clamping), as a range worked out once: the per-step
          * test is two scalar compares and the source address one multiply-add */
         const int st_in_lo = shift > 0 ? 1 : 0;
-        const long in_room = span_end - (long)n_dma * 1024;
+        const long in_room = span_end - (long)n_dma * 1024 - (AL >= 16 ? 0 : 16); /* (hops that are not multiples of 16 bytes: an image starts up to 15 bytes off the step's first hop) */
         const int st_in_hi = __builtin_amdgcn_readfirstlane(in_room < 0 ? -1 : (int)((in_room / hop_bytes + shift) / TILE_HOPS)); /* (the same number on every lane: keep it scalar) */
         /* step st's image starts at p_lane + st * 16 hops; hops that are not multiples of 16 bytes: `delta` bytes in front of the step's first hop, the same
          * for every step (a step is 16 hops), so that every transfer is 16-byte aligned -- the interior test stays valid, it only gets more cautious */
-        const uint8_t* const p_lane = src - (long)shift * hop_bytes - delta + lane * 16;
+        const uint8_t* const p_lane = src + mis - (long)shift * hop_bytes - delta + lane * 16;
         const int step_bytes = TILE_HOPS * hop_bytes;
         auto stage_fast = [&](int step, uint8_t* buf) {
             if (step >= st_in_lo && step <= st_in_hi) {
@@ -541,9 +557,9 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
 bool dft_supported(int fft_size, int hop_bytes, int sfmt, int max_ch) {
     (void)max_ch; /* any channel count: dongles with more than 8 channels are split into groups of 8 */
     if (fft_size < 256 || fft_size > 8192 || (fft_size & (fft_size - 1))) return false; /* >= 1024: window pieces of 512 samples, one wave each (8192: two passes of eight) */
-    /* hops must start on 4-byte boundaries (even hop_samples for u8: 2.4 MS/s -> 300 / 600 bytes); two staging buffers of 16 hops +
-     * one window must leave room for 3+ waves per CU */
-    if (sfmt == AIRBAND_SFMT_U8 || sfmt == AIRBAND_SFMT_S8) return (hop_bytes % 4) == 0 && hop_bytes <= 1024 && hop_bytes >= 64;
+    /* u8 / s8: any hop (2.4 MS/s -> 300 / 600 bytes at 4- / 8-byte alignment, 2.0 MS/s at WAVE_RATE 16000 -> 250 bytes at 2-byte alignment: the AL
+     * variants of the A-fragment reads); two staging buffers of 16 hops + one window must leave room for 3+ waves per CU */
+    if (sfmt == AIRBAND_SFMT_U8 || sfmt == AIRBAND_SFMT_S8) return (hop_bytes % 2) == 0 && hop_bytes <= 1024 && hop_bytes >= 64; /* (a hop is whole I/Q pairs: always even) */
     if (sfmt == AIRBAND_SFMT_S16) return (hop_bytes % 4) == 0 && hop_bytes <= 1280 && hop_bytes >= 128;
     return false;
 }
@@ -575,7 +591,8 @@ template <int FFT_N, bool S16, int NP = 1>
 static void launch_generic(const DftArgs& a, hipStream_t stream) {
     if ((a.hop_bytes & 15) == 0) return launch_al<FFT_N, 0, S16, 16, NP>(a, stream);
     if ((a.hop_bytes & 7) == 0) return launch_al<FFT_N, 0, S16, 8, NP>(a, stream);
-    launch_al<FFT_N, 0, S16, 4, NP>(a, stream);
+    if ((a.hop_bytes & 3) == 0) return launch_al<FFT_N, 0, S16, 4, NP>(a, stream);
+    if constexpr (!S16) launch_al<FFT_N, 0, false, 2, NP>(a, stream); /* u8 / s8 hops of an odd number of samples (CS16 hops are multiples of 4 bytes) */
 }
 
 static void launch_one_piece(const DftArgs& a, hipStream_t stream);

@@ -271,12 +271,13 @@ __global__ __launch_bounds__(256) void retune_kernel(RetuneArgs a) {
     const DevConst dev = a.dev[d];
     const int N = a.fft_size, NP = N > 512 ? N / 512 : 1, NS = N / NP, K = 2 * NS, KS = K / 64;
     const size_t piece_bytes = (size_t)3 * KS * 64 * 16;
-    int my_bin = -1;
+    int my_bin = -1, my_base = -2;
     bool my_away = false, my_stale = false;
     if (lane < 8 && g * 8 + lane < dev.n_ch) {
         const int slot = a.ext_to_slot[dev.chan_base + g * 8 + lane];
         my_bin = a.cs[slot].bin;
-        my_away = my_bin != a.cc[slot].base_bin;
+        my_base = a.cc[slot].base_bin;
+        my_away = my_bin != my_base;
         my_stale = a.bset_bin[bset * 8 + lane] != my_bin;
     }
     const bool away = __ballot(my_away) != 0ull; /* some channel of the group is off its base bin */
@@ -284,6 +285,31 @@ __global__ __launch_bounds__(256) void retune_kernel(RetuneArgs a) {
     for (int c = 0; c < 8; c++) {
         if (!((stale >> c) & 1u)) continue; /* wave-uniform */
         const int bin = __shfl(my_bin, c);
+        /* a channel on its base bin takes its column pair from the group's HOME table, byte for byte: the host built that one (cos / sin / llround of the
+         * platform's libm, params.cpp), this kernel builds with the device's sincospi, and a coefficient may differ by one unit between the two -- a
+         * channel that has not moved must not see a different table because a neighbour's AFC has (its bins would change by ~1e-7) */
+        if (bin == __shfl(my_base, c)) {
+            const int home = a.item_home[item];
+            for (int piece = 0; piece < NP; piece++) {
+                int8_t* tab = a.bfrag + ((size_t)bset * NP + piece) * piece_bytes;
+                const int8_t* src = a.bfrag + ((size_t)home * NP + piece) * piece_bytes;
+                for (int k = lane; k < K; k += 64) {
+                    const int s_ = k / 64, gg = (k % 64) / 16, jj = k % 16;
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        const int ln = gg * 16 + 2 * c + half;
+#pragma unroll
+                        for (int t = 0; t < 3; t++) {
+                            const size_t at = (((size_t)t * KS + s_) * 64 + ln) * 16 + jj;
+                            tab[at] = src[at];
+                        }
+                    }
+                }
+                if (lane < 2) a.corr[((size_t)bset * NP + piece) * 16 + 2 * c + lane] = a.corr[((size_t)home * NP + piece) * 16 + 2 * c + lane];
+            }
+            if (lane == 0) a.bset_bin[bset * 8 + c] = bin;
+            continue;
+        }
         for (int piece = 0; piece < NP; piece++) {
             if (lane < 2) sums[wave][lane] = 0;
             __builtin_amdgcn_wave_barrier();

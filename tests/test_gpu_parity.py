@@ -190,6 +190,42 @@ def test_zero_copy_device_path_matches_host_ring_path(pkg, built):
             off += g.first_batch_bytes if k == 0 else g.batch_bytes
 
 
+def test_zero_copy_spans_that_do_not_start_on_16_bytes(pkg, built):
+    """Hops of 250 bytes (2.0 MS/s at WAVE_RATE 16000): from the second batch on a zero-copy span starts 8 bytes off a 16-byte boundary (2 100 hops = 525 000
+    bytes) and the dongles' rows are 2 bytes apart in alignment -- the matrix-core channelizer stages aligned pieces from the byte in front of the span.
+    process_device on such spans == submit / process on the same bytes (whose staging buffer is aligned), bit for bit."""
+    torch = pytest.importorskip("torch")
+    capi = pkg.capi
+    n_dev, n_batches, wave_rate, sr = 3, 4, 16000, 2_000_000
+    devices, iq = helpers.format_case(pkg, capi.SFMT_U8, 9, sr, wave_rate, n_dev, n_batches)
+    n = min(len(x) for x in iq)
+    stride = (n + 2 + 255) // 256 * 256 + 2   # rows that differ in alignment by 2 bytes
+    host = np.zeros((n_dev, stride), np.uint8)
+    for d in range(n_dev):
+        host[d, :n] = iq[d][:n]
+    with pkg.AirbandHip(devices, wave_rate=wave_rate) as a, pkg.AirbandHip(devices, wave_rate=wave_rate) as b:
+        assert a.channelizer_name() == b.channelizer_name() == "dft_mfma_i8"
+        g = a.geometry
+        assert g.batch_bytes == 250 * 2000 and g.first_batch_bytes % 16 == 8
+        dbuf = torch.from_numpy(host).cuda()
+        off = 0
+        opened = 0
+        for k in range(n_batches):
+            take = (g.first_batch_bytes + g.lookahead_bytes) if k == 0 else g.batch_bytes
+            lo = off if k == 0 else off + g.lookahead_bytes
+            for d in range(n_dev):
+                assert a.submit(d, host[d, lo:lo + take]) == take
+            assert a.process()
+            ra = a.collect()
+            b.process_device(dbuf.data_ptr() + off, stride)
+            rb = b.collect()
+            assert np.array_equal(ra["waveout"].view(np.uint32), rb["waveout"].view(np.uint32)), k
+            assert np.array_equal(ra["axc"], rb["axc"])
+            opened += int((rb["axc"] == ord("*")).sum())
+            off += g.first_batch_bytes if k == 0 else g.batch_bytes
+        assert opened > 0
+
+
 def test_collect_waits_for_a_batch_enqueued_on_the_callers_stream(pkg, built):
     """process_device(..., stream=S) runs the whole batch on S; collect / collect_channels / read_trace / collect_mixers issue
     their copies on the handle's own stream and must order themselves behind S on the GPU.  S is kept busy with a long
@@ -544,11 +580,13 @@ def test_ragged_shapes_and_empty_inputs(pkg, built):
     ("SFMT_S16", 9, 2_400_000, 16000), ("SFMT_U8", 9, 3_200_000, 8000),
     ("SFMT_U8", 10, 2_400_000, 16000), ("SFMT_U8", 11, 2_560_000, 8000), ("SFMT_U8", 10, 1_024_000, 16000),
     ("SFMT_S16", 10, 2_560_000, 16000), ("SFMT_S16", 11, 2_400_000, 8000),
-    ("SFMT_U8", 12, 2_560_000, 16000), ("SFMT_U8", 13, 2_560_000, 8000), ("SFMT_S8", 10, 2_400_000, 16000), ("SFMT_S8", 12, 2_560_000, 8000), ("SFMT_S16", 12, 2_400_000, 16000)])
+    ("SFMT_U8", 12, 2_560_000, 16000), ("SFMT_U8", 13, 2_560_000, 8000), ("SFMT_S8", 10, 2_400_000, 16000), ("SFMT_S8", 12, 2_560_000, 8000), ("SFMT_S16", 12, 2_400_000, 16000),
+    # hops of an odd number of samples (250 / 250 / 150 bytes at 2-byte alignment): u8 and s8 on the matrix-core path since round 4
+    ("SFMT_U8", 9, 2_000_000, 16000), ("SFMT_S8", 10, 2_000_000, 16000), ("SFMT_U8", 8, 1_200_000, 16000), ("SFMT_U8", 11, 2_000_000, 16000)])
 def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sample_rate, wave_rate):
     """Sample formats s8/s16/f32, fft sizes 256..8192, sample rates whose hop is not a multiple of 16 bytes: the matrix-core path
-    takes u8, s8 and CS16 at every fft size (window pieces of 512 samples on cooperating waves from 1024 up, two passes at 8192); f32 and
-    hops that are not multiples of 4 bytes run on the wavefront-FFT channelizer -- same parity bars either way."""
+    takes u8, s8 and CS16 at every fft size and every hop (window pieces of 512 samples on cooperating waves from 1024 up, two passes at 8192; hops of an
+    odd number of samples through 2-byte-aligned fragment reads); f32 runs on the wavefront-FFT channelizer -- same parity bars either way."""
     capi = pkg.capi
     sfmt = getattr(capi, sfmt_name)
     n_dev, n_batches = 2, 7
@@ -560,7 +598,7 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
     opened = 0
     with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=capi.FLAG_TRACE_SQUELCH) as hip:
         hop_bytes = 2 * hop * capi.BYTES_PER_SAMPLE[sfmt]
-        expect_dft = hop_bytes % 4 == 0 and ((sfmt in (capi.SFMT_U8, capi.SFMT_S8) and 64 <= hop_bytes <= 1024) or (sfmt == capi.SFMT_S16 and 128 <= hop_bytes <= 1280))
+        expect_dft = (sfmt in (capi.SFMT_U8, capi.SFMT_S8) and 64 <= hop_bytes <= 1024) or (sfmt == capi.SFMT_S16 and hop_bytes % 4 == 0 and 128 <= hop_bytes <= 1280)
         assert hip.channelizer_name() == ("dft_mfma_i8" if expect_dft else "fft_wave64")
         pos = [0] * n_dev
         for b in range(n_batches):
@@ -695,6 +733,33 @@ def test_afc(pkg, built, force_fft):
             for j in range(8):
                 assert out["stats"][k]["bin"] == orc.stats(d, j)["bin"], (d, j)
                 k += 1
+    assert moved > 0
+
+
+def test_unmoved_channels_do_not_see_a_neighbours_afc(pkg, built):
+    """Matrix-core channelizer: a group goes onto its private coefficient table while one of its channels is away from its base bin.  The columns of
+    the channels that have NOT moved are the home table's, byte for byte (retune_kernel copies them): their stage-1 bins are bit-identical to those of a
+    fleet in which nobody has AFC."""
+    n_batches = 10
+    devices, carriers = helpers.afc_case(1)
+    plain = [dict(channels=[dict(c, afc=0) for c in devices[0]["channels"]])]
+    iq = pkg.siggen.generate_u8(0, 0, helpers.stream_bytes(n_batches, 8000) // 2, carriers)
+    still = [j for j, c in enumerate(devices[0]["channels"]) if c["afc"] == 0]
+    assert len(still) == 2
+    moved = 0
+    with pkg.AirbandHip(devices, wave_rate=8000) as a, pkg.AirbandHip(plain, wave_rate=8000) as b:
+        assert a.channelizer_name() == b.channelizer_name() == "dft_mfma_i8"
+        pa = pb = 0
+        for k in range(n_batches):
+            pa += a.submit(0, iq[pa:])
+            pb += b.submit(0, iq[pb:])
+            assert a.process() and b.process()
+            out = a.collect()
+            moved += int(((out["axc"] == ord("<")) | (out["axc"] == ord(">"))).sum())
+            wa, _ = a.read_bins()
+            wb, _ = b.read_bins()
+            for j in still:
+                assert np.array_equal(wa[j].view(np.uint32), wb[j].view(np.uint32)), (k, j)
     assert moved > 0
 
 
