@@ -658,6 +658,9 @@ def main():
             out["verify_all"] = dict(error="whole-handle check could not run: %r" % (e,))
     need_free = int(iq.numel()) + (24 << 30)  # what a child run of the same workload allocates: the resident I/Q and a handle
     del iq
+    step = offset = None  # (closures over the resident buffer)
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     if use_dist:
         dist.barrier()
@@ -677,6 +680,7 @@ def main():
         if isinstance(detail, dict):
             detail["waited_for_free_memory_s"] = waited
             detail["free_bytes_before_children"] = int(torch.cuda.mem_get_info()[0])
+            detail["torch_allocated_reserved_bytes"] = [int(torch.cuda.memory_allocated()), int(torch.cuda.memory_reserved())]
         out["roofline"]["traffic"] = traffic
         out["roofline"]["traffic_detail"] = detail
         kt = detail.pop("rocprof_kernel_trace", None) if isinstance(detail, dict) else None

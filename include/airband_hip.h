@@ -254,6 +254,10 @@ int airband_hip_batch_ready(airband_hip_handle* h);
  * starts at d_iq + d*stride_bytes and holds at least (first_)batch_bytes + lookahead_bytes bytes:
  * the stream bytes of this batch followed by the bytes the last window overlaps into the next batch
  * (exactly what a tail-replicated ring, src/input-helpers.cpp:43-51, holds at that offset).
+ * Alignment: where a hop is a whole number of 16-byte pieces (2.56 MS/s: 320 / 640 bytes) d_iq and stride_bytes are multiples of 16, and so is every
+ * batch's offset into a stream; for any other hop (2.4 MS/s: 300 bytes, 2.0 MS/s: 250 bytes) they only need to be whole I/Q samples -- the
+ * channelizer then stages aligned pieces from the aligned byte at or in front of the span, i.e. it may READ up to 15 bytes in front of d_iq + d*stride_bytes
+ * (bytes of the same allocation: the tail of the previous batch, or of the previous dongle's row).
  * `stream` is a hipStream_t (NULL = the handle's own stream). */
 int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t stride_bytes, void* stream);
 

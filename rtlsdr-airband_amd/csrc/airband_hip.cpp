@@ -951,8 +951,13 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
 int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t stride_bytes, void* stream) {
     if (!h || !d_iq) return fail(h, AIRBAND_HIP_EINVAL, "NULL argument");
     HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
-    if (h->use_dft && ((((uintptr_t)d_iq) | (uintptr_t)stride_bytes) & 15))
-        return fail(h, AIRBAND_HIP_EINVAL, "d_iq and stride_bytes must be multiples of 16 (the channelizer fetches 16 bytes per lane)");
+    /* hops of whole 16-byte pieces: the channelizer's transfers address the span directly, so it must start on one.  Any other hop (300, 250 bytes ...):
+     * a batch of such hops cannot start on 16 bytes every time anyway (2 100 hops of 250 bytes = 525 000), the kernel stages from the aligned byte in
+     * front of the span and only whole samples are asked for */
+    const uintptr_t need = (h->hop_bytes % 16) == 0 ? 15u : (uintptr_t)(2 * h->plan.dev[0].bytes_per_sample - 1);
+    if (h->use_dft && ((((uintptr_t)d_iq) | (uintptr_t)stride_bytes) & need))
+        return fail(h, AIRBAND_HIP_EINVAL, (h->hop_bytes % 16) == 0 ? "d_iq and stride_bytes must be multiples of 16 (the channelizer fetches 16 bytes per lane)"
+                                                                    : "d_iq and stride_bytes must be multiples of one I/Q sample");
     if (!h->pipeline) {
         hipStream_t s = stream ? (hipStream_t)stream : h->stream;
         h->last_stream = s;

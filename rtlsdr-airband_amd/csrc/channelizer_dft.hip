@@ -30,6 +30,13 @@
 #include "common.h"
 #include "kernels.h"
 
+/* Ablation switches (experiment builds only, AIRBAND_EXTRA_DEFINES: the results are WRONG by construction, only the launch time is of interest --
+ * profiles/r04_experiments.md): what the kernel costs without its HBM reads (AB_ABL_NO_DMA), without the matrix pipe (AB_ABL_NO_MFMA), without its
+ * output stores (AB_ABL_NO_STORE), without the A-fragment reads from LDS (AB_ABL_NO_LDS). */
+#if defined(AB_ABL_NO_DMA) || defined(AB_ABL_NO_MFMA) || defined(AB_ABL_NO_STORE) || defined(AB_ABL_NO_LDS)
+#define AB_ABLATION 1
+#endif
+
 namespace airband {
 
 namespace {
@@ -101,8 +108,23 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 #undef AB_W
 
+__device__ __forceinline__ v4i ab_mfma(v4i x, v4i b, v4i acc) {
+#if defined(AB_ABL_NO_MFMA)
+    asm volatile("" ::"v"(x), "v"(b)); /* the operands stay alive (their loads are not optimised away), the matrix pipe stays idle */
+    acc.x ^= x.x;
+    return acc;
+#else
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b, acc, 0, 0, 0);
+#endif
+}
+
 template <int AL>
 __device__ __forceinline__ v4i lds_read16(const uint8_t* p) {
+#if defined(AB_ABL_NO_LDS)
+    v4i z = {(int)(uintptr_t)p, 1, 2, 3};
+    asm volatile("" : "+v"(z));
+    return z;
+#endif
     if (AL >= 16) return *reinterpret_cast<const v4i*>(p);
     if (AL == 8) {
         typedef int v2i __attribute__((ext_vector_type(2)));
@@ -230,6 +252,11 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
      * the batch span re-read its last 16 bytes: they only feed hops >= n_hops, which are never stored. */
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+#if defined(AB_ABL_NO_DMA)
+#define AB_DMA(G, L, OFF) asm volatile("" ::"v"(G), "v"(L))
+#else
+#define AB_DMA(G, L, OFF) __builtin_amdgcn_global_load_lds((G), (L), 16, (OFF), 0)
+#endif
     const int n_dma = (buf_bytes + 1023) >> 10;
     auto stage = [&](int step, uint8_t* buf) {
         const long base = ((long)step * step_hops - shift) * hop_bytes + mis;
@@ -239,7 +266,7 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
              * the LDS destination alike.  The offset field holds 12 bits: a second base covers the pieces past 4 KiB. */
             const uint8_t* p = src + base + lane * 16;
 #define AB_PIECE(K, BASE, OFF) \
-    if (n_dma > (K)) __builtin_amdgcn_global_load_lds((gptr_t)(p + (BASE)), (lptr_t)(uintptr_t)(buf + (BASE)), 16, (OFF), 0)
+    if (n_dma > (K)) AB_DMA((gptr_t)(p + (BASE)), (lptr_t)(uintptr_t)(buf + (BASE)), (OFF))
             AB_PIECE(0, 0, 0); AB_PIECE(1, 0, 1024); AB_PIECE(2, 0, 2048); AB_PIECE(3, 0, 3072);
             AB_PIECE(4, 4096, 0); AB_PIECE(5, 4096, 1024); AB_PIECE(6, 4096, 2048); AB_PIECE(7, 4096, 3072);
             AB_PIECE(8, 8192, 0); AB_PIECE(9, 8192, 1024); AB_PIECE(10, 8192, 2048); AB_PIECE(11, 8192, 3072);
@@ -251,7 +278,7 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
             long so = base_al + i * 1024 + lane * 16;
             if (so + 16 > span_end) so = span_end - 16;
             if (so < 0) so = 0;
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + so), (lptr_t)(uintptr_t)(buf + i * 1024), 16, 0, 0);
+            AB_DMA((gptr_t)(src + so), (lptr_t)(uintptr_t)(buf + i * 1024), 0);
         }
     };
     /* staging ring of nbuf buffers: step st lives in buffer (st - st_begin) % nbuf; nbuf - 1 steps are in flight */
@@ -321,9 +348,9 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
             }
             v4i x = av[s];
             x.x ^= flipmask; x.y ^= flipmask; x.z ^= flipmask; x.w ^= flipmask; /* u8 -> b - 128 as int8; s8 (mirisdr, SoapySDR CS8) is int8 already: the mask is zero */
-            A.a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b0[s], A.a0, 0, 0, 0);
-            A.a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b1[s], A.a1, 0, 0, 0);
-            if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) A.a2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(x, b2[s], A.a2, 0, 0, 0);
+            A.a0 = ab_mfma(x, b0[s], A.a0);
+            A.a1 = ab_mfma(x, b1[s], A.a1);
+            if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) A.a2 = ab_mfma(x, b2[s], A.a2);
             if (s & 1) __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -407,14 +434,20 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
                     v4f m;
 #pragma unroll
                     for (int r = 0; r < 4; r++) m[r] = __builtin_amdgcn_sqrtf(val[r] * val[r] + im4[r] * im4[r]); /* v_sqrt_f32, 1 ulp: stage 1 is tolerance-bound anyway */
+#if defined(AB_ABL_NO_STORE)
+                    asm volatile("" ::"v"(m));
+#else
                     *reinterpret_cast<v4f*>(mag_lane + toff) = m;
+#endif
                 }
                 if (want_iq) {
                     v4f qa = {val[0], im4[0], val[1], im4[1]}, qb = {val[2], im4[2], val[3], im4[3]};
                     asm volatile("" : "+v"(qa), "+v"(qb));
+#if !defined(AB_ABL_NO_STORE)
                     v4f* q = reinterpret_cast<v4f*>(iq_lane + toff);
                     q[0] = qa;
                     q[1] = qb;
+#endif
                 }
             }
             return;
@@ -452,7 +485,7 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
             if (step >= st_in_lo && step <= st_in_hi) {
                 const uint8_t* p = p_lane + (unsigned long long)(unsigned)step * (unsigned)step_bytes;
 #define AB_PIECE(K, BASE, OFF) \
-    if (n_dma > (K)) __builtin_amdgcn_global_load_lds((gptr_t)(p + (BASE)), (lptr_t)(uintptr_t)(buf + (BASE)), 16, (OFF), 0)
+    if (n_dma > (K)) AB_DMA((gptr_t)(p + (BASE)), (lptr_t)(uintptr_t)(buf + (BASE)), (OFF))
                 AB_PIECE(0, 0, 0); AB_PIECE(1, 0, 1024); AB_PIECE(2, 0, 2048); AB_PIECE(3, 0, 3072);
                 AB_PIECE(4, 4096, 0); AB_PIECE(5, 4096, 1024); AB_PIECE(6, 4096, 2048); AB_PIECE(7, 4096, 3072);
                 AB_PIECE(8, 8192, 0); AB_PIECE(9, 8192, 1024); AB_PIECE(10, 8192, 2048); AB_PIECE(11, 8192, 3072);
