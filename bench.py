@@ -64,9 +64,10 @@ WORKLOADS = {
 }
 SAMPLES_PER_BATCH = 320_000  # complex samples per dongle per batch (2.56 MS/s / 8)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 runs at the f32 vector rate (155 TF measured)
 MFMA_I8_PEAK_TOPS = 5000.0   # MI355X_MICROARCH.md: int8 MFMA at 2x the dense bf16 rate (~2.5 PF); micro-benchmark ceiling >= 3 944 TOPS
 METRIC = "IQ Msamples/sec channelized+demodulated per node; % HBM roofline"
-CHANNELIZER_KERNEL = {"dft_mfma_i8": "channelizer_dft_kernel", "fft_wave64": "channelizer_fft8_kernel"}  # (channelizer_fft_kernel, the shuffle variant, only runs AFC spectrum launches at fft >= 2048 and tiles without LDS room)
+CHANNELIZER_KERNEL = {"dft_mfma_i8": "channelizer_dft_kernel", "dft_mfma_f32": "channelizer_f32_kernel", "fft_wave64": "channelizer_fft8_kernel"}  # (channelizer_fft_kernel, the shuffle variant, only runs AFC spectrum launches at fft >= 2048 and tiles without LDS room)
 
 
 def cpu_model() -> str:
@@ -419,6 +420,14 @@ def main():
         hip.set_mixers(n_mixers, mg.baseline_mixer_inputs(rank * D, (rank + 1) * D, 8, n_mixers))
     hip.set_signal_plan(carriers)
 
+    # The profiled child runs of this very command (roofline.traffic: PMC passes; roofline.rocprof: the profiler's clock) go FIRST, while this process
+    # holds nothing but its handle: the driver hands a freed allocation of > 100 GiB back with a long delay (minutes), and a child that starts behind the
+    # parent's resident I/Q does not fit beside it.  They are separate processes on an otherwise idle GPU either way.
+    early_traffic = None
+    want_traffic = args.traffic if args.traffic is not None else (world == 1)
+    if rank == 0 and world == 1 and want_traffic and not args.child:
+        early_traffic = measure_traffic(args, CHANNELIZER_KERNEL.get(hip.channelizer_name(), hip.channelizer_name()))
+
     # HBM-resident I/Q: lead-in + (ring + 1) batches + look-ahead per dongle, generated on the GPU
     lead = g.first_batch_bytes - g.batch_bytes
     span = lead + (args.ring + 1) * g.batch_bytes + g.lookahead_bytes
@@ -527,6 +536,14 @@ def main():
             roofline.update(bound="mfma", achieved=round(tops, 1), peak=MFMA_I8_PEAK_TOPS, unit="TFLOP/s", frac=round(tops / MFMA_I8_PEAK_TOPS, 4),
                             hbm_frac=round(achieved / HBM_PEAK_GBS, 4),
                             note="int8 operations / s of the 16x16x64 MFMAs; peak = 2x the dense bf16 rate (MI355X_MICROARCH.md; its micro-benchmark ceiling is 3 944)")
+    if name == "dft_mfma_f32":
+        # CF32 on the float32 matrix pipe: a [16 hops x 2N] by [2N x 16] product per tile in v_mfma_f32_16x16x4_f32 -- 16x the instructions per byte of the int8
+        # kernel, so the matrix pipe bounds it (MI355X_MICROARCH.md: 157.3 TFLOP/s, the f32 vector rate), not HBM
+        tiles = -(-(hip.B) // 16) + 1
+        tflops = 16.0 * (2 * g.fft_size) * 16 * 2 * tiles * D / (ch_ms * 1e-3) / 1e12
+        roofline.update(bound="mfma", achieved=round(tflops, 1), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                        hbm_frac=round(achieved / HBM_PEAK_GBS, 4),
+                        note="f32 multiply-adds of the 16x16x4 f32 MFMAs (all 16 columns, 8 channels x re / im); hbm_frac = the 8.2 algorithmic bytes per sample over the launch time against 8 TB/s")
     out = dict(metric=METRIC, value=round(value, 2), unit="Msamples/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="i8x3->i32->f32 (stage 1), f32 (stage 2)" if name == "dft_mfma_i8" else "f32", data="synthetic",
@@ -536,7 +553,8 @@ def main():
                            parallelism="dongle-sharded x%d, %s" % (world, "mixer sums all-reduced over RCCL by airband_hip_allreduce_mixers" if exchange else "no collective"),
                            channelizer=name,
                            arithmetic="stage 1: u8 x 24-bit window*twiddle as 3 int8 digits -> exact int32 MFMA sums -> 3 f32 FMAs -> f32 bins; stage 2: f32, reference operation order"
-                           if name == "dft_mfma_i8" else "stage 1: f32 radix-2 FFT; stage 2: f32, reference operation order",
+                           if name == "dft_mfma_i8" else "stage 1: f32 samples x f32 window*twiddle on v_mfma_f32_16x16x4_f32 (f32 products and sums); stage 2: f32, reference operation order"
+                           if name == "dft_mfma_f32" else "stage 1: f32 radix-2 FFT; stage 2: f32, reference operation order",
                            library=os.path.basename(pkg.LIB_PATH), build_defines=build),
                roofline=roofline,
                stage_ms=dict(channelizer=ch_ms, demod=demod_ms, mixers_and_iq_out=emit_ms),
@@ -656,31 +674,13 @@ def main():
             out["value"] = None
         except Exception as e:  # noqa: BLE001
             out["verify_all"] = dict(error="whole-handle check could not run: %r" % (e,))
-    need_free = int(iq.numel()) + (24 << 30)  # what a child run of the same workload allocates: the resident I/Q and a handle
     del iq
-    step = offset = None  # (closures over the resident buffer)
-    import gc
-    gc.collect()
     torch.cuda.empty_cache()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    want_traffic = args.traffic if args.traffic is not None else (world == 1)
-    if rank == 0 and world == 1 and want_traffic:
-        # the driver hands a freed allocation of > 100 GiB back with a delay: the child runs below need the room the resident I/Q just left
-        t_wait = time.time()
-        while time.time() - t_wait < 90.0:
-            torch.cuda.synchronize()
-            torch.cuda.empty_cache()
-            if torch.cuda.mem_get_info()[0] >= need_free:
-                break
-            time.sleep(0.5)
-        waited = round(time.time() - t_wait, 1)
-        traffic, detail = measure_traffic(args, CHANNELIZER_KERNEL.get(name, name))
-        if isinstance(detail, dict):
-            detail["waited_for_free_memory_s"] = waited
-            detail["free_bytes_before_children"] = int(torch.cuda.mem_get_info()[0])
-            detail["torch_allocated_reserved_bytes"] = [int(torch.cuda.memory_allocated()), int(torch.cuda.memory_reserved())]
+    if early_traffic is not None:
+        traffic, detail = early_traffic
         out["roofline"]["traffic"] = traffic
         out["roofline"]["traffic_detail"] = detail
         kt = detail.pop("rocprof_kernel_trace", None) if isinstance(detail, dict) else None

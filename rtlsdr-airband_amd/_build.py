@@ -26,6 +26,7 @@ LIB = os.path.join(HERE, "libairband_hip" + ("_exp_" + TAG if EXTRA else "") + "
 HIP_SOURCES = {
     "channelizer_fft.hip": ["-O3"],
     "channelizer_dft.hip": ["-O3"],
+    "channelizer_f32.hip": ["-O3"],
     "misc_kernels.hip": ["-O3", "-ffp-contract=off"],  # mixer sums: the reference's multiply-then-add, no FMA
     "demod.hip": ["-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"],
     "airband_hip.cpp": ["-O2", "-x", "hip"],

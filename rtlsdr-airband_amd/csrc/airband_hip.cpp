@@ -113,6 +113,8 @@ struct airband_hip_handle {
     DevBuf<uint8_t> d_tmp_trace;
     int ct_stride = 0;
     /* matrix-core channelizer */
+    bool use_f32 = false;          /* CF32 dongles on the float32 matrix pipe (channelizer_f32.hip) */
+    DevBuf<float> d_ftab;
     bool use_dft = false;
     DevBuf<int> d_item_dev, d_item_group, d_item_bset, d_item_private, d_item_home; /* d_item_bset: what stage 1 reads (the re-tune kernel switches AFC groups between their home and private tables) */
     DevBuf<int8_t> d_bfrag;
@@ -205,7 +207,7 @@ void destroy(airband_hip_handle* h) {
     h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release(); h->d_ct_af.release(); h->d_ct_mask.release();
     h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
     h->d_tmp_wavein.release(); h->d_tmp_iqin.release(); h->d_tmp_trace.release(); h->d_spectrum.release();
-    h->d_item_dev.release(); h->d_item_group.release(); h->d_item_bset.release(); h->d_item_private.release(); h->d_item_home.release(); h->d_bfrag.release(); h->d_bcorr.release(); h->d_dft_partial.release(); h->d_bset_bin.release();
+    h->d_ftab.release(); h->d_item_dev.release(); h->d_item_group.release(); h->d_item_bset.release(); h->d_item_private.release(); h->d_item_home.release(); h->d_bfrag.release(); h->d_bcorr.release(); h->d_dft_partial.release(); h->d_bset_bin.release();
     if (h->h2d) (void)hipStreamSynchronize(h->h2d);
     h->d_stage2[0].release(); h->d_stage2[1].release();
     if (h->h_ring.load()) (void)hipHostFree(h->h_ring.load());
@@ -451,6 +453,12 @@ int airband_hip_dft_selftest(const airband_hip_config* cfg, int32_t windows, dou
     const int rc = build_plan(cfg, plan);
     if (rc != AIRBAND_HIP_OK) return fail(nullptr, rc, plan.error);
     const int hop_bytes = 2 * plan.dev[0].bytes_per_sample * plan.dev[0].hop_samples;
+    if (plan.uniform_hop && f32_supported(plan.fft_size, plan.dev[0].hop_samples, plan.dev[0].sfmt)) { /* CF32: the float tables of channelizer_f32.hip */
+        build_dft_tables(plan);
+        build_f32_tables(plan);
+        *max_rel_err = f32_table_selftest(plan, windows < 1 ? 1 : windows);
+        return AIRBAND_HIP_OK;
+    }
     if (!plan.uniform_hop || !dft_supported(plan.fft_size, hop_bytes, plan.dev[0].sfmt, plan.max_ch))
         return fail(nullptr, AIRBAND_HIP_EBADSIZE, "configuration does not take the matrix-core channelizer");
     build_dft_tables(plan);
@@ -691,7 +699,23 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
                 PREP_TRY(h->d_dft_partial.alloc((size_t)p.item_dev.size() * dft_partial_tiles(h->B + AB_AGC_EXTRA) * 64 * 4), AIRBAND_HIP_ENOMEM);
         }
     }
-    if (!h->use_dft) {
+    /* CF32 (SoapySDR): the float32 matrix pipe, unless a channel has AFC (its tables would have to move at run time: those handles stay on the wavefront FFT) */
+    h->use_f32 = !h->use_dft && !(h->flags & AIRBAND_HIP_FLAG_FORCE_FFT) && !any_afc && f32_supported(p.fft_size, p.dev[0].hop_samples, p.dev[0].sfmt);
+    if (h->use_f32) {
+        build_dft_tables(h->plan, false); /* the work items and the shared bin sets (its int8 tables are not used) */
+        if (p.n_shared_bsets > 1024) {
+            h->use_f32 = false; /* 64 KiB per table: that many would not stay cache resident */
+        } else {
+            build_f32_tables(h->plan);
+            PREP_TRY(upload(h->d_item_dev, p.item_dev), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(upload(h->d_item_group, p.item_group), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(upload(h->d_item_bset, p.item_home), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(upload(h->d_ftab, p.ftab), AIRBAND_HIP_ENOMEM);
+        }
+        h->plan.bfrag.clear(); h->plan.bfrag.shrink_to_fit();
+        h->plan.ftab.clear(); h->plan.ftab.shrink_to_fit();
+    }
+    if (!h->use_dft && !h->use_f32) {
         const size_t lds = fft_lds_bytes(p.fft_log, p.dev[0].hop_samples, p.dev[0].bytes_per_sample);
         if (lds > 160 * 1024) { /* e.g. F32 at 20 MS/s: a 16-hop tile of raw samples does not fit a CU's LDS */
             g_prepare_error = "sample_rate x bytes_per_sample too large for the FFT channelizer's LDS tile (" + std::to_string(lds) + " > 163840 bytes)";
@@ -855,7 +879,42 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
     const Plan& p = h->plan;
     const bool first = h->front_batches == 0;
     hipEvent_t* ev = event_set(h, h->front_batches, 0);
-    if (h->use_dft) {
+    if (h->use_f32) {
+        F32Args a;
+        a.iq = (const uint8_t*)d_iq;
+        a.iq_stride = (long)stride_bytes;
+        a.dev = h->d_dev.p;
+        a.cc = h->d_cc.p;
+        a.ext_to_slot = h->d_ext_to_slot.p;
+        a.item_dev = h->d_item_dev.p;
+        a.item_group = h->d_item_group.p;
+        a.item_bset = h->d_item_bset.p;
+        a.btab = h->d_ftab.p;
+        a.mag = h->d_mag.p;
+        a.iq_bins = h->d_iq.p;
+        a.n_items = (int)p.item_dev.size();
+        a.fft_size = p.fft_size;
+        a.hop_bytes = (int)h->hop_bytes;
+        a.pad = f32_pad_bytes(p.dev[0].hop_samples);
+        a.lds_per_buf = f32_lds_per_buf(p.fft_size, p.dev[0].hop_samples);
+        a.row0 = h->row0_front;
+        a.ring_rows = h->R;
+        a.first_row = first ? 0 : AB_AGC_EXTRA;
+        a.n_hops = first ? h->B + AB_AGC_EXTRA : h->B;
+        /* enough workgroups to fill 256 CUs x 2 even with few dongles: split each dongle's tiles */
+        const int tiles = (a.n_hops + 15) / 16 + 1;
+        int splits = (2048 + a.n_items - 1) / a.n_items;
+        if (splits > tiles / 4) splits = tiles / 4;
+        if (splits < 1) splits = 1;
+        a.splits = splits;
+        h->last_iq = d_iq;
+        h->last_iq_stride = stride_bytes;
+        h->last_n_hops = a.n_hops;
+        h->afc_spectrum_valid = false;
+        (void)hipEventRecord(ev[0], s);
+        launch_channelizer_f32(a, s);
+        (void)hipEventRecord(ev[1], s);
+    } else if (h->use_dft) {
         DftArgs a;
         a.iq = (const uint8_t*)d_iq;
         a.iq_stride = (long)stride_bytes;
@@ -955,6 +1014,8 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
      * a batch of such hops cannot start on 16 bytes every time anyway (2 100 hops of 250 bytes = 525 000), the kernel stages from the aligned byte in
      * front of the span and only whole samples are asked for */
     const uintptr_t need = (h->hop_bytes % 16) == 0 ? 15u : (uintptr_t)(2 * h->plan.dev[0].bytes_per_sample - 1);
+    if (h->use_f32 && ((((uintptr_t)d_iq) | (uintptr_t)stride_bytes) & 15))
+        return fail(h, AIRBAND_HIP_EINVAL, "d_iq and stride_bytes must be multiples of 16 (the channelizer fetches 16 bytes per lane)");
     if (h->use_dft && ((((uintptr_t)d_iq) | (uintptr_t)stride_bytes) & need))
         return fail(h, AIRBAND_HIP_EINVAL, (h->hop_bytes % 16) == 0 ? "d_iq and stride_bytes must be multiples of 16 (the channelizer fetches 16 bytes per lane)"
                                                                     : "d_iq and stride_bytes must be multiples of one I/Q sample");
@@ -1303,7 +1364,7 @@ int airband_hip_timing_totals(airband_hip_handle* h, double* ms4_sum, int64_t* n
 const char* airband_hip_build_info(void) { return AB_BUILD_DEFINES; }
 
 const char* airband_hip_channelizer_name(const airband_hip_handle* h) {
-    return (h && h->use_dft) ? "dft_mfma_i8" : "fft_wave64";
+    return (h && h->use_dft) ? "dft_mfma_i8" : (h && h->use_f32) ? "dft_mfma_f32" : "fft_wave64";
 }
 
 int airband_hip_set_signal_plan(airband_hip_handle* h, const int64_t* carriers, int32_t n_carriers, int32_t noise_q8, const int16_t* sin_table4096) {

@@ -62,6 +62,24 @@ struct DftArgs {
     int row0, ring_rows, first_row, n_hops;
 };
 
+/* CF32 dongles on the float32 matrix pipe (channelizer_f32.hip) */
+struct F32Args {
+    const uint8_t* iq;
+    long iq_stride;
+    const DevConst* dev;
+    const ChanConst* cc;
+    const int* ext_to_slot;
+    const int* item_dev;    /* work items as for DftArgs: (dongle, group of 8 channels, coefficient-table index) */
+    const int* item_group;
+    const int* item_bset;
+    const float* btab;      /* [n_bsets][4 pieces][MFMAs per piece][64 lanes] window x twiddle, ordered as the kernel contracts (params.cpp, build_f32_tables) */
+    float* mag;
+    float2* iq_bins;
+    int n_items, splits, fft_size;
+    int hop_bytes, pad, lds_per_buf; /* bytes per hop (8 x hop_samples), padding per hop in the staged image, bytes per staging buffer */
+    int row0, ring_rows, first_row, n_hops;
+};
+
 struct DemodArgs {
     const ChanConst* cc;
     ChanState* cs;
@@ -144,6 +162,10 @@ int dft_partial_tiles(int n_hops_max); /* 16-hop tiles a work item may touch in 
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream);
 /* side: 3 extra streams, ev: 4 events (fork + 3 joins); both may be null -> everything on `stream`, one kind after the other */
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev);
+bool f32_supported(int fft_size, int hop_samples, int sfmt);
+int f32_pad_bytes(int hop_samples);
+int f32_lds_per_buf(int fft_size, int hop_samples);
+void launch_channelizer_f32(const F32Args& a, hipStream_t stream);
 void launch_emit_iq(const EmitArgs& a, hipStream_t stream);
 void launch_axc(const ChanConst* cc, const ChanState* cs, const int* slot_to_ext, uint8_t* out_axc, int n_slots, hipStream_t stream);
 void launch_mix(const MixArgs& a, hipStream_t stream);

@@ -323,6 +323,26 @@ int build_plan(const airband_hip_config* cfg, Plan& p) {
  *   (I + jQ) * w[n] * exp(-j theta) = (I w cos + Q w sin) + j (Q w cos - I w sin),  theta = 2 pi bin_c n / N
  * (same transform as src/rtl_airband.cpp:451-460 + :483-489 evaluated for one bin).  Values are scaled to 24-bit
  * integers and split into balanced base-256 digits d0 + 256 d1 + 65536 d2, each in [-128, 127]. */
+void build_f32_tables(Plan& p) {
+    const int N = p.fft_size, NW = 4, VPP = 2 * N / NW, KW = VPP / 4; /* values and MFMAs (K = 4) per piece */
+    p.ftab.assign((size_t)p.n_shared_bsets * NW * KW * 64, 0.0f);
+    for (int b = 0; b < p.n_shared_bsets; b++)
+        for (int piece = 0; piece < NW; piece++)
+            for (int s = 0; s < KW; s++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int col = lane & 15, c = col >> 1, g = lane >> 4;
+                    const int bin = p.bset_bins[(size_t)b * 8 + c];
+                    if (bin < 0) continue; /* a group with fewer than 8 channels: unused columns stay zero */
+                    const int k = piece * VPP + 16 * (s / 4) + 4 * g + (s % 4);
+                    const int n = k >> 1;
+                    const double th = 2.0 * M_PI * (double)(((long long)bin * n) % N) / (double)N; /* the phase is reduced exactly in integers first */
+                    const double wc = (double)p.window[n] * std::cos(th), ws = (double)p.window[n] * std::sin(th);
+                    /* (I + jQ) w e^{-j th} = (I w cos + Q w sin) + j (Q w cos - I w sin): value k = 2n is I, 2n + 1 is Q; column 2c is re, 2c + 1 im */
+                    const double v = (col & 1) ? ((k & 1) ? wc : -ws) : ((k & 1) ? ws : wc);
+                    p.ftab[(((size_t)b * NW + piece) * KW + s) * 64 + lane] = (float)v;
+                }
+}
+
 void build_dft_tables(Plan& p, bool host_private) {
     /* fft_size > 512: one table per window piece of 512 samples (NP pieces); a table then covers K = 1024 bytes of the window */
     const int N = p.fft_size, NP = N > 512 ? N / 512 : 1, NS = N / NP, K = 2 * NS, KS = K / 64;
@@ -443,6 +463,57 @@ void build_dft_tables(Plan& p, bool host_private) {
  * integer sums of (byte - 128) x balanced base-256 digits over every window piece, recombined, offset-corrected and scaled exactly as
  * the kernel does -- against the definition  X[bin] = sum_n lev[b_n] w[n] exp(-2 pi i bin n / N)  (src/rtl_airband.cpp:316-351,402-489)
  * evaluated directly in double.  Returns the largest error relative to the RMS of the exact values over all work items. */
+/* host-only: the float tables of channelizer_f32.hip contracted the way the kernel contracts them -- per wave (piece) 64 (32) instructions of K = 4, lane
+ * l supplying stream value 16 (s / 4) + 4 (l >> 4) + s % 4 of its piece against table entry [piece][s][l], partial sums of a piece in float, the four pieces
+ * added in float -- against the double-precision sum, on pseudo-random windows; largest error relative to the RMS of the exact values */
+double f32_table_selftest(const Plan& p, int windows) {
+    const int N = p.fft_size, NW = 4, VPP = 2 * N / NW, KW = VPP / 4;
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() {
+        rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+        return rng;
+    };
+    double worst = 0.0, sumsq = 0.0;
+    long count = 0;
+    for (size_t item = 0; item < p.item_dev.size(); item++) {
+        const int d = p.item_dev[item], g = p.item_group[item], set = p.item_home[item];
+        const int nch = std::min(8, p.dev[d].n_ch - 8 * g);
+        for (int w = 0; w < windows; w++) {
+            std::vector<float> raw(2 * N);
+            for (int k = 0; k < 2 * N; k++) raw[k] = (float)((double)(int32_t)(next() >> 32) / 2147483648.0 * 0.3);
+            for (int c = 0; c < nch; c++) {
+                const int bin = p.cc[p.chan_base[d] + 8 * g + c].base_bin;
+                for (int comp = 0; comp < 2; comp++) {
+                    const int col = 2 * c + comp;
+                    float total = 0.0f;
+                    for (int piece = 0; piece < NW; piece++) {
+                        float acc2[2] = {0.0f, 0.0f}; /* the kernel alternates two accumulators */
+                        for (int s_ = 0; s_ < KW; s_++) {
+                            float part = acc2[s_ & 1]; /* one MFMA: four products added to the accumulator */
+                            for (int gg = 0; gg < 4; gg++)
+                                part += raw[piece * VPP + 16 * (s_ / 4) + 4 * gg + (s_ % 4)] * p.ftab[(((size_t)set * NW + piece) * KW + s_) * 64 + gg * 16 + col];
+                            acc2[s_ & 1] = part;
+                        }
+                        const float acc = acc2[0] + acc2[1];
+                        total = piece == 0 ? acc : total + acc;
+                    }
+                    const double got = (double)(total * p.dev[d].scale);
+                    double want = 0.0;
+                    for (int n = 0; n < N; n++) {
+                        const double th = 2.0 * M_PI * (double)(((long long)bin * n) % N) / (double)N;
+                        const double xi = (double)p.dev[d].scale * raw[2 * n], xq = (double)p.dev[d].scale * raw[2 * n + 1], wn = (double)p.window[n];
+                        want += comp == 0 ? wn * (xi * std::cos(th) + xq * std::sin(th)) : wn * (xq * std::cos(th) - xi * std::sin(th));
+                    }
+                    worst = std::max(worst, std::fabs(got - want));
+                    sumsq += want * want;
+                    count++;
+                }
+            }
+        }
+    }
+    return count ? worst / std::sqrt(sumsq / (double)count) : 0.0;
+}
+
 double dft_table_selftest(const Plan& p, int windows) {
     const int N = p.fft_size, NP = N > 512 ? N / 512 : 1, NS = N / NP, K = 2 * NS, KS = K / 64;
     const bool s16 = p.dev[0].sfmt == AIRBAND_SFMT_S16, s8 = p.dev[0].sfmt == AIRBAND_SFMT_S8;

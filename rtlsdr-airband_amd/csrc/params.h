@@ -35,6 +35,7 @@ struct Plan {
     std::vector<int> item_home;                       /* the SHARED table of the item's base bins: what a group with an AFC channel reads while none of its channels has moved */
     std::vector<int8_t> bfrag;         /* [n_bsets][3][fft_size / 32][64][16] */
     std::vector<double> bcorr;         /* [n_bsets][16] */
+    std::vector<float> ftab;           /* CF32 dongles (channelizer_f32.hip): [n_shared_bsets][4 pieces][fft_size / 8 MFMAs][64 lanes] window x twiddle */
     double b_unscale = 0.0;
     bool b_edge_hi_zero = false;       /* digit 2 is zero in the outer k-steps (fft_size / 256 at either end) of every table */
     int n_bsets = 0, n_shared_bsets = 0; /* coefficient tables in all / those shared between work items (the rest belong to groups with an AFC channel) */
@@ -51,6 +52,11 @@ int build_plan(const airband_hip_config* cfg, Plan& plan);
  * to the device (retune kernel); their slots exist (item_bset, n_bsets) but plan.bfrag / bcorr hold the shared tables only. */
 void build_dft_tables(Plan& plan, bool host_private = true);
 
+/* CF32 dongles on the float32 matrix pipe (channelizer_f32.hip): one float table per shared bin set of build_dft_tables() (call that first), window x twiddle
+ * evaluated in double and rounded once, in the order the kernel contracts: entry [bset][piece][s][lane] is coefficient (k, column lane & 15) with
+ * k = piece * (fft_size / 2) + 16 (s / 4) + 4 (lane >> 4) + s % 4, value k = 2 n + {0: I, 1: Q} of the window */
+void build_f32_tables(Plan& plan);
+
 /* exact_math.h: RN(1 / g) if x * r corrected once equals the IEEE x / g for every x (all 2^23 significands are tried, ~70 ms), else 0 */
 float div_const_reciprocal(float g);
 
@@ -58,6 +64,7 @@ float div_const_reciprocal(float g);
 void channel_constants(const Plan& plan, int ext_index, double* out16);
 /* host-only: largest error (relative to the RMS of the exact values) of the matrix-core coefficient tables on `windows` pseudo-random windows per work item */
 double dft_table_selftest(const Plan& plan, int windows);
+double f32_table_selftest(const Plan& plan, int windows);
 
 }  // namespace airband
 #endif

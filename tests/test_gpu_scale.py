@@ -60,6 +60,7 @@ CASES = [
     pytest.param(65536, False, 8000, 32, False, False, "", id="65536_am"),
     pytest.param(4096, True, 16000, 32, False, True, "force_fft", id="4096_mixed_fft_wave64"),
     pytest.param(4099, True, 16000, 32, False, False, "f32", id="4099_mixed_SFMT_F32"),
+    pytest.param(1030, True, 16000, 16, False, False, "f32_fft", id="1030_mixed_SFMT_F32_fft_wave64"),
 ]
 
 
@@ -74,21 +75,21 @@ def test_sampled_dongles_of_large_handles(pkg, built, n_dev, mixed, wave_rate, k
         ch = [dict(c) for c in chans]
         if tweak:
             _tweak(d, ch)
-        return dict(channels=ch, sfmt=pkg.capi.SFMT_F32) if path == "f32" else dict(channels=ch)
+        return dict(channels=ch, sfmt=pkg.capi.SFMT_F32) if path.startswith("f32") else dict(channels=ch)
 
     devices = [device(d) for d in range(n_dev)]
-    flags = pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_PIPELINE if pipelined else 0) | (pkg.capi.FLAG_FORCE_FFT if path == "force_fft" else 0)
+    flags = pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_PIPELINE if pipelined else 0) | (pkg.capi.FLAG_FORCE_FFT if path in ("force_fft", "f32_fft") else 0)
     dongles = pyverify.sample_dongles(n_dev, k)
     hip = pkg.AirbandHip(devices, wave_rate=wave_rate, flags=flags)
     iq = spot = None
     try:
-        assert hip.channelizer_name() == ("fft_wave64" if path else "dft_mfma_i8")
+        assert hip.channelizer_name() == {"": "dft_mfma_i8", "force_fft": "fft_wave64", "f32": "dft_mfma_f32", "f32_fft": "fft_wave64"}[path]
         g = hip.geometry
         lead = g.first_batch_bytes - g.batch_bytes
         span = lead + (RING + 1) * g.batch_bytes + g.lookahead_bytes
         stride = (span + 255) // 256 * 256
         iq = _resident_iq(torch, n_dev * stride)[:n_dev * stride].view(n_dev, stride)
-        if path != "f32":
+        if not path.startswith("f32"):
             hip.set_signal_plan(carriers)
             hip.generate_iq(iq.data_ptr(), stride, 0, span, seed=0x5EED)
             hip.synchronize()
@@ -110,7 +111,7 @@ def test_sampled_dongles_of_large_handles(pkg, built, n_dev, mixed, wave_rate, k
         # the on-device generator is the host generator, also at the far end of the handle
         last = dongles[-1]
         assert last == n_dev - 1
-        if path != "f32":
+        if not path.startswith("f32"):
             assert np.array_equal(host[last][:65536], pkg.siggen.generate_u8(last, 0, 32768, carriers))
 
         spot = pyverify.SpotCheck(device, dongles, wave_rate=wave_rate)

@@ -66,18 +66,23 @@ FORMAT_CASES = [("SFMT_S16", 9, 2_560_000, 16000), ("SFMT_U8", 10, 2_560_000, 80
                 ("SFMT_U8", 9, 2_000_000, 16000), ("SFMT_F32", 10, 2_400_000, 8000), ("SFMT_F32", 11, 2_560_000, 16000)]
 
 
+# round 4: the configurations the GPU suite newly runs (CF32 on the float32 matrix pipe, hops of an odd number of samples on the int8 one) -- one dongle,
+# four batches each: the arithmetic that differs (convert x window per format, hop, bin) is per hop, not per dongle
+FORMAT_CASES_SHORT = [("SFMT_F32", 9, 2_560_000, 8000), ("SFMT_F32", 8, 2_560_000, 16000), ("SFMT_F32", 9, 2_400_000, 16000), ("SFMT_F32", 9, 2_400_000, 8000),
+                      ("SFMT_F32", 10, 2_560_000, 16000), ("SFMT_S8", 10, 2_000_000, 16000), ("SFMT_U8", 8, 1_200_000, 16000), ("SFMT_U8", 11, 2_000_000, 16000)]
+
+
 @need_ref
-@pytest.mark.parametrize("sfmt_name,fft_log,sample_rate,wave_rate", FORMAT_CASES)
-def test_stream_bit_exact_other_formats(pkg, built, sfmt_name, fft_log, sample_rate, wave_rate):
+@pytest.mark.parametrize("sfmt_name,fft_log,sample_rate,wave_rate,n_dev,n_batches", [c + (2, 6) for c in FORMAT_CASES] + [c + (1, 4) for c in FORMAT_CASES_SHORT])
+def test_stream_bit_exact_other_formats(pkg, built, sfmt_name, fft_log, sample_rate, wave_rate, n_dev, n_batches):
     sfmt = getattr(pkg.capi, sfmt_name)
-    n_batches = 6
-    devices, iq = helpers.format_case(pkg, sfmt, fft_log, sample_rate, wave_rate, 2, n_batches, first_dongle=5)
+    devices, iq = helpers.format_case(pkg, sfmt, fft_log, sample_rate, wave_rate, n_dev, n_batches, first_dongle=5)
     # one reference process per dongle: demodulate() sleeps 10 ms whenever its round robin meets a device without a full hop
     # (src/rtl_airband.cpp:395-400), so feeding two devices of one instance one after the other would take minutes
-    ref = [pyref.run_reference([devices[d]], [iq[d]], n_batches, nfm=wave_rate == 16000, fft_log=fft_log)[0] for d in range(2)]
+    ref = [pyref.run_reference([devices[d]], [iq[d]], n_batches, nfm=wave_rate == 16000, fft_log=fft_log)[0] for d in range(n_dev)]
     orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fft_log=fft_log)
     opened = 0
-    for d in range(2):  # dongle 1 of a CS16 case has its own input->fullscale
+    for d in range(n_dev):  # dongle 1 of a CS16 case has its own input->fullscale
         got = orc.run_device(d, iq[d], n_batches)
         assert ref[d]["n_batches"] == got["n_batches"] == n_batches
         assert np.array_equal(ref[d]["axc"], got["axc"])
