@@ -532,10 +532,16 @@ def main():
         roofline["mfma_int8_tops"] = round(tops, 1)
         roofline["mfma_frac"] = round(tops / MFMA_I8_PEAK_TOPS, 4)
         if n_fft >= 1024:
-            # two and more window pieces: 2x ... 16x the matrix work on the same bytes -- the matrix pipe, not HBM, bounds the kernel
-            roofline.update(bound="mfma", achieved=round(tops, 1), peak=MFMA_I8_PEAK_TOPS, unit="TFLOP/s", frac=round(tops / MFMA_I8_PEAK_TOPS, 4),
-                            hbm_frac=round(achieved / HBM_PEAK_GBS, 4),
-                            note="int8 operations / s of the 16x16x64 MFMAs; peak = 2x the dense bf16 rate (MI355X_MICROARCH.md; its micro-benchmark ceiling is 3 944)")
+            # two and more window pieces: 2x ... 16x the matrix work on the same bytes.  Neither pipe is full at these sizes (profiles/r04_experiments.md G: the matrix pipe
+            # is 40 % busy at every window length, HBM falls from 0.38 to 0.10 of peak, the clock rises): the line names the NEARER ceiling and says what the counters show
+            limiter = ("neither ceiling binds: SQ_VALU_MFMA_BUSY_CYCLES puts the matrix pipe at ~0.40 busy at fft 512 ... 4096 alike; the per-tile chain across the workgroup "
+                       "barrier (fragment reads -> MFMAs -> recombination -> partial sums through LDS -> barrier) with two waves per SIMD is what the launch time follows")
+            if tops / MFMA_I8_PEAK_TOPS > achieved / HBM_PEAK_GBS:
+                roofline.update(bound="mfma", achieved=round(tops, 1), peak=MFMA_I8_PEAK_TOPS, unit="TFLOP/s", frac=round(tops / MFMA_I8_PEAK_TOPS, 4),
+                                hbm_frac=round(achieved / HBM_PEAK_GBS, 4), limiter=limiter,
+                                note="int8 operations / s of the 16x16x64 MFMAs; peak = 2x the dense bf16 rate (MI355X_MICROARCH.md; its micro-benchmark ceiling is 3 944)")
+            else:
+                roofline["limiter"] = limiter
     if name == "dft_mfma_f32":
         # CF32 on the float32 matrix pipe: a [16 hops x 2N] by [2N x 16] product per tile in v_mfma_f32_16x16x4_f32 -- 16x the instructions per byte of the int8
         # kernel, so the matrix pipe bounds it (MI355X_MICROARCH.md: 157.3 TFLOP/s, the f32 vector rate), not HBM
