@@ -234,7 +234,7 @@ def dry_run(args, rank, world):
               flush=True)
 
 
-def measure_traffic(args, kernel_substr):
+def measure_traffic(args, kernel_substr, dongles):
     """HBM traffic of the dominant kernel, measured NOW: two short child runs of this very script under
     `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and WRITE_SIZE cannot share a pass: TCC slots), first launch
     dropped (it also produces the AGC_EXTRA lead-in).  Corrections per MI355X_MICROARCH.md "HBM": FETCH_SIZE [KB] x 1024 x 2
@@ -248,13 +248,15 @@ def measure_traffic(args, kernel_substr):
     total = 0.0
     env = dict(os.environ)
     env["TMPDIR"] = "/tmp"
+    # PMC children: half the fleet when the whole one is large (see the caller), every figure scaled back -- dongles are independent, bytes per launch linear in them
+    child_dongles = dongles // 2 if dongles >= 32768 else dongles
+    scale_up = dongles / float(child_dongles)
+    detail["pmc_child_dongles"] = child_dongles
     for counter, mult in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
         out_dir = tempfile.mkdtemp(prefix="airband_pmc_", dir="/tmp")
         cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
                "--child", "--no-verify-all", "--workload", args.workload, "--steps", str(max(3, args.ring)), "--warmup", "1", "--ring", str(args.ring),
-               "--signal-start-batch", str(args.signal_start_batch)]  # first launch dropped: the average is over the resident ring, like the timed region
-        if args.dongles:
-            cmd += ["--dongles", str(args.dongles)]
+               "--signal-start-batch", str(args.signal_start_batch), "--dongles", str(child_dongles)]  # first launch dropped: the average is over the resident ring, like the timed region
         if args.sample_format != "u8":
             cmd += ["--sample-format", args.sample_format]
         if args.sample_rate != 2_560_000:
@@ -280,12 +282,12 @@ def measure_traffic(args, kernel_substr):
                         others.setdefault(short, []).append(float(row["Counter_Value"]))
             for short, v in others.items():  # every other kernel of a step (stage 2 ...): same corrections, all launches but the first
                 if len(v) >= 2:
-                    per_kernel.setdefault(short, {})[counter.lower() + "_bytes"] = sum(v[1:]) / (len(v) - 1) * mult
+                    per_kernel.setdefault(short, {})[counter.lower() + "_bytes"] = sum(v[1:]) / (len(v) - 1) * mult * scale_up
             if len(vals) < 2:
                 detail["error"] = "%s: %d launches of %s seen" % (counter, len(vals), kernel_substr)
                 detail.setdefault(counter + "_child", dict(returncode=child.returncode, stderr_tail=child.stderr.decode(errors="replace")[-600:]))
                 return None, detail
-            per = sum(vals[1:]) / (len(vals) - 1) * mult
+            per = sum(vals[1:]) / (len(vals) - 1) * mult * scale_up
             detail[counter.lower() + "_bytes"] = per
             total += per
         except Exception as e:  # noqa: BLE001
@@ -293,15 +295,15 @@ def measure_traffic(args, kernel_substr):
         finally:
             shutil.rmtree(out_dir, ignore_errors=True)
     detail["other_kernels"] = per_kernel
-    detail["method"] = "rocprofv3 --pmc FETCH_SIZE x1024x2 + WRITE_SIZE x1024 (separate passes, launches 2.. of a 4-step child run of this command)"
+    detail["method"] = ("rocprofv3 --pmc FETCH_SIZE x1024x2 + WRITE_SIZE x1024 (separate passes, launches 2.. of a child run of this command on the same resident ring, "
+                        "%d of the %d dongles, bytes scaled by %.0f)" % (child_dongles, dongles, scale_up))
     # a third child pass, counters off: the profiler's own clock on the dominant kernel (`rocprofv3 --kernel-trace --stats`), next to the HIP events of
     # the timed region -- the two disagree by a few per cent in either direction from box to box, so the line carries both
     out_dir = tempfile.mkdtemp(prefix="airband_kt_", dir="/tmp")
     try:
         cmd = [rocprof, "--kernel-trace", "--stats", "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__),
-               "--child", "--no-verify-all", "--workload", args.workload, "--steps", "10", "--warmup", "2", "--ring", str(args.ring), "--signal-start-batch", str(args.signal_start_batch)]
-        if args.dongles:
-            cmd += ["--dongles", str(args.dongles)]
+               "--child", "--no-verify-all", "--workload", args.workload, "--steps", "10", "--warmup", "2", "--ring", "1", "--signal-start-batch", str(args.signal_start_batch),
+               "--dongles", str(dongles)]
         if args.sample_format != "u8":
             cmd += ["--sample-format", args.sample_format]
         if args.sample_rate != 2_560_000:
@@ -419,14 +421,6 @@ def main():
     if n_mixers:  # BASELINE configs[4] wiring; weak scaling: rank r holds the global dongles [r D, (r + 1) D)
         hip.set_mixers(n_mixers, mg.baseline_mixer_inputs(rank * D, (rank + 1) * D, 8, n_mixers))
     hip.set_signal_plan(carriers)
-
-    # The profiled child runs of this very command (roofline.traffic: PMC passes; roofline.rocprof: the profiler's clock) go FIRST, while this process
-    # holds nothing but its handle: the driver hands a freed allocation of > 100 GiB back with a long delay (minutes), and a child that starts behind the
-    # parent's resident I/Q does not fit beside it.  They are separate processes on an otherwise idle GPU either way.
-    early_traffic = None
-    want_traffic = args.traffic if args.traffic is not None else (world == 1)
-    if rank == 0 and world == 1 and want_traffic and not args.child:
-        early_traffic = measure_traffic(args, CHANNELIZER_KERNEL.get(hip.channelizer_name(), hip.channelizer_name()))
 
     # HBM-resident I/Q: lead-in + (ring + 1) batches + look-ahead per dongle, generated on the GPU
     lead = g.first_batch_bytes - g.batch_bytes
@@ -685,8 +679,22 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    if early_traffic is not None:
-        traffic, detail = early_traffic
+    want_traffic = args.traffic if args.traffic is not None else (world == 1)
+    if rank == 0 and world == 1 and want_traffic:
+        # The driver hands a freed allocation of > 100 GiB back slowly and, it seems, never all of it while the process lives (138 GB free 90 s after 170 GB were
+        # dropped; 103 GiB free right after a child PROCESS of that size had exited): the profiled children are sized for what is certainly there -- HALF the
+        # dongles on the same resident ring for the PMC passes (traffic per launch is linear in the dongles, which are independent: scaled back by 2), the full
+        # fleet on a one-batch ring for the profiler's clock on the channelizer (its launch time does not depend on what the signal carries).
+        t_wait = time.time()
+        while time.time() - t_wait < 45.0:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            if torch.cuda.mem_get_info()[0] >= (130 << 30):
+                break
+            time.sleep(0.5)
+        traffic, detail = measure_traffic(args, CHANNELIZER_KERNEL.get(name, name), D)
+        if isinstance(detail, dict):
+            detail["free_bytes_after_children"] = int(torch.cuda.mem_get_info()[0])
         out["roofline"]["traffic"] = traffic
         out["roofline"]["traffic_detail"] = detail
         kt = detail.pop("rocprof_kernel_trace", None) if isinstance(detail, dict) else None

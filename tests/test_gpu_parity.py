@@ -508,9 +508,11 @@ def test_full_slot_blocks_of_every_kind(pkg, built, mixed, wave_rate, n_dev):
     assert opened > 50
 
 
-def test_ragged_shapes_and_empty_inputs(pkg, built):
+@pytest.mark.parametrize("fmt", ["u8", "SFMT_F32"])
+def test_ragged_shapes_and_empty_inputs(pkg, built, fmt):
     """Edge shapes: a dongle with ONE channel, one with the maximum of 64 (every feature combination, all five demod kinds,
-    mostly padding-free blocks), one with 8; zero-length submits, process() before enough data, collect() before any batch."""
+    mostly padding-free blocks), one with 8; zero-length submits, process() before enough data, collect() before any batch.
+    Once with u8 dongles (int8 matrix-core channelizer) and once with CF32 ones (float32 matrix-core channelizer: eight groups of 8, unused columns)."""
     sg = pkg.siggen
     wave_rate, n_batches = 16000, 6
     base = dict(modulation=0, afc=0, squelch_threshold_dbfs=0, squelch_snr_threshold_db=-1.0, notch_freq=0.0, notch_q=0.0, ctcss_freq=0.0, bandwidth_hz=0,
@@ -541,10 +543,15 @@ def test_ragged_shapes_and_empty_inputs(pkg, built):
     n_dev = len(devices)
     nbytes = helpers.stream_bytes(n_batches, wave_rate)
     iq = [sg.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)]
+    if fmt != "u8":
+        for dev in devices:
+            dev["sfmt"] = pkg.capi.SFMT_F32
+        iq = [helpers.convert_format(x, pkg.capi.SFMT_F32, pkg.capi).view(np.uint8) for x in iq]
+        nbytes *= 4
     orc = pyoracle.Oracle(devices, wave_rate=wave_rate)
     ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
     with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=pkg.capi.FLAG_TRACE_SQUELCH) as hip:
-        assert hip.channelizer_name() == "dft_mfma_i8"  # the 64-channel dongle runs as eight groups of 8 on the matrix-core path
+        assert hip.channelizer_name() == ("dft_mfma_i8" if fmt == "u8" else "dft_mfma_f32")  # the 64-channel dongle runs as eight groups of 8 on the matrix-core path
         assert hip.total_channels == 73
         with pytest.raises(pkg.AirbandError) as e:
             hip.collect()
