@@ -11,7 +11,7 @@
  * Work per sample is 16x the int8 kernel's per byte moved (K = 4 per instruction instead of 64), so this kernel is bound by the float32 matrix pipe,
  * not by HBM: 256 instructions of 32 cycles per 16-hop tile.  Mapping: one WORKGROUP of four waves per work item (dongle, group of 8 channels) and
  * tile range; the four waves share one staged copy of the stream and split the contraction index -- wave p owns window samples [128 p, 128 p + 128),
- * 64 resident B registers -- and wave 0 adds the four partial sums (through LDS) and writes the rings.
+ * 64 resident B registers -- and one wave (which one rotates with the workgroup) adds the four partial sums (through LDS) and writes the rings.
  *   A (16 hops x 4 values per MFMA): lane l supplies value k = l >> 4 of hop l & 15.  The contraction index is ORDERED so that one 16-byte LDS read
  *     feeds four consecutive MFMAs: MFMA s = 4 j + i of a wave uses the stream values 16 j + 4 (l >> 4) + i of its piece, i = 0 .. 3.
  *   B: [piece][s][lane] floats, built on the host in double with the same ordering (params.cpp, build_f32_tables).
@@ -84,6 +84,10 @@ __global__ __launch_bounds__(64 * NW, MAX_LD <= 6 ? 3 : 1) void channelizer_f32_
     const int buf_bytes = a.lds_per_buf;
     uint8_t* lds = lds_all;
     float4* exch = reinterpret_cast<float4*>(lds_all + 2 * buf_bytes); /* [tile parity][NW - 1][64] partial sums on their way to wave 0 */
+
+    /* the wave that adds the partial sums up and writes the rings: a different one from workgroup to workgroup -- wave i of every workgroup sits on SIMD i, and
+     * with wave 0 everywhere SIMD 0 of a CU would carry the finishing work of all its workgroups */
+    const int fin = wg & (NW - 1);
 
     /* ---- B fragments: KW registers, resident ---- */
     const float* btab = a.btab + ((long)a.item_bset[item] * NW + piece) * KW * 64 + lane;
@@ -179,10 +183,10 @@ __global__ __launch_bounds__(64 * NW, MAX_LD <= 6 ? 3 : 1) void channelizer_f32_
         acc += acc1;
         /* the other pieces' partial sums reach wave 0 through LDS; two areas alternate so that a wave a tile ahead never overwrites what wave 0 still adds up */
         float4* ex = exch + (t & 1) * (NW - 1) * 64;
-        if (piece > 0) ex[(piece - 1) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (piece != fin) ex[((piece - fin - 1) & (NW - 1)) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         if (t + 1 < t_end) park_tile(lds + ((t + 1 - t_begin) & 1) * buf_bytes); /* the other buffer: every wave left it at the previous tile's barrier */
         __syncthreads();
-        if (piece > 0) continue;
+        if (piece != fin) continue;
         float val[4] = {acc[0], acc[1], acc[2], acc[3]};
 #pragma unroll
         for (int q = 0; q < NW - 1; q++) {
