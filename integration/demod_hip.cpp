@@ -120,16 +120,12 @@ struct hip_part {
     bool have_batch;
 };
 
-struct served_mixer {
-    int mixer;  // index into mixers[]
-};
-
 struct hip_class {
     std::vector<int> devs;
     std::vector<hip_part> parts;
     std::vector<int> leader;         // per part: the first part on the same GPU (partial sums of one GPU are added up there)
     std::vector<int> fabric;         // the leaders: one per distinct GPU, all-reduced over RCCL when there are several
-    std::vector<served_mixer> served;
+    std::vector<int> served;         // indices into mixers[]: the mixers this class sums on the GPUs
     std::vector<float> mix_left, mix_right;
     std::vector<uint8_t> mix_signal;
 };
@@ -205,8 +201,7 @@ static void hip_check(airband_hip_handle* h, int rc, const char* what) {
 // Mixers whose inputs ALL come from channels of this class are served on the GPUs (mixer_connect_input(), mixer.cpp:57-94, has
 // recorded ampfactor / ampl / ampr per input; the connection order inside a mixer is its input index, which is also the order
 // mix_waveforms() adds them in, mixer.cpp:189-214).  Any other mixer stays with mixer_thread().
-struct mixer_conn { int part, dev_in_part, chan, input; };
-typedef mixer_conn conn;
+struct conn { int part, dev_in_part, chan, input; };  // one O_MIXER output of a channel: where the channel lives, which input of the mixer it feeds
 static void wire_mixers(hip_class& c, int device_start, int device_end, bool mark_only) {
     std::vector<std::vector<conn> > per_mixer(mixer_count);
     std::vector<char> foreign(mixer_count, 0);
@@ -239,8 +234,7 @@ static void wire_mixers(hip_class& c, int device_start, int device_end, bool mar
         // alone -- a mixer_thread() that still saw them would emit an (empty) batch every third interval (mixer.cpp:225-248)
         for (int m = 0; m < mixer_count; m++) {
             if (!mixers[m].enabled || foreign[m] || per_mixer[m].empty() || (int)per_mixer[m].size() != mixers[m].input_count) continue;
-            served_mixer s = {m};
-            c.served.push_back(s);
+            c.served.push_back(m);
             mixers[m].gpu_served = true;
         }
         return;
@@ -250,10 +244,10 @@ static void wire_mixers(hip_class& c, int device_start, int device_end, bool mar
     for (size_t p = 0; p < c.parts.size(); p++) {
         std::vector<airband_hip_mixer_input> in;
         for (int s = 0; s < S; s++) {
-            const mixer_t* mx = mixers + c.served[s].mixer;
+            const mixer_t* mx = mixers + c.served[s];
             for (int input = 0; input < mx->input_count; input++)  // connection order = input index
-                for (size_t q = 0; q < per_mixer[c.served[s].mixer].size(); q++) {
-                    const conn& k = per_mixer[c.served[s].mixer][q];
+                for (size_t q = 0; q < per_mixer[c.served[s]].size(); q++) {
+                    const conn& k = per_mixer[c.served[s]][q];
                     if (k.input != input || k.part != (int)p) continue;
                     const mixinput_t* mi = mx->inputs + input;
                     airband_hip_mixer_input e;
@@ -268,7 +262,7 @@ static void wire_mixers(hip_class& c, int device_start, int device_end, bool mar
         }
         hip_check(c.parts[p].h, airband_hip_set_mixers(c.parts[p].h, S, in.empty() ? NULL : in.data(), (int32_t)in.size()), "set_mixers");
         for (int s = 0; s < S; s++)
-            if (mixers[c.served[s].mixer].channel.mode == MM_STEREO) hip_check(c.parts[p].h, airband_hip_mixer_set_stereo(c.parts[p].h, s, 1), "mixer_set_stereo");
+            if (mixers[c.served[s]].channel.mode == MM_STEREO) hip_check(c.parts[p].h, airband_hip_mixer_set_stereo(c.parts[p].h, s, 1), "mixer_set_stereo");
     }
     c.mix_left.resize((size_t)S * WAVE_BATCH);
     c.mix_right.resize((size_t)S * WAVE_BATCH);
@@ -563,7 +557,7 @@ void* demodulate_hip(void* params) {
                 airband_hip_collect_mixers(cls.parts[0].h, cls.mix_left.data(), cls.mix_right.data(), cls.mix_signal.data()) == AIRBAND_HIP_OK) {
                 bool sent = false;
                 for (size_t s = 0; s < cls.served.size(); s++) {
-                    mixer_t* mixer = mixers + cls.served[s].mixer;
+                    mixer_t* mixer = mixers + cls.served[s];
                     if (!mixer->enabled) continue;
                     channel_t* channel = &mixer->channel;
                     if (channel->state == CH_READY) mixer->output_overrun_count++;  // previous output not yet handled by the output thread (mixer.cpp:180-187)

@@ -1545,7 +1545,7 @@ int airband_hip_allreduce_mixers(airband_hip_handle* h, void* stream) {
     RCCL_TRY(h, R, R->AllReduce(h->d_mix_right.p, h->d_mix_right.p, n, ncclFloat, ncclSum, h->comm, s));
     RCCL_TRY(h, R, R->AllReduce(h->d_mix_signal.p, h->d_mix_signal.p, (size_t)h->n_mixers, ncclUint8, ncclMax, h->comm, s));
     RCCL_TRY(h, R, R->GroupEnd());
-    if (stream && (hipStream_t)stream != h->stream) { /* whatever the handle does next to these buffers (the next batch's sums, collect_mixers) comes behind the exchange */
+    if (s != h->stream) { /* (a caller's stream, handed in here or to process_device) whatever the handle does next to these buffers (the next batch's sums, collect_mixers) comes behind the exchange */
         if (!h->ev_last) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
         HIP_TRY(h, hipEventRecord(h->ev_last, s), AIRBAND_HIP_ERUNTIME);
         h->ev_last_pending = true;

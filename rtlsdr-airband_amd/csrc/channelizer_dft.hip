@@ -608,7 +608,11 @@ static void launch_al(const DftArgs& a, hipStream_t stream) {
     const long groups = (long)a.n_items * a.splits;
     const size_t lds = (size_t)a.nbuf * a.lds_per_buf + (NP > 1 ? 2 * (NP - 1) * 64 * sizeof(float4) : 0);
     /* more than the default 64 KiB of dynamic LDS (eight-piece windows): opt in to the CU's 160 KiB, once per kernel variant */
-    static bool big_lds[2] = {false, false};
+    /* (once per kernel variant AND device: the attribute belongs to the function as loaded on the current device, and a process may drive several GPUs) */
+    static bool big_lds_dev[64][2] = {{false, false}};
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    bool* big_lds = big_lds_dev[cur_dev & 63];
     if (lds > 64 * 1024 && !big_lds[a.edge_hi_zero ? 1 : 0]) {
         const void* fn = a.edge_hi_zero ? reinterpret_cast<const void*>(&channelizer_dft_kernel<FFT_N, true, HOPB, S16, AL, NP>)
                                         : reinterpret_cast<const void*>(&channelizer_dft_kernel<FFT_N, false, HOPB, S16, AL, NP>);

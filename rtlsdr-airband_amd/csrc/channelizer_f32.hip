@@ -260,9 +260,13 @@ template <int FFT_N, int MAX_LD>
 static void launch_f32(const F32Args& a, hipStream_t stream) {
     const long groups = (long)a.n_items * a.splits;
     const size_t lds = (size_t)2 * a.lds_per_buf + 2 * (NW - 1) * 64 * sizeof(float4);
-    static bool big_lds = false; /* (one flag per instantiation) */
-    if (lds > 64 * 1024 && !big_lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_f32_kernel<FFT_N, MAX_LD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) big_lds = true;
+    /* more than the default 64 KiB of dynamic LDS: opt in to the CU's 160 KiB, once per kernel variant AND device (the attribute belongs to the function as loaded
+     * on the current device; a process may drive several GPUs) */
+    static bool big_lds[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (lds > 64 * 1024 && !big_lds[dev & 63]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_f32_kernel<FFT_N, MAX_LD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) big_lds[dev & 63] = true;
     }
     hipLaunchKernelGGL((channelizer_f32_kernel<FFT_N, MAX_LD>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, a);
 }

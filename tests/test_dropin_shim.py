@@ -197,9 +197,9 @@ def test_configs0_file_input_with_the_hip_backend(pkg, built, tmp_path):
     iq = pkg.siggen.generate_u8(0, 0, helpers.stream_bytes(n_batches + 2, wave_rate) // 2, carriers)
     path = tmp_path / "dongle0.u8"
     iq.tofile(path)
-    kw = dict(nfm=False, file_inputs={0: (str(path), 8.0)}, wait_exit_s=20.0, timeout_s=60.0)
-    ref = pyref.run_reference_all(devices, [np.zeros(0, np.uint8)], n_batches, **kw)
-    hip = pyref.run_reference_all(devices, [np.zeros(0, np.uint8)], n_batches, hip_lib=pkg.LIB_PATH, **kw)
+    from test_reference_plumbing import file_input_run
+    ref = file_input_run(devices, path, n_batches, None)
+    hip = file_input_run(devices, path, n_batches, pkg.LIB_PATH)
     assert ref["batches"] == hip["batches"] == [n_batches] and hip["output_overruns"] == [0]
     assert np.array_equal(ref["axc"], hip["axc"]) and (hip["axc"] == ord("*")).any()
     assert helpers.rms(ref["waveout"] - hip["waveout"]) <= 1e-4

@@ -29,6 +29,17 @@ def configs0_devices():
     return [dict(channels=chans)], carriers
 
 
+def file_input_run(devices, path, n_batches, hip_lib, tries=4):
+    """The driver appends half a ring (two batches) at a time and the demodulator never waits for its consumer (src/rtl_airband.cpp:649-654): a consumer that is
+    descheduled for a few milliseconds on a busy box loses a batch (output_overrun_count) and everything behind it shifts.  That is the reference's own hand-off, not what is
+    under test: the run is repeated until one comes through without an overrun."""
+    for _ in range(tries):
+        r = pyref.run_reference_all(devices, [np.zeros(0, np.uint8)], n_batches, nfm=False, file_inputs={0: (str(path), 8.0)}, wait_exit_s=20.0, timeout_s=60.0, hip_lib=hip_lib)
+        if r["output_overruns"] == [0] and r["batches"][0] == n_batches:
+            break
+    return r
+
+
 @need_ref
 def test_partition_of_a_class_over_the_gpus():
     lib = C.CDLL(pyref.ref_lib_path(False, "patched"))
@@ -76,7 +87,7 @@ def test_configs0_through_the_reference_file_input(pkg, built, tmp_path):
     iq = pkg.siggen.generate_u8(0, 0, nbytes // 2, carriers)
     path = tmp_path / "dongle0.u8"
     iq.tofile(path)
-    r = pyref.run_reference_all(devices, [np.zeros(0, np.uint8)], n_batches, nfm=False, file_inputs={0: (str(path), 8.0)}, wait_exit_s=20.0, timeout_s=60.0)
+    r = file_input_run(devices, path, n_batches, None)
     nb = r["batches"][0]
     assert nb == n_batches and r["output_overruns"] == [0], (nb, r["output_overruns"])
     orc = pyoracle.Oracle(devices, wave_rate=wave_rate)
