@@ -48,12 +48,12 @@ def test_reference_harness_with_hip_backend(pkg, built, mixed, wave_rate):
 INPUT_DISABLED = 5  # input_state_t (src/input-common.h:34)
 
 
-def _failure_run(pkg, hip_lib):
+def _failure_run(pkg, hip_lib, env=None):
     n_dev, n_batches, wave_rate = 3, 8, 16000
     devices, carriers = helpers.plan_devices(n_dev, True, None)
     nbytes = helpers.stream_bytes(n_batches, wave_rate) + 4 * 640
     iq = [pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)]
-    return pyref.run_reference_all(devices, iq, n_batches, nfm=True, hip_lib=hip_lib, fail_after=[None, 3, None], end_of_streams=True)
+    return pyref.run_reference_all(devices, iq, n_batches, nfm=True, hip_lib=hip_lib, fail_after=[None, 3, None], end_of_streams=True, env=env)
 
 
 @pytest.mark.skipif(not (pyref.have_ref(True) and os.path.exists(pyref.ref_lib_path(True, "patched"))), reason="oracle/_ref not built")
@@ -206,3 +206,19 @@ def test_configs0_file_input_with_the_hip_backend(pkg, built, tmp_path):
     assert hip["stats"][0][0]["bin"] == 411 and hip["stats"][0][5]["bin"] == 44
     for r in (ref, hip):
         assert r["exited_on_its_own"] and r["devices_running_at_exit"] == 0 and r["input_state_at_exit"] == [5]
+
+
+@need_patched_nfm
+def test_failed_inputs_with_the_shard_on_two_parts(pkg, built):
+    """The end-of-file scenario of test_one_input_at_end_of_file_then_all with the shard cut into two parts (AIRBAND_HIP_GPUS = "0,0": devices {0} and {1, 2}): device 1 fails
+    after three batches inside the second part, the other device of that part and the other part carry on, the last failures end the process -- and every batch is the
+    one-part run's, bit for bit."""
+    one = _failure_run(pkg, pkg.LIB_PATH, env={"AIRBAND_HIP_GPUS": "0"})
+    two = _failure_run(pkg, pkg.LIB_PATH, env={"AIRBAND_HIP_GPUS": "0,0"})
+    for r in (one, two):
+        assert r["batches"] == [8, 3, 8] and r["outputs_disabled"] == [0, 1, 0] and r["devices_running"] == 2
+        assert r["exited_on_its_own"] and r["devices_running_at_exit"] == 0 and r["outputs_disabled_at_exit"] == [1, 1, 1]
+    for d, nb in enumerate(one["batches"]):
+        assert np.array_equal(one["axc"][d, :nb], two["axc"][d, :nb])
+        assert np.array_equal(one["waveout"][d, :nb].view(np.uint32), two["waveout"][d, :nb].view(np.uint32))
+    assert (one["axc"][0] == ord("*")).any()
