@@ -14,10 +14,9 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
-# GPU cases that run on the wavefront-FFT channelizer (csrc/channelizer_fft.hip) go to the END of a `-m gpu` run.  Round 3's last session rewrote that kernel
-# without a GPU (checked on the host emulation only), and the driver runs the GPU suite with `-x`: ordered like this, the run first says
-# everything about the path the benchmark measures, and then what the GPU makes of the rewritten kernel -- instead of stopping at the first FFT case and
-# saying nothing about the rest.
+# GPU cases on the side paths (the wavefront-FFT channelizer, CF32) go to the END of a `-m gpu` run: the driver runs the suite with `-x`, and ordered like this a run
+# first says everything about the path the benchmark measures.  (Round 3 introduced the ordering for a kernel written without a GPU; round 4's first GPU call validated
+# that kernel -- profiles/r04_experiments.md A -- and the ordering stayed as a convention.)
 _FFT_PATH = ("fft_wave64", "SFMT_F32", "test_fft_channelizer_lds_budget", "test_gpu_wavefront_fft")  # (AFC on the matrix-core path: its one-hop spectrum launch stays on the shuffle kernel)
 
 
