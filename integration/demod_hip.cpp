@@ -211,6 +211,8 @@ static void wire_mixers(hip_class& c, int device_start, int device_end, bool mar
             part_of[c.parts[p].devs[i]] = (int)p;
             idx_in_part[c.parts[p].devs[i]] = (int)i;
         }
+    if (mark_only)  // the parts do not exist yet: which mixers are served depends on the class alone
+        for (size_t i = 0; i < c.devs.size(); i++) part_of[c.devs[i]] = 0;
     for (int d = 0; d < device_count; d++) {
         const bool ours = d >= device_start && d < device_end && part_of[d] >= 0;
         for (int j = 0; j < devices[d].channel_count; j++) {
@@ -230,8 +232,9 @@ static void wire_mixers(hip_class& c, int device_start, int device_end, bool mar
         }
     }
     if (mark_only) {
-        // first thing, before the handles are built (which takes a while): from here on mixer_thread() and mixer_put_samples() leave these mixers
-        // alone -- a mixer_thread() that still saw them would emit an (empty) batch every third interval (mixer.cpp:225-248)
+        // first thing, before the HIP runtime comes up and the handles are built (which takes a while): from here on mixer_thread() and
+        // mixer_put_samples() leave these mixers alone -- a mixer_thread() that still saw them would emit an (empty) batch every third interval
+        // (mixer.cpp:225-248)
         for (int m = 0; m < mixer_count; m++) {
             if (!mixers[m].enabled || foreign[m] || per_mixer[m].empty() || (int)per_mixer[m].size() != mixers[m].input_count) continue;
             c.served.push_back(m);
@@ -417,7 +420,6 @@ static void tui_line(int device_num, device_t* dev) {
 
 void* demodulate_hip(void* params) {
     demod_params_t* dp = (demod_params_t*)params;  // device_start / device_end shard (rtl_airband.h demod_params_t)
-    const std::vector<int> gpus = gpu_list();
     std::vector<hip_class> classes;
     for (int d = dp->device_start; d < dp->device_end; d++) {
         if (devices[d].mode != R_MULTICHANNEL) {  // scan mode retunes the dongle between batches (rtl_airband.cpp:556-565 of the controller thread)
@@ -431,6 +433,8 @@ void* demodulate_hip(void* params) {
     }
     // A class goes over the GPUs in contiguous ranges.  With multiple_demod_threads a shard is ONE device (rtl_airband.cpp:1052-1086):
     // the shards then go round robin, device_start picks the GPU.
+    for (size_t c = 0; c < classes.size(); c++) wire_mixers(classes[c], dp->device_start, dp->device_end, true);
+    const std::vector<int> gpus = gpu_list();  // the first call into the HIP runtime
     size_t max_parts = 1;
     for (size_t c = 0; c < classes.size(); c++) {
         hip_class& cls = classes[c];
@@ -446,7 +450,6 @@ void* demodulate_hip(void* params) {
             part.devs.assign(cls.devs.begin() + first[g], cls.devs.begin() + first[g + 1]);
             cls.parts.push_back(part);
         }
-        wire_mixers(cls, dp->device_start, dp->device_end, true);
         for (size_t p = 0; p < cls.parts.size(); p++) prepare_part(cls.parts[p]);
         wire_mixers(cls, dp->device_start, dp->device_end, false);
         if (cls.parts.size() > max_parts) max_parts = cls.parts.size();

@@ -215,9 +215,16 @@ def _all_worker(q, nfm, fft_log, fm_demod, devices, iq_list, n_batches, hip_lib,
             mix_a = np.zeros((n_mix, n_batches), np.uint8)
             mix_got = (C.c_int * n_mix)()
             lib.refh_set_mixer_outputs(mix_l.ctypes.data, mix_r.ctypes.data, mix_a.ctypes.data, C.cast(mix_got, C.c_void_p))
-            assert lib.refh_start_mixer_thread() == 0
+            if not hip_lib:
+                assert lib.refh_start_mixer_thread() == 0
         rc = lib.refh_start_hip(hip_lib.encode()) if hip_lib else lib.refh_start(1)
         assert rc == 0, rc
+        if n_mix and hip_lib:
+            # mixer_thread() only once demodulate_hip() has claimed its mixers: started first (as main() does) it emits silence while the HIP runtime
+            # comes up, and the batch-by-batch comparison with the demodulate() run would be off by that many batches
+            lib.refh_wait_mixers_served.argtypes = [C.c_double]
+            lib.refh_wait_mixers_served(30.0)
+            assert lib.refh_start_mixer_thread() == 0
         if files:
             assert lib.refh_start_inputs() == 0
         wave = np.zeros((nd, n_batches, nch, wb), np.float32)

@@ -405,6 +405,33 @@ int refh_start_mixer_thread(void) {
     return 0;
 }
 
+/* HIP backend only: waits until demodulate_hip() has marked every enabled mixer gpu_served (it does so before it first calls into the HIP runtime) or the
+ * time is up; returns how many are marked.  The harness starts mixer_thread() after this: the reference starts it before the demodulators
+ * (src/rtl_airband.cpp:1098-1111) and emits silence until they deliver, which is timing, not behaviour -- a comparison batch by batch must not see it. */
+int refh_wait_mixers_served(double timeout_s) {
+    int served = 0;
+#ifdef REFH_PATCHED
+    struct timeval t0, t1;
+    gettimeofday(&t0, NULL);
+    for (;;) {
+        int enabled = 0;
+        served = 0;
+        for (int m = 0; m < mixer_count; m++) {
+            if (!mixers[m].enabled) continue;
+            enabled++;
+            if (mixers[m].gpu_served) served++;
+        }
+        if (served == enabled) break;
+        gettimeofday(&t1, NULL);
+        if ((t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec) > timeout_s) break;
+        usleep(1000);
+    }
+#else
+    (void)timeout_s;
+#endif
+    return served;
+}
+
 void refh_mixer_counters(int m, uint64_t* out4) {
     out4[0] = mixers[m].output_overrun_count;
     out4[1] = mixers[m].enabled ? 1 : 0;
