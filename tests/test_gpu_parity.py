@@ -3,6 +3,8 @@
 Bars (BASELINE.json north_star): squelch open/close decisions bit-exact, float audio within 1e-4 RMS; stage 2 alone
 (same stage-1 input) bit-identical; stage-1 bins within 1e-5 relative RMS of the oracle's float64 FFT.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -101,6 +103,37 @@ def test_opening_timer_expires_on_the_first_sample_of_a_batch(pkg, built):
             assert np.array_equal(out["waveout"].view(np.uint32), ww.view(np.uint32))
     assert orc.stats(0, 0)["squelch_level"] == level and 4 in outcomes
     orc.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_GPU", "8"))))
+def test_random_plans_on_the_gpu(pkg, built, seed):
+    """The GPU twin of tests/test_host_wave64.py::test_random_plans_with_wavefront_semantics (same seeds, same scenarios): random plans over every kind -- CTCSS
+    on FM and AM channels, lowpass + CTCSS, raw-I/Q outputs, notch, manual squelch, both discriminators -- on made-up stage-1 output with awkward values (exact
+    zeros, squares that underflow, large values), dense keying, squelch transitions aimed at the batch boundaries.  Stage 2 on the real wavefront (its own
+    v_sqrt / v_rcp sequences, DPP, cooperative stores) against the oracle: squelch trace, axcindicate, audio, raw I/Q bit for bit; NaN where the oracle has NaN.
+    AIRBAND_FUZZ_SEEDS_GPU=N runs N seeds (profiles/r04_experiments.md I: the campaign that was run)."""
+    from test_host_wave64 import random_scenario
+    devices, wave_rate, fm_demod, B, n_batches, streams = random_scenario(seed, max_dev=40 if seed % 5 == 4 else 9)  # every fifth seed fills whole 64-slot blocks
+    n_dev = len(devices)
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fm_demod=fm_demod)
+    try:
+        with pkg.AirbandHip(devices, wave_rate=wave_rate, fm_demod=fm_demod, flags=pkg.capi.FLAG_TRACE_SQUELCH) as hip:
+            for b in range(n_batches):
+                w = np.concatenate([s[0][:, b * B:(b + 1) * B] for s in streams])
+                q = np.concatenate([s[1][:, 2 * b * B:2 * (b + 1) * B] for s in streams])
+                want = [orc.run_bins(d, streams[d][0][:, b * B:(b + 1) * B], streams[d][1][:, 2 * b * B:2 * (b + 1) * B]) for d in range(n_dev)]
+                hip.process_bins(np.ascontiguousarray(w), np.ascontiguousarray(q))
+                out = hip.collect(iq=True)
+                tr = hip.read_trace()
+                wt = np.concatenate([x["trace"] for x in want])
+                assert np.array_equal(tr, wt), "seed %d batch %d: squelch trace (channels %s)" % (seed, b, np.nonzero((tr != wt).any(axis=1))[0])
+                assert np.array_equal(out["axc"], np.concatenate([x["axc"] for x in want])), "seed %d batch %d: axc" % (seed, b)
+                for key in ("waveout", "iq_out"):
+                    ww = np.concatenate([x[key] for x in want])
+                    same = (out[key].view(np.uint32) == ww.view(np.uint32)) | (np.isnan(out[key]) & np.isnan(ww))
+                    assert same.all(), "seed %d batch %d: %s (channels %s)" % (seed, b, key, np.nonzero((~same).any(axis=1))[0])
+    finally:
+        orc.close()
 
 
 @pytest.mark.parametrize("force_fft", [False, True], ids=["dft_mfma", "fft_wave64"])

@@ -160,7 +160,7 @@ def test_harness_refuses_the_kinds_it_cannot_run(hostdemod):
     assert hostdemod.hostdemod_create(C.byref(cfg), 0, C.byref(h)) == -100
 
 
-def _fuzz_streams(rng, n_ch, B, n_batches, nfm):
+def _fuzz_streams(rng, n_ch, B, n_batches, nfm, dense=False):
     """Stage-1 outputs made up directly (no channelizer): per channel a noise floor, keyed bursts of random strength and length, stretches of exact
     zeros, of values whose squares underflow, and of large values -- the seams of the kernels' short sqrt / division sequences and of the squelch."""
     n = B * n_batches
@@ -171,9 +171,12 @@ def _fuzz_streams(rng, n_ch, B, n_batches, nfm):
         env = np.full(n, floor, np.float64) * (1.0 + 0.3 * rng.standard_normal(n))
         t = 0
         while t < n:
-            gap, on = int(rng.integers(50, 3000)), int(rng.integers(5, 2500))
+            gap, on = (int(rng.integers(20, 500)), int(rng.integers(20, 600))) if dense else (int(rng.integers(50, 3000)), int(rng.integers(5, 2500)))
             t += gap
             env[t:t + on] += floor * float(10.0 ** rng.uniform(-0.3, 1.8)) * (1.0 + 0.15 * rng.standard_normal(min(on, max(0, n - t))))
+            if dense and rng.random() < 0.5:  # a step inside the transmission: the delayed and the current level differ for ~100 samples
+                a = t + int(rng.integers(0, on))
+                env[a:t + on] *= float(rng.choice([0.3, 0.6, 1.7, 4.0]))
             t += on
         for _ in range(3):  # the odd stretches
             a, ln = int(rng.integers(0, n - 400)), int(rng.integers(1, 400))
@@ -187,6 +190,53 @@ def _fuzz_streams(rng, n_ch, B, n_batches, nfm):
             wave[c] = np.sqrt(re * re + im * im)  # float32 throughout: what stage 1 hands over (src/rtl_airband.cpp:484-487)
         else:
             wave[c] = env.astype(np.float32)
+    return wave, iq
+
+
+def _aim_at_boundaries(rng, make_oracle, wave, iq, B, n_batches):
+    """Moves every channel's stream in time so that one of its squelch transitions (found with a scratch oracle; into OPEN by preference) lands on or within
+    three samples of a batch boundary, and -- half of the time -- puts a step in the level ~101 samples before that boundary (what the squelch's delay line
+    hands the post-filter gate there).  A random stream puts a transition on a boundary once in WAVE_BATCH tries; the state a kernel carries from batch to
+    batch is looked at on exactly those samples (the round-4 delay-line defect sat there, and thousands of unaimed seeds did not see it)."""
+    n_ch, n = wave.shape
+
+    def states():
+        probe = make_oracle()
+        try:
+            return np.concatenate([probe.run_bins(0, wave[:, b * B:(b + 1) * B], iq[:, 2 * b * B:2 * (b + 1) * B])["trace"] for b in range(n_batches)], axis=1) & 7
+        finally:
+            probe.close()
+
+    def shift(c, by):
+        wave[c] = np.roll(wave[c], by)
+        iq[c] = np.roll(iq[c], 2 * by)
+
+    st = states()
+    aim = {}
+    for c in range(n_ch):
+        tr = np.nonzero(st[c, 1:] != st[c, :-1])[0] + 1
+        tr = tr[tr > 150]
+        if len(tr) == 0:
+            continue
+        opens = tr[st[c, tr] == 4]
+        t = int(rng.choice(opens if len(opens) and rng.random() < 0.7 else tr))
+        at = int(rng.integers(1, n_batches)) * B + (0 if rng.random() < 0.5 else int(rng.integers(-3, 4)))
+        aim[c] = (at, int(st[c, t]))
+        shift(c, at - t)
+        if rng.random() < 0.5:
+            a = at - 101 + int(rng.integers(-2, 3))
+            ln = int(rng.integers(1, 40))
+            f = np.float32(rng.choice([0.02, 0.2, 5.0, 40.0]))
+            wave[c, a:a + ln] *= f
+            iq[c, 2 * a:2 * (a + ln)] *= f
+    for _ in range(2):  # the moved stream has another past: the transition may have moved by a few samples; follow it
+        st = states()
+        for c, (at, to) in aim.items():
+            tr = np.nonzero((st[c, 1:] != st[c, :-1]) & (st[c, 1:] == to))[0] + 1
+            if len(tr):
+                t = int(tr[np.argmin(np.abs(tr - at))])
+                if t != at and abs(t - at) < 200:
+                    shift(c, at - t)
     return wave, iq
 
 
@@ -222,7 +272,9 @@ def test_random_plans_and_made_up_stage1_output(hostdemod, seed):
     hd = HostDemod(hostdemod, devices, wave_rate, fm_demod)
     try:
         B, n_batches = hd.B, 4
-        wave, iq = _fuzz_streams(rng, len(chans), B, n_batches, [c["modulation"] == 1 for c in chans])
+        wave, iq = _fuzz_streams(rng, len(chans), B, n_batches, [c["modulation"] == 1 for c in chans], dense=seed % 4 >= 2)  # dense: a transition every few hundred samples
+        if seed % 2:  # every other seed with its transitions aimed at the batch boundaries
+            wave, iq = _aim_at_boundaries(rng, lambda: pyoracle.Oracle(devices, wave_rate=wave_rate, fm_demod=fm_demod), wave, iq, B, n_batches)
         for b in range(n_batches):
             w, q = wave[:, b * B:(b + 1) * B], iq[:, 2 * b * B:2 * (b + 1) * B]
             want = orc.run_bins(0, w, q)

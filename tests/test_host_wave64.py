@@ -108,11 +108,11 @@ def test_all_kinds_with_wavefront_semantics(wave64, style, n_dev, mixed, wave_ra
         orc.close()
 
 
-def _fuzz_streams_ct(rng, chans, wave_rate, B, n_batches):
+def _fuzz_streams_ct(rng, chans, wave_rate, B, n_batches, dense=False):
     """test_host_demod._fuzz_streams with a CTCSS sub-tone on the FM channels that ask for one: the right tone, a neighbouring standard tone, or none."""
     from test_host_demod import _fuzz_streams
     nfm = [c["modulation"] == 1 for c in chans]
-    wave, iq = _fuzz_streams(rng, len(chans), B, n_batches, nfm)
+    wave, iq = _fuzz_streams(rng, len(chans), B, n_batches, nfm, dense)
     n = B * n_batches
     t = np.arange(n) / wave_rate
     for c, ch in enumerate(chans):
@@ -142,16 +142,14 @@ def _fuzz_streams_ct(rng, chans, wave_rate, B, n_batches):
     return wave, iq
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_WAVE64", "4"))))
-def test_random_plans_with_wavefront_semantics(wave64, seed):
-    """Random plans over EVERY kind -- CTCSS on FM and AM channels, lowpass + CTCSS, raw-I/Q outputs, notch, manual squelch -- on made-up stage-1 output
-    with awkward values, several dongles (so that a wavefront's lanes sit in different squelch states and blocks are partly filled): the kernels with
-    their wavefront semantics against the oracle, bit for bit, squelch trace (tone bit included), axcindicate, audio."""
+def random_scenario(seed, max_dev=9):
+    """(devices, wave_rate, fm_demod, B, n_batches, streams): a random plan over EVERY kind and made-up stage-1 output for it -- shared with the GPU twin
+    (tests/test_gpu_parity.py::test_random_plans_on_the_gpu), so a seed means the same scenario on the emulated and on the real wavefront."""
     rng = np.random.default_rng(5000 + seed)
     nfm_build = bool(seed % 4)
     wave_rate = 16000 if nfm_build else 8000
     fm_demod = int(rng.integers(0, 2)) if nfm_build else 0
-    n_dev = int(rng.integers(1, 10))
+    n_dev = int(rng.integers(1, max_dev + 1))
     devices = []
     for d in range(n_dev):
         chans = []
@@ -178,11 +176,26 @@ def test_random_plans_with_wavefront_semantics(wave64, seed):
                 c["has_iq_outputs"] = 1
             chans.append(c)
         devices.append(dict(channels=chans))
+    B, n_batches = wave_rate // 8, (6 if seed % 3 == 0 else 3)  # WAVE_BATCH (src/rtl_airband.h:90); six batches: the slow CTCSS detector (0.4 s) completes windows
+    streams = [_fuzz_streams_ct(rng, devices[d]["channels"], wave_rate, B, n_batches, dense=seed % 4 >= 2) for d in range(n_dev)]
+    if seed % 2:  # every other seed with its squelch transitions aimed at the batch boundaries (test_host_demod._aim_at_boundaries)
+        from test_host_demod import _aim_at_boundaries
+        streams = [_aim_at_boundaries(rng, lambda d=d: pyoracle.Oracle([devices[d]], wave_rate=wave_rate, fm_demod=fm_demod), streams[d][0], streams[d][1], B, n_batches)
+                   for d in range(n_dev)]
+    return devices, wave_rate, fm_demod, B, n_batches, streams
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_WAVE64", "4"))))
+def test_random_plans_with_wavefront_semantics(wave64, seed):
+    """Random plans over EVERY kind -- CTCSS on FM and AM channels, lowpass + CTCSS, raw-I/Q outputs, notch, manual squelch -- on made-up stage-1 output
+    with awkward values, several dongles (so that a wavefront's lanes sit in different squelch states and blocks are partly filled): the kernels with
+    their wavefront semantics against the oracle, bit for bit, squelch trace (tone bit included), axcindicate, audio."""
+    devices, wave_rate, fm_demod, B, n_batches, streams = random_scenario(seed)
+    n_dev = len(devices)
     orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fm_demod=fm_demod)
     hd = HostDemod(wave64, devices, wave_rate, fm_demod)
     try:
-        B, n_batches = hd.B, (6 if seed % 3 == 0 else 3)  # six batches: the slow CTCSS detector (0.4 s) completes windows
-        streams = [_fuzz_streams_ct(rng, devices[d]["channels"], wave_rate, B, n_batches) for d in range(n_dev)]
+        assert hd.B == B
         for b in range(n_batches):
             w = np.concatenate([s[0][:, b * B:(b + 1) * B] for s in streams])
             q = np.concatenate([s[1][:, 2 * b * B:2 * (b + 1) * B] for s in streams])
