@@ -660,6 +660,124 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
     assert opened > 0
 
 
+STAGE1_RATES = {8000: [960_000, 1_024_000, 1_200_000, 1_440_000, 1_800_000, 2_000_000, 2_048_000, 2_400_000, 2_560_000, 2_880_000, 3_200_000],
+                16000: [960_000, 1_024_000, 1_200_000, 1_440_000, 1_920_000, 2_000_000, 2_048_000, 2_400_000, 2_560_000, 2_880_000, 3_200_000]}
+
+
+def random_stage1_case(pkg, seed, n_batches=2):
+    """(devices, iq, fft_log, wave_rate, n_batches): a random channelizer configuration -- sample format, fft size, sample rate (hops of 60 ... 400 samples, even and
+    odd, 16-byte aligned or not), 1 ... 5 dongles with 1 ... 8 (now and then up to 24) channels each at random frequencies (negative offsets = bins in the upper half, channels sharing a bin)
+    -- and I/Q for it: noise plus a tone on every channel's bin at a random level, driven into the rails now and then."""
+    capi = pkg.capi
+    rng = np.random.default_rng(9000 + seed)
+    sfmt = [capi.SFMT_U8, capi.SFMT_U8, capi.SFMT_S8, capi.SFMT_S16, capi.SFMT_F32][int(rng.integers(0, 5))]
+    fft_log = int(rng.choice([8, 9, 9, 9, 10, 11, 12, 13]))
+    wave_rate = int(rng.choice([8000, 16000]))
+    rates = [r for r in STAGE1_RATES[wave_rate] if r // wave_rate < (1 << fft_log)]
+    sample_rate = int(rng.choice(rates))
+    hop, n_fft = sample_rate // wave_rate, 1 << fft_log
+    n_dev = int(rng.integers(1, 6))
+    gains = [float(rng.choice([8.0, 50.0, 200.0])) for _ in range(n_dev)] if sfmt == capi.SFMT_S16 else [1.0] * n_dev
+    devices = []
+    for d in range(n_dev):
+        chans = []
+        for k in range(int(rng.integers(9, 25)) if rng.random() < 0.15 else int(rng.integers(1, 9))):  # more than eight: several column sets of the DFT tables
+            off = int(rng.uniform(-0.42, 0.42) * sample_rate / 1000) * 1000
+            chans.append(dict(frequency=120_000_000 + off, modulation=int(rng.integers(0, 2)) if wave_rate == 16000 else 0, afc=0, squelch_threshold_dbfs=0,
+                              squelch_snr_threshold_db=-1.0, notch_freq=0.0, notch_q=0.0, ctcss_freq=0.0, bandwidth_hz=0, ampfactor=1.0, tau_us=-1, has_iq_outputs=0))
+        devices.append(dict(channels=chans, sample_rate=sample_rate, sfmt=sfmt, fullscale=0.0 if sfmt != capi.SFMT_S16 else 127.5 * gains[d]))
+    n = (n_batches * (wave_rate // 8) + 100) * hop + n_fft + 8
+    t = np.arange(n)
+    iq = []
+    for d in range(n_dev):
+        z = rng.normal(0.0, float(rng.uniform(1.0, 25.0)), (n, 2)) @ np.array([1.0, 1j])
+        for k in range(len(devices[d]["channels"])):
+            b = int(pkg.derive_constants([devices[d]], k, wave_rate=wave_rate, fft_log=fft_log)[0])
+            f = (b if b < n_fft // 2 else b - n_fft) / n_fft + float(rng.uniform(-0.3, 0.3)) / n_fft
+            z += float(10.0 ** rng.uniform(0.0, 1.9)) * np.exp(2j * np.pi * (f * t + rng.random()))
+        u8 = np.empty(2 * n, np.uint8)
+        u8[0::2] = np.clip(np.round(z.real + 127.5), 0, 255)
+        u8[1::2] = np.clip(np.round(z.imag + 127.5), 0, 255)
+        iq.append(helpers.convert_format(u8, sfmt, capi, gains[d]))
+    return devices, iq, fft_log, wave_rate, n_batches, (capi.FLAG_FORCE_FFT if rng.random() < 0.15 else 0)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_STAGE1", "10"))))
+def test_random_channelizer_configurations(pkg, built, seed):
+    """Whatever channelizer the library picks for a random configuration (int8 matrix cores at any alignment, CF32 on the float32 matrix pipe, the wavefront FFT),
+    its bins are the oracle's within 1e-5 relative RMS, magnitudes and raw I/Q, dongle by dongle."""
+    devices, iq, fft_log, wave_rate, n_batches, flags = random_stage1_case(pkg, seed)
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fft_log=fft_log)
+    try:
+        ref = [orc.run_device(d, iq[d], n_batches) for d in range(len(devices))]
+        assert all(r["n_batches"] == n_batches for r in ref)
+        with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=flags) as hip:
+            what = "seed %d: %s, sfmt %d, fft %d, %d S/s, WAVE_RATE %d, channels %s" % (seed, hip.channelizer_name(), devices[0]["sfmt"], 1 << fft_log, devices[0]["sample_rate"],
+                                                                                      wave_rate, [len(d["channels"]) for d in devices])
+            pos = [0] * len(devices)
+            for b in range(n_batches):
+                for d in range(len(devices)):
+                    raw = iq[d].view(np.uint8)
+                    pos[d] += hip.submit(d, raw[pos[d]:])
+                assert hip.process(), what
+                hip.collect()
+                w, q = hip.read_bins()
+                k = 0
+                for d, r in enumerate(ref):
+                    nc = len(devices[d]["channels"])
+                    assert helpers.rel_rms(w[k:k + nc], r["raw_wavein"][b]) <= 1e-5, "%s; batch %d dongle %d: |bin| %g" % (what, b, d, helpers.rel_rms(w[k:k + nc], r["raw_wavein"][b]))
+                    assert helpers.rel_rms(q[k:k + nc], r["raw_iq"][b]) <= 1e-5, "%s; batch %d dongle %d: bin I/Q %g" % (what, b, d, helpers.rel_rms(q[k:k + nc], r["raw_iq"][b]))
+                    k += nc
+    finally:
+        orc.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_CHUNKS", "6"))))
+def test_results_do_not_depend_on_how_the_bytes_arrive(pkg, built, seed):
+    """The reference's input drivers append whatever the hardware hands them -- any number of bytes, in the middle of an I/Q pair if need be -- to the device's
+    circular buffer (src/input-common.cpp circbuffer_append; src/input-file.cpp:113-147) and demodulate() only sees whole batches.  So: one random configuration
+    (test_random_channelizer_configurations' generator), the same streams submitted once in large pieces and once in random ones (1 byte ... 1.3 batches, odd
+    lengths, dongles in random order, process() whenever it says yes): every batch bit-identical -- bins, squelch trace, audio."""
+    devices, iq, fft_log, wave_rate, _, flags = random_stage1_case(pkg, seed + 40_000, n_batches=4)
+    n_dev, n_batches = len(devices), 4
+    raw = [x.view(np.uint8) for x in iq]
+    rng = np.random.default_rng(77_000 + seed)
+
+    def run(chunked):
+        got = []
+        with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=flags | pkg.capi.FLAG_TRACE_SQUELCH) as hip:
+            batch_bytes = int(hip.geometry.batch_bytes)
+            pos = [0] * n_dev
+            stalled = 0
+            while len(got) < n_batches and stalled < 100_000:
+                order = rng.permutation(n_dev) if chunked else range(n_dev)
+                moved = 0
+                for d in order:
+                    left = len(raw[d]) - pos[d]
+                    if left <= 0:
+                        continue
+                    want = min(left, int(rng.integers(1, int(1.3 * batch_bytes))) if chunked else left)
+                    if chunked and rng.random() < 0.2:
+                        want = min(left, int(rng.integers(1, 64)))
+                    n = hip.submit(int(d), raw[d][pos[d]:pos[d] + want])
+                    pos[d] += n
+                    moved += n
+                while len(got) < n_batches and hip.process():
+                    out = hip.collect()
+                    w, q = hip.read_bins()
+                    got.append((out["waveout"].copy(), out["axc"].copy(), hip.read_trace(), w, q))
+                    moved += 1
+                stalled = 0 if moved else stalled + 1
+        assert len(got) == n_batches, "only %d batches came out" % len(got)
+        return got
+
+    a, b = run(False), run(True)
+    for k in range(n_batches):
+        for name, x, y in zip(("waveout", "axc", "trace", "|bin|", "bin I/Q"), a[k], b[k]):
+            xv, yv = (x.view(np.uint32), y.view(np.uint32)) if x.dtype == np.float32 else (x, y)
+            assert np.array_equal(xv, yv), "seed %d batch %d: %s differs between the two ways of submitting" % (seed, k, name)
+
+
 @pytest.mark.parametrize("force_fft", [False, True], ids=["dft_mfma", "fft_wave64"])
 def test_s8_negative_rail(pkg, built, force_fft):
     """The byte -128 of an s8 source: the reference never initialises its table entry (src/rtl_airband.cpp:322-324); library and oracle
