@@ -462,6 +462,63 @@ def test_mixers_match_reference_order_sum(pkg, built):
             hip.mixer_enable_input(len(inputs), False)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_MIXERS", "6"))))
+def test_random_mixer_wirings(pkg, built, seed):
+    """Random mixer wiring -- 1 ... 6 mixers, every channel into 0 ... 2 of them in random connection order, random ampfactor and balance (mono mixers, hard left /
+    right), some connections disabled (mixer_disable_input), mixers with no input at all -- against the reference's summation (src/mixer.cpp:133-140,189-214)
+    restated by the oracle on the GPU's own channel audio: signal flags equal, mixers of up to 64 inputs (one sequential run) bit for bit, larger ones within 1e-5."""
+    capi = pkg.capi
+    rng = np.random.default_rng(31_000 + seed)
+    n_dev, n_batches, wave_rate = int(rng.integers(1, 14)), 3, 8000
+    devices, carriers = helpers.plan_devices(n_dev, False)
+    nbytes = helpers.stream_bytes(n_batches, wave_rate)
+    iq = [pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)]
+    n_mixers = int(rng.integers(1, 7))
+    conns = []
+    for d in range(n_dev):
+        for c in range(8):
+            for _ in range(int(rng.choice([0, 1, 1, 2]))):
+                bal = float(rng.choice([0.0, 0.0, -1.0, 1.0, -0.5, 0.25, 0.8]))
+                conns.append((d, c, int(rng.integers(0, n_mixers)), float(rng.choice([1.0, 0.5, 2.0, 0.0, 3.7])), bal))
+    order = rng.permutation(len(conns))
+    conns = [conns[i] for i in order]  # connection order = input index = summation order inside a mixer
+    if not conns:
+        conns = [(0, 0, 0, 1.0, 0.0)]
+    off = set(int(i) for i in np.nonzero(rng.random(len(conns)) < 0.15)[0])
+    rest = [t for i, t in enumerate(conns) if i not in off]
+    arr = (capi.MixerInput * max(1, len(rest)))(*[capi.MixerInput(a, b, c, d, e) for a, b, c, d, e in rest])
+    per_mixer = [sum(1 for t in conns if t[2] == m) for m in range(n_mixers)]  # the library's runs of 64 count the disabled connections too
+    # a mixer is stereo once ANY input was connected with a balance (mixer_connect_input, src/mixer.cpp:84-91), disabled or not; the oracle's helper only sees the
+    # enabled ones: where those are all centred, the right channel is the left one (ampl = ampr = 1)
+    right_is_left = [any(t[4] != 0.0 for t in conns if t[2] == m) and not any(t[4] != 0.0 for t in rest if t[2] == m) for m in range(n_mixers)]
+    base = np.arange(n_dev, dtype=np.int32) * 8
+    L = pyoracle.lib()
+    with pkg.AirbandHip(devices, wave_rate=wave_rate) as hip:
+        hip.set_mixers(n_mixers, conns)
+        for i in off:
+            hip.mixer_enable_input(i, False)
+        pos = [0] * n_dev
+        for b in range(n_batches):
+            for d in range(n_dev):
+                pos[d] += hip.submit(d, iq[d][pos[d]:])
+            assert hip.process()
+            out = hip.collect()
+            left, right, sig = hip.collect_mixers()
+            B = hip.B
+            wl, wr, ws = np.zeros((n_mixers, B), np.float32), np.zeros((n_mixers, B), np.float32), np.zeros(n_mixers, np.uint8)
+            w, a = np.ascontiguousarray(out["waveout"]), np.ascontiguousarray(out["axc"])
+            L.orc_mix(arr, len(rest), base.ctypes.data, w.ctypes.data, a.ctypes.data, B, n_mixers, wl.ctypes.data, wr.ctypes.data, ws.ctypes.data)
+            assert np.array_equal(sig, ws), "seed %d batch %d: signal flags %s vs %s" % (seed, b, sig, ws)
+            for m in range(n_mixers):
+                if right_is_left[m]:
+                    wr[m] = wl[m]
+                if per_mixer[m] <= 64:
+                    assert np.array_equal(left[m].view(np.uint32), wl[m].view(np.uint32)), "seed %d batch %d mixer %d (%d inputs): left" % (seed, b, m, per_mixer[m])
+                    assert np.array_equal(right[m].view(np.uint32), wr[m].view(np.uint32)), "seed %d batch %d mixer %d (%d inputs): right" % (seed, b, m, per_mixer[m])
+                else:
+                    assert helpers.rms(left[m] - wl[m]) <= 1e-5 * max(1.0, helpers.rms(wl[m])) and helpers.rms(right[m] - wr[m]) <= 1e-5 * max(1.0, helpers.rms(wr[m]))
+
+
 def test_mixer_exchange_between_handles(pkg, built):
     """The mixer exchange of include/airband_hip.h at the library boundary, on one GPU: the dongles of a 12-dongle fleet on two handles (5 + 7, the way the
     shim or `bench.py --gpus 2` shards them), every handle summing its own inputs of the three mixers -- one handle has NO input of mixer 2, and none with a
