@@ -789,7 +789,11 @@ def test_random_channelizer_configurations(pkg, built, seed):
         orc.close()
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_CHUNKS", "6"))))
+_CHUNK_SEEDS = ([int(x) for x in os.environ["AIRBAND_FUZZ_CHUNKS_LIST"].split(",")] if os.environ.get("AIRBAND_FUZZ_CHUNKS_LIST")
+                else list(range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_CHUNKS", "6")))))
+
+
+@pytest.mark.parametrize("seed", _CHUNK_SEEDS)
 def test_results_do_not_depend_on_how_the_bytes_arrive(pkg, built, seed):
     """The reference's input drivers append whatever the hardware hands them -- any number of bytes, in the middle of an I/Q pair if need be -- to the device's
     circular buffer (src/input-common.cpp circbuffer_append; src/input-file.cpp:113-147) and demodulate() only sees whole batches.  So: one random configuration
@@ -800,13 +804,17 @@ def test_results_do_not_depend_on_how_the_bytes_arrive(pkg, built, seed):
     raw = [x.view(np.uint8) for x in iq]
     rng = np.random.default_rng(77_000 + seed)
 
+    reread = []
+    pipelined = seed % 3 == 2 and os.environ.get("AIRBAND_FUZZ_CHUNKS_PIPE", "1") != "0"  # every third seed: the randomly fed handle also runs AIRBAND_HIP_FLAG_PIPELINE (results one process() late, flush() for the last)
+
     def run(chunked):
         got = []
-        with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=flags | pkg.capi.FLAG_TRACE_SQUELCH) as hip:
+        started = 0
+        with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=flags | pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_PIPELINE if chunked and pipelined else 0)) as hip:
             batch_bytes = int(hip.geometry.batch_bytes)
             pos = [0] * n_dev
             stalled = 0
-            while len(got) < n_batches and stalled < 100_000:
+            while started < n_batches and stalled < 100_000:
                 order = rng.permutation(n_dev) if chunked else range(n_dev)
                 moved = 0
                 for d in order:
@@ -819,20 +827,50 @@ def test_results_do_not_depend_on_how_the_bytes_arrive(pkg, built, seed):
                     n = hip.submit(int(d), raw[d][pos[d]:pos[d] + want])
                     pos[d] += n
                     moved += n
-                while len(got) < n_batches and hip.process():
-                    out = hip.collect()
-                    w, q = hip.read_bins()
-                    got.append((out["waveout"].copy(), out["axc"].copy(), hip.read_trace(), w, q))
+                while started < n_batches and hip.process():
+                    started += 1
                     moved += 1
+                    if chunked and pipelined:
+                        if started == 1:
+                            continue  # stage 1 of the first batch only
+                        if started == n_batches:  # the last call: batch n - 2 is out, flush() brings batch n - 1
+                            out = hip.collect()
+                            got.append((out["waveout"].copy(), out["axc"].copy(), hip.read_trace()))
+                            hip.flush()
+                    out = hip.collect()
+                    again = hip.collect(first_channel=0, n_channels=hip.total_channels)  # the same device rows read a second time: a transfer, not a computation
+                    if not np.array_equal(out["waveout"].view(np.uint32), again["waveout"].view(np.uint32)):
+                        x, y = out["waveout"].view(np.uint32), again["waveout"].view(np.uint32)
+                        ch = np.nonzero((x != y).any(axis=1))[0]
+                        reread.append("%s pieces, batch %d: two reads of the same result rows differ on channels %s, first index %s, count %s" % (
+                            "random" if chunked else "large", len(got), list(ch[:8]), [int(np.nonzero(x[c] != y[c])[0][0]) for c in ch[:8]], [int((x[c] != y[c]).sum()) for c in ch[:8]]))
+                    got.append((out["waveout"].copy(), out["axc"].copy(), hip.read_trace()) + (() if chunked and pipelined else hip.read_bins()))
                 stalled = 0 if moved else stalled + 1
         assert len(got) == n_batches, "only %d batches came out" % len(got)
         return got
 
     a, b = run(False), run(True)
+    problems = []
+    against_oracle = ""
     for k in range(n_batches):
-        for name, x, y in zip(("waveout", "axc", "trace", "|bin|", "bin I/Q"), a[k], b[k]):
+        for name, x, y in zip(("waveout", "axc", "trace", "|bin|", "bin I/Q"), a[k], b[k]):  # (the rings of a pipelined handle already hold the next batch's bins)
             xv, yv = (x.view(np.uint32), y.view(np.uint32)) if x.dtype == np.float32 else (x, y)
-            assert np.array_equal(xv, yv), "seed %d batch %d: %s differs between the two ways of submitting" % (seed, k, name)
+            if not np.array_equal(xv, yv):
+                ch = np.nonzero((xv != yv).reshape(xv.shape[0], -1).any(axis=1))[0]
+                problems.append("batch %d %s: channels %s, first differing index %s, count %s, max |diff| %s" % (
+                    k, name, list(ch[:8]), [int(np.nonzero((xv[c] != yv[c]).ravel())[0][0]) for c in ch[:8]], [int((xv[c] != yv[c]).sum()) for c in ch[:8]],
+                    ["%.3g" % float(np.abs(x[c].astype(np.float64) - y[c]).max()) for c in ch[:8]]))
+    if problems and not pipelined:  # which of the two is it?  Stage-1 bins of both against the oracle, channel by channel
+        orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fft_log=fft_log)
+        ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
+        orc.close()
+        for k in range(n_batches):
+            rw = np.concatenate([r["raw_wavein"][k] for r in ref])
+            for who, g in (("large pieces", a[k]), ("random pieces", b[k])):
+                worst = max(range(rw.shape[0]), key=lambda c: helpers.rel_rms(g[3][c], rw[c]))
+                against_oracle += " | batch %d %s: |bin| vs oracle %.2e (worst channel %d: %.2e)" % (k, who, helpers.rel_rms(g[3], rw), worst, helpers.rel_rms(g[3][worst], rw[worst]))
+    assert not problems and not reread, "seed %d (sfmt %d, fft %d, %d S/s, pipelined %s, flags %d, channels %s): the two ways of submitting differ: %s%s  REREAD: %s" % (
+        seed, devices[0]["sfmt"], 1 << fft_log, devices[0]["sample_rate"], pipelined, flags, [len(d["channels"]) for d in devices], "; ".join(problems), against_oracle, "; ".join(reread))
 
 
 @pytest.mark.parametrize("force_fft", [False, True], ids=["dft_mfma", "fft_wave64"])
