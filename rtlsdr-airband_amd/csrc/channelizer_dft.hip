@@ -616,7 +616,8 @@ static void launch_al(const DftArgs& a, hipStream_t stream) {
     if (lds > 64 * 1024 && !big_lds[a.edge_hi_zero ? 1 : 0]) {
         const void* fn = a.edge_hi_zero ? reinterpret_cast<const void*>(&channelizer_dft_kernel<FFT_N, true, HOPB, S16, AL, NP>)
                                         : reinterpret_cast<const void*>(&channelizer_dft_kernel<FFT_N, false, HOPB, S16, AL, NP>);
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) big_lds[a.edge_hi_zero ? 1 : 0] = true;
+        /* the CU's whole 160 KiB, not this launch's size: the flag is per variant, and a later handle of the same process may need more (runtime hop lengths) */
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) big_lds[a.edge_hi_zero ? 1 : 0] = true;
     }
     if (a.edge_hi_zero)
         hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, true, HOPB, S16, AL, NP>), dim3((unsigned)groups), dim3(64 * NP), lds, stream, a);

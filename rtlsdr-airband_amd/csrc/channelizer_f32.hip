@@ -266,7 +266,8 @@ static void launch_f32(const F32Args& a, hipStream_t stream) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (lds > 64 * 1024 && !big_lds[dev & 63]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_f32_kernel<FFT_N, MAX_LD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) big_lds[dev & 63] = true;
+        /* (the CU's whole 160 KiB, not this launch's size: a later handle of the same process may have longer hops) */
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_f32_kernel<FFT_N, MAX_LD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) big_lds[dev & 63] = true;
     }
     hipLaunchKernelGGL((channelizer_f32_kernel<FFT_N, MAX_LD>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, a);
 }

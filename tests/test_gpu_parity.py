@@ -873,6 +873,29 @@ def test_results_do_not_depend_on_how_the_bytes_arrive(pkg, built, seed):
         seed, devices[0]["sfmt"], 1 << fft_log, devices[0]["sample_rate"], pipelined, flags, [len(d["channels"]) for d in devices], "; ".join(problems), against_oracle, "; ".join(reread))
 
 
+def test_a_later_handle_with_larger_workgroups(pkg, built):
+    """Two CF32 handles in one process on the same kernel variant, the second with longer hops: 2.56 MS/s then 2.88 MS/s at WAVE_RATE 8000 need 90 and 99 KiB of LDS
+    per workgroup.  The opt-in beyond 64 KiB (hipFuncSetAttribute) is per kernel variant and was made with the FIRST handle's size -- the second handle's launch was
+    refused (found reading the launch code in round 4; the shim's one-handle-per-device-class is such a process).  Both against the oracle."""
+    capi = pkg.capi
+    wave_rate, n_batches = 8000, 2
+    for sample_rate in (2_560_000, 2_880_000):
+        devices, iq = helpers.format_case(pkg, capi.SFMT_F32, 9, sample_rate, wave_rate, 1, n_batches)
+        orc = pyoracle.Oracle(devices, wave_rate=wave_rate)
+        ref = orc.run_device(0, iq[0], n_batches)
+        orc.close()
+        with pkg.AirbandHip(devices, wave_rate=wave_rate, flags=capi.FLAG_TRACE_SQUELCH) as hip:
+            assert hip.channelizer_name() == "dft_mfma_f32"
+            raw, pos = iq[0].view(np.uint8), 0
+            for b in range(n_batches):
+                pos += hip.submit(0, raw[pos:])
+                assert hip.process(), sample_rate
+                out = hip.collect()
+                w, _ = hip.read_bins()
+                assert helpers.rel_rms(w, ref["raw_wavein"][b]) <= 1e-5
+                assert np.array_equal(out["axc"], ref["axc"][b]) and np.array_equal(hip.read_trace(), ref["trace"][b])
+
+
 @pytest.mark.parametrize("force_fft", [False, True], ids=["dft_mfma", "fft_wave64"])
 def test_s8_negative_rail(pkg, built, force_fft):
     """The byte -128 of an s8 source: the reference never initialises its table entry (src/rtl_airband.cpp:322-324); library and oracle
