@@ -310,7 +310,12 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
     constexpr int N = NS * M;           /* fft_size */
     static_assert(LOGP == 2 || LOGP == 3, "transforms of 256 or 512 points: four or eight values per lane, ONE exchange round of P 64-point FFTs, eight lanes each");
     static_assert(LOGM == 0 || LOGP == 3, "decimated transforms are 512 points long");
-    AB_DYNAMIC_LDS_BYTES(lds_raw);
+    /* LDS: the four wavefronts' exchange buffers FIRST, the tile's raw samples behind them.  (Round 4: with the buffers behind the samples they lay above 64 KiB
+     * for CF32 at fft >= 4096, and with a dozen processes time-sharing the GPU one hop in ~10^6 came out wrong -- a wavefront's transform in flight lost its
+     * exchange buffer; profiles/r04_experiments.md I.  Whatever takes LDS contents above 64 KiB away from a preempted workgroup, here it can only reach the
+     * last samples of a tile's span, which the window multiplies by ~1e-5.) */
+    AB_DYNAMIC_LDS_BYTES(lds_all);
+    uint8_t* const lds_raw = lds_all + (blockDim.x >> 6) * XBUF_BYTES;
 
     const int tiles = (a.n_hops + HOPS_PER_TILE - 1) / HOPS_PER_TILE;
     const int d = blockIdx.x / tiles, tile = blockIdx.x - d * tiles;
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
         my_mag_ring += base;
         my_iq_ring += base;
     }
-    v2f* xb = reinterpret_cast<v2f*>(lds_raw + fft_raw_bytes(a.fft_log, a.hop_samples, a.bytes_per_sample) + (long)wave * XBUF_BYTES);
+    v2f* xb = reinterpret_cast<v2f*>(lds_all + (long)wave * XBUF_BYTES);
     v2f* x_w1 = xb + lane;                     /* [j][lane]: value k1_j of lane l                     */
     v2f* x_r1 = xb + jj * XS + b8;             /* [jj][8 a + b], a = 0 .. 7                           */
     v2f* x_w2 = xb + jj * XS + b8 * 9;         /* [jj][9 b + c]: rows of nine, a transpose without bank conflicts */
