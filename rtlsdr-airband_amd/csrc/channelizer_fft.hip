@@ -315,7 +315,11 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
      * exchange buffer; profiles/r04_experiments.md I.  Whatever takes LDS contents above 64 KiB away from a preempted workgroup, here it can only reach the
      * last samples of a tile's span, which the window multiplies by ~1e-5.) */
     AB_DYNAMIC_LDS_BYTES(lds_all);
+#if defined(AB_FFT_XB_BEHIND) /* experiment builds only (scripts/r05_lds_layout_ab.sh): the layout before round 4's change, for the A/B statistics */
+    uint8_t* const lds_raw = lds_all;
+#else
     uint8_t* const lds_raw = lds_all + (blockDim.x >> 6) * XBUF_BYTES;
+#endif
 
     const int tiles = (a.n_hops + HOPS_PER_TILE - 1) / HOPS_PER_TILE;
     const int d = blockIdx.x / tiles, tile = blockIdx.x - d * tiles;
@@ -385,7 +389,11 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
         my_mag_ring += base;
         my_iq_ring += base;
     }
+#if defined(AB_FFT_XB_BEHIND)
+    v2f* xb = reinterpret_cast<v2f*>(lds_all + fft_raw_bytes(a.fft_log, a.hop_samples, a.bytes_per_sample) + (long)wave * XBUF_BYTES);
+#else
     v2f* xb = reinterpret_cast<v2f*>(lds_all + (long)wave * XBUF_BYTES);
+#endif
     v2f* x_w1 = xb + lane;                     /* [j][lane]: value k1_j of lane l                     */
     v2f* x_r1 = xb + jj * XS + b8;             /* [jj][8 a + b], a = 0 .. 7                           */
     v2f* x_w2 = xb + jj * XS + b8 * 9;         /* [jj][9 b + c]: rows of nine, a transpose without bank conflicts */
