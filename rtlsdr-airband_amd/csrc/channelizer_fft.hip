@@ -310,10 +310,9 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
     constexpr int N = NS * M;           /* fft_size */
     static_assert(LOGP == 2 || LOGP == 3, "transforms of 256 or 512 points: four or eight values per lane, ONE exchange round of P 64-point FFTs, eight lanes each");
     static_assert(LOGM == 0 || LOGP == 3, "decimated transforms are 512 points long");
-    /* LDS: the four wavefronts' exchange buffers FIRST, the tile's raw samples behind them.  (Round 4: with the buffers behind the samples they lay above 64 KiB
-     * for CF32 at fft >= 4096, and with a dozen processes time-sharing the GPU one hop in ~10^6 came out wrong -- a wavefront's transform in flight lost its
-     * exchange buffer; profiles/r04_experiments.md I.  Whatever takes LDS contents above 64 KiB away from a preempted workgroup, here it can only reach the
-     * last samples of a tile's span, which the window multiplies by ~1e-5.) */
+    /* LDS: the four wavefronts' exchange buffers FIRST, the tile's raw samples behind them.  (Round 4, profiles/r04_experiments.md I: with a dozen PROCESSES
+     * time-sharing the GPU one transform in ~10^9 came out wrong -- never with one process, 4.6e9 transforms compared bit for bit.  The layout was changed while
+     * the events all sat in configurations whose buffers lay above 64 KiB; a later one did not.  It costs nothing and stays; the cause is outside this file.) */
     AB_DYNAMIC_LDS_BYTES(lds_all);
 #if defined(AB_FFT_XB_BEHIND) /* experiment builds only (scripts/r05_lds_layout_ab.sh): the layout before round 4's change, for the A/B statistics */
     uint8_t* const lds_raw = lds_all;

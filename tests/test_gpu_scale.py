@@ -154,17 +154,20 @@ def _tweak_all(d, ch):
 
 
 REPLICA_CASES = [
-    # n_dev, mixed, wave_rate, tweak (the same for every dongle), pipelined
-    pytest.param(5000, True, 16000, True, False, id="5000_mixed_tweaked_partial_group"),
-    pytest.param(4096, True, 16000, False, True, id="4096_mixed_pipelined"),
-    pytest.param(65536, True, 16000, False, False, id="configs2_65536_mixed"),
-    pytest.param(65536, False, 8000, False, False, id="65536_am"),
+    # n_dev, mixed, wave_rate, tweak (the same for every dongle), pipelined, path ("force_fft": the wavefront FFT)
+    pytest.param(5000, True, 16000, True, False, "", id="5000_mixed_tweaked_partial_group"),
+    pytest.param(4096, True, 16000, False, True, "", id="4096_mixed_pipelined"),
+    pytest.param(65536, True, 16000, False, False, "", id="configs2_65536_mixed"),
+    pytest.param(65536, False, 8000, False, False, "", id="65536_am"),
+    # ~10^9 transforms through the wavefronts' LDS exchange in ONE process, every dongle bit-identical to dongle 0: the single-process twin of the rare event the
+    # chunking fuzz saw with twelve processes on the GPU (profiles/r04_experiments.md I)
+    pytest.param(65536, True, 16000, False, False, "force_fft", id="configs2_65536_mixed_fft_wave64"),
 ]
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("n_dev,mixed,wave_rate,tweak,pipelined", REPLICA_CASES)
-def test_every_dongle_of_a_replicated_handle(pkg, built, n_dev, mixed, wave_rate, tweak, pipelined):
+@pytest.mark.parametrize("n_dev,mixed,wave_rate,tweak,pipelined,path", REPLICA_CASES)
+def test_every_dongle_of_a_replicated_handle(pkg, built, n_dev, mixed, wave_rate, tweak, pipelined, path):
     """The WHOLE handle, not a sample: every dongle gets dongle 0's channel plan and dongle 0's bytes, dongle 0 is checked against
     the oracle (trace, axcindicate, counters exact, audio <= 1e-4 RMS) and ALL other dongles' result rows, axcindicate, statistics
     and per-sample squelch traces must be bit-identical to dongle 0's (pyverify.replica_check)."""
@@ -172,10 +175,11 @@ def test_every_dongle_of_a_replicated_handle(pkg, built, n_dev, mixed, wave_rate
     n_batches = 7
     devices, carriers = helpers.plan_devices(1, mixed, _tweak_all if tweak else None)
     one = devices[0]
-    flags = pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_PIPELINE if pipelined else 0)
+    flags = pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_PIPELINE if pipelined else 0) | (pkg.capi.FLAG_FORCE_FFT if path == "force_fft" else 0)
     hip = pkg.AirbandHip([one] * n_dev, wave_rate=wave_rate, flags=flags)
     iq = spot = None
     try:
+        assert hip.channelizer_name() == ("fft_wave64" if path == "force_fft" else "dft_mfma_i8")
         g = hip.geometry
         lead = g.first_batch_bytes - g.batch_bytes
         span = lead + (RING + 1) * g.batch_bytes + g.lookahead_bytes
