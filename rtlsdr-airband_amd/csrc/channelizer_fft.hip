@@ -48,9 +48,15 @@ namespace {
 /* Lanes of ONE wavefront exchange data through LDS: a wavefront's LDS operations execute in order, so all that is needed is that the compiler keeps
  * them in program order across the exchange (no instruction is emitted).  tests/hostshim_wave64 makes the lanes, which it runs as fibers, meet here. */
 #if !defined(AB_WAVE_SYNC)
+#if defined(AB_WAVE_SYNC_WAITS) /* experiment builds only (scripts/r05_lds_layout_ab.sh): every exchange also waits until the wavefront's LDS operations have completed */
+#define AB_WAVE_SYNC_EXTRA() __builtin_amdgcn_s_waitcnt(0xc07f) /* vmcnt(63) expcnt(7) lgkmcnt(0) */
+#else
+#define AB_WAVE_SYNC_EXTRA() (void)0
+#endif
 #define AB_WAVE_SYNC()                                           \
     do {                                                         \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        AB_WAVE_SYNC_EXTRA();                                    \
         __builtin_amdgcn_wave_barrier();                         \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
     } while (0)
