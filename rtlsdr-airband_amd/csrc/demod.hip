@@ -380,14 +380,40 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
      * that is read back AGC_EXTRA = 100 samples later: far outside the 16 samples a prefetch runs ahead. */
     constexpr int GS = 4; /* samples per group; 2 * GS divides WAVE_BATCH = 1000 / 2000 */
     constexpr int GQ = GS / 4;
+    /* Experiment builds only (-DAB_MASKED_DELAY, DESIGN 7.1 d; the product's source is token for token what it was): the AGC_EXTRA-delayed values are only USED by lanes
+     * whose squelch lets samples through -- the AM kind's delayed magnitude by OPEN / CLOSING lanes (src/rtl_airband.cpp:553-557), the plain NFM and CTCSS-front kinds'
+     * delayed raw I/Q by lanes that filter (:510-530).  The fetch stays unconditional (wait pairing, below) but a lane that is CLOSED when the fetch is issued points it at
+     * the line it reads anyway (the CURRENT hops), so its piece of the delayed line is not requested from memory.  Group::real says which lanes fetched the real thing; a
+     * lane that turns out to need it re-fetches (once per squelch opening and lane).  The lowpass kind feeds its delay-line shadow from the delayed values and the generic
+     * kind is rare: both fetch as ever. */
+#if defined(AB_MASKED_DELAY)
+    constexpr bool MASKD = KIND == AB_KIND_AM || KIND == AB_KIND_NFM || KIND == AB_KIND_NFM_CTCSS;
+#define AB_MD_PARAM , const int r
+#define AB_MD_ARG(r) , r
+#else
+#define AB_MD_PARAM
+#define AB_MD_ARG(r)
+#endif
     struct Group {
         float4 mc[GQ], md[GQ], c01[GQ], c23[GQ], q01[GQ], q23[GQ];
+#if defined(AB_MASKED_DELAY)
+        lmask real; /* lanes whose delayed values are the real ones */
+#endif
     };
     auto fetch = [&](Group& q, int j0, int tail0) { /* tail0 = squelch delay-line tail at the start of the group (lowpass kind) */
+#if defined(AB_MASKED_DELAY)
+        const lmask need = MASKD ? (~s.cC & s.active) : ~(lmask)0;
+        const bool real_lane = !MASKD || ab_lane(need);
+        q.real = need;
+#endif
 #pragma unroll
         for (int g = 0; g < GQ; g++) {
             const int rc = ring_row(a.row0 + AB_AGC_EXTRA + j0 + 4 * g, R); /* current hops */
+#if defined(AB_MASKED_DELAY)
+            const int rd = real_lane ? ring_row(a.row0 + j0 + 4 * g, R) : rc;
+#else
             const int rd = ring_row(a.row0 + j0 + 4 * g, R);                /* hops AGC_EXTRA earlier */
+#endif
             if (!nfm) {
                 q.mc[g] = *reinterpret_cast<const float4*>(mag + ab_tile_off(rc));
                 q.md[g] = *reinterpret_cast<const float4*>(mag + ab_tile_off(rd));
@@ -404,6 +430,27 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         }
         (void)tail0; /* (the NFM + lowpass kind used to fetch its four delay-line entries here; it recomputes them now: SqShadow) */
     };
+#if defined(AB_MASKED_DELAY)
+    /* the current group's delayed values (the per-sample code takes them from here, so that a re-fetch reaches the group's later samples too) */
+    float g_md[4] = {0.0f, 0.0f, 0.0f, 0.0f}, g_qr[4] = {0.0f, 0.0f, 0.0f, 0.0f}, g_qi[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    lmask g_real = 0;
+    int g_jq = 0;
+    auto refetch = [&](const lmask miss) { /* wave-uniform call; the lanes of `miss` load their real delayed values of the current group */
+        if (ab_lane(miss)) {
+            const int rd = ring_row(a.row0 + g_jq, R);
+            if (!nfm) {
+                const float4 v = *reinterpret_cast<const float4*>(mag + ab_tile_off(rd));
+                g_md[0] = v.x; g_md[1] = v.y; g_md[2] = v.z; g_md[3] = v.w;
+            } else {
+                const float4* qp = reinterpret_cast<const float4*>(iqin + ab_tile_off(rd));
+                const float4 u = qp[0], v = qp[1];
+                g_qr[0] = u.x; g_qi[0] = u.y; g_qr[1] = u.z; g_qi[1] = u.w;
+                g_qr[2] = v.x; g_qi[2] = v.y; g_qr[3] = v.z; g_qi[3] = v.w;
+            }
+        }
+        g_real |= miss;
+    };
+#endif
     /* "these registers are needed now": the compiler puts its wait for the group's loads here, BEFORE the next group's loads are issued */
     auto touch = [&](const Group& q) {
 #pragma unroll
@@ -424,12 +471,26 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
      * OPEN lanes, and the code is one straight run with a few seldom-taken exits. */
     /* the AM kind and the CTCSS front get the second version; it doubles the per-sample code, and the register-hungry kinds lose more to spills than they gain */
     constexpr bool SPLIT_REST = KIND == AB_KIND_AM || KIND == AB_KIND_NFM_CTCSS;
+#if defined(AB_MASKED_DELAY)
+    auto rest = [&](auto quiet_tag, const int j, float cur_mag, float delayed_mag, float re, float im, const lmask went_closed AB_MD_PARAM) {
+#else
     auto rest = [&](auto quiet_tag, const int j, float cur_mag, const float delayed_mag, float re, float im, const lmask went_closed) {
+#endif
         constexpr bool Q = decltype(quiet_tag)::value;
         /* (in a specialised NFM kind every lane works on raw I/Q: m_raw_iq is the set of live lanes, which the compiler cannot know to be non-empty) */
         constexpr bool ALL_RAW_IQ = (KindBits<KIND>::value & AB_F_RAW_IQ) != 0;
         if (ALL_RAW_IQ || ab_any(m_raw_iq)) { /* src/rtl_airband.cpp:510-530 */
             const lmask filt = ALL_RAW_IQ ? sq_should_filter(s) : sq_should_filter(s) & m_raw_iq;
+#if defined(AB_MASKED_DELAY)
+            if (MASKD && ALL_RAW_IQ) { /* a lane that filters from this very sample on (pre-filter signal on a CLOSED lane) and fetched the stand-in */
+                const lmask miss = filt & ~g_real;
+                if (AB_UNLIKELY(ab_any(miss))) {
+                    refetch(miss);
+                    re = g_qr[r];
+                    im = g_qi[r];
+                }
+            }
+#endif
             if (ab_lane(filt)) { /* per-lane float work only: lane masks are not touched inside divergent code */
                 const unsigned idx = dm_phi >> 16; /* sincosf_lut (src/util.cpp:113-127) */
                 const float fract = (float)(dm_phi & 0xffffu) / 65536.0f;
@@ -479,6 +540,15 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         const bool fade = (Q || KIND_IS_NFM) ? false : ab_lane(fade_m);
 
         float out = 0.0f;
+#if defined(AB_MASKED_DELAY)
+        if (MASKD && !ALL_RAW_IQ) { /* AM kind: OPENING precedes OPEN by the opening delay, so this does not happen; kept as the general rule */
+            const lmask miss = (Q ? s.cO : sq_should_audio(s)) & ~g_real;
+            if (AB_UNLIKELY(ab_any(miss))) {
+                refetch(miss);
+                delayed_mag = g_md[r];
+            }
+        }
+#endif
         const bool audio = ab_lane(Q ? s.cO : sq_should_audio(s));
         if (audio) {
             if (!nfm) { /* AM: src/rtl_airband.cpp:553-563 */
@@ -526,13 +596,13 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             emit_sample(a, cc, o, wrow, rz, iqout, trace, j, audio, fade, true, state, out, re, im, true);
         }
     };
-    auto sample = [&](const int j, const float cur_mag, const float delayed_mag /* lowpass kind: the prefetched delay-line entry */, const float re, const float im, const bool first_of_group) {
+    auto sample = [&](const int j, const float cur_mag, const float delayed_mag /* lowpass kind: the prefetched delay-line entry */, const float re, const float im, const bool first_of_group AB_MD_PARAM) {
         lmask went_closed = 0;
         if (AB_LIKELY(s.quiet)) sq_raw_quiet(s, L, cur_mag, delayed_mag, first_of_group || !aligned4);
         else went_closed = sq_raw_full(s, L, cur_mag, delayed_mag);
         /* a request raised by this very sample ends the quiet spell at once: its last-open handling is in the general version */
-        if (SPLIT_REST && AB_LIKELY(s.quiet)) rest(std::true_type{}, j, cur_mag, delayed_mag, re, im, went_closed); /* the sample that settles the last lane still reports who just closed */
-        else rest(std::false_type{}, j, cur_mag, delayed_mag, re, im, went_closed);
+        if (SPLIT_REST && AB_LIKELY(s.quiet)) rest(std::true_type{}, j, cur_mag, delayed_mag, re, im, went_closed AB_MD_ARG(r)); /* the sample that settles the last lane still reports who just closed */
+        else rest(std::false_type{}, j, cur_mag, delayed_mag, re, im, went_closed AB_MD_ARG(r));
     };
     /* ---- four samples of a STABLE wavefront as ONE basic block (AM kind, NFM + CTCSS front) ------------------------------------------
      * sq_raw_stable4() (squelch_fsm.h) runs the four squelch steps on a copy of the state and commits it only if no lane asked for a
@@ -667,6 +737,27 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                 }
             }
             if ((jq % RUN) == 0) wrow.j0 = jq;
+#if defined(AB_MASKED_DELAY)
+            if (MASKD) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) { g_md[r] = mds[r]; g_qr[r] = qr[r]; g_qi[r] = qi[r]; }
+                g_real = q.real;
+                g_jq = jq;
+                /* lanes that already let samples through (or are about to) but were CLOSED when this group's fetch was issued, one or two groups ago */
+                const lmask want0 = nfm ? ((~s.cC | ~s.nC) & ~s.cA & s.active) : (s.cO | s.cCg | s.nO | s.nCg);
+                const lmask miss0 = want0 & ~g_real;
+                if (AB_UNLIKELY(ab_any(miss0))) refetch(miss0);
+                if (SPEC4 && AB_LIKELY(aligned4 && sq_stable4(s))) { /* wave-uniform */
+                    if (AB_LIKELY(sq_raw_stable4(s, L, mcs))) {
+                        stable_tail4(jq, mcs, g_md, g_qr, g_qi);
+                        continue;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) sample(jq + r, mcs[r], g_md[r], g_qr[r], g_qi[r], r == 0, r);
+                continue;
+            }
+#endif
             if (SPEC4 && AB_LIKELY(aligned4 && sq_stable4(s))) { /* wave-uniform */
                 if (AB_LIKELY(sq_raw_stable4(s, L, mcs))) {
                     stable_tail4(jq, mcs, mds, qr, qi);
@@ -674,7 +765,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; r++) sample(jq + r, mcs[r], mds[r], qr[r], qi[r], r == 0);
+            for (int r = 0; r < 4; r++) sample(jq + r, mcs[r], mds[r], qr[r], qi[r], r == 0 AB_MD_ARG(r));
         }
     };
     /* finished output runs leave AFTER the next group's loads have been waited for: the compiler's wait is `s_waitcnt vmcnt(0)`, which

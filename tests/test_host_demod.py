@@ -31,8 +31,10 @@ def hostdemod(tmp_path_factory):
     if not os.path.exists(CLANG):
         pytest.skip("no host clang++ in this image")
     out = str(tmp_path_factory.mktemp("hostdemod") / "libhostdemod.so")
+    # AIRBAND_HOST_DEFINES="-DAB_..." compiles an experiment variant of the kernel source (e.g. -DAB_MASKED_DELAY) instead of the product's
     cmd = [CLANG, "-x", "c++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-I" + os.path.join(HERE, "hostshim"),
-           "-I" + os.path.join(REPO, "include"), "-o", out, os.path.join(HERE, "host_demod_harness.cpp"), os.path.join(CSRC, "params.cpp")]
+           "-I" + os.path.join(REPO, "include")] + os.environ.get("AIRBAND_HOST_DEFINES", "").split() + [
+           "-o", out, os.path.join(HERE, "host_demod_harness.cpp"), os.path.join(CSRC, "params.cpp")]
     subprocess.run(cmd, check=True)
     lib = C.CDLL(out)
     vp = C.c_void_p

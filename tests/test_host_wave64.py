@@ -24,8 +24,8 @@ def wave64(tmp_path_factory):
         pytest.skip("no host clang++ in this image")
     out = str(tmp_path_factory.mktemp("hostwave64") / "libhostwave64.so")
     cmd = [CLANG, "-x", "c++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-DAB_WAVE64_EMU",
-           "-I" + os.path.join(HERE, "hostshim_wave64"), "-I" + os.path.join(REPO, "include"), "-o", out, os.path.join(HERE, "host_demod_harness.cpp"),
-           os.path.join(CSRC, "params.cpp")]
+           "-I" + os.path.join(HERE, "hostshim_wave64"), "-I" + os.path.join(REPO, "include")] + os.environ.get("AIRBAND_HOST_DEFINES", "").split() + [
+           "-o", out, os.path.join(HERE, "host_demod_harness.cpp"), os.path.join(CSRC, "params.cpp")]
     subprocess.run(cmd, check=True)
     lib = C.CDLL(out)
     vp = C.c_void_p
