@@ -3,6 +3,8 @@
 #  2. the default bench line (what BENCH_rNN.json records), with its profiled children;
 #  3. the three side paths that moved to the matrix cores in round 4, one line each (hops of 250 bytes, CF32 at both WAVE_RATEs).
 # Everything lands under gpurun_out/first/; scripts/profile_round.sh + scripts/collect_profiles.py regenerate the whole of profiles/.
+# Experiments round 4 left ready (each its own call): scripts/r05_masked_delay.sh (stage 2's delayed fetch only for lanes that use it: parity, time, counters of an experiment
+# build, DESIGN 7.1 d) and scripts/r05_lds_layout_ab.sh (statistics on the wavefront FFT's rare event under twelve processes per GPU, profiles/r04_experiments.md I).
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/first; rm -rf $O; mkdir -p $O
