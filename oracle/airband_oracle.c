@@ -296,7 +296,7 @@ static void sq_avg(squelch_t* s, float* full, float* capped, float x) { /* src/s
         *capped = s->cap;
     } else {
         float v = *capped * decay + x * fresh;
-        *capped = s->cap < v ? s->cap : v;
+        *capped = v < s->cap ? v : s->cap; /* std::min(moving_avg_cap_, v) = (v < cap) ? v : cap: a NaN (an unstable lowpass: bandwidth above WAVE_RATE) yields the cap, not the NaN */
     }
 }
 
@@ -306,7 +306,7 @@ static void sq_raw(squelch_t* s, float x) { /* src/squelch.cpp:195-246 */
     if (s->sample_count % 16 == 0) { /* :477-490 noise floor follows min(level, floor) */
         const float decay = 0.97f;
         const float fresh = (float)(1.0 - (double)decay);
-        float lo = s->pre_capped < s->noise_floor ? s->pre_capped : s->noise_floor;
+        float lo = s->noise_floor < s->pre_capped ? s->noise_floor : s->pre_capped; /* std::min(pre_filter_.capped_, noise_floor_) */
         s->noise_floor = s->noise_floor * decay + lo * fresh + 1e-6f;
         sq_recalc_cap(s);
         s->level_cache = 0.0f;

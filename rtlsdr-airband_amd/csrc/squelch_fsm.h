@@ -188,7 +188,7 @@ AB_FSM_FN void sq_avg(float cap, float& full, float& capped, float x) {
     const float xf = x * fresh;
     full = full * decay + xf;
     const float v = capped * decay + xf;
-    const float vm = cap < v ? cap : v;
+    const float vm = v < cap ? v : cap; /* std::min(moving_avg_cap_, v) as libstdc++ spells it, (v < cap) ? v : cap: a NaN -- an unstable lowpass, bandwidth above WAVE_RATE -- yields the cap */
     capped = (capped >= cap && x >= cap) ? cap : vm; /* the reference short-circuits this case; the value is `cap` either way it is written */
 }
 
@@ -209,7 +209,7 @@ AB_FSM_FN void sq_delay_line_push(const SqRegs& s, const Lane& L) {
 AB_FSM_FN void sq_noise_floor(SqRegs& s, const Lane& L) {
     const float decay = 0.97f;
     const float fresh = (float)(1.0 - (double)0.97f);
-    const float lo = s.pre_capped < s.noise_floor ? s.pre_capped : s.noise_floor;
+    const float lo = s.noise_floor < s.pre_capped ? s.noise_floor : s.pre_capped; /* std::min(pre_filter_.capped_, noise_floor_), src/squelch.cpp:481 */
     s.noise_floor = s.noise_floor * decay + lo * fresh + 1e-6f;
     s.cap = ab_lane(L.m_manual) ? 1.5f * L.manual_level : 1.5f * L.normal_ratio * s.noise_floor;
     s.lvl = sq_level_compute(s, L);
@@ -232,7 +232,7 @@ AB_FSM_FN void sq_shadow_step(SqShadow& h, const Lane& L, float x, unsigned phas
     if (((phase - 101u) & 15u) == 0u) { /* calculate_noise_floor + calculate_moving_avg_cap: sq_noise_floor() without the level cache */
         const float decay = 0.97f;
         const float fresh = (float)(1.0 - (double)0.97f);
-        const float lo = h.capped < h.nf ? h.capped : h.nf;
+        const float lo = h.nf < h.capped ? h.nf : h.capped;
         h.nf = h.nf * decay + lo * fresh + 1e-6f;
         h.cap = ab_lane(L.m_manual) ? 1.5f * L.manual_level : 1.5f * L.normal_ratio * h.nf;
     }
@@ -240,7 +240,7 @@ AB_FSM_FN void sq_shadow_step(SqShadow& h, const Lane& L, float x, unsigned phas
     const float fresh = (float)(1.0 - (double)0.99f);
     const float xf = x * fresh;
     const float v = h.capped * decay + xf;
-    const float vm = h.cap < v ? h.cap : v;
+    const float vm = v < h.cap ? v : h.cap;
     h.capped = (h.capped >= h.cap && x >= h.cap) ? h.cap : vm;
 }
 

@@ -99,6 +99,102 @@ def test_stream_bit_exact_other_formats(pkg, built, sfmt_name, fft_log, sample_r
 
 
 @need_ref
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_ORACLE", "4"))))
+def test_oracle_is_the_reference_on_random_configurations(pkg, built, seed):
+    """The GPU fuzz over channelizer configurations (tests/test_gpu_parity.py::test_random_channelizer_configurations) measures the library against the C restatement
+    on configurations no fixed list holds -- sample rates like 1.44 / 1.8 / 2.88 MS/s, 1 ... 24 channels per dongle at random frequencies (bins in the upper half, shared
+    bins), per-dongle CS16 full scales.  The same generator, the same seeds, here against the REFERENCE itself: audio, axcindicate, statistics and the bin / dm_dphi
+    constants of every channel bit for bit, so that the restatement is pinned where the fuzz uses it (AIRBAND_FUZZ_SEEDS_ORACLE=N for more seeds)."""
+    import test_gpu_parity
+    devices, iq, fft_log, wave_rate, n_batches, _ = test_gpu_parity.random_stage1_case(pkg, seed)
+    orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fft_log=fft_log)
+    try:
+        for d in range(len(devices)):
+            nc = len(devices[d]["channels"])
+            ref = pyref.run_reference([devices[d]], [iq[d]], n_batches, nfm=wave_rate == 16000, fft_log=fft_log)[0]
+            got = orc.run_device(d, iq[d], n_batches)
+            what = "seed %d dongle %d (sfmt %d, fft %d, %d S/s, %d channels)" % (seed, d, devices[d]["sfmt"], 1 << fft_log, devices[d]["sample_rate"], nc)
+            assert ref["n_batches"] == got["n_batches"] == n_batches, what
+            assert np.array_equal(ref["axc"], got["axc"]), what
+            assert np.array_equal(ref["waveout"].view(np.uint32), got["waveout"].view(np.uint32)), what
+            for j in range(nc):
+                a, b = ref["stats"][j], orc.stats(d, j)
+                for k in a:
+                    if k != "squelch_state":
+                        assert a[k] == b[k], (what, j, k, a[k], b[k])
+                assert ref["consts"][j][0] == orc.constants(d, j)[0] and ref["consts"][j][1] == orc.constants(d, j)[1], (what, j)
+    finally:
+        orc.close()
+
+
+def random_plan_case(pkg, seed):
+    """(device, carriers, wave_rate, fm_demod, n_batches): ONE dongle with a random plan over every kind -- CTCSS on FM and AM channels, lowpass with and without CTCSS,
+    notch, manual / SNR squelch, de-emphasis, amplification, raw-I/Q outputs -- and transmitters for it: keyed in random rhythms and strengths (some too weak to open a
+    squelch, some that make it flap), sub-tones that are right, a neighbouring standard tone, or absent."""
+    sg = pkg.siggen
+    rng = np.random.default_rng(61_000 + seed)
+    nfm_build = bool(seed % 4)
+    wave_rate = 16000 if nfm_build else 8000
+    fm_demod = int(rng.integers(0, 2)) if nfm_build else 0
+    chans, carriers = [], []
+    for k, off in enumerate(sg.PLAN_OFFSETS_HZ):
+        c = dict(frequency=sg.CENTERFREQ + off, modulation=0, afc=0, squelch_threshold_dbfs=0, squelch_snr_threshold_db=-1.0, notch_freq=0.0, notch_q=0.0, ctcss_freq=0.0,
+                 bandwidth_hz=0, ampfactor=1.0, tau_us=-1, has_iq_outputs=0)
+        if nfm_build and rng.random() < 0.6:
+            c["modulation"] = 1
+            c["tau_us"] = int(rng.choice([-1, 0, 50, 200, 750]))
+        if rng.random() < 0.3:
+            c["bandwidth_hz"] = int(rng.choice([5000, 6250, 12500, 25000]))
+        if rng.random() < 0.4:
+            c["ctcss_freq"] = float(rng.choice([67.0, 100.0, 123.0, 254.1]))
+        mode = rng.random()
+        if mode < 0.3:
+            c["squelch_threshold_dbfs"] = int(rng.integers(-60, -25))
+        elif mode < 0.6:
+            c["squelch_snr_threshold_db"] = float(rng.choice([3.0, 6.0, 9.5, 14.0]))
+        if rng.random() < 0.3:
+            c["notch_freq"], c["notch_q"] = float(rng.choice([100.0, 150.0, 1000.0])), float(rng.choice([0.0, 4.0, 10.0]))
+        if rng.random() < 0.3:
+            c["ampfactor"] = float(rng.choice([0.25, 2.0, 8.0]))
+        if rng.random() < 0.15:
+            c["has_iq_outputs"] = 1
+        chans.append(c)
+        tone = rng.random()
+        ct = c["ctcss_freq"] if tone < 0.6 else (c["ctcss_freq"] * 1.035 if tone < 0.8 else 0.0)
+        period, on = [(1.5, 0.75), (0.5, 0.3), (0.11, 0.045), (0.31, 0.02), (0.26, 0.19), (2.0, 1.7)][int(rng.integers(0, 6))]
+        carriers.append(sg.make_carrier(off, sg.SAMPLE_RATE, amplitude=float(rng.choice([0.08, 0.05, 0.03, 0.012, 0.004])), kind=c["modulation"],
+                                        ctcss_hz=ct if c["modulation"] == 1 else 0.0, key_slot=k, key_period_s=period, key_on_s=on, key_slot_s=float(rng.choice([0.125, 0.04, 0.013]))))
+    return dict(channels=chans), carriers, wave_rate, fm_demod, (8 if seed % 3 == 0 else 4)
+
+
+@need_ref
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_ORACLE_PLANS", "4"))))
+def test_oracle_is_the_reference_on_random_plans(pkg, built, seed):
+    """The stage-2 fuzz (tests/test_host_demod.py, test_host_wave64.py, test_gpu_parity.py::test_random_plans_on_the_gpu) measures kernels against the C restatement on plans
+    drawn from the same parameter space as here; this pins the restatement to the REFERENCE over that space: whole streams through demodulate() and through the oracle,
+    audio, raw-I/Q output, axcindicate and every statistic (CTCSS counters included) bit for bit (AIRBAND_FUZZ_SEEDS_ORACLE_PLANS=N for more seeds)."""
+    device, carriers, wave_rate, fm_demod, n_batches = random_plan_case(pkg, seed)
+    nbytes = helpers.stream_bytes(n_batches, wave_rate)
+    iq = pkg.siggen.generate_u8(seed, 0, nbytes // 2, carriers)
+    ref = pyref.run_reference([device], [iq], n_batches, nfm=wave_rate == 16000, fm_demod=fm_demod)[0]
+    orc = pyoracle.Oracle([device], wave_rate=wave_rate, fm_demod=fm_demod)
+    try:
+        got = orc.run_device(0, iq, n_batches)
+        assert ref["n_batches"] == got["n_batches"] == n_batches
+        assert np.array_equal(ref["axc"], got["axc"]), "seed %d: axcindicate" % seed
+        for key in ("waveout", "iq_out"):
+            same = (ref[key].view(np.uint32) == got[key].view(np.uint32)) | (np.isnan(ref[key]) & np.isnan(got[key]))
+            assert same.all(), "seed %d: %s differs on channels %s" % (seed, key, sorted(set(np.nonzero(~same)[1].tolist())))
+        for j in range(8):
+            a, b = ref["stats"][j], orc.stats(0, j)
+            for k in a:
+                if k != "squelch_state":  # (an unstable lowpass -- bandwidth above WAVE_RATE, which the reference's parser accepts -- leaves NaN in agcavgfast / signal_level: NaN on both sides is agreement)
+                    assert a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]), (seed, j, k, a[k], b[k])
+    finally:
+        orc.close()
+
+
+@need_ref
 def test_tone_coefficients_all_standard_tones(built):
     ref = pyref.load_units(True)
     L = pyoracle.lib()
