@@ -7,6 +7,10 @@
  *
  * Build flags matter: -O2 -ffp-contract=off -fno-fast-math (IEEE float, no FMA contraction), the same
  * flags oracle/_ref is built with.  The FFT behind the reference's fftwf_* calls is oracle_fft.c in both.
+ *
+ * Comparisons are restated operand for operand (std::min(a, b) is (b < a) ? b : a): round 4 found the squelch's
+ * two minima written the other way round -- equal for finite values, different for the NaN an unstable
+ * lowpass produces (test_oracle_is_the_reference_on_random_plans, profiles/r04_experiments.md I).
  */
 #define _GNU_SOURCE 1
 #include "airband_oracle.h"
