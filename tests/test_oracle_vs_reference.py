@@ -13,6 +13,16 @@ import pyref
 need_ref = pytest.mark.skipif(not (pyref.have_ref(True) and pyref.have_ref(False)), reason="oracle/_ref not built (needs /root/reference)")
 
 
+def _reference_run(devices, iq_list, n_batches, **kw):
+    """pyref.run_reference, again if the harness came back a batch short: its feeding loop ends when the stream is used up and demodulate() has not YET flagged the last batch
+    (a scheduling race of the harness, not of what is compared: a complete run is bit-identical every time)."""
+    for _ in range(4):
+        ref = pyref.run_reference(devices, iq_list, n_batches, **kw)
+        if all(r["n_batches"] == n_batches for r in ref):
+            break
+    return ref
+
+
 def _tweak(d, ch):
     ch[3]["has_iq_outputs"] = 1
     ch[0]["bandwidth_hz"] = 8000
@@ -29,7 +39,7 @@ def test_stream_bit_exact(pkg, built, mixed, wave_rate, fm_demod, tmp_path):
     devices, carriers = helpers.plan_devices(1, mixed, _tweak if mixed else None)
     n_batches = 14
     iq = pkg.siggen.generate_u8(3, 0, helpers.stream_bytes(n_batches, wave_rate) // 2, carriers)
-    ref = pyref.run_reference(devices, [iq], n_batches, nfm=wave_rate == 16000, fm_demod=fm_demod, trace_dir=str(tmp_path))[0]
+    ref = _reference_run(devices, [iq], n_batches, nfm=wave_rate == 16000, fm_demod=fm_demod, trace_dir=str(tmp_path))[0]
     orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fm_demod=fm_demod)
     got = orc.run_device(0, iq, n_batches)
     assert ref["n_batches"] == got["n_batches"] == n_batches
@@ -79,7 +89,7 @@ def test_stream_bit_exact_other_formats(pkg, built, sfmt_name, fft_log, sample_r
     devices, iq = helpers.format_case(pkg, sfmt, fft_log, sample_rate, wave_rate, n_dev, n_batches, first_dongle=5)
     # one reference process per dongle: demodulate() sleeps 10 ms whenever its round robin meets a device without a full hop
     # (src/rtl_airband.cpp:395-400), so feeding two devices of one instance one after the other would take minutes
-    ref = [pyref.run_reference([devices[d]], [iq[d]], n_batches, nfm=wave_rate == 16000, fft_log=fft_log)[0] for d in range(n_dev)]
+    ref = [_reference_run([devices[d]], [iq[d]], n_batches, nfm=wave_rate == 16000, fft_log=fft_log)[0] for d in range(n_dev)]
     orc = pyoracle.Oracle(devices, wave_rate=wave_rate, fft_log=fft_log)
     opened = 0
     for d in range(n_dev):  # dongle 1 of a CS16 case has its own input->fullscale
@@ -111,7 +121,7 @@ def test_oracle_is_the_reference_on_random_configurations(pkg, built, seed):
     try:
         for d in range(len(devices)):
             nc = len(devices[d]["channels"])
-            ref = pyref.run_reference([devices[d]], [iq[d]], n_batches, nfm=wave_rate == 16000, fft_log=fft_log)[0]
+            ref = _reference_run([devices[d]], [iq[d]], n_batches, nfm=wave_rate == 16000, fft_log=fft_log)[0]
             got = orc.run_device(d, iq[d], n_batches)
             what = "seed %d dongle %d (sfmt %d, fft %d, %d S/s, %d channels)" % (seed, d, devices[d]["sfmt"], 1 << fft_log, devices[d]["sample_rate"], nc)
             assert ref["n_batches"] == got["n_batches"] == n_batches, what
@@ -176,7 +186,7 @@ def test_oracle_is_the_reference_on_random_plans(pkg, built, seed):
     device, carriers, wave_rate, fm_demod, n_batches = random_plan_case(pkg, seed)
     nbytes = helpers.stream_bytes(n_batches, wave_rate)
     iq = pkg.siggen.generate_u8(seed, 0, nbytes // 2, carriers)
-    ref = pyref.run_reference([device], [iq], n_batches, nfm=wave_rate == 16000, fm_demod=fm_demod)[0]
+    ref = _reference_run([device], [iq], n_batches, nfm=wave_rate == 16000, fm_demod=fm_demod)[0]
     orc = pyoracle.Oracle([device], wave_rate=wave_rate, fm_demod=fm_demod)
     try:
         got = orc.run_device(0, iq, n_batches)
@@ -280,7 +290,7 @@ def test_afc_bit_exact(pkg, built):
     devices, carriers = helpers.afc_case(1)
     n_batches = 14
     iq = pkg.siggen.generate_u8(1, 0, helpers.stream_bytes(n_batches, 8000) // 2, carriers)
-    ref = pyref.run_reference(devices, [iq], n_batches, nfm=False)[0]
+    ref = _reference_run(devices, [iq], n_batches, nfm=False)[0]
     orc = pyoracle.Oracle(devices, wave_rate=8000)
     got = orc.run_device(0, iq, n_batches)
     assert np.array_equal(ref["axc"], got["axc"])
