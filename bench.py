@@ -456,9 +456,7 @@ def main():
     # carries rank 0's 128-byte communicator id to the other ranks.
     exchange = False
     if n_mixers and use_dist:
-        box = [pkg.AirbandHip.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        hip.comm_init_rank(box[0], world, rank)
+        mg.init_mixer_exchange(hip, rank, world, dist)
         exchange = True
     consumer = 0
 

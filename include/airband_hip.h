@@ -175,7 +175,8 @@ int airband_hip_mixer_set_stereo(airband_hip_handle* h, int32_t mixer, int32_t s
 /* ---- the mixer exchange: the one step of the path where dongles on different GPUs meet (src/mixer.cpp:133-140,201-214) ----------------
  * Every handle holds PARTIAL sums of the mixers over its own dongles (airband_hip_set_mixers with the same mixer_count on each).  The
  * exchange is an in-place all-reduce of those buffers -- SUM of left and right, MAX of the signal flags -- over RCCL (xGMI between the
- * GPUs of a node), enqueued on the GPU behind the batch's results: no host synchronisation.  librccl.so is loaded on first use.
+ * GPUs of a node), enqueued on the GPU behind the batch's results: no host synchronisation.  librccl.so is loaded on first use
+ * (AIRBAND_HIP_RCCL_LIB=<path> names another library with the same eight entry points).
  *   one process per GPU (bench.py --gpus N):  rank 0 calls airband_hip_comm_unique_id and hands the 128 bytes to the others (any
  *       transport), every rank calls airband_hip_comm_init_rank(h, id, nranks, rank);
  *   one process, one handle per GPU (the reference-side shim, integration/demod_hip.cpp):  airband_hip_comm_init_all(handles, n) --
@@ -194,6 +195,11 @@ int airband_hip_comm_group_end(void);
 int airband_hip_allreduce_mixers(airband_hip_handle* h, void* stream);
 int airband_hip_add_mixers(airband_hip_handle* dst, airband_hip_handle* src);
 int airband_hip_comm_destroy(airband_hip_handle* h);
+/* Zeroes the handle's partial sums and signal flags, ordered on the GPU behind whatever touched them last.  For a handle that takes part in
+ * an exchange (add_mixers / allreduce_mixers) but ran NO batch this round because every dongle of it is switched off: the reference keeps
+ * mixing the inputs that are left (mixer_disable_input(), src/mixer.cpp:96-112, called for a failed device's outputs, src/rtl_airband.cpp:383-391),
+ * so such a handle must add nothing -- while its buffers still hold its last batch's sums or, after an in-place all-reduce, the node's. */
+int airband_hip_clear_mixers(airband_hip_handle* h);
 
 /* Masks one mixer connection out (enabled = 0) or back in, by its index in the `inputs` array handed to airband_hip_set_mixers:
  * a masked input adds nothing and does not raise the mixer's signal flag -- mixer_disable_input(), which the reference
@@ -255,9 +261,10 @@ int airband_hip_batch_ready(airband_hip_handle* h);
  * the stream bytes of this batch followed by the bytes the last window overlaps into the next batch
  * (exactly what a tail-replicated ring, src/input-helpers.cpp:43-51, holds at that offset).
  * Alignment: where a hop is a whole number of 16-byte pieces (2.56 MS/s: 320 / 640 bytes) d_iq and stride_bytes are multiples of 16, and so is every
- * batch's offset into a stream; for any other hop (2.4 MS/s: 300 bytes, 2.0 MS/s: 250 bytes) they only need to be whole I/Q samples -- the
+ * batch's offset into a stream; for any other hop they are multiples of the largest power of two that divides the hop's bytes (2.4 MS/s: 300 bytes -> 4,
+ * 600 -> 8; 2.0 MS/s: 250 bytes -> 2, i.e. whole I/Q samples) -- batch offsets, being multiples of the hop, keep that alignment -- and the
  * channelizer then stages aligned pieces from the aligned byte at or in front of the span, i.e. it may READ up to 15 bytes in front of d_iq + d*stride_bytes
- * (bytes of the same allocation: the tail of the previous batch, or of the previous dongle's row).
+ * (bytes of the same allocation: the tail of the previous batch, or of the previous dongle's row).  AIRBAND_HIP_EINVAL otherwise.
  * `stream` is a hipStream_t (NULL = the handle's own stream). */
 int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t stride_bytes, void* stream);
 

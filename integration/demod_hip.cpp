@@ -271,10 +271,14 @@ static void wire_mixers(hip_class& c, int device_start, int device_end, bool mar
     c.mix_right.resize((size_t)S * WAVE_BATCH);
     c.mix_signal.resize(S);
     // the parts of one GPU add their sums up on that GPU; the GPUs exchange theirs over RCCL
+    // (AIRBAND_HIP_FABRIC_PER_PART=1: every part is a fabric rank of its own even where parts share a GPU -- RCCL proper refuses that; the test suite
+    // sets it together with AIRBAND_HIP_RCCL_LIB=<its in-process stand-in> to run the exchange below with several ranks on a one-GPU box)
+    const char* per_part = getenv("AIRBAND_HIP_FABRIC_PER_PART");
     c.leader.assign(c.parts.size(), 0);
     for (size_t p = 0; p < c.parts.size(); p++) {
         size_t l = 0;
         while (c.parts[l].gpu != c.parts[p].gpu) l++;
+        if (per_part && *per_part == '1') l = p;
         c.leader[p] = (int)l;
         if (l == p) c.fabric.push_back((int)p);
     }
@@ -522,9 +526,13 @@ void* demodulate_hip(void* params) {
             }
             if (!any) continue;
             // 3. the mixer exchange (mixer.cpp:133-140,201-214), enqueued on the GPUs behind the batches: the parts of one GPU add up on
-            //    its first part, the GPUs all-reduce over RCCL.  A part without a batch (all its devices gone) contributes what its last
-            //    batch left masked out: device_enable() has taken its connections out of the sums.
+            //    its first part, the GPUs all-reduce over RCCL.  A part without a batch (all its devices gone: demodulate() has called
+            //    mixer_disable_input() for every one of their outputs, mixer.cpp:96-112, rtl_airband.cpp:383-391, and keeps mixing the rest)
+            //    adds nothing -- its buffers have to be CLEARED for that: they hold its last batch's sums, a leader's hold what the other parts
+            //    of its GPU added, a fabric rank's the whole node's (the all-reduce is in place).
             if (!cls.served.empty()) {
+                for (size_t p = 0; p < cls.parts.size(); p++)
+                    if (!cls.parts[p].have_batch) hip_check(cls.parts[p].h, airband_hip_clear_mixers(cls.parts[p].h), "clear_mixers");
                 for (size_t p = 0; p < cls.parts.size(); p++)
                     if (cls.leader[p] != (int)p && cls.parts[p].have_batch)
                         hip_check(cls.parts[cls.leader[p]].h, airband_hip_add_mixers(cls.parts[cls.leader[p]].h, cls.parts[p].h), "add_mixers");
@@ -555,8 +563,9 @@ void* demodulate_hip(void* params) {
                 }
             }
             dp->mp3_signal->send();  // rtl_airband.cpp:662
-            // 5. the mixers this class serves: what mixer_thread() leaves in mixer->channel (mixer.cpp:189-248), from the first part's sums
-            if (!cls.served.empty() && cls.parts[0].have_batch &&
+            // 5. the mixers this class serves: what mixer_thread() leaves in mixer->channel (mixer.cpp:189-248).  Part 0 leads its GPU and is a
+            //    fabric rank, so after the exchange it holds the class's sums -- whether or not it ran a batch itself (`any` says some part did)
+            if (!cls.served.empty() &&
                 airband_hip_collect_mixers(cls.parts[0].h, cls.mix_left.data(), cls.mix_right.data(), cls.mix_signal.data()) == AIRBAND_HIP_OK) {
                 bool sent = false;
                 for (size_t s = 0; s < cls.served.size(); s++) {

@@ -281,6 +281,7 @@ struct HipApi {
     int (*comm_group_end)(void);
     int (*allreduce_mixers)(airband_hip_handle*, void*);
     int (*add_mixers)(airband_hip_handle*, airband_hip_handle*);
+    int (*clear_mixers)(airband_hip_handle*);
 };
 static HipApi g_hip;
 
@@ -303,6 +304,7 @@ int airband_hip_comm_group_begin(void) { return g_hip.comm_group_begin(); }
 int airband_hip_comm_group_end(void) { return g_hip.comm_group_end(); }
 int airband_hip_allreduce_mixers(airband_hip_handle* h, void* s) { return g_hip.allreduce_mixers(h, s); }
 int airband_hip_add_mixers(airband_hip_handle* a, airband_hip_handle* b) { return g_hip.add_mixers(a, b); }
+int airband_hip_clear_mixers(airband_hip_handle* h) { return g_hip.clear_mixers(h); }
 }
 
 /* statistics exactly as the stats file / TUI would read them with the HIP backend: through the reference's own Squelch getters
@@ -339,7 +341,7 @@ int refh_start_hip(const char* lib_path) {
     REFH_SYM(submit, "submit") REFH_SYM(process, "process") REFH_SYM(collect, "collect") REFH_SYM(device_enable, "device_enable") REFH_SYM(gpu_count, "gpu_count")
     REFH_SYM(batch_ready, "batch_ready") REFH_SYM(set_mixers, "set_mixers") REFH_SYM(mixer_set_stereo, "mixer_set_stereo") REFH_SYM(collect_mixers, "collect_mixers")
     REFH_SYM(comm_init_all, "comm_init_all") REFH_SYM(comm_group_begin, "comm_group_begin") REFH_SYM(comm_group_end, "comm_group_end")
-    REFH_SYM(allreduce_mixers, "allreduce_mixers") REFH_SYM(add_mixers, "add_mixers")
+    REFH_SYM(allreduce_mixers, "allreduce_mixers") REFH_SYM(add_mixers, "add_mixers") REFH_SYM(clear_mixers, "clear_mixers")
 #undef REFH_SYM
     devices_running = device_count;
     g_demod_params[0].mp3_signal = &g_signal;

@@ -31,7 +31,7 @@ EXPORTS = [
     "airband_hip_flush", "airband_hip_timing_totals", "airband_hip_stream_wait_results", "airband_hip_mixer_enable_input",
     "airband_hip_device_enable", "airband_hip_gpu_count", "airband_hip_build_info", "airband_hip_dft_selftest", "airband_hip_collect_channels", "airband_hip_read_bins_channels", "airband_hip_read_trace_channels",
     "airband_hip_batch_ready", "airband_hip_mixer_set_stereo", "airband_hip_comm_unique_id", "airband_hip_comm_init_rank", "airband_hip_comm_init_all",
-    "airband_hip_comm_group_begin", "airband_hip_comm_group_end", "airband_hip_allreduce_mixers", "airband_hip_add_mixers", "airband_hip_comm_destroy",
+    "airband_hip_comm_group_begin", "airband_hip_comm_group_end", "airband_hip_allreduce_mixers", "airband_hip_add_mixers", "airband_hip_comm_destroy", "airband_hip_clear_mixers",
 ]
 
 _lib = None
@@ -77,6 +77,9 @@ def load_library() -> C.CDLL:
     L.airband_hip_allreduce_mixers.argtypes = [vp, vp]
     L.airband_hip_add_mixers.argtypes = [vp, vp]
     L.airband_hip_comm_destroy.argtypes = [vp]
+    L.airband_hip_clear_mixers.argtypes = [vp]
+    L.airband_hip_comm_group_begin.argtypes = []
+    L.airband_hip_comm_group_end.argtypes = []
     L.airband_hip_process_device.argtypes = [vp, vp, sz, vp]
     L.airband_hip_collect.argtypes = [vp, vp, vp, vp, vp]
     L.airband_hip_collect_channels.argtypes = [vp, i64, i64, vp, vp, vp, vp]
@@ -306,6 +309,32 @@ class AirbandHip:
 
     def add_mixers(self, src: "AirbandHip"):
         self._check(self.L.airband_hip_add_mixers(self.h, src.h))
+
+    def clear_mixers(self):
+        """A handle that ran no batch this round adds nothing to the exchange (mixer_disable_input(), src/mixer.cpp:96-112)."""
+        self._check(self.L.airband_hip_clear_mixers(self.h))
+
+    @staticmethod
+    def comm_init_all(handles: Sequence["AirbandHip"]):
+        """One process, one handle per GPU (the reference-side shim's form): ncclCommInitAll over the handles' GPUs."""
+        L = load_library()
+        arr = (C.c_void_p * len(handles))(*[h.h for h in handles])
+        rc = L.airband_hip_comm_init_all(arr, len(handles))
+        if rc < 0:
+            raise AirbandError(rc, (L.airband_hip_last_error(handles[0].h) or L.airband_hip_last_error(None) or b"").decode())
+
+    @staticmethod
+    def allreduce_mixers_group(handles: Sequence["AirbandHip"]):
+        """The per-batch exchange of one thread that owns several handles: every handle's all-reduce inside one RCCL group."""
+        L = load_library()
+        rc = L.airband_hip_comm_group_begin()
+        if rc < 0:
+            raise AirbandError(rc, (L.airband_hip_last_error(None) or b"").decode())
+        for h in handles:
+            h.allreduce_mixers()
+        rc = L.airband_hip_comm_group_end()
+        if rc < 0:
+            raise AirbandError(rc, (L.airband_hip_last_error(None) or b"").decode())
 
     def batch_ready(self) -> bool:
         rc = self.L.airband_hip_batch_ready(self.h)

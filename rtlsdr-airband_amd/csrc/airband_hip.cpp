@@ -1002,6 +1002,10 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         launch_channelizer_fft(ca, s);
         (void)hipEventRecord(ev[1], s);
     }
+    {   /* a refused launch (an LDS opt-in that failed, a bad grid) is this call's error, not a puzzle for whoever synchronises next */
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(h, AIRBAND_HIP_ERUNTIME, std::string("channelizer launch: ") + hipGetErrorString(e));
+    }
     h->row0_front = (h->row0_front + h->B) % h->R;
     h->front_batches++;
     return AIRBAND_HIP_OK;
@@ -1013,12 +1017,18 @@ int airband_hip_process_device(airband_hip_handle* h, const void* d_iq, size_t s
     /* hops of whole 16-byte pieces: the channelizer's transfers address the span directly, so it must start on one.  Any other hop (300, 250 bytes ...):
      * a batch of such hops cannot start on 16 bytes every time anyway (2 100 hops of 250 bytes = 525 000), the kernel stages from the aligned byte in
      * front of the span and only whole samples are asked for */
-    const uintptr_t need = (h->hop_bytes % 16) == 0 ? 15u : (uintptr_t)(2 * h->plan.dev[0].bytes_per_sample - 1);
+    /* ... at the alignment of the fragment reads the kernel variant for this hop uses (channelizer_dft.hip, launch_generic: the largest power of two up to 16
+     * that divides the hop -- 300 bytes: 4, 600: 8, 250: 2): the staged bytes keep the span's offset from 16 bytes, and a 4- or 8-byte LDS read must not land
+     * on a 2-byte boundary.  Batch offsets are multiples of the hop, so a stream that starts aligned stays aligned. */
+    uintptr_t al = 16;
+    while (al > 2 && (h->hop_bytes % (int64_t)al) != 0) al >>= 1;
+    if (al < (uintptr_t)(2 * h->plan.dev[0].bytes_per_sample)) al = (uintptr_t)(2 * h->plan.dev[0].bytes_per_sample);
+    const uintptr_t need = al - 1;
     if (h->use_f32 && ((((uintptr_t)d_iq) | (uintptr_t)stride_bytes) & 15))
         return fail(h, AIRBAND_HIP_EINVAL, "d_iq and stride_bytes must be multiples of 16 (the channelizer fetches 16 bytes per lane)");
     if (h->use_dft && ((((uintptr_t)d_iq) | (uintptr_t)stride_bytes) & need))
         return fail(h, AIRBAND_HIP_EINVAL, (h->hop_bytes % 16) == 0 ? "d_iq and stride_bytes must be multiples of 16 (the channelizer fetches 16 bytes per lane)"
-                                                                    : "d_iq and stride_bytes must be multiples of one I/Q sample");
+                                                                    : "d_iq and stride_bytes must be multiples of the largest power of two (up to 16) that divides the hop's bytes");
     if (!h->pipeline) {
         hipStream_t s = stream ? (hipStream_t)stream : h->stream;
         h->last_stream = s;
@@ -1418,6 +1428,7 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool named = false; /* loaded from AIRBAND_HIP_RCCL_LIB */
     std::string why;
 };
 Rccl g_rccl;
@@ -1429,12 +1440,27 @@ Rccl* rccl() {
     if (g_rccl.dl) return &g_rccl;
     if (!g_rccl.why.empty()) return nullptr;
     void* dl = nullptr;
-    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-        dl = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (dl) break;
+    std::string tried;
+    /* AIRBAND_HIP_RCCL_LIB names the library instead (a site's own RCCL build; the in-process stand-in tests/fake_rccl/ the GPU suite uses to run
+     * the exchange with two ranks on a one-GPU box).  A library named this way also decides by itself whether two ranks may share a GPU. */
+    const char* named = getenv("AIRBAND_HIP_RCCL_LIB");
+    if (named && *named) {
+        dl = dlopen(named, RTLD_NOW | RTLD_GLOBAL);
+        if (!dl) {
+            const char* e = dlerror(); /* once: dlerror() clears the message it returns */
+            tried = std::string(named) + ": " + (e ? e : "not found");
+        }
+        g_rccl.named = dl != nullptr;
+    } else {
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            dl = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (dl) break;
+            const char* e = dlerror();
+            if (tried.empty()) tried = std::string("librccl.so: ") + (e ? e : "not found");
+        }
     }
     if (!dl) {
-        g_rccl.why = std::string("librccl.so: ") + (dlerror() ? dlerror() : "not found");
+        g_rccl.why = tried.empty() ? std::string("librccl.so: not found") : tried;
         return nullptr;
     }
 #define AB_RCCL_SYM(field, name)                              \
@@ -1500,12 +1526,14 @@ int airband_hip_comm_init_all(airband_hip_handle** hs, int32_t n) {
     for (int i = 0; i < n; i++) {
         if (!hs[i] || hs[i]->comm) return fail(hs[i], AIRBAND_HIP_EINVAL, "NULL handle, or a handle that already has a communicator");
         devs[i] = hs[i]->hip_device;
-        for (int k = 0; k < i; k++)
-            if (devs[k] == devs[i]) return fail(hs[i], AIRBAND_HIP_EINVAL, "two handles of the clique share a GPU: use airband_hip_add_mixers between them");
         if (hs[i]->n_mixers != hs[0]->n_mixers || hs[i]->B != hs[0]->B) return fail(hs[i], AIRBAND_HIP_EINVAL, "the handles of a clique need the same mixer_count and WAVE_BATCH");
     }
     Rccl* R = rccl();
     if (!R) return fail(hs[0], AIRBAND_HIP_ENODEV, g_rccl.why);
+    if (!R->named) /* RCCL proper refuses a communicator with one GPU twice, late and with a generic message */
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < i; k++)
+                if (devs[k] == devs[i]) return fail(hs[i], AIRBAND_HIP_EINVAL, "two handles of the clique share a GPU: use airband_hip_add_mixers between them");
     std::vector<ncclComm_t> comms(n, nullptr);
     RCCL_TRY(hs[0], R, R->CommInitAll(comms.data(), n, devs.data()));
     for (int i = 0; i < n; i++) hs[i]->comm = comms[i];
@@ -1569,6 +1597,22 @@ int airband_hip_add_mixers(airband_hip_handle* dst, airband_hip_handle* src) {
     src->ev_last_pending = true;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(dst, AIRBAND_HIP_ERUNTIME, std::string("mixer add launch: ") + hipGetErrorString(e));
+    return AIRBAND_HIP_OK;
+}
+
+/* A handle that ran no batch this round (every dongle of it switched off) still stands in the exchange: its partial sums are those of a
+ * mixer whose inputs are all masked out (mixer_disable_input(), src/mixer.cpp:96-112) -- zeros, no signal.  Its buffers do NOT hold that by
+ * themselves: the last batch's sums are still in them, and after an in-place all-reduce the whole node's. */
+int airband_hip_clear_mixers(airband_hip_handle* h) {
+    if (!h) return AIRBAND_HIP_EINVAL;
+    if (h->n_mixers <= 0) return fail(h, AIRBAND_HIP_EINVAL, "no mixers configured");
+    HIP_TRY(h, hipSetDevice(h->hip_device), AIRBAND_HIP_ENODEV);
+    hipStream_t s = results_stream(h); /* behind whatever wrote or read the sums last: the handle's last batch, an exchange, add_mixers */
+    if (h->ev_last && h->ev_last_pending) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_last, 0), AIRBAND_HIP_ERUNTIME); /* a peer's add_mixers still reading them */
+    const size_t n = (size_t)h->n_mixers * h->B;
+    HIP_TRY(h, hipMemsetAsync(h->d_mix_left.p, 0, n * sizeof(float), s), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipMemsetAsync(h->d_mix_right.p, 0, n * sizeof(float), s), AIRBAND_HIP_ERUNTIME);
+    HIP_TRY(h, hipMemsetAsync(h->d_mix_signal.p, 0, (size_t)h->n_mixers, s), AIRBAND_HIP_ERUNTIME);
     return AIRBAND_HIP_OK;
 }
 

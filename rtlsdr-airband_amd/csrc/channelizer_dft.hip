@@ -26,6 +26,7 @@
  *   D: lane l holds column (l&15) = (channel, re|im) of hops (l>>4)*4 + {0..3}; |bin| needs the neighbour lane.
  */
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include "common.h"
 #include "kernels.h"
@@ -609,15 +610,16 @@ static void launch_al(const DftArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)a.nbuf * a.lds_per_buf + (NP > 1 ? 2 * (NP - 1) * 64 * sizeof(float4) : 0);
     /* more than the default 64 KiB of dynamic LDS (eight-piece windows): opt in to the CU's 160 KiB, once per kernel variant */
     /* (once per kernel variant AND device: the attribute belongs to the function as loaded on the current device, and a process may drive several GPUs) */
-    static bool big_lds_dev[64][2] = {{false, false}};
+    static std::atomic<bool> big_lds_dev[64][2]; /* (zero-initialised; one launching thread per GPU in the shim: setting it twice is harmless) */
     int cur_dev = 0;
     (void)hipGetDevice(&cur_dev);
-    bool* big_lds = big_lds_dev[cur_dev & 63];
-    if (lds > 64 * 1024 && !big_lds[a.edge_hi_zero ? 1 : 0]) {
+    const bool tracked = cur_dev >= 0 && cur_dev < 64; /* devices beyond the table opt in on every launch */
+    std::atomic<bool>* big_lds = big_lds_dev[tracked ? cur_dev : 0];
+    if (lds > 64 * 1024 && (!tracked || !big_lds[a.edge_hi_zero ? 1 : 0].load(std::memory_order_acquire))) {
         const void* fn = a.edge_hi_zero ? reinterpret_cast<const void*>(&channelizer_dft_kernel<FFT_N, true, HOPB, S16, AL, NP>)
                                         : reinterpret_cast<const void*>(&channelizer_dft_kernel<FFT_N, false, HOPB, S16, AL, NP>);
         /* the CU's whole 160 KiB, not this launch's size: the flag is per variant, and a later handle of the same process may need more (runtime hop lengths) */
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) big_lds[a.edge_hi_zero ? 1 : 0] = true;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess && tracked) big_lds[a.edge_hi_zero ? 1 : 0].store(true, std::memory_order_release);
     }
     if (a.edge_hi_zero)
         hipLaunchKernelGGL((channelizer_dft_kernel<FFT_N, true, HOPB, S16, AL, NP>), dim3((unsigned)groups), dim3(64 * NP), lds, stream, a);

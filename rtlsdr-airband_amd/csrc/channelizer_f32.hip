@@ -24,6 +24,7 @@
  * from its row number by a constant per fragment read -- sixteen per-lane offsets, computed once.
  */
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include "common.h"
 #include "kernels.h"
@@ -262,12 +263,12 @@ static void launch_f32(const F32Args& a, hipStream_t stream) {
     const size_t lds = (size_t)2 * a.lds_per_buf + 2 * (NW - 1) * 64 * sizeof(float4);
     /* more than the default 64 KiB of dynamic LDS: opt in to the CU's 160 KiB, once per kernel variant AND device (the attribute belongs to the function as loaded
      * on the current device; a process may drive several GPUs) */
-    static bool big_lds[64] = {false};
+    static std::atomic<bool> big_lds[64]; /* (zero-initialised; the shim launches from one thread per GPU: set twice is harmless, torn is not possible) */
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (lds > 64 * 1024 && !big_lds[dev & 63]) {
+    if (lds > 64 * 1024 && (dev >= 64 || !big_lds[dev].load(std::memory_order_acquire))) {
         /* (the CU's whole 160 KiB, not this launch's size: a later handle of the same process may have longer hops) */
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_f32_kernel<FFT_N, MAX_LD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) big_lds[dev & 63] = true;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_f32_kernel<FFT_N, MAX_LD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess && dev < 64) big_lds[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((channelizer_f32_kernel<FFT_N, MAX_LD>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, a);
 }

@@ -1,8 +1,9 @@
 """Multi-GPU host logic: one process per GPU, dongles sharded contiguously across ranks (the reference's own
 multiple_demod_threads partitioning, src/rtl_airband.cpp:1052-1086), no data-path collective -- except the mixer
 sum of BASELINE config #5, the one real exchange step in the reference's data flow (src/mixer.cpp:133-140,201-214):
-every rank reduces its local inputs into per-mixer partial sums and the partials are all-reduced (RCCL over xGMI on
-GPUs, gloo in the CPU tests)."""
+every rank reduces its local inputs into per-mixer partial sums on its GPU and the partials are all-reduced in place by the
+library itself (airband_hip_allreduce_mixers: librccl over xGMI, on the handle's stream).  What lives here is the host logic around
+it: the partition, BASELINE configs[4]'s wiring, how the communicator id reaches the ranks, and a reference-order host sum."""
 from __future__ import annotations
 
 from typing import List, Sequence, Tuple
@@ -21,37 +22,20 @@ def baseline_mixer_inputs(d_start: int, d_end: int, channels_per_dongle: int, n_
     return [(d - d_start, c, (d * channels_per_dongle + c) % n_mixers, 1.0, 0.0) for d in range(d_start, d_end) for c in range(channels_per_dongle)]
 
 
-class _DevicePtr:
-    """__cuda_array_interface__ shim: a torch view over memory the library owns (no copy, no ownership)."""
-
-    def __init__(self, ptr: int, shape, typestr: str):
-        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=2)
-
-
-def device_mixer_views(hip, n_mixers: int, stereo: bool = False):
-    """torch tensors over a handle's device-side mixer sums (airband_hip_device_results): (left [M][B] f32, right or None, has_signal [M] u8).
-    They alias the library's buffers: what an RCCL all-reduce writes is what airband_hip_collect_mixers() then reads."""
-    import torch
-
-    res = hip.device_results()
-    left = torch.as_tensor(_DevicePtr(res["mix_left"], (n_mixers, hip.B), "<f4"), device="cuda")
-    right = torch.as_tensor(_DevicePtr(res["mix_right"], (n_mixers, hip.B), "<f4"), device="cuda") if stereo else None
-    sig = torch.as_tensor(_DevicePtr(res["mix_signal"], (n_mixers,), "|u1"), device="cuda")
-    return left, right, sig
-
-
-def allreduce_mixers(left, right, has_signal, force: bool = False):
-    """In-place all-reduce of per-rank mixer partials: SUM for the waveforms (the right channel too when any mixer is stereo), MAX
-    for the signal flags (mixer channel axcindicate, src/mixer.cpp:209).  Tensors may live on CPU (gloo) or GPU (nccl = RCCL).
-    force: also at world size 1 (plumbing check of the collective leg)."""
-    import torch.distributed as dist
-
-    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
-        return
-    dist.all_reduce(left, op=dist.ReduceOp.SUM)
-    if right is not None:
-        dist.all_reduce(right, op=dist.ReduceOp.SUM)
-    dist.all_reduce(has_signal, op=dist.ReduceOp.MAX)
+def init_mixer_exchange(hip, rank: int, world: int, dist=None, unique_id=None):
+    """One process per GPU: gives the handle its rank in the RCCL communicator the mixer sums are all-reduced over
+    (airband_hip_comm_unique_id on rank 0, airband_hip_comm_init_rank on every rank; include/airband_hip.h).  torch.distributed (`dist`,
+    any backend: nccl under bench.py --gpus N, gloo in the CPU tests) only carries rank 0's 128-byte id to the other ranks; the data
+    path never goes through it -- the per-batch exchange is hip.allreduce_mixers(), librccl called by the library on the handle's stream.
+    `unique_id`: rank 0's id source (default: the library's).  Returns the id every rank ended up with."""
+    if dist is None:
+        import torch.distributed as dist
+    box = [(unique_id() if unique_id is not None else type(hip).comm_unique_id()) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    if not isinstance(box[0], (bytes, bytearray)) or len(box[0]) != 128:
+        raise RuntimeError("rank %d: no communicator id arrived from rank 0" % rank)
+    hip.comm_init_rank(bytes(box[0]), world, rank)
+    return bytes(box[0])
 
 
 def mix_on_host(inputs: Sequence[tuple], chan_base: Sequence[int], waveout: np.ndarray, axc: np.ndarray, n_mixers: int):

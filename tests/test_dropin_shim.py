@@ -222,3 +222,98 @@ def test_failed_inputs_with_the_shard_on_two_parts(pkg, built):
         assert np.array_equal(one["axc"][d, :nb], two["axc"][d, :nb])
         assert np.array_equal(one["waveout"][d, :nb].view(np.uint32), two["waveout"][d, :nb].view(np.uint32))
     assert (one["axc"][0] == ord("*")).any()
+
+
+# ---- served mixers when a WHOLE part loses its devices (src/mixer.cpp:96-112 mixer_disable_input, :189-214; called for a failed device's outputs,
+# src/rtl_airband.cpp:383-391): the reference keeps mixing the inputs that are left ------------------------------------------------------------------
+FAKE_RCCL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "fake_rccl", "libfake_rccl.so")
+PART_CONNS = [(d, 0, 0, 1.0, 0.0) for d in range(4)] + [(0, 2, 1, 2.0, -0.25), (3, 2, 1, 1.0, 0.5)] + [(2, 4, 2, 1.0, 0.0), (3, 6, 2, 0.5, 0.0)] + [(0, 4, 3, 1.0, 0.0), (1, 6, 3, 1.5, 0.0)]
+N_PART_MIXERS = 4
+
+
+def _fabric_env(tmp_path, tag):
+    """"0,0" as two FABRIC ranks: the shim's RCCL leg (comm_init_all, group begin / allreduce_mixers per part / group end) through the in-process stand-in
+    for librccl (tests/fake_rccl/), which lets two ranks share the box's one GPU and logs every collective it completes."""
+    log = tmp_path / ("fake_rccl_%s.log" % tag)
+    return {"AIRBAND_HIP_GPUS": "0,0", "AIRBAND_HIP_FABRIC_PER_PART": "1", "AIRBAND_HIP_RCCL_LIB": FAKE_RCCL, "FAKE_RCCL_LOG": str(log)}, log
+
+
+def _collectives(log):
+    return [l for l in log.read_text().splitlines() if l.startswith("allreduce ")] if log.exists() else []
+
+
+@need_patched_nfm
+@pytest.mark.parametrize("dead_part", [0, 1], ids=["part0_dies", "part1_dies"])
+@pytest.mark.parametrize("exchange", ["add_mixers", "fabric"])
+def test_served_mixers_survive_the_loss_of_a_whole_part(pkg, built, tmp_path, dead_part, exchange):
+    """Four devices in two parts ({0, 1} and {2, 3}), four served mixers: one fed by all four devices, a stereo one fed from both parts, one fed by the second part
+    only, one by the first only.  After three batches BOTH devices of one part fail.  From then on that part runs no batch; the other part's devices and the mixers
+    must carry on: every mixer keeps reaching CH_READY, its sum is the reference-order sum over the inputs that are left (no stale partial sums of the dead part, no
+    feedback of an earlier all-reduce), the mixer fed by the dead part alone falls silent without a signal flag.  Once with the parts' sums meeting through
+    airband_hip_add_mixers (two parts on one GPU), once through the RCCL leg with two ranks (the stand-in library)."""
+    if exchange == "fabric" and not os.path.exists(FAKE_RCCL):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built")
+    n_dev, n_batches, k_fail = 4, 8, 3
+    devices, iq = _mixer_scenario(pkg, n_dev, n_batches, True)
+    fail_after = [k_fail, k_fail, None, None] if dead_part == 0 else [None, None, k_fail, k_fail]
+    env, log = ({"AIRBAND_HIP_GPUS": "0,0"}, None) if exchange == "add_mixers" else _fabric_env(tmp_path, "dead%d" % dead_part)
+    one = pyref.run_reference_all(devices, iq, n_batches, nfm=True, mixers=(N_PART_MIXERS, PART_CONNS), hip_lib=pkg.LIB_PATH, fail_after=fail_after, env={"AIRBAND_HIP_GPUS": "0"})
+    two = pyref.run_reference_all(devices, iq, n_batches, nfm=True, mixers=(N_PART_MIXERS, PART_CONNS), hip_lib=pkg.LIB_PATH, fail_after=fail_after, env=env)
+    want_batches = [k_fail if f is not None else n_batches for f in fail_after]
+    for r in (one, two):
+        assert r["batches"] == want_batches, r["batches"]
+        assert r["mix_batches"] == [n_batches] * N_PART_MIXERS, "a served mixer stopped being published: %s" % r["mix_batches"]
+        assert [m["gpu_served"] for m in r["mixers"]] == [1] * N_PART_MIXERS
+    live = [d for d in range(n_dev) if fail_after[d] is None]
+    for d, nb in enumerate(want_batches):
+        assert np.array_equal(one["axc"][d, :nb], two["axc"][d, :nb])
+        assert np.array_equal(one["waveout"][d, :nb].view(np.uint32), two["waveout"][d, :nb].view(np.uint32))
+    assert any((one["axc"][d, k_fail:] == ord("*")).any() for d in live), "the scenario must have signal after the failure"
+    dead_only = 3 if dead_part == 0 else 2  # the mixer all of whose inputs sit in the dead part
+    for b in range(n_batches):
+        axc = two["axc"][:, b].copy()
+        for d in range(n_dev):
+            if fail_after[d] is not None and b >= k_fail:
+                axc[d, :] = ord(" ")  # mixer_disable_input(): a failed device's inputs are masked out
+        left, right, sig = helpers.mixer_reference_sum(PART_CONNS, N_PART_MIXERS, two["waveout"][:, b], axc)
+        assert np.array_equal(two["mix_axc"][:, b] != ord(" "), sig != 0), (b, two["mix_axc"][:, b], sig)
+        assert np.array_equal(one["mix_axc"][:, b], two["mix_axc"][:, b]), b
+        scale = max(1.0, helpers.rms(left))
+        for r in (one, two):
+            assert helpers.rms(r["mix_left"][:, b] - left) <= 1e-6 * scale, "batch %d: mixer sums are not the sums over the live inputs" % b
+            assert helpers.rms(r["mix_right"][1, b] - right[1]) <= 1e-6 * scale, b
+        # one handle adds in the reference's order: bit for bit (a masked input is skipped, not added as zero)
+        assert np.array_equal(one["mix_left"][:, b], left) and np.array_equal(one["mix_right"][1, b], right[1]), b
+        if b >= k_fail:
+            assert not two["mix_left"][dead_only, b].any() and two["mix_axc"][dead_only, b] == ord(" ")
+            # the live part's sums arrive unchanged: zeros + x (the cleared part first or second)
+            assert np.array_equal(two["mix_left"][:, b], left) and np.array_equal(two["mix_right"][1, b], right[1]), b
+    assert (two["mix_axc"][:, k_fail:] != ord(" ")).any()
+    if exchange == "fabric":
+        lines = _collectives(log)
+        assert lines and all("nranks=2" in l for l in lines), lines[:3]
+        # three collectives (left, right, flags) per rank and batch
+        assert len(lines) == 2 * 3 * n_batches, len(lines)
+
+
+@need_patched_nfm
+def test_a_shard_spread_over_two_fabric_ranks(pkg, built, tmp_path):
+    """test_a_shard_spread_over_two_parts with the parts' sums meeting over the RCCL leg instead of airband_hip_add_mixers: comm_init_all over two handles,
+    per batch one group with both handles' allreduce_mixers -- two ranks, through the stand-in library.  Rank order = part order, so the sums are bit for bit
+    those of the add_mixers run (part 0's partial + part 1's)."""
+    if not os.path.exists(FAKE_RCCL):
+        pytest.skip("tests/fake_rccl/libfake_rccl.so not built")
+    n_dev, n_batches = 5, 6
+    devices, iq = _mixer_scenario(pkg, n_dev, n_batches, True)
+    conns = [(d, 0, 0, 1.0, 0.0) for d in range(5)] + [(0, 2, 1, 2.0, -0.25), (4, 2, 1, 1.0, 0.5)] + [(3, 4, 2, 1.0, 0.0), (4, 6, 2, 0.5, 0.0)]
+    env, log = _fabric_env(tmp_path, "spread")
+    add = pyref.run_reference_all(devices, iq, n_batches, nfm=True, mixers=(3, conns), hip_lib=pkg.LIB_PATH, env={"AIRBAND_HIP_GPUS": "0,0"})
+    fab = pyref.run_reference_all(devices, iq, n_batches, nfm=True, mixers=(3, conns), hip_lib=pkg.LIB_PATH, env=env)
+    for r in (add, fab):
+        assert r["batches"] == [n_batches] * n_dev and r["mix_batches"] == [n_batches] * 3 and [m["gpu_served"] for m in r["mixers"]] == [1, 1, 1]
+    assert np.array_equal(add["axc"], fab["axc"]) and np.array_equal(add["waveout"].view(np.uint32), fab["waveout"].view(np.uint32))
+    assert np.array_equal(add["mix_axc"], fab["mix_axc"]) and (fab["mix_axc"] != ord(" ")).any()
+    assert np.array_equal(add["mix_left"], fab["mix_left"]) and np.array_equal(add["mix_right"], fab["mix_right"])
+    assert np.abs(fab["mix_left"]).max() > 0 and np.abs(fab["mix_right"][1]).max() > 0
+    lines = _collectives(log)
+    assert len(lines) == 2 * 3 * n_batches and all("nranks=2" in l for l in lines), (len(lines), lines[:2])

@@ -24,7 +24,7 @@ def _paths():
 
 
 def _run_handle(pkg, torch, gpu, d_start, d_end, comm=None):
-    """Handle with the global dongles [d_start, d_end) on GPU `gpu`; returns per batch (left, has_signal), all-reduced over comm = (id, nranks, rank) if given."""
+    """Handle with the global dongles [d_start, d_end) on GPU `gpu`; returns per batch (left, has_signal), all-reduced if `comm` (a callable that gives the handle its communicator) is given."""
     mg = importlib.import_module("rtlsdr-airband_amd.multigpu")
     chans, carriers = pkg.siggen.baseline_plan(mixed=True)
     n = d_end - d_start
@@ -40,7 +40,7 @@ def _run_handle(pkg, torch, gpu, d_start, d_end, comm=None):
         hip.generate_iq(iq.data_ptr(), stride, 0, span, seed=0x5EED, device_index_offset=d_start)
         hip.synchronize()
         if comm is not None:
-            hip.comm_init_rank(*comm)
+            comm(hip)
         for b in range(N_BATCHES):
             off = 0 if b == 0 else g.first_batch_bytes + (b - 1) * g.batch_bytes
             hip.process_device(iq.data_ptr() + off, stride)
@@ -63,9 +63,7 @@ def _rank_main(rank, world, port, per_rank, q):
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     d0, d1 = mg.shard_range(per_rank * world, rank, world)
-    box = [pkg.AirbandHip.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    res = _run_handle(pkg, torch, rank, d0, d1, comm=(box[0], world, rank))
+    res = _run_handle(pkg, torch, rank, d0, d1, comm=lambda hip: mg.init_mixer_exchange(hip, rank, world, dist))
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:

@@ -259,6 +259,47 @@ def test_zero_copy_spans_that_do_not_start_on_16_bytes(pkg, built):
         assert opened > 0
 
 
+def test_zero_copy_spans_of_300_byte_hops(pkg, built):
+    """Hops of 300 bytes (2.4 MS/s at WAVE_RATE 16000, config/noaa.conf's rate): the kernel variant reads its fragments 4 bytes at a time, so spans may sit at any
+    multiple of 4 bytes off a 16-byte boundary (rows 4 bytes apart in alignment here: 0, 4, 8 off) and == submit / process bit for bit; a span only 2 bytes
+    off would put those reads on a 2-byte boundary: refused (round-4 ADVICE)."""
+    torch = pytest.importorskip("torch")
+    capi = pkg.capi
+    n_dev, n_batches, wave_rate, sr = 3, 3, 16000, 2_400_000
+    devices, iq = helpers.format_case(pkg, capi.SFMT_U8, 9, sr, wave_rate, n_dev, n_batches)
+    n = min(len(x) for x in iq)
+    stride = (n + 4 + 255) // 256 * 256 + 4
+    host = np.zeros((n_dev, stride), np.uint8)
+    for d in range(n_dev):
+        host[d, :n] = iq[d][:n]
+    with pkg.AirbandHip(devices, wave_rate=wave_rate) as a, pkg.AirbandHip(devices, wave_rate=wave_rate) as b:
+        assert a.channelizer_name() == b.channelizer_name() == "dft_mfma_i8"
+        g = a.geometry
+        assert g.batch_bytes == 300 * 2000
+        dbuf = torch.from_numpy(host).cuda()
+        with pytest.raises(pkg.AirbandError) as e:
+            b.process_device(dbuf.data_ptr() + 2, stride)
+        assert e.value.code == capi.EINVAL
+        with pytest.raises(pkg.AirbandError):
+            b.process_device(dbuf.data_ptr(), stride + 2)
+        off = 0
+        opened = 0
+        for k in range(n_batches):
+            take = (g.first_batch_bytes + g.lookahead_bytes) if k == 0 else g.batch_bytes
+            lo = off if k == 0 else off + g.lookahead_bytes
+            for d in range(n_dev):
+                assert a.submit(d, host[d, lo:lo + take]) == take
+            assert a.process()
+            ra = a.collect()
+            b.process_device(dbuf.data_ptr() + off, stride)
+            rb = b.collect()
+            assert np.array_equal(ra["waveout"].view(np.uint32), rb["waveout"].view(np.uint32)), k
+            assert np.array_equal(ra["axc"], rb["axc"])
+            opened += int((rb["axc"] == ord("*")).sum())
+            off += g.first_batch_bytes if k == 0 else g.batch_bytes
+        assert opened > 0
+
+
 def test_collect_waits_for_a_batch_enqueued_on_the_callers_stream(pkg, built):
     """process_device(..., stream=S) runs the whole batch on S; collect / collect_channels / read_trace / collect_mixers issue
     their copies on the handle's own stream and must order themselves behind S on the GPU.  S is kept busy with a long
