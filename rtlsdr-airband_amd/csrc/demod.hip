@@ -857,9 +857,19 @@ __global__ __launch_bounds__(64, KIND == AB_KIND_AM ? AB_AM_WAVES : KIND == AB_K
  * with the state in registers; audio and flags come from the front kernel 50 samples at a time (lane u fetches sample u,
  * v_readlane feeds the serial loop), the verdict leaves as a 50-bit mask per step.  Tiny register footprint -> 8 waves per
  * SIMD hide the dependent-issue latency of the recurrence. */
+/* (experiment builds: -DAB_TONE_WAVES8 holds the register allocation to eight waves per SIMD, at the price of a few spilled registers) */
+#if defined(AB_TONE_WAVES8)
+#define AB_TONE_RESIDENCY __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define AB_TONE_RESIDENCY
+#endif
 template <bool PACKED>
-__global__ __launch_bounds__(256) void tone_kernel(DemodArgs a, int first_block, int n_blocks) { /* blocks [first_block, first_block + n_blocks) of the kind: any sub-range */
+__global__ __launch_bounds__(256) AB_TONE_RESIDENCY void tone_kernel(DemodArgs a, int first_block, int n_blocks) { /* blocks [first_block, first_block + n_blocks) of the kind: any sub-range */
     __shared__ float power[4][64];
+    /* a step's 50 audio samples, parked by the lanes that fetched them and read back as wave-wide BROADCASTS (every lane the same address, four samples per
+     * ds_read_b128): the steady-state recurrences then take their input from a vector register -- a v_readlane per sample was a quarter of their vector
+     * instructions (round 5: stage 2 is bound by vector issue, its critical path is front -> tone -> back) */
+    __shared__ __attribute__((aligned(16))) float xs_all[4][64];
     /* the wave index is the same number on every lane: told so, the compiler keeps the channel's constants and counters in scalar
      * registers and fetches them with scalar loads */
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
@@ -871,6 +881,7 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a, int first_block,
     const ChanConst cc = a.cc[slot];
     ChanState* sp = a.cs + slot;
     float* scratch = power[threadIdx.x >> 6];
+    float* xs = xs_all[threadIdx.x >> 6];
     const int B = a.wave_batch, NG = B / TONE_GROUP;
     int enough0 = sp->ct_enough[0], enough1 = sp->ct_enough[1], count0 = sp->ct_count[0], count1 = sp->ct_count[1];
     int has0 = sp->ct_has_tone[0], has1 = sp->ct_has_tone[1];
@@ -926,6 +937,7 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a, int first_block,
         } else if (all_audio && count1 + TONE_GROUP < win1 && (enough1 || count0 + TONE_GROUP < win0)) {
             /* steady state: squelch open throughout and no detector window ends inside the step -> only the recurrences
              * (ToneDetector::process_sample, src/ctcss.cpp:44-54) */
+#if defined(AB_TONE_READLANE) /* experiment builds: round 4's loops (a v_readlane per sample), for A/B timing */
             if (enough1) {
                 for (int u = 0; u < TONE_GROUP; u++) {
                     const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
@@ -933,7 +945,7 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a, int first_block,
                     q2s = q1s;
                     q1s = q0;
                 }
-            } else { /* the fast detector runs until the slow one has a full window (src/squelch.cpp:288-293) */
+            } else {
                 for (int u = 0; u < TONE_GROUP; u++) {
                     const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ax), u));
                     const float q0 = c1 * q1s - q2s + x;
@@ -945,6 +957,64 @@ __global__ __launch_bounds__(256) void tone_kernel(DemodArgs a, int first_block,
                 }
                 count0 += TONE_GROUP;
             }
+#else
+            AB_LOCKSTEP(); /* (the previous step's broadcasts have been read: a wavefront's LDS operations complete in order) */
+            xs[lane] = ax;  /* lanes past the 50th park zeros that nobody reads */
+            AB_LOCKSTEP();
+            static_assert(TONE_GROUP % 4 == 2 && TONE_GROUP + 2 <= 64, "twelve quads and one pair; the last quad read covers two parked zeros");
+            /* one quad ahead (the next broadcast flies under this quad's twelve dependent operations); unrolled by three only: all thirteen reads at once
+             * cost 45 more registers and half the kernel's residency, which is what hides the recurrence's dependent-issue latency */
+            const float4* xs4 = reinterpret_cast<const float4*>(xs);
+            float4 v = xs4[0];
+            if (enough1) {
+#pragma unroll 2
+                for (int u4 = 0; u4 < TONE_GROUP / 4; u4++) {
+                    const float4 nxt = xs4[u4 + 1];
+                    const float x4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float q0 = c1 * q1s - q2s + x4[r];
+                        q2s = q1s;
+                        q1s = q0;
+                    }
+                    v = nxt;
+                }
+                const float x2[2] = {v.x, v.y};
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const float q0 = c1 * q1s - q2s + x2[r];
+                    q2s = q1s;
+                    q1s = q0;
+                }
+            } else { /* the fast detector runs until the slow one has a full window (src/squelch.cpp:288-293) */
+#pragma unroll 2
+                for (int u4 = 0; u4 < TONE_GROUP / 4; u4++) {
+                    const float4 nxt = xs4[u4 + 1];
+                    const float x4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float q0 = c1 * q1s - q2s + x4[r];
+                        q2s = q1s;
+                        q1s = q0;
+                        const float p0 = c0 * q1f - q2f + x4[r];
+                        q2f = q1f;
+                        q1f = p0;
+                    }
+                    v = nxt;
+                }
+                const float x2[2] = {v.x, v.y};
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const float q0 = c1 * q1s - q2s + x2[r];
+                    q2s = q1s;
+                    q1s = q0;
+                    const float p0 = c0 * q1f - q2f + x2[r];
+                    q2f = q1f;
+                    q1f = p0;
+                }
+                count0 += TONE_GROUP;
+            }
+#endif
             count1 += TONE_GROUP;
             mask = (enough1 ? has1 : has0) ? ~0ull : 0ull;
         } else {

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""Round 5: the decisive experiment for round 4's rare event (profiles/r04_experiments.md I -- one transform in ~10^9 wrong on the wavefront FFT's LDS exchange
-when a dozen PROCESSES share the GPU, none in 4.6e9 with one process).  One worker of a P-process load: a handle whose dongles ALL replay dongle 0's bytes, on the
-exchange kernel (u8 at fft 512 with FORCE_FFT, or CF32 at fft 4096: eight decimated transforms per hop), carriers keyed permanently so that every channel's audio
-depends on every hop's bin; after every batch every dongle's result rows are compared with dongle 0's ON THE GPU (bit for bit: dongles are independent and
-identical).  The handle is torn down and rebuilt every few batches (the fuzz campaign that saw the events created and destroyed handles all the time).
-usage: r05_exchange_stress.py <tag> <seconds> <u8|f32> <dongles> <out.jsonl>      (the library under test: AIRBAND_HIP_LIB)"""
+"""Round 5: the experiment for round 4's rare event (profiles/r04_experiments.md I -- about one transform in 10^9 wrong on the wavefront FFT's LDS exchange while a
+dozen PROCESSES shared the GPU, none in 4.6e9 with one process).  One worker of a P-process load.  A handle whose dongles ALL replay dongle 0's bytes runs on the
+exchange kernel (u8 at fft 512 with FORCE_FFT, or CF32 at fft 4096 / 8192: 8 / 16 decimated transforms per hop); after every batch the stage-1 bins of every dongle
+-- |bin| and raw I/Q of every hop -- are compared with dongle 0's, bit for bit (dongles are independent and identical).  Two shapes of load:
+  big    hundreds of dongles per handle, results compared on the GPU (audio rows): ~10^9 hop transforms per process and minute, few launches;
+  small  a few dongles per handle (the fuzz campaign's shape: 1 - 5), bins compared on the host: ~10^5 launches per process and minute, the GPU switching
+         between the processes' queues all the time; every other small worker feeds the host path (submit / process) as the fuzz did.
+The handle is torn down and rebuilt every few dozen batches (the fuzz created and destroyed handles all the time).
+usage: r05_exchange_stress.py <tag> <seconds> <u8|f32|f32x> <dongles> <out.jsonl> [host]      (the library under test: AIRBAND_HIP_LIB)"""
 import importlib
 import json
 import os
@@ -22,27 +25,26 @@ class DevPtr:
 
 def main():
     tag, seconds, fmt, D, out_path = sys.argv[1], float(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
+    host_path = len(sys.argv) > 6 and sys.argv[6] == "host"
     import numpy as np
     import torch
 
     pkg = importlib.import_module("rtlsdr-airband_amd")
     sg = pkg.siggen
     chans, carriers = sg.baseline_plan(mixed=True)
-    # every transmitter keyed all the time: a wrong bin anywhere shows in the audio
-    import dataclasses
-
-    carriers = [dataclasses.replace(c, key_period=0) for c in carriers]
     wave_rate, ring = 16000, 2
-    f32 = fmt == "f32"
-    fft_log = 12 if f32 else 9
+    f32 = fmt.startswith("f32")
+    fft_log = (13 if fmt == "f32x" else 12) if f32 else 9
     dev = dict(channels=chans, sfmt=pkg.capi.SFMT_F32) if f32 else dict(channels=chans)
     flags = 0 if f32 else pkg.capi.FLAG_FORCE_FFT
+    small = D <= 16
     t_end = time.time() + seconds
-    stats = dict(tag=tag, fmt=fmt, dongles=D, batches=0, hop_transforms=0, events=0, handles=0, lib=os.environ.get("AIRBAND_HIP_LIB", "product"))
+    stats = dict(tag=tag, fmt=fmt, fft_log=fft_log, dongles=D, host_path=host_path, batches=0, hop_transforms=0, events=0, handles=0, lib=os.environ.get("AIRBAND_HIP_LIB", "product"))
     events = []
     gen = pkg.AirbandHip([dict(channels=chans)], wave_rate=wave_rate)  # the generator emits u8
     gen.set_signal_plan(carriers)
-    iq = None
+    iq = host_iq = None
+    per_handle = 48 if small else 6
     while time.time() < t_end:
         hip = pkg.AirbandHip([dev] * D, wave_rate=wave_rate, flags=flags, fft_log=fft_log)
         stats["handles"] += 1
@@ -65,25 +67,40 @@ def main():
                 gen.synchronize()
             iq[1:] = iq[0:1]
             torch.cuda.synchronize()
+            host_iq = iq[0].cpu().numpy() if host_path else None
         res = hip.device_results()
         ws, B = g.wave_stride, hip.B
         wave = torch.as_tensor(DevPtr(res["waveout"], (D, 8, ws), "<i4"), device="cuda")[:, :, :B]  # bit patterns
-        n_hops = B
-        for i in range(2 * ring + 2):
+        for i in range(per_handle):
             off = 0 if i == 0 else g.first_batch_bytes + ((i - 1) % ring) * g.batch_bytes
-            hip.process_device(iq.data_ptr() + off, stride)
-            hip.synchronize()
-            ne = (wave != wave[0:1])
-            bad = int(ne.any(dim=2).any(dim=1).sum().item())
+            if host_path:  # the same bytes through submit / process: pinned ring, DMA into the staging buffers
+                n = (g.first_batch_bytes + g.lookahead_bytes) if i == 0 else g.batch_bytes
+                lo = off if i == 0 else off + g.lookahead_bytes
+                for d in range(D):
+                    assert hip.submit(d, host_iq[lo:lo + n]) == n
+                assert hip.process()
+            else:
+                hip.process_device(iq.data_ptr() + off, stride)
             stats["batches"] += 1
-            stats["hop_transforms"] += D * (n_hops + (100 if i == 0 else 0))
-            if i > 0 and not bool((wave[0] != 0).any().item()):
-                raise RuntimeError("no audio: the comparison would see nothing")
+            stats["hop_transforms"] += D * (B + (100 if i == 0 else 0))
+            if small:
+                w, q = hip.read_bins()
+                w = w.view(np.uint32).reshape(D, 8, B)
+                q = q.view(np.uint32).reshape(D, 8, 2 * B)
+                nw, nq = (w != w[0:1]), (q != q[0:1])
+                bad = int(nw.any(axis=(1, 2)).sum() + nq.any(axis=(1, 2)).sum())
+                if bad:
+                    idx = np.argwhere(nq)[:6].tolist() or np.argwhere(nw)[:6].tolist()
+                    ev = dict(tag=tag, fmt=fmt, handle=stats["handles"], batch=i, host_path=host_path, what="iq" if nq.any() else "mag", n_mag=int(nw.sum()), n_iq=int(nq.sum()), first=idx)
+            else:
+                hip.synchronize()
+                ne = (wave != wave[0:1])
+                bad = int(ne.any(dim=2).any(dim=1).sum().item())
+                if bad:
+                    idx = ne.nonzero()[:8].cpu().numpy().tolist()
+                    ev = dict(tag=tag, fmt=fmt, handle=stats["handles"], batch=i, what="audio", dongles_differing=bad, first=idx)
             if bad:
                 stats["events"] += 1
-                idx = ne.nonzero()[:8].cpu().numpy().tolist()
-                ev = dict(tag=tag, fmt=fmt, handle=stats["handles"], batch=i, dongles_differing=bad, first=idx,
-                          values=[(int(wave[d, c, s].item()), int(wave[0, c, s].item())) for d, c, s in idx[:4]])
                 events.append(ev)
                 print("EVENT", json.dumps(ev), flush=True)
             if time.time() >= t_end:
