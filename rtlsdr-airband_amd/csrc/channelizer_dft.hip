@@ -127,6 +127,9 @@ __device__ __forceinline__ v4i lds_read16(const uint8_t* p) {
     return z;
 #endif
     if (AL >= 16) return *reinterpret_cast<const v4i*>(p);
+    /* (round 5, measured and dropped: ONE unaligned ds_read_b128 per fragment instead of the assembled reads below -- gfx950 under HSA runs with unaligned DS
+     * access and the compiler itself emits that instruction for a 16-byte LDS load of alignment 2 -- is correct and 58 % SLOWER at 250-byte hops: 13.97 against
+     * 8.85 ms per launch, profiles/r05_misc/r2000k_*.json; a misaligned wide LDS access is served a few bytes at a time) */
     if (AL == 8) {
         typedef int v2i __attribute__((ext_vector_type(2)));
         const v2i lo = *reinterpret_cast<const v2i*>(p), hi = *reinterpret_cast<const v2i*>(p + 8);
@@ -363,6 +366,9 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
             tile_body(arow, pre, A);
         } else {
             /* CS16: plane k-step s of the lane = 16 plane bytes = 8 samples x (I, Q) = 32 raw bytes [Ilo Ihi Qlo Qhi] x 8 */
+            /* (round 5, measured and dropped: pulling the planes apart ONCE per landed step, in place in LDS -- 32 raw bytes -> [16 low bytes - 128 | 16 high bytes], 96
+             * instructions per step instead of 192 v_perm / v_xor per tile -- is correct and 8 % SLOWER: 21.05 against 19.48 ms per launch, profiles/r05_misc/cs16_*.json.
+             * Like the u8 flip moved into LDS in round 3: on this kernel vector instructions are cheaper than LDS traffic) */
             A.a0 = (v4i){0, 0, 0, 0}; A.a1 = (v4i){0, 0, 0, 0}; A.a2 = (v4i){0, 0, 0, 0};
             A.h0 = (v4i){0, 0, 0, 0}; A.h1 = (v4i){0, 0, 0, 0}; A.h2 = (v4i){0, 0, 0, 0};
             const uint8_t* arow = buf + delta + (sb * TILE_HOPS + row_l) * hop_bytes + grp * 32 + piece * WIN_BYTES;

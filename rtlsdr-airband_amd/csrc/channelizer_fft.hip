@@ -45,13 +45,20 @@ namespace {
 #define AB_DYNAMIC_LDS_BYTES(name) extern __shared__ __attribute__((aligned(16))) uint8_t name[]
 #endif
 
-/* Lanes of ONE wavefront exchange data through LDS: a wavefront's LDS operations execute in order, so all that is needed is that the compiler keeps
- * them in program order across the exchange (no instruction is emitted).  tests/hostshim_wave64 makes the lanes, which it runs as fibers, meet here. */
+/* Lanes of ONE wavefront exchange data through LDS: a wavefront's LDS operations execute in order, so what is NEEDED is that the compiler keeps them in
+ * program order across the exchange (the two wavefront-scope fences around the wave barrier: no instruction).  tests/hostshim_wave64 makes the lanes, which it
+ * runs as fibers, meet here. */
 #if !defined(AB_WAVE_SYNC)
-#if defined(AB_WAVE_SYNC_WAITS) /* experiment builds only (scripts/r05_lds_layout_ab.sh): every exchange also waits until the wavefront's LDS operations have completed */
-#define AB_WAVE_SYNC_EXTRA() __builtin_amdgcn_s_waitcnt(0xc07f) /* vmcnt(63) expcnt(7) lgkmcnt(0) */
-#else
+/* Round 5: every exchange also WAITS until the wavefront's own LDS operations have completed (s_waitcnt lgkmcnt(0)) before any lane reads what another lane wrote.
+ * In-order execution of one wavefront's LDS instructions already orders them; the wait takes the kernel off that assumption.  Why: round 4's fuzz campaign saw about one
+ * transform in 10^9 wrong on this kernel while a dozen processes shared the GPU (profiles/r04_experiments.md I).  Round 5 could not make it happen again -- 1.6e10 hop
+ * transforms under 6- and 12-process loads with and without the wait, handles of the fuzz's size included, not one difference (profiles/r05_exchange_stress.md) -- so the
+ * cause stays unnamed and the wait is insurance, at a measured cost of 0 (u8, fft 512) to 2.3 % (CF32, fft 4096) of this kernel's time (profiles/r05_misc/fft_*.json,
+ * f32_4096_*.json).  -DAB_WAVE_SYNC_NO_WAIT builds the kernel without it. */
+#if defined(AB_WAVE_SYNC_NO_WAIT)
 #define AB_WAVE_SYNC_EXTRA() (void)0
+#else
+#define AB_WAVE_SYNC_EXTRA() __builtin_amdgcn_s_waitcnt(0xc07f) /* vmcnt(63) expcnt(7) lgkmcnt(0) */
 #endif
 #define AB_WAVE_SYNC()                                           \
     do {                                                         \

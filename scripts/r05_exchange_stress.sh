@@ -1,12 +1,14 @@
-# Round 5: product build against -DAB_WAVE_SYNC_WAITS (s_waitcnt lgkmcnt(0) at every wavefront-level LDS exchange) under a twelve-process load on one GPU,
+# Round 5: the exchange kernel with and without s_waitcnt lgkmcnt(0) at every wavefront-level LDS exchange under a twelve-process load on one GPU (when the
+# experiment ran, the wait was the experiment build -DAB_WAVE_SYNC_WAITS; it has shipped since, and the build without it is -DAB_WAVE_SYNC_NO_WAIT:
+#   AIRBAND_EXTRA_DEFINES=-DAB_WAVE_SYNC_NO_WAIT AIRBAND_BUILD_TAG=sync_nowait python rtlsdr-airband_amd/_build.py),
 # every process pushing replicated dongles through the exchange kernel and comparing them bit for bit (scripts/r05_exchange_stress.py).
 #   gpurun --timeout 900 -- 'bash scripts/r05_exchange_stress.sh 50 12 small'      (shape: small = the fuzz campaign's handle sizes, big = hundreds of dongles)
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 SECS=${1:-50}; P=${2:-12}; SHAPE=${3:-small}
 O=$GRAFT_REPO_ROOT/gpurun_out/exchange_stress_$SHAPE; rm -rf $O; mkdir -p $O
-WAITS=$GRAFT_REPO_ROOT/rtlsdr-airband_amd/libairband_hip_exp_sync_waits.so
-ls $WAITS || exit 1
+NOWAIT=$GRAFT_REPO_ROOT/rtlsdr-airband_amd/libairband_hip_exp_sync_nowait.so
+ls $NOWAIT || exit 1
 python -c "import torch" # page the image in once, outside the timed arms
 run_arm() { # name, processes, [library]
   local name=$1 procs=$2 lib=$3 pids=""
@@ -23,9 +25,9 @@ run_arm() { # name, processes, [library]
   grep -h EVENT $O/$name.*.log | cut -c1-400 | head -20
   grep -L '"batches"' $O/$name.*.log | head -3 | while read f; do echo "== $f"; tail -5 $f; done
 }
-run_arm control $P ""
-run_arm waits $P $WAITS
-run_arm control2 $P ""
+run_arm control $P $NOWAIT
+run_arm waits $P ""
+run_arm control2 $P $NOWAIT
 python - <<PY
 import json, glob, os
 O = "$O"
