@@ -84,7 +84,9 @@ def main():
     for name, title in (("kt_cfg3", "configs[2], default run (kinds side by side)"), ("kt_cfg3_serial", "configs[2], every stage-2 kernel alone (AIRBAND_BENCH_FLAGS=8)"),
                         ("kt_cfg3_afc", "configs[2] with AFC on one channel of every dongle, stage-2 kernels alone (bench.py --afc 2)"),
                         ("kt_cfg3_force_fft", "configs[2] on the wavefront-FFT channelizer (AIRBAND_BENCH_FLAGS=4)"), ("kt_cfg2", "configs[1] (1 024 AM dongles)"),
-                        ("kt_am65536", "65 536 AM dongles"), ("kt_cs16", "configs[2] with CS16 dongles")):
+                        ("kt_cfg4", "configs[3]'s per-GPU shard (32 768 dongles), kinds side by side"),
+                        ("kt_cfg4_serial", "configs[3]'s per-GPU shard (32 768 dongles), every stage-2 kernel alone"),
+                        ("kt_am65536", "65 536 AM dongles"), ("kt_cs16", "configs[2] with CS16 dongles"), ("kt_f32", "32 768 CF32 dongles")):
         rows = stats(name)
         if not rows:
             continue

@@ -1,8 +1,8 @@
 # Regenerates the round's measurements on a GPU box:  rm -rf gpurun_out/final; gpurun --timeout 2400 -- 'bash scripts/profile_round.sh'
-# (gpurun MERGES into the local gpurun_out/, so remove the old copy first), then `python scripts/collect_profiles.py r04` copies the summaries into profiles/.
+# (gpurun MERGES into the local gpurun_out/, so remove the old copy first), then `python scripts/collect_profiles.py r05` copies the summaries into profiles/.
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=${R:-r04}
+R=${R:-r05}
 O=gpurun_out/final; rm -rf $O; mkdir -p $O
 nproc > $O/host.txt; grep -m1 "model name" /proc/cpuinfo >> $O/host.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -n 1 $O/smoke.log
@@ -34,6 +34,8 @@ AIRBAND_BENCH_FLAGS=8 timeout 300 rocprofv3 --kernel-trace --stats --output-form
 AIRBAND_BENCH_FLAGS=8 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg3_afc -- python bench.py $K --afc 2 > $O/kt_afc.log 2>&1
 AIRBAND_BENCH_FLAGS=4 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg3_force_fft -- python bench.py --no-cpu-baseline --no-traffic --no-verify-all --verify 0 --steps 3 --warmup 1 > $O/kt_fft.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg2 -- python bench.py $K --workload cfg2 > $O/kt_cfg2.log 2>&1
+AIRBAND_BENCH_FLAGS=8 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg4_serial -- python bench.py $K --workload cfg4 > $O/kt_cfg4_serial.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg4 -- python bench.py $K --workload cfg4 > $O/kt_cfg4.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_am65536 -- python bench.py $K --workload cfg2 --dongles 65536 > $O/kt_am.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cs16 -- python bench.py $K --sample-format s16 --ring 1 > $O/kt_cs16.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_f32 -- python bench.py $K --sample-format f32 --ring 1 --dongles 32768 > $O/kt_f32.log 2>&1
