@@ -586,7 +586,7 @@ def main():
         # how busy the benchmarked signal keeps the squelches: one more pass over the resident ring (untimed), share of channels whose batch had signal
         try:
             total_ch = hip.geometry.total_channels
-            axc_view = torch.as_tensor(mg._DevicePtr(hip.device_results()["axc"], (total_ch,), "|u1"), device="cuda")
+            axc_view = torch.as_tensor(pkg.DevicePtr(hip.device_results()["axc"], (total_ch,), "|u1"), device="cuda")
             fr = []
             for i in range(total_steps, total_steps + args.ring):
                 step(i)

@@ -37,6 +37,14 @@ EXPORTS = [
 _lib = None
 
 
+class DevicePtr:
+    """A view of DEVICE memory the library owns (airband_hip_device_results) for consumers that stay on the GPU: `torch.as_tensor(DevicePtr(ptr, shape, "<f4"),
+    device="cuda")` aliases the buffer through __cuda_array_interface__ -- no copy, no ownership.  bench.py reads the axcindicate row that way."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=2)
+
+
 class AirbandError(RuntimeError):
     def __init__(self, code: int, text: str):
         super().__init__("airband_hip error %d: %s" % (code, text))

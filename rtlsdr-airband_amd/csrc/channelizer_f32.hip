@@ -37,15 +37,16 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4))); /* (not HIP's uint4: an array of that class type ends up in scratch memory) */
 
 constexpr int TILE_HOPS = 16;
-constexpr int NW = 4; /* waves per workgroup = pieces of the contraction index */
 
 __host__ __device__ constexpr int f32_pad(int hop_bytes) { return ((hop_bytes / 16) & 1) ? 0 : 16; }
 __host__ __device__ constexpr long f32_padded(long o, int hop_bytes, int pad) { return o + (long)pad * (o / hop_bytes); }
 
-/* FFT_N: 256 or 512 (window of 2 FFT_N floats = 8 FFT_N bytes); KW = MFMAs per wave and tile = 2 FFT_N / 4 / NW */
-/* MAX_LD: 16-byte pieces of a tile per thread (6: tiles up to 24 KiB -- 2.56 MS/s at WAVE_RATE 16000 -- three workgroups per CU; 12: up to 48 KiB) */
-template <int FFT_N, int MAX_LD>
-__global__ __launch_bounds__(64 * NW, MAX_LD <= 6 ? 3 : 1) void channelizer_f32_kernel(F32Args a) {
+/* FFT_N: 256 ... 2048 (window of 2 FFT_N floats = 8 FFT_N bytes); NW: waves per workgroup = pieces of the contraction index (f32_nw: 4 up to fft 512, 8 for 1024 / 2048,
+ * round 5); KW = MFMAs per wave and tile = 2 FFT_N / 4 / NW = resident B registers: 32 (fft 256), 64 (512, 1024), 128 (2048) */
+/* MAX_LD: 16-byte pieces of a tile per thread (6: tiles up to 24 KiB at NW = 4 -- 2.56 MS/s at WAVE_RATE 16000 -- three workgroups per CU; 12: up to 48 KiB; twice that at NW = 8) */
+/* residency the register allocation is held to: NW = 4: three waves per SIMD (168 VGPRs) for the small tiles, one for the large; NW = 8: a workgroup is two waves per SIMD */
+template <int FFT_N, int MAX_LD, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void channelizer_f32_kernel(F32Args a) {
     constexpr int WIN_BYTES = 8 * FFT_N;
     constexpr int KW = 2 * FFT_N / 4 / NW;   /* 64 (fft 512) or 32 (fft 256) */
     constexpr int READS = KW / 4;            /* 16-byte fragment reads per wave and tile */
@@ -242,8 +243,9 @@ __global__ __launch_bounds__(64 * NW, MAX_LD <= 6 ? 3 : 1) void channelizer_f32_
  * two workgroups per CU; dongles with an AFC channel stay on the wavefront FFT (their tables move at run time: the re-tune kernel builds int8 tables) */
 bool f32_supported(int fft_size, int hop_samples, int sfmt) {
     if (sfmt != AIRBAND_SFMT_F32) return false;
-    if (fft_size != 256 && fft_size != 512) return false;
+    if (fft_size != 256 && fft_size != 512 && fft_size != 1024 && fft_size != 2048) return false; /* (4096 and beyond: 256+ B registers per wave of eight, or workgroups beyond 1 024 threads) */
     if (hop_samples < 8 || (hop_samples & 1)) return false;
+    const int NW = f32_nw(fft_size);
     if ((TILE_HOPS - 1) * 8 * hop_samples + 8 * fft_size > 12 * 64 * NW * 16) return false; /* a tile's bytes: twelve 16-byte pieces per thread */
     /* two workgroups per CU up to ~78 KiB each (2.56 MS/s at WAVE_RATE 16000: 54 KiB), one beyond (WAVE_RATE 8000: 92 KiB) */
     return f32_lds_per_buf(fft_size, hop_samples) * 2 + 2 * (NW - 1) * 64 * (int)sizeof(float4) <= 154 * 1024;
@@ -257,7 +259,7 @@ int f32_lds_per_buf(int fft_size, int hop_samples) {
     return (int)((f32_padded(tile_bytes, hop_bytes, pad) + 16 + 255) / 256 * 256);
 }
 
-template <int FFT_N, int MAX_LD>
+template <int FFT_N, int MAX_LD, int NW>
 static void launch_f32(const F32Args& a, hipStream_t stream) {
     const long groups = (long)a.n_items * a.splits;
     const size_t lds = (size_t)2 * a.lds_per_buf + 2 * (NW - 1) * 64 * sizeof(float4);
@@ -268,16 +270,18 @@ static void launch_f32(const F32Args& a, hipStream_t stream) {
     (void)hipGetDevice(&dev);
     if (lds > 64 * 1024 && (dev >= 64 || !big_lds[dev].load(std::memory_order_acquire))) {
         /* (the CU's whole 160 KiB, not this launch's size: a later handle of the same process may have longer hops) */
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_f32_kernel<FFT_N, MAX_LD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess && dev < 64) big_lds[dev].store(true, std::memory_order_release);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_f32_kernel<FFT_N, MAX_LD, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess && dev < 64) big_lds[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((channelizer_f32_kernel<FFT_N, MAX_LD>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, a);
+    hipLaunchKernelGGL((channelizer_f32_kernel<FFT_N, MAX_LD, NW>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, a);
 }
 
 void launch_channelizer_f32(const F32Args& a, hipStream_t stream) {
     const int tile_bytes = (TILE_HOPS - 1) * a.hop_bytes + 8 * a.fft_size;
-    const bool small = tile_bytes <= 6 * 64 * NW * 16; /* six pieces per thread: the register budget of three workgroups per CU */
-    if (a.fft_size == 512) return small ? launch_f32<512, 6>(a, stream) : launch_f32<512, 12>(a, stream);
-    return small ? launch_f32<256, 6>(a, stream) : launch_f32<256, 12>(a, stream);
+    const bool small = tile_bytes <= 6 * 64 * f32_nw(a.fft_size) * 16; /* six pieces per thread: the register budget of three workgroups per CU (NW = 4) */
+    if (a.fft_size == 2048) return small ? launch_f32<2048, 6, 8>(a, stream) : launch_f32<2048, 12, 8>(a, stream);
+    if (a.fft_size == 1024) return small ? launch_f32<1024, 6, 8>(a, stream) : launch_f32<1024, 12, 8>(a, stream);
+    if (a.fft_size == 512) return small ? launch_f32<512, 6, 4>(a, stream) : launch_f32<512, 12, 4>(a, stream);
+    return small ? launch_f32<256, 6, 4>(a, stream) : launch_f32<256, 12, 4>(a, stream);
 }
 
 }  // namespace airband

@@ -72,7 +72,7 @@ struct F32Args {
     const int* item_dev;    /* work items as for DftArgs: (dongle, group of 8 channels, coefficient-table index) */
     const int* item_group;
     const int* item_bset;
-    const float* btab;      /* [n_bsets][4 pieces][MFMAs per piece][64 lanes] window x twiddle, ordered as the kernel contracts (params.cpp, build_f32_tables) */
+    const float* btab;      /* [n_bsets][f32_nw pieces][MFMAs per piece][64 lanes] window x twiddle, ordered as the kernel contracts (params.cpp, build_f32_tables) */
     float* mag;
     float2* iq_bins;
     int n_items, splits, fft_size;
@@ -162,6 +162,9 @@ int dft_partial_tiles(int n_hops_max); /* 16-hop tiles a work item may touch in 
 void launch_channelizer_dft(const DftArgs& a, hipStream_t stream);
 /* side: 3 extra streams, ev: 4 events (fork + 3 joins); both may be null -> everything on `stream`, one kind after the other */
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev);
+/* waves per workgroup = pieces the contraction index (2 fft_size values) is cut into: four up to fft_size 512 (64 / 32 resident B registers per wave), eight for 1024 and 2048
+ * (64 / 128): a workgroup of eight waves is two per SIMD, which is what 128 B registers beside everything else allow anyway */
+inline int f32_nw(int fft_size) { return fft_size <= 512 ? 4 : 8; }
 bool f32_supported(int fft_size, int hop_samples, int sfmt);
 int f32_pad_bytes(int hop_samples);
 int f32_lds_per_buf(int fft_size, int hop_samples);

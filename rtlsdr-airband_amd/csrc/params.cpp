@@ -324,7 +324,7 @@ int build_plan(const airband_hip_config* cfg, Plan& p) {
  * (same transform as src/rtl_airband.cpp:451-460 + :483-489 evaluated for one bin).  Values are scaled to 24-bit
  * integers and split into balanced base-256 digits d0 + 256 d1 + 65536 d2, each in [-128, 127]. */
 void build_f32_tables(Plan& p) {
-    const int N = p.fft_size, NW = 4, VPP = 2 * N / NW, KW = VPP / 4; /* values and MFMAs (K = 4) per piece */
+    const int N = p.fft_size, NW = N <= 512 ? 4 : 8, VPP = 2 * N / NW, KW = VPP / 4; /* values and MFMAs (K = 4) per piece; NW = kernels.h f32_nw() */
     p.ftab.assign((size_t)p.n_shared_bsets * NW * KW * 64, 0.0f);
     for (int b = 0; b < p.n_shared_bsets; b++)
         for (int piece = 0; piece < NW; piece++)
@@ -467,7 +467,7 @@ void build_dft_tables(Plan& p, bool host_private) {
  * l supplying stream value 16 (s / 4) + 4 (l >> 4) + s % 4 of its piece against table entry [piece][s][l], partial sums of a piece in float, the four pieces
  * added in float -- against the double-precision sum, on pseudo-random windows; largest error relative to the RMS of the exact values */
 double f32_table_selftest(const Plan& p, int windows) {
-    const int N = p.fft_size, NW = 4, VPP = 2 * N / NW, KW = VPP / 4;
+    const int N = p.fft_size, NW = N <= 512 ? 4 : 8, VPP = 2 * N / NW, KW = VPP / 4;
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     auto next = [&]() {
         rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;

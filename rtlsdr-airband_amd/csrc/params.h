@@ -35,7 +35,7 @@ struct Plan {
     std::vector<int> item_home;                       /* the SHARED table of the item's base bins: what a group with an AFC channel reads while none of its channels has moved */
     std::vector<int8_t> bfrag;         /* [n_bsets][3][fft_size / 32][64][16] */
     std::vector<double> bcorr;         /* [n_bsets][16] */
-    std::vector<float> ftab;           /* CF32 dongles (channelizer_f32.hip): [n_shared_bsets][4 pieces][fft_size / 8 MFMAs][64 lanes] window x twiddle */
+    std::vector<float> ftab;           /* CF32 dongles (channelizer_f32.hip): [n_shared_bsets][NW pieces][2 fft_size / 4 / NW MFMAs][64 lanes], NW = 4 up to fft_size 512, 8 beyond (kernels.h f32_nw) window x twiddle */
     double b_unscale = 0.0;
     bool b_edge_hi_zero = false;       /* digit 2 is zero in the outer k-steps (fft_size / 256 at either end) of every table */
     int n_bsets = 0, n_shared_bsets = 0; /* coefficient tables in all / those shared between work items (the rest belong to groups with an AFC channel) */

@@ -39,3 +39,21 @@ def test_world_size_mismatch_is_refused():
     r = _run(["--gpus", "2", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_uses_only_names_the_package_has():
+    """bench.py reaches into the package and its multigpu module by attribute; a helper removed from either must not surface as an error string in a JSON field on the GPU box
+    (round 5: `open_fraction` carried an AttributeError for one profile run after the dead torch all-reduce path had been deleted)."""
+    import importlib
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    pkg = importlib.import_module("rtlsdr-airband_amd")
+    mg = importlib.import_module("rtlsdr-airband_amd.multigpu")
+    for name in set(re.findall(r"\bmg\.([A-Za-z_]\w*)", src)):
+        assert hasattr(mg, name), "bench.py uses multigpu.%s" % name
+    for name in set(re.findall(r"\bpkg\.([A-Za-z_]\w*)", src)):
+        assert hasattr(pkg, name), "bench.py uses <package>.%s" % name
+    for name in set(re.findall(r"\bhip\.([a-z_]\w*)\(", src)):
+        assert hasattr(pkg.AirbandHip, name), "bench.py calls AirbandHip.%s" % name

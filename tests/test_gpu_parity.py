@@ -722,7 +722,9 @@ def test_ragged_shapes_and_empty_inputs(pkg, built, fmt):
     # hops of an odd number of samples (250 / 250 / 150 bytes at 2-byte alignment): u8 and s8 on the matrix-core path since round 4
     ("SFMT_U8", 9, 2_000_000, 16000), ("SFMT_S8", 10, 2_000_000, 16000), ("SFMT_U8", 8, 1_200_000, 16000), ("SFMT_U8", 11, 2_000_000, 16000),
     # CF32 (SoapySDR) on the float32 matrix pipe since round 4: fft 512 / 256, 2.56 / 2.4 MS/s, both WAVE_RATEs (hops of 160 / 320 / 150 / 300 samples: padded and unpadded rows)
-    ("SFMT_F32", 9, 2_560_000, 8000), ("SFMT_F32", 8, 2_560_000, 16000), ("SFMT_F32", 9, 2_400_000, 16000), ("SFMT_F32", 9, 2_400_000, 8000), ("SFMT_F32", 10, 2_560_000, 16000)])
+    ("SFMT_F32", 9, 2_560_000, 8000), ("SFMT_F32", 8, 2_560_000, 16000), ("SFMT_F32", 9, 2_400_000, 16000), ("SFMT_F32", 9, 2_400_000, 8000), ("SFMT_F32", 10, 2_560_000, 16000),
+    # ... and at fft 1024 / 2048 since round 5 (workgroups of eight waves; 2048: 128 resident B registers per wave; WAVE_RATE 8000: the large-tile variants)
+    ("SFMT_F32", 11, 2_560_000, 16000), ("SFMT_F32", 10, 2_400_000, 8000), ("SFMT_F32", 11, 2_560_000, 8000), ("SFMT_F32", 11, 2_400_000, 16000)])
 def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sample_rate, wave_rate):
     """Sample formats s8/s16/f32, fft sizes 256..8192, sample rates whose hop is not a multiple of 16 bytes: the matrix-core path
     takes u8, s8 and CS16 at every fft size and every hop (window pieces of 512 samples on cooperating waves from 1024 up, two passes at 8192; hops of an
@@ -739,7 +741,7 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
     with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=capi.FLAG_TRACE_SQUELCH) as hip:
         hop_bytes = 2 * hop * capi.BYTES_PER_SAMPLE[sfmt]
         expect_dft = (sfmt in (capi.SFMT_U8, capi.SFMT_S8) and 64 <= hop_bytes <= 1024) or (sfmt == capi.SFMT_S16 and hop_bytes % 4 == 0 and 128 <= hop_bytes <= 1280)
-        expect_f32 = sfmt == capi.SFMT_F32 and fft_log in (8, 9) and hop % 2 == 0   # CF32 on the float32 matrix pipe (channelizer_f32.hip)
+        expect_f32 = sfmt == capi.SFMT_F32 and fft_log in (8, 9, 10, 11) and hop % 2 == 0   # CF32 on the float32 matrix pipe (channelizer_f32.hip; fft 1024 / 2048 since round 5)
         assert hip.channelizer_name() == ("dft_mfma_i8" if expect_dft else "dft_mfma_f32" if expect_f32 else "fft_wave64")
         pos = [0] * n_dev
         for b in range(n_batches):

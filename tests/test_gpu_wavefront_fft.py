@@ -11,8 +11,9 @@ import pyoracle
 CASES = [
     # sfmt, fft_log, sample_rate, wave_rate, force the FFT path
     ("SFMT_U8", 9, 2_000_000, 16000, True),   # (round 4: the matrix-core path takes 250-byte hops too; forced here to keep the FFT path's odd-hop case)
-    ("SFMT_F32", 10, 2_400_000, 8000, False),
-    ("SFMT_F32", 11, 2_560_000, 16000, False),
+    ("SFMT_F32", 10, 2_400_000, 8000, True),    # (round 5: CF32 at fft 1024 / 2048 runs on the float32 matrix pipe; forced here to keep the FFT path's decimated f32 cases)
+    ("SFMT_F32", 11, 2_560_000, 16000, True),
+    ("SFMT_F32", 12, 2_560_000, 16000, False),  # fft 4096 and beyond: still this kernel's
     ("SFMT_U8", 12, 2_560_000, 8000, True),
 ]
 

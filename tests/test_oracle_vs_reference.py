@@ -79,7 +79,8 @@ FORMAT_CASES = [("SFMT_S16", 9, 2_560_000, 16000), ("SFMT_U8", 10, 2_560_000, 80
 # round 4: the configurations the GPU suite newly runs (CF32 on the float32 matrix pipe, hops of an odd number of samples on the int8 one) -- one dongle,
 # four batches each: the arithmetic that differs (convert x window per format, hop, bin) is per hop, not per dongle
 FORMAT_CASES_SHORT = [("SFMT_F32", 9, 2_560_000, 8000), ("SFMT_F32", 8, 2_560_000, 16000), ("SFMT_F32", 9, 2_400_000, 16000), ("SFMT_F32", 9, 2_400_000, 8000),
-                      ("SFMT_F32", 10, 2_560_000, 16000), ("SFMT_S8", 10, 2_000_000, 16000), ("SFMT_U8", 8, 1_200_000, 16000), ("SFMT_U8", 11, 2_000_000, 16000)]
+                      ("SFMT_F32", 10, 2_560_000, 16000), ("SFMT_S8", 10, 2_000_000, 16000), ("SFMT_U8", 8, 1_200_000, 16000), ("SFMT_U8", 11, 2_000_000, 16000),
+                      ("SFMT_F32", 11, 2_560_000, 8000), ("SFMT_F32", 11, 2_400_000, 16000), ("SFMT_F32", 12, 2_560_000, 16000)]  # round 5: the new GPU cases of CF32 at fft 1024 / 2048 / 4096
 
 
 @need_ref
