@@ -51,7 +51,10 @@ def main():
     while time.time() < t_end:
         seed += 1
         devices, iq, fft_log, wave_rate, _, flags = T.random_stage1_case(pkg, seed + 40_000, n_batches=n_batches)
-        if fft_log < 12 or not (devices[0]["sfmt"] == capi.SFMT_F32 or (flags & capi.FLAG_FORCE_FFT)):
+        victim = os.environ.get("R05_VICTIM", "fft_wave64")  # which channelizer the victims run: the exchange kernel (default), or "dft_mfma_i8" / "dft_mfma_f32" as the library picks them
+        if victim != "fft_wave64":
+            flags &= ~capi.FLAG_FORCE_FFT
+        elif fft_log < 12 or not (devices[0]["sfmt"] == capi.SFMT_F32 or (flags & capi.FLAG_FORCE_FFT)):
             if fft_log < 12:
                 continue
             flags |= capi.FLAG_FORCE_FFT  # u8 / s8 / CS16 at fft >= 4096: forced onto the exchange kernel
@@ -61,7 +64,7 @@ def main():
         def run():
             got = []
             with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=flags | capi.FLAG_TRACE_SQUELCH) as hip:
-                if hip.channelizer_name() != "fft_wave64":
+                if hip.channelizer_name() != victim:
                     return None
                 pos = [0] * n_dev
                 started = 0
