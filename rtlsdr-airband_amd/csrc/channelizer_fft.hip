@@ -541,6 +541,16 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
     }
 }
 
+/* threads per workgroup of the exchange kernel: 256 (four wavefronts share a tile's staged samples), or 64 with AIRBAND_HIP_FFT_THREADS=64 in the environment -- ONE wavefront per
+ * workgroup (round 5, profiles/r05_event_hunt.md: the experiment that tells whether the kernel's rare wrong transforms under multi-process GPU sharing need several wavefronts per workgroup) */
+static int fft8_threads() {
+    static const int n = [] {
+        const char* e = getenv("AIRBAND_HIP_FFT_THREADS");
+        return (e && atoi(e) == 64) ? 64 : 256;
+    }();
+    return n;
+}
+
 template <int LOGP, int LOGM, int LOGP_SHUFFLE>
 void launch_one(const ChannelizerArgs& a, hipStream_t stream) {
     const int tiles = (a.n_hops + HOPS_PER_TILE - 1) / HOPS_PER_TILE;
@@ -564,7 +574,7 @@ void launch_one(const ChannelizerArgs& a, hipStream_t stream) {
     ChannelizerArgs b = a;
     if (LOGM > 0) b.last_spectrum = nullptr; /* decimated transforms produce the channels' bins only */
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_fft8_kernel<LOGP, LOGM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((channelizer_fft8_kernel<LOGP, LOGM>), dim3((unsigned)blocks), dim3(256), lds, stream, b);
+    hipLaunchKernelGGL((channelizer_fft8_kernel<LOGP, LOGM>), dim3((unsigned)blocks), dim3(fft8_threads()), lds, stream, b);
     if (LOGM > 0 && a.last_spectrum) { /* ... and AFC's spectrum of the batch's last hop comes from a one-hop, one-wavefront launch of the shuffle kernel */
         ChannelizerArgs c = a;
         c.iq = a.iq + (long)(a.n_hops - 1) * a.hop_samples * 2 * a.bytes_per_sample;

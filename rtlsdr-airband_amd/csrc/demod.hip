@@ -24,6 +24,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -872,7 +873,7 @@ __global__ __launch_bounds__(256) AB_TONE_RESIDENCY void tone_kernel(DemodArgs a
     __shared__ __attribute__((aligned(16))) float xs_all[4][64];
     /* the wave index is the same number on every lane: told so, the compiler keeps the channel's constants and counters in scalar
      * registers and fetches them with scalar loads */
-    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int lane = threadIdx.x & 63;
     if (wave >= n_blocks * 64) return;
     const int slot = first_block * 64 + wave;
@@ -1198,6 +1199,15 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a, int first_block) 
  * config #3.  So the split chain (front -> tone -> back, the longest) goes on the caller's stream and the fused kinds run
  * beside it on side streams, forked and joined with events (works the same under graph capture). */
 
+/* threads per workgroup of the tone kernel (one wavefront per channel either way): 256, or 64 with AIRBAND_HIP_TONE_THREADS=64 (round 5 experiment, profiles/r05_event_hunt.md) */
+static int tone_threads() {
+    static const int n = [] {
+        const char* e = getenv("AIRBAND_HIP_TONE_THREADS");
+        return (e && atoi(e) == 64) ? 64 : 256;
+    }();
+    return n;
+}
+
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev) {
     auto lds_of = [](int k) { /* sincos table, output-line staging, ext_of */
         return (size_t)(k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)RUN * OSTRIDE * sizeof(float) + 2 * 64 * sizeof(int); /* ext_of, skip_of */
@@ -1224,8 +1234,9 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
      * worse -- profiles/r03_experiments.md B, H; the stage is bound by the sum of its work.) */
     launch_kind(AB_KIND_NFM_CTCSS, stream);
     launch_kind(AB_KIND_GENERIC, stream);
-    if (a.ct_pk_n_blocks > 0) hipLaunchKernelGGL(tone_kernel<true>, dim3((a.ct_pk_n_blocks * 64 * 64 + 255) / 256), dim3(256), 0, stream, a, a.ct_pk_first_block, a.ct_pk_n_blocks);
-    if (a.ct_gen_n_blocks > 0) hipLaunchKernelGGL(tone_kernel<false>, dim3((a.ct_gen_n_blocks * 64 * 64 + 255) / 256), dim3(256), 0, stream, a, a.ct_gen_first_block, a.ct_gen_n_blocks);
+    const int tt = tone_threads();
+    if (a.ct_pk_n_blocks > 0) hipLaunchKernelGGL(tone_kernel<true>, dim3((a.ct_pk_n_blocks * 64 * 64 + tt - 1) / tt), dim3(tt), 0, stream, a, a.ct_pk_first_block, a.ct_pk_n_blocks);
+    if (a.ct_gen_n_blocks > 0) hipLaunchKernelGGL(tone_kernel<false>, dim3((a.ct_gen_n_blocks * 64 * 64 + tt - 1) / tt), dim3(tt), 0, stream, a, a.ct_gen_first_block, a.ct_gen_n_blocks);
     if (a.ct_pk_n_blocks > 0) hipLaunchKernelGGL(back_kernel<true>, dim3(a.ct_pk_n_blocks), dim3(64), 0, stream, a, a.ct_pk_first_block);
     if (a.ct_gen_n_blocks > 0) hipLaunchKernelGGL(back_kernel<false>, dim3(a.ct_gen_n_blocks), dim3(64), 0, stream, a, a.ct_gen_first_block);
     /* the fused kinds as forked launches (one kernel per kind keeps each kind's own register budget: the AM kind runs four waves per

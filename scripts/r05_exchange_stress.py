@@ -36,7 +36,8 @@ def main():
     f32 = fmt.startswith("f32")
     fft_log = (13 if fmt == "f32x" else 12) if f32 else 9
     dev = dict(channels=chans, sfmt=pkg.capi.SFMT_F32) if f32 else dict(channels=chans)
-    flags = 0 if f32 else pkg.capi.FLAG_FORCE_FFT
+    main_path = os.environ.get("R05_MAIN_PATH") == "1"  # u8 on the int8 matrix-core channelizer + stage 2: the path bench.py measures
+    flags = 0 if (f32 or main_path) else pkg.capi.FLAG_FORCE_FFT
     small = D <= 16
     t_end = time.time() + seconds
     stats = dict(tag=tag, fmt=fmt, fft_log=fft_log, dongles=D, host_path=host_path, batches=0, hop_transforms=0, events=0, handles=0, lib=os.environ.get("AIRBAND_HIP_LIB", "product"))
@@ -48,7 +49,7 @@ def main():
     while time.time() < t_end:
         hip = pkg.AirbandHip([dev] * D, wave_rate=wave_rate, flags=flags, fft_log=fft_log)
         stats["handles"] += 1
-        assert hip.channelizer_name() == "fft_wave64", hip.channelizer_name()
+        assert hip.channelizer_name() == ("dft_mfma_i8" if (main_path and not f32) else "fft_wave64"), hip.channelizer_name()
         g = hip.geometry
         bpc = 4 if f32 else 1
         lead = g.first_batch_bytes - g.batch_bytes
