@@ -11,6 +11,9 @@
  * error codes with the same meaning (-1 no device, -2 unsupported size, -3 out of memory).
  *
  * What each entry point replaces in the reference is cited next to it.
+ *
+ * Deployment rule: ONE PROCESS PER GPU (any number of handles, streams and threads inside it).  Several processes running this library's launches on one GPU at the same
+ * time have produced wrong results (profiles/r05_event_hunt.md); one process never has.
  */
 #ifndef AIRBAND_HIP_H
 #define AIRBAND_HIP_H

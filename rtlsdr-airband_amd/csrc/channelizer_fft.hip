@@ -50,11 +50,10 @@ namespace {
  * runs as fibers, meet here. */
 #if !defined(AB_WAVE_SYNC)
 /* Round 5: every exchange also WAITS until the wavefront's own LDS operations have completed (s_waitcnt lgkmcnt(0)) before any lane reads what another lane wrote.
- * In-order execution of one wavefront's LDS instructions already orders them; the wait takes the kernel off that assumption.  Why: round 4's fuzz campaign saw about one
- * transform in 10^9 wrong on this kernel while a dozen processes shared the GPU (profiles/r04_experiments.md I).  Round 5 could not make it happen again -- 1.6e10 hop
- * transforms under 6- and 12-process loads with and without the wait, handles of the fuzz's size included, not one difference (profiles/r05_exchange_stress.md) -- so the
- * cause stays unnamed and the wait is insurance, at a measured cost of 0 (u8, fft 512) to 2.3 % (CF32, fft 4096) of this kernel's time (profiles/r05_misc/fft_*.json,
- * f32_4096_*.json).  -DAB_WAVE_SYNC_NO_WAIT builds the kernel without it. */
+ * In-order execution of one wavefront's LDS instructions already orders them; the wait takes the kernel off that assumption, at 0 (u8, fft 512) to 2.3 % (CF32, fft 4096) of
+ * its time (profiles/r05_misc/fft_*.json, f32_4096_*.json).  It is NOT a fix for round 4's rare wrong transforms: round 5 reproduced those at will -- they need a SECOND PROCESS
+ * running this library's long int8 launches on the same GPU, they happen with this wait and with one wavefront per workgroup, they spare the shuffle kernel, and the same kind of
+ * fault then hits the main path's CTCSS chain (profiles/r05_event_hunt.md).  One process per GPU: never seen.  -DAB_WAVE_SYNC_NO_WAIT builds the kernel without the wait. */
 #if defined(AB_WAVE_SYNC_NO_WAIT)
 #define AB_WAVE_SYNC_EXTRA() (void)0
 #else
@@ -542,7 +541,7 @@ __global__ __launch_bounds__(256) void channelizer_fft8_kernel(ChannelizerArgs a
 }
 
 /* threads per workgroup of the exchange kernel: 256 (four wavefronts share a tile's staged samples), or 64 with AIRBAND_HIP_FFT_THREADS=64 in the environment -- ONE wavefront per
- * workgroup (round 5, profiles/r05_event_hunt.md: the experiment that tells whether the kernel's rare wrong transforms under multi-process GPU sharing need several wavefronts per workgroup) */
+ * workgroup (round 5, profiles/r05_event_hunt.md: the kernel's wrong transforms under multi-process GPU sharing do NOT need several wavefronts per workgroup) */
 static int fft8_threads() {
     static const int n = [] {
         const char* e = getenv("AIRBAND_HIP_FFT_THREADS");

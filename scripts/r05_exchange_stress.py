@@ -99,7 +99,8 @@ def main():
                 bad = int(ne.any(dim=2).any(dim=1).sum().item())
                 if bad:
                     idx = ne.nonzero()[:8].cpu().numpy().tolist()
-                    ev = dict(tag=tag, fmt=fmt, handle=stats["handles"], batch=i, what="audio", dongles_differing=bad, first=idx)
+                    chans = sorted(set(ne.any(dim=2).nonzero()[:, 1].cpu().numpy().tolist()))
+                    ev = dict(tag=tag, fmt=fmt, handle=stats["handles"], batch=i, what="audio", dongles_differing=bad, channels=chans, first=idx)
             if bad:
                 stats["events"] += 1
                 events.append(ev)
