@@ -23,6 +23,14 @@ TAG = os.environ.get("AIRBAND_BUILD_TAG") or (hashlib.sha1(" ".join(EXTRA).encod
 OBJ = os.path.join(HERE, "build" + ("_exp_" + TAG if EXTRA else ""))
 LIB = os.path.join(HERE, "libairband_hip" + ("_exp_" + TAG if EXTRA else "") + ".so")
 
+# No packed-f32 vector instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) in any kernel of this library.  Round 5 (profiles/r05_event_hunt.md): while ANOTHER
+# PROCESS runs long launches on the same GPU, a packed-f32 instruction now and then leaves lanes 48 - 63 of its result wrong -- the notch filter of the CTCSS
+# chain's back kernel (28 % of 1 024-dongle handles with four processes on a GPU), the butterflies of the wavefront FFT's exchange kernel (6 - 11 % of the
+# fuzz's runs).  Built without them: 0 of 2 487 handles, 0 of 724 runs on the same loads -- and stage 2 is 0.34 ms FASTER (the compiler's pairing cost more
+# moves than it saved).  The host pass of hipcc prints "not a recognized feature" for the flag and ignores it.  An experiment build gets them back with
+# AIRBAND_EXTRA_DEFINES="-Xclang -target-feature -Xclang +packed-fp32-ops".
+DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+
 HIP_SOURCES = {
     "channelizer_fft.hip": ["-O3"],
     "channelizer_dft.hip": ["-O3"],
@@ -63,7 +71,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
         if force or _newer(src, obj):
             info = ["-DAB_BUILD_DEFINES=\"%s\"" % " ".join(EXTRA)] if name == "airband_hip.cpp" else []
-            cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + flags + EXTRA + info + ["-c", src, "-o", obj]
+            cmd = [hipcc, "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + flags + DEVICE_FLAGS + EXTRA + info + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             _run(cmd)

@@ -279,10 +279,11 @@ __global__ __launch_bounds__(256) void channelizer_fft_kernel(ChannelizerArgs a)
     }
 }
 
-typedef float v2f __attribute__((ext_vector_type(2))); /* (re, im): the compiler turns arithmetic on these into v_pk_*_f32 */
+typedef float v2f __attribute__((ext_vector_type(2))); /* (re, im).  Until round 5 arithmetic on these became v_pk_*_f32; the library is now built WITHOUT packed-f32 instructions
+                                                         (_build.py, DEVICE_FLAGS: beside another process's long launches they leave lanes 48 - 63 wrong now and then), so a pair is two scalar operations */
 
-/* x * w with the twiddle as the pair w = (c, s), wr = i w = (-s, c): (x.re, x.re) * w + (x.im, x.im) * wr -- one packed multiply and one packed FMA
- * (left to itself the compiler spends five instructions on a complex product: it does not negate one half of a packed operand) */
+/* x * w with the twiddle as the pair w = (c, s), wr = i w = (-s, c): (x.re, x.re) * w + (x.im, x.im) * wr -- two multiplies and two FMAs (one packed
+ * multiply and one packed FMA in a build with packed-f32 instructions; left to itself the compiler spends five instructions on a complex product: it does not negate one half of a packed operand) */
 __device__ __forceinline__ v2f cmul(const v2f x, const v2f w, const v2f wr) { return __builtin_elementwise_fma(x.xx, w, x.yy * wr); }
 __device__ __forceinline__ v2f rot_i(const v2f w) { return v2f{-w.y, w.x}; }
 

@@ -337,7 +337,12 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                 AB_LOCKSTEP(); /* every lane has parked its words */
                 if (4 * q < n) {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) {
+                    for (int i0 = 0; i0 < 8; i0++) {
+#if defined(AB_FLUSH_REVERSED) /* experiment builds (profiles/r05_event_hunt.md): the eight cooperative stores of a flush in the opposite order */
+                        const int i = 7 - i0;
+#else
+                        const int i = i0;
+#endif
                         const int c = i * 8 + (lane >> 3);
                         const unsigned* src = handw_base + (4 * q) * OSTRIDE + c;
                         *reinterpret_cast<uint4*>(ct_blockw + (long)c * a.ct_pk_pitch + jstart + 4 * q) = make_uint4(src[0], src[OSTRIDE], src[2 * OSTRIDE], src[3 * OSTRIDE]);

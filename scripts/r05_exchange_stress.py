@@ -38,6 +38,9 @@ def main():
     dev = dict(channels=chans, sfmt=pkg.capi.SFMT_F32) if f32 else dict(channels=chans)
     main_path = os.environ.get("R05_MAIN_PATH") == "1"  # u8 on the int8 matrix-core channelizer + stage 2: the path bench.py measures
     flags = 0 if (f32 or main_path) else pkg.capi.FLAG_FORCE_FFT
+    diagnose = os.environ.get("R05_TRACE") == "1"  # per-sample squelch / tone trace: on an event, which of the chain's kernels went wrong first
+    if diagnose:
+        flags |= pkg.capi.FLAG_TRACE_SQUELCH
     small = D <= 16
     t_end = time.time() + seconds
     stats = dict(tag=tag, fmt=fmt, fft_log=fft_log, dongles=D, host_path=host_path, batches=0, hop_transforms=0, events=0, handles=0, lib=os.environ.get("AIRBAND_HIP_LIB", "product"))
@@ -101,6 +104,20 @@ def main():
                     idx = ne.nonzero()[:8].cpu().numpy().tolist()
                     chans = sorted(set(ne.any(dim=2).nonzero()[:, 1].cpu().numpy().tolist()))
                     ev = dict(tag=tag, fmt=fmt, handle=stats["handles"], batch=i, what="audio", dongles_differing=bad, channels=chans, first=idx)
+                    if diagnose:  # trace byte: squelch state (bits 0-2) | open 8 | audio 16 | tone present 32
+                        d, c, j = idx[0]
+                        tr = hip.read_trace().reshape(D, 8, B)
+                        dt = np.flatnonzero(tr[d, c] != tr[0, c])
+                        jt = int(dt[0]) if len(dt) else -1
+                        ev["trace_first"] = jt
+                        ev["trace_n"] = int(len(dt))
+                        if jt >= 0:
+                            ev["trace_bits"] = [int(tr[0, c, jt]), int(tr[d, c, jt])]
+                            ev["trace_xor_all"] = int(np.bitwise_or.reduce(tr[d, c] ^ tr[0, c]))
+                        lo = max(0, j - 2)
+                        ev["audio_good"] = wave[0, c, lo:lo + 8].view(torch.float32).cpu().numpy().tolist()
+                        ev["audio_bad"] = wave[d, c, lo:lo + 8].view(torch.float32).cpu().numpy().tolist()
+                        ev["lanes"] = sorted(set((ne[:, c].any(dim=1).nonzero()[:, 0] % 32).cpu().numpy().tolist()))
             if bad:
                 stats["events"] += 1
                 events.append(ev)
