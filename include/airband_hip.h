@@ -12,8 +12,9 @@
  *
  * What each entry point replaces in the reference is cited next to it.
  *
- * Deployment rule: ONE PROCESS PER GPU (any number of handles, streams and threads inside it).  Several processes running this library's launches on one GPU at the same
- * time have produced wrong results (profiles/r05_event_hunt.md); one process never has.
+ * Deployment: one process per GPU (any number of handles, streams and threads inside it) is how the library is meant to run.  Until round 5 several processes running its
+ * launches on ONE GPU at the same time produced wrong results now and then; what failed were packed-f32 vector instructions, and the library is built without them since
+ * (profiles/r05_event_hunt.md).  No wrong value is known of the present build in either arrangement.
  */
 #ifndef AIRBAND_HIP_H
 #define AIRBAND_HIP_H
