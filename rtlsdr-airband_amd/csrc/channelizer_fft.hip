@@ -53,7 +53,8 @@ namespace {
  * In-order execution of one wavefront's LDS instructions already orders them; the wait takes the kernel off that assumption, at 0 (u8, fft 512) to 2.3 % (CF32, fft 4096) of
  * its time (profiles/r05_misc/fft_*.json, f32_4096_*.json).  It is NOT a fix for round 4's rare wrong transforms: round 5 reproduced those at will -- they need a SECOND PROCESS
  * running this library's long int8 launches on the same GPU, they happen with this wait and with one wavefront per workgroup, they spare the shuffle kernel, and the same kind of
- * fault then hits the main path's CTCSS chain (profiles/r05_event_hunt.md).  One process per GPU: never seen.  -DAB_WAVE_SYNC_NO_WAIT builds the kernel without the wait. */
+ * fault then hits the main path's CTCSS chain (profiles/r05_event_hunt.md).  One process per GPU: never seen.  What failed turned out to be packed-f32 instructions (lanes 48 - 63 of a
+ * result); the library is built without them (_build.py, DEVICE_FLAGS) and the events are gone.  -DAB_WAVE_SYNC_NO_WAIT builds the kernel without the wait. */
 #if defined(AB_WAVE_SYNC_NO_WAIT)
 #define AB_WAVE_SYNC_EXTRA() (void)0
 #else

@@ -14,7 +14,11 @@ def main():
     key = sys.argv[1]
     extra = sys.argv[2:]
     out = os.path.join(tempfile.gettempdir(), "demod_prof.s")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    import importlib.util  # the product's own flags (rtlsdr-airband_amd/_build.py: optimisation level, contraction, no packed-f32 instructions)
+    spec = importlib.util.spec_from_file_location("airband_build_flags", os.path.join(ROOT, "rtlsdr-airband_amd", "_build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17"] + list(b.HIP_SOURCES["demod.hip"]) + list(b.DEVICE_FLAGS) + [
            "-gline-tables-only", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out, SRC] + extra
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
