@@ -52,6 +52,9 @@ def main():
     md = ["# Round %s measurements (1x MI355X; `scripts/profile_round.sh` on one gpurun box, committed build)\n" % R[1:].lstrip("0")]
     host = open(os.path.join(SRC, "host.txt")).read().split("\n") if os.path.exists(os.path.join(SRC, "host.txt")) else ["?", "?"]
     md.append("Host of the GPU box: %s hardware threads, %s.\n" % (host[0], host[1].split(":")[-1].strip() if len(host) > 1 else "?"))
+    preface = os.path.join(DST, R + "_summary_preface.md")  # hand-written: which commit / build the run is of
+    if os.path.exists(preface):
+        md.append(open(preface).read().rstrip("\n") + "\n")
     md.append("## bench.py lines\n")
     md.append("| file | workload | Msamples/s | ms/step | channelizer ms | stage 2 ms | bound | frac | read-only frac (8 TB/s) | end-to-end frac | verified | extra |")
     md.append("|---|---|---|---|---|---|---|---|---|---|---|---|")
