@@ -1,0 +1,16 @@
+"""DESIGN.md section 5's table is PRINTED from the tracked bench lines (scripts/design_table.py reads profiles/r05_bench_*.json): a figure quoted there that no longer matches its
+file -- a profile run filed without the table being regenerated, a hand-edited number -- fails here."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_design_section_5_is_the_table_the_tracked_bench_lines_print():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "design_table.py"), "r05"], check=True, stdout=subprocess.PIPE, text=True, cwd=ROOT).stdout
+    rows = [l for l in out.split("\n") if l.startswith("| ")]
+    assert len(rows) >= 20
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    missing = [r[:120] for r in rows if r not in design]
+    assert not missing, missing
