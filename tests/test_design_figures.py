@@ -14,3 +14,15 @@ def test_design_section_5_is_the_table_the_tracked_bench_lines_print():
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     missing = [r[:120] for r in rows if r not in design]
     assert not missing, missing
+
+
+def test_at_a_glance_quotes_the_tracked_headline_line():
+    import json
+
+    j = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_cfg3.json")))
+    head = open(os.path.join(ROOT, "DESIGN.md")).read().split("## 1. The path and its boundary")[0]
+    ms, value = j["ms_per_step"], j["value"]
+    assert "%.2f ms" % ms in head
+    assert "{:,}".format(int(round(value, -2))).replace(",", " ") in head  # Msamples/s, rounded to hundreds, thin-space grouped
+    assert "**%.3f**" % j["roofline"]["frac"] in head and "**%.3f**" % j["roofline"]["frac_read_only"] in head
+    assert "**%.2f ms**" % j["stage_ms"]["demod"] in head
