@@ -338,9 +338,11 @@ class AirbandHip:
         rc = L.airband_hip_comm_group_begin()
         if rc < 0:
             raise AirbandError(rc, (L.airband_hip_last_error(None) or b"").decode())
-        for h in handles:
-            h.allreduce_mixers()
-        rc = L.airband_hip_comm_group_end()
+        try:
+            for h in handles:
+                h.allreduce_mixers()
+        finally:  # a failing rank must not leave the thread's RCCL group open: every later collective of the process would queue behind it
+            rc = L.airband_hip_comm_group_end()
         if rc < 0:
             raise AirbandError(rc, (L.airband_hip_last_error(None) or b"").decode())
 

@@ -58,6 +58,60 @@ def _run(cmd):
     return r.stdout
 
 
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+FORBIDDEN = r"^\s+v_pk_(mul|fma|add)_f32"
+
+
+def device_disassembly(lib: str):
+    """[(kernel symbols, disassembly text)] per translation unit of a BUILT library: every gfx950 code object of its .hip_fatbin section, taken out with
+    llvm-objcopy / clang-offload-bundler and disassembled with llvm-objdump -- the linked product, not a recompilation of the sources."""
+    import re
+    import shutil
+    import tempfile
+
+    def tool(name):
+        t = os.path.join(LLVM_BIN, name)
+        t = t if os.path.exists(t) else shutil.which(name)
+        if not t:
+            raise RuntimeError("the packed-f32 guard needs " + name + " (ROCm's llvm/bin)")
+        return t
+
+    units = []
+    with tempfile.TemporaryDirectory(prefix="airband_fatbin_") as d:
+        fat = os.path.join(d, "fat.bin")
+        _run([tool("llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib, os.devnull])
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        if not starts:
+            raise RuntimeError("no offload bundle in .hip_fatbin of " + lib)
+        for n, (a, b) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+            piece, co = os.path.join(d, "bundle%d.bin" % n), os.path.join(d, "unit%d.co" % n)
+            open(piece, "wb").write(blob[a:b])
+            _run([tool("clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--" + ARCH, "--input=" + piece, "--output=" + co])
+            text = _run([tool("llvm-objdump"), "-d", co])
+            units.append((re.findall(r"^[0-9a-f]+ <(\w+)>:", text, re.M), text))
+    return units
+
+
+def check_no_packed_f32(lib: str) -> int:
+    """THE BUILD'S OWN GATE (round 6; profiles/r05_event_hunt.md): a library whose device code holds a packed-f32 vector instruction is not handed out.  DEVICE_FLAGS
+    asks the compiler not to emit them; this looks at what it did -- a different compiler, a flag that stops meaning what it meant, hand-written asm: the build fails
+    instead of shipping code whose lanes 48 - 63 can go wrong beside another process.  Returns the number of instructions looked at."""
+    import re
+
+    n = 0
+    for kernels, text in device_disassembly(lib):
+        for line in text.split("\n"):
+            if re.match(r"^\s+[sv]_\w+|^\s+(ds|global|buffer|flat|scratch)_\w+", line):
+                n += 1
+                if re.match(FORBIDDEN, line):
+                    raise RuntimeError("packed-f32 instruction in the device code of %s (kernels of the unit: %s ...): %s" % (lib, ", ".join(kernels[:3]), line.strip()))
+    if n < 100000 and not EXTRA:  # the product library is ~4e5 instructions: an empty disassembly must not pass as clean
+        raise RuntimeError("packed-f32 guard: only %d device instructions found in %s" % (n, lib))
+    return n
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -90,7 +144,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,--no-undefined"]
         if verbose:
             print(" ".join(cmd))
+        tmp = LIB + ".unchecked"
+        cmd[cmd.index("-o") + 1] = tmp
         _run(cmd)
+        # experiment builds that ask for the instructions back (AIRBAND_EXTRA_DEFINES="... +packed-fp32-ops", the A/B partner of profiles/r05_event_hunt.md) are the one exception
+        if not any("+packed-fp32-ops" in e for e in EXTRA):
+            try:
+                check_no_packed_f32(tmp)
+            except Exception:
+                os.unlink(tmp)
+                raise
+        os.replace(tmp, LIB)
     return LIB
 
 

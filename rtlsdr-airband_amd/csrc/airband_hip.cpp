@@ -27,6 +27,11 @@
 #define AB_PRIVATE_TABLE_BUDGET ((size_t)8 << 30)
 #endif
 
+/* upper bound for the float coefficient tables (CF32 dongles on the float32 matrix pipe) of a handle, host-built: 512 MiB = 8 192 distinct channel plans at fft 512 */
+#ifndef AB_F32_TABLE_BUDGET
+#define AB_F32_TABLE_BUDGET ((size_t)512 << 20)
+#endif
+
 using namespace airband;
 
 namespace {
@@ -703,8 +708,12 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     h->use_f32 = !h->use_dft && !(h->flags & AIRBAND_HIP_FLAG_FORCE_FFT) && !any_afc && f32_supported(p.fft_size, p.dev[0].hop_samples, p.dev[0].sfmt);
     if (h->use_f32) {
         build_dft_tables(h->plan, false); /* the work items and the shared bin sets (its int8 tables are not used) */
-        if (p.n_shared_bsets > 1024) {
-            h->use_f32 = false; /* 64 KiB per table: that many would not stay cache resident */
+        /* bytes, not a count: a float table is f32_nw x (2 N / 4 / f32_nw) x 64 lanes x 4 bytes = 128 N bytes -- 64 KiB at fft 512, 256 KiB at 2048.  The tables are built
+         * on the host (params.cpp, build_f32_tables) and read once per work item per launch: past a budget the handle runs on the wavefront FFT rather than on a
+         * gigabyte-sized host build */
+        const size_t ftab_bytes = (size_t)p.n_shared_bsets * 128u * (size_t)p.fft_size;
+        if (ftab_bytes > AB_F32_TABLE_BUDGET) {
+            h->use_f32 = false;
         } else {
             build_f32_tables(h->plan);
             PREP_TRY(upload(h->d_item_dev, p.item_dev), AIRBAND_HIP_ENOMEM);
@@ -879,6 +888,9 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
     const Plan& p = h->plan;
     const bool first = h->front_batches == 0;
     hipEvent_t* ev = event_set(h, h->front_batches, 0);
+    /* hipGetLastError() is sticky: whatever an earlier, unchecked call of this thread left behind (ours or the host application's) is not this launch's error */
+    (void)hipGetLastError();
+    hipError_t launch_err = hipSuccess;
     if (h->use_f32) {
         F32Args a;
         a.iq = (const uint8_t*)d_iq;
@@ -913,6 +925,7 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         h->afc_spectrum_valid = false;
         (void)hipEventRecord(ev[0], s);
         launch_channelizer_f32(a, s);
+        launch_err = hipGetLastError(); /* right behind the launch: the event record below would mask it (or be blamed for it) */
         (void)hipEventRecord(ev[1], s);
     } else if (h->use_dft) {
         DftArgs a;
@@ -970,6 +983,7 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         }
         (void)hipEventRecord(ev[0], s);
         launch_channelizer_dft(a, s);
+        launch_err = hipGetLastError();
         (void)hipEventRecord(ev[1], s);
     } else {
         ChannelizerArgs ca;
@@ -1000,12 +1014,11 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         (void)hipEventRecord(ev[0], s);
         h->afc_spectrum_valid = h->any_afc;
         launch_channelizer_fft(ca, s);
+        launch_err = hipGetLastError();
         (void)hipEventRecord(ev[1], s);
     }
-    {   /* a refused launch (an LDS opt-in that failed, a bad grid) is this call's error, not a puzzle for whoever synchronises next */
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(h, AIRBAND_HIP_ERUNTIME, std::string("channelizer launch: ") + hipGetErrorString(e));
-    }
+    /* a refused launch (an LDS opt-in that failed, a bad grid) is this call's error, not a puzzle for whoever synchronises next */
+    if (launch_err != hipSuccess) return fail(h, AIRBAND_HIP_ERUNTIME, std::string("channelizer launch: ") + hipGetErrorString(launch_err));
     h->row0_front = (h->row0_front + h->B) % h->R;
     h->front_batches++;
     return AIRBAND_HIP_OK;
@@ -1428,7 +1441,8 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    bool named = false; /* loaded from AIRBAND_HIP_RCCL_LIB */
+    bool named = false;         /* loaded from AIRBAND_HIP_RCCL_LIB */
+    bool shared_gpu_ok = false; /* the library says (exported symbol airband_rccl_allows_shared_gpu) that two ranks of a communicator may sit on ONE GPU: the test stand-in does, RCCL does not */
     std::string why;
 };
 Rccl g_rccl;
@@ -1442,7 +1456,8 @@ Rccl* rccl() {
     void* dl = nullptr;
     std::string tried;
     /* AIRBAND_HIP_RCCL_LIB names the library instead (a site's own RCCL build; the in-process stand-in tests/fake_rccl/ the GPU suite uses to run
-     * the exchange with two ranks on a one-GPU box).  A library named this way also decides by itself whether two ranks may share a GPU. */
+     * the exchange with two ranks on a one-GPU box).  Whether two ranks of a communicator may share a GPU is a capability the library exports
+     * (airband_rccl_allows_shared_gpu, below): the stand-in has it, RCCL does not. */
     const char* named = getenv("AIRBAND_HIP_RCCL_LIB");
     if (named && *named) {
         dl = dlopen(named, RTLD_NOW | RTLD_GLOBAL);
@@ -1474,6 +1489,12 @@ Rccl* rccl() {
     AB_RCCL_SYM(AllReduce, "ncclAllReduce") AB_RCCL_SYM(CommDestroy, "ncclCommDestroy") AB_RCCL_SYM(GroupStart, "ncclGroupStart")
     AB_RCCL_SYM(GroupEnd, "ncclGroupEnd") AB_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef AB_RCCL_SYM
+    {   /* a capability the library declares itself, not something inferred from how it was named: a site's own RCCL build named through AIRBAND_HIP_RCCL_LIB
+         * keeps the duplicate-GPU check of comm_init_all */
+        typedef int (*cap_fn)(void);
+        cap_fn cap = reinterpret_cast<cap_fn>(dlsym(dl, "airband_rccl_allows_shared_gpu"));
+        g_rccl.shared_gpu_ok = cap && cap() != 0;
+    }
     g_rccl.dl = dl;
     return &g_rccl;
 }
@@ -1530,7 +1551,7 @@ int airband_hip_comm_init_all(airband_hip_handle** hs, int32_t n) {
     }
     Rccl* R = rccl();
     if (!R) return fail(hs[0], AIRBAND_HIP_ENODEV, g_rccl.why);
-    if (!R->named) /* RCCL proper refuses a communicator with one GPU twice, late and with a generic message */
+    if (!R->shared_gpu_ok) /* RCCL proper refuses a communicator with one GPU twice, late and with a generic message */
         for (int i = 0; i < n; i++)
             for (int k = 0; k < i; k++)
                 if (devs[k] == devs[i]) return fail(hs[i], AIRBAND_HIP_EINVAL, "two handles of the clique share a GPU: use airband_hip_add_mixers between them");
@@ -1613,6 +1634,11 @@ int airband_hip_clear_mixers(airband_hip_handle* h) {
     HIP_TRY(h, hipMemsetAsync(h->d_mix_left.p, 0, n * sizeof(float), s), AIRBAND_HIP_ERUNTIME);
     HIP_TRY(h, hipMemsetAsync(h->d_mix_right.p, 0, n * sizeof(float), s), AIRBAND_HIP_ERUNTIME);
     HIP_TRY(h, hipMemsetAsync(h->d_mix_signal.p, 0, (size_t)h->n_mixers, s), AIRBAND_HIP_ERUNTIME);
+    if (s != h->stream) { /* a caller's stream (the last batch ran there): collect_mixers, or a later batch on another stream, comes behind the clear -- as behind allreduce_mixers */
+        if (!h->ev_last) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
+        HIP_TRY(h, hipEventRecord(h->ev_last, s), AIRBAND_HIP_ERUNTIME);
+        h->ev_last_pending = true;
+    }
     return AIRBAND_HIP_OK;
 }
 

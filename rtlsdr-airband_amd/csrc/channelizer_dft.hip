@@ -256,12 +256,31 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
      * the batch span re-read its last 16 bytes: they only feed hops >= n_hops, which are never stored. */
     typedef __attribute__((address_space(1))) const void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    /* Cache policy of the transfers (the instruction's aux field; 2 = nt, non-temporal).  A staging step's FIRST piece holds the window overlap the previous step
+     * fetched (its last piece: the same 1 KiB at hops of 320 bytes) and its LAST piece is what the next step fetches again -- those two are re-read from L2 and keep
+     * the default policy; the pieces in between are read exactly once by exactly one CU, which is what MI355X_MICROARCH.md's "nt-weights" / "ldsdma-fill" rows
+     * measure nt on (6.4 -> 6.5 - 6.8 TB/s chip-wide, issued -> landed -18 %).  Round 6 A/B: profiles/r06_experiments.md A. */
+#ifndef AB_DMA_NT_AUX
+#define AB_DMA_NT_AUX 0 /* interior (read-once) pieces of the hop-specialised variants */
+#endif
+#ifndef AB_DMA_EDGE_AUX
+#define AB_DMA_EDGE_AUX 0 /* first and last piece of a step (the L2-hit overlap), and every piece of the run-time-hop variants */
+#endif
 #if defined(AB_ABL_NO_DMA)
-#define AB_DMA(G, L, OFF) asm volatile("" ::"v"(G), "v"(L))
+#define AB_DMA(G, L, OFF, AUX) asm volatile("" ::"v"(G), "v"(L))
 #else
-#define AB_DMA(G, L, OFF) __builtin_amdgcn_global_load_lds((G), (L), 16, (OFF), 0)
+#define AB_DMA(G, L, OFF, AUX) __builtin_amdgcn_global_load_lds((G), (L), 16, (OFF), (AUX))
 #endif
     const int n_dma = (buf_bytes + 1023) >> 10;
+    /* the same number as a constant where the hop is one (pieces per step of the hop-specialised variants: 6 at 320 bytes, 11 at 640) */
+    constexpr int N_DMA_C = HOPB ? ((TILE_HOPS * c_sub(HOPB ? HOPB : 64) - 1) * (HOPB ? HOPB : 64) + WIN_ALL + 1023) >> 10 : 0;
+#ifndef AB_DMA_FIRST_AUX
+#define AB_DMA_FIRST_AUX AB_DMA_EDGE_AUX /* a step's first piece: the LAST use of the overlap bytes */
+#endif
+#ifndef AB_DMA_LAST_AUX
+#define AB_DMA_LAST_AUX AB_DMA_EDGE_AUX /* a step's last piece: the FIRST use of the bytes the next step reads again */
+#endif
+#define AB_PIECE_AUX(K) (!HOPB ? AB_DMA_EDGE_AUX : (K) == 0 ? AB_DMA_FIRST_AUX : (K) + 1 >= N_DMA_C ? AB_DMA_LAST_AUX : AB_DMA_NT_AUX)
     auto stage = [&](int step, uint8_t* buf) {
         const long base = ((long)step * step_hops - shift) * hop_bytes + mis;
         if (HOPB && base >= 0 && base + (long)n_dma * 1024 <= span_end) {
@@ -270,7 +289,7 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
              * the LDS destination alike.  The offset field holds 12 bits: a second base covers the pieces past 4 KiB. */
             const uint8_t* p = src + base + lane * 16;
 #define AB_PIECE(K, BASE, OFF) \
-    if (n_dma > (K)) AB_DMA((gptr_t)(p + (BASE)), (lptr_t)(uintptr_t)(buf + (BASE)), (OFF))
+    if (n_dma > (K)) AB_DMA((gptr_t)(p + (BASE)), (lptr_t)(uintptr_t)(buf + (BASE)), (OFF), AB_PIECE_AUX(K))
             AB_PIECE(0, 0, 0); AB_PIECE(1, 0, 1024); AB_PIECE(2, 0, 2048); AB_PIECE(3, 0, 3072);
             AB_PIECE(4, 4096, 0); AB_PIECE(5, 4096, 1024); AB_PIECE(6, 4096, 2048); AB_PIECE(7, 4096, 3072);
             AB_PIECE(8, 8192, 0); AB_PIECE(9, 8192, 1024); AB_PIECE(10, 8192, 2048); AB_PIECE(11, 8192, 3072);
@@ -282,7 +301,7 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
             long so = base_al + i * 1024 + lane * 16;
             if (so + 16 > span_end) so = span_end - 16;
             if (so < 0) so = 0;
-            AB_DMA((gptr_t)(src + so), (lptr_t)(uintptr_t)(buf + i * 1024), 0);
+            AB_DMA((gptr_t)(src + so), (lptr_t)(uintptr_t)(buf + i * 1024), 0, AB_DMA_EDGE_AUX);
         }
     };
     /* staging ring of nbuf buffers: step st lives in buffer (st - st_begin) % nbuf; nbuf - 1 steps are in flight */
@@ -492,7 +511,7 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
             if (step >= st_in_lo && step <= st_in_hi) {
                 const uint8_t* p = p_lane + (unsigned long long)(unsigned)step * (unsigned)step_bytes;
 #define AB_PIECE(K, BASE, OFF) \
-    if (n_dma > (K)) AB_DMA((gptr_t)(p + (BASE)), (lptr_t)(uintptr_t)(buf + (BASE)), (OFF))
+    if (n_dma > (K)) AB_DMA((gptr_t)(p + (BASE)), (lptr_t)(uintptr_t)(buf + (BASE)), (OFF), AB_PIECE_AUX(K))
                 AB_PIECE(0, 0, 0); AB_PIECE(1, 0, 1024); AB_PIECE(2, 0, 2048); AB_PIECE(3, 0, 3072);
                 AB_PIECE(4, 4096, 0); AB_PIECE(5, 4096, 1024); AB_PIECE(6, 4096, 2048); AB_PIECE(7, 4096, 3072);
                 AB_PIECE(8, 8192, 0); AB_PIECE(9, 8192, 1024); AB_PIECE(10, 8192, 2048); AB_PIECE(11, 8192, 3072);

@@ -51,8 +51,23 @@ namespace {
 /* The 64 lanes of a wavefront execute in lockstep, and LDS operations of one wavefront complete in order: where lanes exchange data through LDS
  * WITHOUT a barrier (the cooperative row stores, the tone kernel's power sum) the code relies on that.  AB_LOCKSTEP() marks those places; it is
  * nothing on the GPU.  tests/hostshim_wave64 runs the lanes as fibers and makes them meet there. */
+/* AB_LOCKSTEP_FENCED(): the same rendezvous with the COMPILER's order pinned as well -- a wavefront-scope fence and a wave barrier, no instruction in the ISA -- where a
+ * value parked in LDS by one lane is read back by OTHER lanes (the tone kernel's broadcasts): without it the order of the park and the reads rests on the compiler's
+ * may-alias analysis alone (round-5 ADVICE; channelizer_fft.hip's AB_WAVE_SYNC pins its exchanges the same way). */
 #if !defined(AB_LOCKSTEP)
 #define AB_LOCKSTEP() ((void)0)
+#if defined(__HIPCC__)
+#define AB_LOCKSTEP_FENCED()                                     \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
+#else
+#define AB_LOCKSTEP_FENCED() ((void)0)
+#endif
+#elif !defined(AB_LOCKSTEP_FENCED)
+#define AB_LOCKSTEP_FENCED() AB_LOCKSTEP()
 #endif
 /* the kernel's dynamic LDS array */
 #if !defined(AB_DYNAMIC_LDS)
@@ -964,11 +979,11 @@ __global__ __launch_bounds__(256) AB_TONE_RESIDENCY void tone_kernel(DemodArgs a
                 count0 += TONE_GROUP;
             }
 #else
-            AB_LOCKSTEP(); /* (the previous step's broadcasts have been read: a wavefront's LDS operations complete in order) */
+            AB_LOCKSTEP_FENCED(); /* (the previous step's broadcasts have been read: a wavefront's LDS operations complete in order) */
             xs[lane] = ax;  /* lanes past the 50th park zeros that nobody reads */
-            AB_LOCKSTEP();
+            AB_LOCKSTEP_FENCED(); /* the park is ordered before every lane's reads, for the compiler too */
             static_assert(TONE_GROUP % 4 == 2 && TONE_GROUP + 2 <= 64, "twelve quads and one pair; the last quad read covers two parked zeros");
-            /* one quad ahead (the next broadcast flies under this quad's twelve dependent operations); unrolled by three only: all thirteen reads at once
+            /* one quad ahead (the next broadcast flies under this quad's twelve dependent operations); unrolled by two only (#pragma unroll 2 below): all thirteen reads at once
              * cost 45 more registers and half the kernel's residency, which is what hides the recurrence's dependent-issue latency */
             const float4* xs4 = reinterpret_cast<const float4*>(xs);
             float4 v = xs4[0];

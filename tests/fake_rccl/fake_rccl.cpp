@@ -276,6 +276,10 @@ ncclResult_t flush() {
 
 extern "C" {
 
+/* capability libairband_hip.so looks for (csrc/airband_hip.cpp, rccl()): ranks of one communicator may share a GPU here -- the duplicate-GPU check of
+ * airband_hip_comm_init_all, which protects callers from RCCL's late and generic refusal, is skipped for this library only */
+int airband_rccl_allows_shared_gpu(void) { return 1; }
+
 ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
     if (!id) return ncclInvalidArgument;
     memset(id, 0, sizeof(*id));
