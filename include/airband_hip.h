@@ -70,6 +70,13 @@ extern "C" {
                                                last.  Same values, bit for bit, as the sequential mode.       \
                                                Ignored when a channel has AFC (stage 1 of the next batch needs \
                                                stage 2's verdict, src/rtl_airband.cpp:222-251).               */
+#define AIRBAND_HIP_FLAG_REGROUP 0x20u      /* stage 2 re-sorts its channels at every batch boundary so that   \
+                                               channels whose squelch is closed share wavefronts (csrc/demod.hip,\
+                                               "regrouping"): same values, bit for bit; what changes is which   \
+                                               64 channels a wavefront works on.  Pays on a band whose channels \
+                                               are mostly quiet; costs ring-line fetches where neighbouring     \
+                                               channels differ in state.  AIRBAND_HIP_REGROUP=0|1 in the         \
+                                               environment overrides the flag either way (A/B measurements).    */
 
 /* Per-channel configuration: the values a multichannel-mode `channels` entry carries after
  * parse_channels() (reference: src/config.cpp:306-726).  The library derives bin index, derotation
@@ -368,12 +375,20 @@ int airband_hip_timing_totals(airband_hip_handle* h, double* ms4_sum, int64_t* n
  * different file name and say here what they changed, so that a measurement can always be traced to the code that produced it). */
 const char* airband_hip_build_info(void);
 
+/* 1 if stage 2 of this handle re-sorts its channels at batch boundaries (AIRBAND_HIP_FLAG_REGROUP or AIRBAND_HIP_REGROUP=1 in the environment), else 0. */
+int airband_hip_regrouped(const airband_hip_handle* h);
+
 /* Name of the channelizer variant the handle selected ("fft_wave64" / "dft_mfma_i8"). */
 const char* airband_hip_channelizer_name(const airband_hip_handle* h);
 
 /* Uploads the transmitter table of the synthetic dongles: carriers [n_carriers][12] int64 rows
  * (rtlsdr-airband_amd/siggen.py::Carrier.as_row), the Q8 noise multiplier and the 4096-entry int16 sine table. */
 int airband_hip_set_signal_plan(airband_hip_handle* h, const int64_t* carriers, int32_t n_carriers, int32_t noise_q8, const int16_t* sin_table4096);
+
+/* Synthetic fleets whose dongles do NOT share a channel plan (every device_t derives its own bins, src/config.cpp:666-667): dongle d (global index, see
+ * device_index_offset below) belongs to plan p = d mod n_plans, and its carrier c is generated ((p >> 2c) & 3) * shift_step (u32 turns per sample) above the
+ * table's frequency -- up to 4^8 = 65 536 distinct plans of eight carriers.  The caller configures the channels' frequencies to match.  n_plans = 1 (default): off. */
+int airband_hip_set_signal_plan_shift(airband_hip_handle* h, int32_t n_plans, uint32_t shift_step);
 
 /* Deterministic synthetic dongles, generated on the GPU straight into HBM (integer-only arithmetic so
  * the numpy generator in the tests produces identical bytes).  Fills, for every device d in

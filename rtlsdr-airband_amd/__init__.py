@@ -31,7 +31,7 @@ EXPORTS = [
     "airband_hip_flush", "airband_hip_timing_totals", "airband_hip_stream_wait_results", "airband_hip_mixer_enable_input",
     "airband_hip_device_enable", "airband_hip_gpu_count", "airband_hip_build_info", "airband_hip_dft_selftest", "airband_hip_collect_channels", "airband_hip_read_bins_channels", "airband_hip_read_trace_channels",
     "airband_hip_batch_ready", "airband_hip_mixer_set_stereo", "airband_hip_comm_unique_id", "airband_hip_comm_init_rank", "airband_hip_comm_init_all",
-    "airband_hip_comm_group_begin", "airband_hip_comm_group_end", "airband_hip_allreduce_mixers", "airband_hip_add_mixers", "airband_hip_comm_destroy", "airband_hip_clear_mixers",
+    "airband_hip_comm_group_begin", "airband_hip_comm_group_end", "airband_hip_allreduce_mixers", "airband_hip_add_mixers", "airband_hip_comm_destroy", "airband_hip_clear_mixers", "airband_hip_set_signal_plan_shift", "airband_hip_regrouped",
 ]
 
 _lib = None
@@ -106,6 +106,8 @@ def load_library() -> C.CDLL:
     L.airband_hip_channelizer_name.restype = C.c_char_p
     L.airband_hip_set_signal_plan.argtypes = [vp, vp, i32, i32, vp]
     L.airband_hip_generate_iq.argtypes = [vp, vp, sz, u64, sz, u64, i32, vp]
+    L.airband_hip_set_signal_plan_shift.argtypes = [vp, i32, C.c_uint32]
+    L.airband_hip_regrouped.argtypes = [vp]
     L.airband_hip_dft_selftest.argtypes = [C.POINTER(capi.Config), i32, C.POINTER(C.c_double)]
     L.airband_hip_build_info.argtypes = []
     L.airband_hip_build_info.restype = C.c_char_p
@@ -377,6 +379,13 @@ class AirbandHip:
         if noise_q8 is None:
             noise_q8 = siggen.noise_mul_q8()
         self._check(self.L.airband_hip_set_signal_plan(self.h, tab.ctypes.data, len(carriers), int(noise_q8), sin.ctypes.data))
+
+    def stage2_regrouped(self) -> bool:
+        return bool(self.L.airband_hip_regrouped(self.h))
+
+    def set_signal_plan_shift(self, n_plans: int, shift_hz: float, sample_rate: int):
+        """Dongle d's carrier c is generated ((d mod n_plans) >> 2c & 3) * shift_hz above the plan's frequency (siggen.plan_shift_bins / generate_u8's twin)."""
+        self._check(self.L.airband_hip_set_signal_plan_shift(self.h, int(n_plans), siggen._turns(shift_hz, sample_rate)))
 
     def generate_iq(self, d_iq_ptr: int, stride_bytes: int, start_byte: int, nbytes: int, *, seed: int = 0x5EED, device_index_offset: int = 0, stream: int = 0):
         self._check(self.L.airband_hip_generate_iq(self.h, C.c_void_p(d_iq_ptr), stride_bytes, start_byte, nbytes, seed, device_index_offset, C.c_void_p(stream)))

@@ -11,6 +11,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -22,7 +23,8 @@
 #include "kernels.h"
 #include "params.h"
 
-/* upper bound for the private (per AFC group) coefficient tables of a handle; past it prepare() picks the wavefront-FFT channelizer (override for tests) */
+/* upper bound for the int8 coefficient tables of a handle -- one per distinct group of eight bins plus one per AFC group; past it prepare() picks the wavefront-FFT
+ * channelizer (override for tests) */
 #ifndef AB_PRIVATE_TABLE_BUDGET
 #define AB_PRIVATE_TABLE_BUDGET ((size_t)8 << 30)
 #endif
@@ -109,6 +111,10 @@ struct airband_hip_handle {
     DevBuf<float2> d_iq, d_iq_out, d_ct_af;
     DevBuf<unsigned long long> d_ct_mask;
     int ct_first_block = 0, ct_n_blocks = 0, ct_pk_pitch = 0;
+    /* AIRBAND_HIP_FLAG_REGROUP: the batch's slot order (demod.hip, "regrouping") */
+    bool regroup = false;
+    DevBuf<int> d_perm, d_rg_count, d_rg_offset;
+    DevBuf<uint8_t> d_sq_key;
     DevBuf<uint8_t> d_trace;
     DevBuf<float> d_out_wave, d_out_iq;
     DevBuf<uint8_t> d_out_axc;
@@ -171,6 +177,8 @@ struct airband_hip_handle {
     DevBuf<int16_t> d_sin_tab;
     DevBuf<long long> d_carriers;
     int n_carriers = 0, noise_q8 = 0;
+    int sig_n_plans = 1;            /* airband_hip_set_signal_plan_shift */
+    unsigned sig_shift_step = 0;
 };
 
 namespace {
@@ -212,6 +220,7 @@ void destroy(airband_hip_handle* h) {
     h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release(); h->d_ct_af.release(); h->d_ct_mask.release();
     h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
     h->d_tmp_wavein.release(); h->d_tmp_iqin.release(); h->d_tmp_trace.release(); h->d_spectrum.release();
+    h->d_perm.release(); h->d_rg_count.release(); h->d_rg_offset.release(); h->d_sq_key.release();
     h->d_ftab.release(); h->d_item_dev.release(); h->d_item_group.release(); h->d_item_bset.release(); h->d_item_private.release(); h->d_item_home.release(); h->d_bfrag.release(); h->d_bcorr.release(); h->d_dft_partial.release(); h->d_bset_bin.release();
     if (h->h2d) (void)hipStreamSynchronize(h->h2d);
     h->d_stage2[0].release(); h->d_stage2[1].release();
@@ -374,7 +383,23 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.wave_batch = h->B;
     da.row0 = h->row0;
     da.ring_rows = h->R;
+    da.perm = h->regroup ? h->d_perm.p : nullptr;
+    da.sq_key = h->regroup ? h->d_sq_key.p : nullptr;
     launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
+    if (h->regroup) { /* the NEXT batch's slot order, from the squelch states this batch ended in (the kinds' streams have joined `s` again) */
+        RegroupArgs ra;
+        ra.cc = h->d_cc.p;
+        ra.sq_key = h->d_sq_key.p;
+        ra.perm = h->d_perm.p;
+        ra.block_count = h->d_rg_count.p;
+        ra.block_offset = h->d_rg_offset.p;
+        ra.n_blocks = h->n_slots / AB_SLOT_BLOCK;
+        for (int k = 0; k < AB_KIND_COUNT; k++) {
+            ra.kind_first_block[k] = h->kind_first_block[k];
+            ra.kind_n_blocks[k] = h->kind_n_blocks[k];
+        }
+        launch_regroup(ra, s);
+    }
     if (h->any_afc && h->afc_spectrum_valid) { /* afc.finalize(), src/rtl_airband.cpp:626-630: may turn '*' into '<' / '>' */
         if (h->use_dft) (void)hipStreamWaitEvent(s, h->ev_spec[1], 0); /* the last hop's spectrum, computed beside stage 1 */
         const int epoch = (int)(h->batches_done % 0x7fffffff) + 1; /* never 0: that is the start-up build's */
@@ -634,6 +659,20 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
                  AIRBAND_HIP_ENOMEM);
         PREP_TRY(h->d_ct_mask.alloc((size_t)h->ct_n_blocks * (h->B / 50) * AB_SLOT_BLOCK), AIRBAND_HIP_ENOMEM);
     }
+    {   /* regrouped stage 2: the first batch runs in slot order (every squelch starts CLOSED) */
+        const char* e = getenv("AIRBAND_HIP_REGROUP");
+        h->regroup = e && *e ? (*e != '0') : (h->flags & AIRBAND_HIP_FLAG_REGROUP) != 0;
+        if (h->regroup) {
+            std::vector<int> ident((size_t)h->n_slots);
+            for (int i = 0; i < h->n_slots; i++) ident[(size_t)i] = i;
+            PREP_TRY(upload(h->d_perm, ident), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(h->d_sq_key.alloc((size_t)h->n_slots), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(hipMemset(h->d_sq_key.p, 0, (size_t)h->n_slots), AIRBAND_HIP_ENOMEM);
+            const size_t nb = (size_t)h->n_slots / AB_SLOT_BLOCK;
+            PREP_TRY(h->d_rg_count.alloc(2 * nb), AIRBAND_HIP_ENOMEM);
+            PREP_TRY(h->d_rg_offset.alloc(2 * nb + 2 * AB_KIND_COUNT), AIRBAND_HIP_ENOMEM);
+        }
+    }
     if (h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH) {
         PREP_TRY(h->d_trace.alloc((size_t)h->B * h->n_slots), AIRBAND_HIP_ENOMEM);
         PREP_TRY(hipMemset(h->d_trace.p, 0, (size_t)h->B * h->n_slots), AIRBAND_HIP_ENOMEM);
@@ -669,12 +708,14 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
     h->use_dft = !(h->flags & AIRBAND_HIP_FLAG_FORCE_FFT) && dft_supported(p.fft_size, (int)h->hop_bytes, p.dev[0].sfmt, p.max_ch);
     if (h->use_dft) {
         build_dft_tables(h->plan, false);
-        /* private tables (one per group with an AFC channel) are only bounded by the fleet: 65 536 AFC dongles are 3.2 GB of them at fft 512 and ~51 GB at
-         * fft 8192.  Past a budget the handle runs on the wavefront FFT, which is what AFC configurations ran on before the matrix-core path took them */
+        /* One table per DISTINCT group of eight bins (shared between the work items that have it: a fleet of identical dongles has one, a fleet in which every
+         * device_t derives its own bins -- src/config.cpp:666-667 -- as many as it has groups) plus one private table per group with an AFC channel.  Bounded by
+         * their bytes alone (65 536 tables are 3.2 GB at fft 512, ~51 GB at fft 8192); past the budget the handle runs on the wavefront FFT.  Round 6: a COUNT used to
+         * stand here (more than 4 096 distinct plans -> wavefront FFT, 7x slower), which contradicted the private tables of the AFC path right beside it. */
         const size_t tab_bytes_each = (size_t)3 * (p.fft_size > 512 ? 16 : p.fft_size / 32) * 64 * 16 * (p.fft_size > 512 ? p.fft_size / 512 : 1);
-        const size_t private_bytes = (size_t)(p.n_bsets - p.n_shared_bsets) * tab_bytes_each;
-        if (p.n_shared_bsets > 4096 || private_bytes > AB_PRIVATE_TABLE_BUDGET) {
-            h->use_dft = false; /* that many different shared tables would not stay cache resident; fall back */
+        const size_t table_bytes = (size_t)p.n_bsets * tab_bytes_each;
+        if (table_bytes > AB_PRIVATE_TABLE_BUDGET) {
+            h->use_dft = false;
         } else {
             PREP_TRY(upload(h->d_item_dev, p.item_dev), AIRBAND_HIP_ENOMEM);
             PREP_TRY(upload(h->d_item_group, p.item_group), AIRBAND_HIP_ENOMEM);
@@ -696,8 +737,12 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
                 with_epoch.push_back(0); /* the "last moved in batch" stamp: 0 = the start-up build below */
                 PREP_TRY(upload(h->d_bset_bin, with_epoch), AIRBAND_HIP_ENOMEM);
             }
-            if (p.n_bsets > p.n_shared_bsets) {
-                launch_retune_tables(h, h->stream, 0);
+            /* shared tables the host did not build (fleets with more than a few thousand distinct channel plans), then the private ones: a private table's columns
+             * are copied from its home table, so the home tables come first */
+            launch_build_tables(h->d_bfrag.p, h->d_bcorr.p, h->d_window.p, h->d_bset_bin.p, p.n_host_bsets, p.n_shared_bsets - p.n_host_bsets, p.fft_size, h->stream);
+            if (p.n_bsets > p.n_shared_bsets) launch_retune_tables(h, h->stream, 0);
+            if (p.n_bsets > p.n_host_bsets) {
+                PREP_TRY(hipGetLastError(), AIRBAND_HIP_ENODEV);
                 PREP_TRY(hipStreamSynchronize(h->stream), AIRBAND_HIP_ENODEV);
             }
             if (p.fft_size > 4096) /* [work items][tiles][64 lanes] float4 */
@@ -1386,6 +1431,8 @@ int airband_hip_timing_totals(airband_hip_handle* h, double* ms4_sum, int64_t* n
 #endif
 const char* airband_hip_build_info(void) { return AB_BUILD_DEFINES; }
 
+int airband_hip_regrouped(const airband_hip_handle* h) { return (h && h->regroup) ? 1 : 0; }
+
 const char* airband_hip_channelizer_name(const airband_hip_handle* h) {
     return (h && h->use_dft) ? "dft_mfma_i8" : (h && h->use_f32) ? "dft_mfma_f32" : "fft_wave64";
 }
@@ -1401,6 +1448,13 @@ int airband_hip_set_signal_plan(airband_hip_handle* h, const int64_t* carriers, 
     HIP_TRY(h, upload(h->d_sin_tab, t), AIRBAND_HIP_ENOMEM);
     h->n_carriers = n_carriers;
     h->noise_q8 = noise_q8;
+    return AIRBAND_HIP_OK;
+}
+
+int airband_hip_set_signal_plan_shift(airband_hip_handle* h, int32_t n_plans, uint32_t shift_step) {
+    if (!h || n_plans < 1 || n_plans > 65536) return fail(h, AIRBAND_HIP_EINVAL, "bad plan count (1..65536)");
+    h->sig_n_plans = n_plans;
+    h->sig_shift_step = shift_step;
     return AIRBAND_HIP_OK;
 }
 
@@ -1423,6 +1477,8 @@ int airband_hip_generate_iq(airband_hip_handle* h, void* d_iq, size_t stride_byt
     a.n_samples = (long)(nbytes / 2);
     a.seed = seed;
     a.noise_q8 = h->noise_q8;
+    a.n_plans = h->sig_n_plans;
+    a.plan_shift_step = h->sig_shift_step;
     launch_siggen(a, stream ? (hipStream_t)stream : h->stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, AIRBAND_HIP_ERUNTIME, std::string("siggen launch: ") + hipGetErrorString(e));

@@ -254,7 +254,8 @@ struct KindBits {
 };
 
 template <int KIND, bool WAVE_HAS_CTCSS>
-__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, const float2* lut, float* ostage, const int* ext_of, int* skip_of, bool full_block) {
+__device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, const float2* lut, float* ostage, const int* ext_of, int* skip_of, const int* slot_of,
+                                           bool full_block) {
     const int lane = threadIdx.x & 63;
     constexpr long S = AB_SLOT_BLOCK;
     const int R = a.ring_rows, B = a.wave_batch;
@@ -343,8 +344,10 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     float2* hand = hand_base + lane;
     unsigned* handw_base = reinterpret_cast<unsigned*>(ostage);
     unsigned* handw = handw_base + lane;
-    float2* ct_block = (WAVE_HAS_CTCSS && !PACKED) ? a.ct_af + (long)((slot & ~63) - a.ct_gen_first_block * 64) * B : nullptr;
-    unsigned* ct_blockw = PACKED ? a.ct_ap + (long)((slot & ~63) - a.ct_pk_first_block * 64) * a.ct_pk_pitch : nullptr;
+    /* the cooperative flush stores OTHER lanes' rows: row of the wavefront's channel c = the row of slot_of[c] (LDS; the lanes of a regrouped wavefront do not
+     * work on consecutive slots) */
+    auto ct_row = [&](int c) { return a.ct_af + (long)(slot_of[c] - a.ct_gen_first_block * 64) * B; };
+    auto ct_roww = [&](int c) { return a.ct_ap + (long)(slot_of[c] - a.ct_pk_first_block * 64) * a.ct_pk_pitch; };
     auto hand_flush = [&](int n, int jstart) { /* n samples starting at batch sample jstart */
         if (PACKED) {
             if (full_block) { /* wave-uniform */
@@ -360,7 +363,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
 #endif
                         const int c = i * 8 + (lane >> 3);
                         const unsigned* src = handw_base + (4 * q) * OSTRIDE + c;
-                        *reinterpret_cast<uint4*>(ct_blockw + (long)c * a.ct_pk_pitch + jstart + 4 * q) = make_uint4(src[0], src[OSTRIDE], src[2 * OSTRIDE], src[3 * OSTRIDE]);
+                        *reinterpret_cast<uint4*>(ct_roww(c) + jstart + 4 * q) = make_uint4(src[0], src[OSTRIDE], src[2 * OSTRIDE], src[3 * OSTRIDE]);
                     }
                 }
                 AB_LOCKSTEP();
@@ -378,7 +381,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                 for (int i = 0; i < 8; i++) {
                     const int c = i * 8 + (lane >> 3);
                     const float2 p0 = hand_base[(2 * q) * OSTRIDE + c], p1 = hand_base[(2 * q + 1) * OSTRIDE + c];
-                    *reinterpret_cast<float4*>(ct_block + (long)c * B + jstart + 2 * q) = make_float4(p0.x, p0.y, p1.x, p1.y);
+                    *reinterpret_cast<float4*>(ct_row(c) + jstart + 2 * q) = make_float4(p0.x, p0.y, p1.x, p1.y);
                 }
             }
             AB_LOCKSTEP();
@@ -830,6 +833,8 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     if (KIND == AB_KIND_NFM_LOWPASS) { sp->sh_nf = sh.nf; sp->sh_cap = sh.cap; sp->sh_capped = sh.capped; sp->sh_dly = s.dly; }
     if (KIND == AB_KIND_GENERIC) sp->sh_dly = sq_delayed(s, L); /* buffer_[buffer_tail_] for the stats mirror (signal_outside_filter); this kind keeps the delay line in memory */
     sq_store(s, L, sp, B);
+    /* regrouped handles: is this channel's squelch at rest in CLOSED?  (the next batch's slot order puts the others first: regroup kernels below) */
+    if (a.sq_key) a.sq_key[slot] = ab_lane(s.cC & s.nC) ? 0 : 1;
     sp->lxr[1] = lxr1; sp->lxr[2] = lxr2; sp->lxi[1] = lxi1; sp->lxi[2] = lxi2;
     sp->lyr[1] = lyr1; sp->lyr[2] = lyr2; sp->lyi[1] = lyi1; sp->lyi[2] = lyi2;
 }
@@ -845,7 +850,9 @@ constexpr int TONE_GROUP = 50; /* samples per tone-kernel step; divides WAVE_BAT
 constexpr int AB_DEMOD_WAVES = 3, AB_AM_WAVES = 4, AB_FRONT_WAVES = 3; /* (the front at four waves: 128 VGPRs with 18 of them spilled once it carries the quiet-group path -- 6.30 ms of stage 2 against 6.20 at three) */
 template <int KIND, bool WAVE_HAS_CTCSS>
 __device__ __forceinline__ void demod_block(const DemodArgs& a, int block, float* lds_demod) {
-    const int slot = block * 64 + threadIdx.x; /* padding slots carry flags == 0 */
+    /* the lane's channel: slot = wavefront position, or what the batch's slot order says (DemodArgs::perm); padding slots carry flags == 0 */
+    const int pos = block * 64 + threadIdx.x;
+    const int slot = a.perm ? a.perm[pos] : pos;
     const ChanConst cc = a.cc[slot];
     /* the (sin, cos) table of sincosf_lut (src/util.cpp:105-127), 257 float2 -- a sample's
      * derotation then costs one LDS read instead of four dependent trips to L2 on the serial path */
@@ -857,10 +864,12 @@ __device__ __forceinline__ void demod_block(const DemodArgs& a, int block, float
     float* ostage = reinterpret_cast<float*>(lut + (KIND == AB_KIND_AM ? 0 : 258));
     int* ext_of = reinterpret_cast<int*>(ostage + RUN * OSTRIDE);
     int* skip_of = ext_of + 64;
+    int* slot_of = skip_of + 64;
     ext_of[threadIdx.x] = a.slot_to_ext[slot];
+    slot_of[threadIdx.x] = slot;
     const bool full_block = __ballot((cc.flags & AB_F_VALID) != 0) == ~0ull; /* padding lanes leave early and cannot take part in a cooperative store */
     __syncthreads();
-    demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lut, ostage, ext_of, skip_of, full_block);
+    demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lut, ostage, ext_of, skip_of, slot_of, full_block);
 }
 
 template <int KIND, bool WAVE_HAS_CTCSS>
@@ -1120,7 +1129,8 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a, int first_block) 
     __shared__ int ext_of[64];
     __shared__ int skip_of[64];
     const int lane = threadIdx.x;
-    const int slot = (first_block + blockIdx.x) * 64 + lane;
+    const int pos = (first_block + blockIdx.x) * 64 + lane;
+    const int slot = a.perm ? a.perm[pos] : pos; /* regrouped handles: the batch's slot order (DemodArgs::perm) */
     const ChanConst cc = a.cc[slot];
     ext_of[lane] = a.slot_to_ext[slot];
     const bool full_block = __ballot((cc.flags & AB_F_VALID) != 0) == ~0ull;
@@ -1151,7 +1161,8 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a, int first_block) 
      * lines it touches are its own, the re-use is served by L2 */
     const float4* af = PACKED ? reinterpret_cast<const float4*>(a.ct_ap + (long)(slot - a.ct_pk_first_block * 64) * a.ct_pk_pitch)
                               : reinterpret_cast<const float4*>(a.ct_af + (long)(slot - a.ct_gen_first_block * 64) * B);
-    const unsigned long long* maskp = a.ct_mask + ((long)(blockIdx.x + first_block - a.ct_first_block) * NG) * AB_SLOT_BLOCK + lane;
+    /* the tone kernel (one wavefront per SLOT) leaves a channel's verdicts at (slot's block, slot's lane) */
+    const unsigned long long* maskp = a.ct_mask + ((long)((slot >> 6) - a.ct_first_block) * NG) * AB_SLOT_BLOCK + (slot & 63);
     const bool is_ct = (cc.flags & AB_F_CTCSS) != 0;
     constexpr int PIECE = 8; /* samples per fetch; WAVE_BATCH = 1000 / 2000 is a whole number of them */
     /* A piece = 8 (audio, flags) pairs + the tone kernel's verdict masks of the one or two 50-sample steps it lies in.  Piece k + 1
@@ -1230,7 +1241,7 @@ static int tone_threads() {
 
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev) {
     auto lds_of = [](int k) { /* sincos table, output-line staging, ext_of */
-        return (size_t)(k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)RUN * OSTRIDE * sizeof(float) + 2 * 64 * sizeof(int); /* ext_of, skip_of */
+        return (size_t)(k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)RUN * OSTRIDE * sizeof(float) + 3 * 64 * sizeof(int); /* ext_of, skip_of, slot_of */
     };
     auto launch_kind = [&](int k, hipStream_t s) {
         const size_t lds = lds_of(k);
@@ -1277,6 +1288,101 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
             (void)hipStreamWaitEvent(stream, ev[1 + i], 0);
         }
     }
+}
+
+/* ---- regrouping (AIRBAND_HIP_FLAG_REGROUP): closed channels share wavefronts -----------------------------------------------------
+ * Slots are assigned by demod KIND when a handle is prepared, and a wavefront works on 64 consecutive slots: at any time about half of its lanes (on the
+ * BASELINE signal; nine in ten on a real band) are channels whose squelch is closed, and they ride through the open lanes' instructions under an exec mask --
+ * ~180 of the NFM + lowpass kind's ~240 vector instructions per sample, ~35 of the AM kind's ~60.  Stage 2 is bound by vector issue, so those are
+ * paid in full.  A wavefront whose lanes are ALL closed skips them (the exec-masked regions are branched over when no lane takes them).
+ * Everything a lane touches is addressed by its slot, so WHICH 64 slots a wavefront works on is free: at the end of a batch every lane leaves one byte -- is my
+ * squelch at rest in CLOSED? (DemodArgs::sq_key) -- and three small kernels turn the bytes into the next batch's slot order, a STABLE partition inside each kind's
+ * block range: active channels first, closed ones behind them, slots without a channel last.  Stable, so that slots sharing a 128-byte line of the stage-1 rings
+ * (four AM / two NFM neighbours) stay neighbours inside their wavefront whenever they are in the same state.  The price is the rings' lines: where neighbours are
+ * in DIFFERENT states their line is fetched by two wavefronts instead of one (profiles/r06_experiments.md B sizes it).  Results do not depend on the order -- same
+ * operations on the same values, lane for lane. */
+namespace {
+__device__ __forceinline__ int regroup_key(const RegroupArgs& a, int slot) {
+    if (!(a.cc[slot].flags & AB_F_VALID)) return 2;
+    return a.sq_key[slot] ? 0 : 1;
+}
+__device__ __forceinline__ int regroup_kind_of(const RegroupArgs& a, int block) {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < AB_KIND_COUNT; i++)
+        if (a.kind_n_blocks[i] > 0 && block >= a.kind_first_block[i] && block < a.kind_first_block[i] + a.kind_n_blocks[i]) k = i;
+    return k;
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void regroup_count_kernel(RegroupArgs a) {
+    const int block = blockIdx.x, lane = threadIdx.x;
+    const int key = regroup_key(a, block * 64 + lane);
+    const unsigned long long m0 = __ballot(key == 0), m1 = __ballot(key == 1);
+    if (lane == 0) {
+        a.block_count[2 * block] = __builtin_popcountll(m0);
+        a.block_count[2 * block + 1] = __builtin_popcountll(m1);
+    }
+}
+
+/* one workgroup per kind: exclusive sums of the per-block counts over the kind's blocks, and the kind's totals */
+__global__ __launch_bounds__(256) void regroup_scan_kernel(RegroupArgs a) {
+    __shared__ int part[256][2];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int first = a.kind_first_block[k], n = a.kind_n_blocks[k];
+    if (n <= 0) return; /* block-uniform */
+    const int per = (n + 255) / 256;
+    const int b0 = tid * per < n ? tid * per : n, b1 = b0 + per < n ? b0 + per : n;
+    int s0 = 0, s1 = 0;
+    for (int b = b0; b < b1; b++) {
+        s0 += a.block_count[2 * (first + b)];
+        s1 += a.block_count[2 * (first + b) + 1];
+    }
+    part[tid][0] = s0;
+    part[tid][1] = s1;
+    __syncthreads();
+    if (tid == 0) { /* 256 partial sums: one lane walks them (a fraction of a microsecond; the launch is what costs) */
+        int r0 = 0, r1 = 0;
+        for (int i = 0; i < 256; i++) {
+            const int c0 = part[i][0], c1 = part[i][1];
+            part[i][0] = r0;
+            part[i][1] = r1;
+            r0 += c0;
+            r1 += c1;
+        }
+        a.block_offset[2 * a.n_blocks + 2 * k] = r0;
+        a.block_offset[2 * a.n_blocks + 2 * k + 1] = r1;
+    }
+    __syncthreads();
+    int o0 = part[tid][0], o1 = part[tid][1];
+    for (int b = b0; b < b1; b++) {
+        a.block_offset[2 * (first + b)] = o0;
+        a.block_offset[2 * (first + b) + 1] = o1;
+        o0 += a.block_count[2 * (first + b)];
+        o1 += a.block_count[2 * (first + b) + 1];
+    }
+}
+
+__global__ __launch_bounds__(64) void regroup_scatter_kernel(RegroupArgs a) {
+    const int block = blockIdx.x, lane = threadIdx.x;
+    const int slot = block * 64 + lane;
+    const int key = regroup_key(a, slot);
+    const unsigned long long m0 = __ballot(key == 0), m1 = __ballot(key == 1), m2 = __ballot(key == 2);
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int k = regroup_kind_of(a, block);
+    const int first = a.kind_first_block[k];
+    const int tot0 = a.block_offset[2 * a.n_blocks + 2 * k], tot1 = a.block_offset[2 * a.n_blocks + 2 * k + 1];
+    const int off0 = a.block_offset[2 * block], off1 = a.block_offset[2 * block + 1];
+    const int off2 = (block - first) * 64 - off0 - off1; /* slots without a channel in the kind's earlier blocks */
+    const int at = key == 0 ? off0 + __builtin_popcountll(m0 & below) : key == 1 ? tot0 + off1 + __builtin_popcountll(m1 & below) : tot0 + tot1 + off2 + __builtin_popcountll(m2 & below);
+    a.perm[first * 64 + at] = slot;
+}
+
+void launch_regroup(const RegroupArgs& a, hipStream_t stream) {
+    if (a.n_blocks <= 0) return;
+    hipLaunchKernelGGL(regroup_count_kernel, dim3(a.n_blocks), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(regroup_scan_kernel, dim3(AB_KIND_COUNT), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(regroup_scatter_kernel, dim3(a.n_blocks), dim3(64), 0, stream, a);
 }
 
 /* ---- raw I/Q outputs: time-major device rows -> the channel-major layout the output thread consumes (reference:

@@ -109,7 +109,25 @@ struct DemodArgs {
     const float* cos_lut;   /* 257 */
     int ct_stride;
     int n_slots, wave_batch, row0, ring_rows;
+    /* REGROUPED handles (AIRBAND_HIP_FLAG_REGROUP, demod.hip "regrouping"): which slot the lane at wavefront position p = block * 64 + lane works on.  Everything a
+     * lane touches is addressed by its SLOT (rings, state, result rows, hand-off rows), so any permutation inside a kind's block range computes the same results;
+     * the one the library uses puts the channels whose squelch is not CLOSED at a batch's start first, so that wavefronts of closed channels never run the open
+     * channels' instructions.  null: position p works on slot p. */
+    const int* perm;
+    uint8_t* sq_key;        /* [n_slots] written by the kernels that run the squelch: 1 = the channel's squelch is not at rest in CLOSED at the end of the batch (null: not kept) */
 };
+
+/* slot order of the NEXT batch from sq_key (stable partition inside each kind's block range: active channels, closed ones, slots without a channel) */
+struct RegroupArgs {
+    const ChanConst* cc;
+    const uint8_t* sq_key;
+    int* perm;              /* [n_slots] */
+    int* block_count;       /* [n_blocks][2] scratch: active / closed slots per home block */
+    int* block_offset;      /* [n_blocks][2] scratch: exclusive sums inside the kind + [AB_KIND_COUNT][2] kind totals behind them */
+    int n_blocks;           /* all kinds */
+    int kind_first_block[AB_KIND_COUNT], kind_n_blocks[AB_KIND_COUNT];
+};
+void launch_regroup(const RegroupArgs& a, hipStream_t stream);
 
 struct EmitArgs { /* raw I/Q outputs only: audio goes straight to its channel row */
     const float2* iq_out;
@@ -150,6 +168,10 @@ struct SiggenArgs {
     long n_samples;
     unsigned long long seed;
     int noise_q8;
+    /* fleets whose dongles do not share a channel plan (bench.py --distinct-plans): dongle `dev` belongs to plan p = dev mod n_plans, and its carrier c sits
+     * ((p >> 2c) & 3) * plan_shift_step further up than the table says -- 4^8 = 65 536 distinct plans of eight carriers; n_plans <= 1: every dongle as the table says */
+    int n_plans;
+    unsigned plan_shift_step; /* u32 turns per sample */
 };
 
 void launch_channelizer_fft(const ChannelizerArgs& a, hipStream_t stream);
@@ -198,6 +220,9 @@ struct RetuneArgs {
     int epoch;
 };
 void launch_retune(const RetuneArgs& a, hipStream_t stream);
+/* shared coefficient tables [first, first + n) built on the device, every column from bset_bin[table][8] (the host builds the first few thousand of a fleet's distinct
+ * channel plans, params.cpp; the rest here, at prepare() time) */
+void launch_build_tables(int8_t* bfrag, double* corr, const float* window, const int* bset_bin, int first, int n, int fft_size, hipStream_t stream);
 /* scatter channel-major host-provided bins into the time-major rings (airband_hip_process_bins) */
 void launch_scatter_bins(const float* wavein, const float* iqin, const int* slot_to_ext, const ChanConst* cc, float* mag, float2* iq, int n_slots,
                          int wave_batch, int row0, int ring_rows, hipStream_t stream);

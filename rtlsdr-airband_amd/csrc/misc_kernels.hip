@@ -25,6 +25,11 @@ __global__ __launch_bounds__(256) void siggen_kernel(SiggenArgs a) {
     const int dev = a.dev_offset + d;
     if ((int)threadIdx.x < a.n_carriers)
         ph0[threadIdx.x] = (unsigned)mix64((a.seed ^ 0xC0FFEEull) + (unsigned long long)((dev << 8) | (int)threadIdx.x));
+    __shared__ unsigned step_of[16];
+    if ((int)threadIdx.x < a.n_carriers) { /* the carrier's phase step for THIS dongle: the table's, moved by the dongle's plan (SiggenArgs::n_plans) */
+        const unsigned plan = a.n_plans > 1 ? (unsigned)(dev % a.n_plans) : 0u;
+        step_of[threadIdx.x] = (unsigned)a.carriers[threadIdx.x * 12] + a.plan_shift_step * ((plan >> (2 * (threadIdx.x & 15))) & 3u);
+    }
     __syncthreads();
     uint8_t* out = a.iq + (long)d * a.stride;
     /* each thread produces 8 complex samples = 16 bytes per pass */
@@ -37,7 +42,7 @@ __global__ __launch_bounds__(256) void siggen_kernel(SiggenArgs a) {
             long long acc_i = 0, acc_q = 0;
             for (int c = 0; c < a.n_carriers; c++) {
                 const long long* k = car + c * 12;
-                unsigned ph = (unsigned)k[0] * n32 + ph0[c];
+                unsigned ph = step_of[c] * n32 + ph0[c];
                 const unsigned pa = (unsigned)k[3] * n32;
                 const long long s_mod = tab[pa >> 20];
                 long long amp;
@@ -247,6 +252,68 @@ void launch_afc(const ChanConst* cc, ChanState* cs, const float* spectrum, int f
     hipLaunchKernelGGL(afc_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, stream, cc, cs, reinterpret_cast<const float2*>(spectrum), fft_size, n_slots, moved_epoch, epoch);
 }
 
+/* One (re, im) column pair of a coefficient table, built on the device: w[n] exp(-2 pi i bin n / N) scaled to 24 bits, three balanced base-256 digits in the MFMA
+ * B-fragment layout, plus the column's offset correction -- the host builder's arithmetic (params.cpp, build_dft_tables) with the device's sincospi.  One wavefront
+ * works on one table; `sums` = two LDS words of its own. */
+__device__ __forceinline__ void build_column_pair(int8_t* bfrag, double* corr, const float* window, int bset, int c, int bin, int N, int lane, long long* sums) {
+    const int NP = N > 512 ? N / 512 : 1, NS = N / NP, K = 2 * NS, KS = K / 64;
+    const size_t piece_bytes = (size_t)3 * KS * 64 * 16;
+    for (int piece = 0; piece < NP; piece++) {
+        if (lane < 2) sums[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        int8_t* tab = bfrag + ((size_t)bset * NP + piece) * piece_bytes;
+        long long part_re = 0, part_im = 0;
+        for (int k = lane; k < K; k += 64) {
+            const int n = piece * NS + (k >> 1);
+            double sn, cs_;
+            sincospi(2.0 * (double)(((long long)bin * n) % N) / (double)N, &sn, &cs_); /* the phase is reduced exactly in integers first */
+            const double wc = (double)window[n] * cs_ * AB_DFT_COEF_SCALE, ws = (double)window[n] * sn * AB_DFT_COEF_SCALE;
+            /* byte k = 2n + {0: I, 1: Q}:  (I + jQ) w e^{-j th} = (I w cos + Q w sin) + j (Q w cos - I w sin) */
+            const int v_re = (int)llround((k & 1) ? ws : wc), v_im = (int)llround((k & 1) ? wc : -ws);
+            part_re += v_re;
+            part_im += v_im;
+            const int s_ = k / 64, gg = (k % 64) / 16, jj = k % 16;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                int rest = half ? v_im : v_re;
+                const int ln = gg * 16 + 2 * c + half;
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const int lo = ((rest + 128) & 255) - 128; /* balanced digit */
+                    tab[(((size_t)t * KS + s_) * 64 + ln) * 16 + jj] = (int8_t)lo;
+                    rest = (rest - lo) / 256;
+                }
+            }
+        }
+        atomicAdd((unsigned long long*)&sums[0], (unsigned long long)part_re); /* integer sums: exact, order-free */
+        atomicAdd((unsigned long long*)&sums[1], (unsigned long long)part_im);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* LDS operations of one wave complete in order; this keeps the compiler from reordering them */
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 2) corr[((size_t)bset * NP + piece) * 16 + 2 * c + lane] = 0.5 * (double)sums[lane]; /* (b - 127.5) = (b - 128) + 0.5 */
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+/* Shared coefficient tables beyond the ones the host builds (round 6: a fleet whose dongles do NOT share a channel plan -- every device_t derives its own bins,
+ * src/config.cpp:666-667 -- has one table per distinct group of eight bins; the host builds the first few thousand, the rest are built here at prepare() time, one
+ * wavefront per table): tables [first, first + n), every column from bset_bin. */
+__global__ __launch_bounds__(256) void build_tables_kernel(int8_t* bfrag, double* corr, const float* window, const int* bset_bin, int first, int n, int fft_size) {
+    __shared__ long long sums[4][2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= n) return;
+    const int bset = first + t;
+    for (int c = 0; c < 8; c++) {
+        const int bin = bset_bin[bset * 8 + c];
+        if (bin < 0) continue; /* a group with fewer than eight channels: the column pair stays zero */
+        build_column_pair(bfrag, corr, window, bset, c, bin, fft_size, lane, sums[wave]);
+    }
+}
+
+void launch_build_tables(int8_t* bfrag, double* corr, const float* window, const int* bset_bin, int first, int n, int fft_size, hipStream_t stream) {
+    if (n > 0) hipLaunchKernelGGL(build_tables_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, bfrag, corr, window, bset_bin, first, n, fft_size);
+}
+
 /* ---- AFC on the matrix-core channelizer: coefficient columns follow the bins ---------------------------------------------------
  * The pruned DFT has the channel's bin baked into its coefficient table (params.cpp, build_dft_tables).  A group of channels with an AFC
  * channel owns its table; one wavefront per such work item compares, a lane per channel, the bin the table is built for with the bin the
@@ -310,40 +377,7 @@ __global__ __launch_bounds__(256) void retune_kernel(RetuneArgs a) {
             if (lane == 0) a.bset_bin[bset * 8 + c] = bin;
             continue;
         }
-        for (int piece = 0; piece < NP; piece++) {
-            if (lane < 2) sums[wave][lane] = 0;
-            __builtin_amdgcn_wave_barrier();
-            int8_t* tab = a.bfrag + ((size_t)bset * NP + piece) * piece_bytes;
-            long long part_re = 0, part_im = 0;
-            for (int k = lane; k < K; k += 64) {
-                const int n = piece * NS + (k >> 1);
-                double sn, cs_;
-                sincospi(2.0 * (double)(((long long)bin * n) % N) / (double)N, &sn, &cs_); /* the phase is reduced exactly in integers first */
-                const double wc = (double)a.window[n] * cs_ * AB_DFT_COEF_SCALE, ws = (double)a.window[n] * sn * AB_DFT_COEF_SCALE;
-                /* byte k = 2n + {0: I, 1: Q}:  (I + jQ) w e^{-j th} = (I w cos + Q w sin) + j (Q w cos - I w sin) */
-                const int v_re = (int)llround((k & 1) ? ws : wc), v_im = (int)llround((k & 1) ? wc : -ws);
-                part_re += v_re;
-                part_im += v_im;
-                const int s_ = k / 64, gg = (k % 64) / 16, jj = k % 16;
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    int rest = half ? v_im : v_re;
-                    const int ln = gg * 16 + 2 * c + half;
-#pragma unroll
-                    for (int t = 0; t < 3; t++) {
-                        const int lo = ((rest + 128) & 255) - 128; /* balanced digit */
-                        tab[(((size_t)t * KS + s_) * 64 + ln) * 16 + jj] = (int8_t)lo;
-                        rest = (rest - lo) / 256;
-                    }
-                }
-            }
-            atomicAdd((unsigned long long*)&sums[wave][0], (unsigned long long)part_re); /* integer sums: exact, order-free */
-            atomicAdd((unsigned long long*)&sums[wave][1], (unsigned long long)part_im);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* LDS operations of one wave complete in order; this keeps the compiler from reordering them */
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 2) a.corr[((size_t)bset * NP + piece) * 16 + 2 * c + lane] = 0.5 * (double)sums[wave][lane]; /* (b - 127.5) = (b - 128) + 0.5 */
-            __builtin_amdgcn_wave_barrier();
-        }
+        build_column_pair(a.bfrag, a.corr, a.window, bset, c, bin, N, lane, sums[wave]);
         if (lane == 0) a.bset_bin[bset * 8 + c] = bin;
     }
     /* the table the next batch's stage 1 reads for this work item: the fleet's shared one while the group is at home */

@@ -12,6 +12,7 @@
 #include <climits>
 #include <cmath>
 #include <complex>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -343,6 +344,17 @@ void build_f32_tables(Plan& p) {
                 }
 }
 
+/* shared coefficient tables the host builds; the rest are built on the device at prepare() time.  AIRBAND_HIP_HOST_TABLES_MAX overrides (tests: small fleets through the
+ * device builder) */
+static int host_tables_max() {
+    static const int n = [] {
+        const char* e = getenv("AIRBAND_HIP_HOST_TABLES_MAX");
+        const long v = e ? strtol(e, nullptr, 10) : 4096;
+        return (int)(v < 0 ? 0 : v > (1 << 20) ? (1 << 20) : v);
+    }();
+    return n;
+}
+
 void build_dft_tables(Plan& p, bool host_private) {
     /* fft_size > 512: one table per window piece of 512 samples (NP pieces); a table then covers K = 1024 bytes of the window */
     const int N = p.fft_size, NP = N > 512 ? N / 512 : 1, NS = N / NP, K = 2 * NS, KS = K / 64;
@@ -399,6 +411,11 @@ void build_dft_tables(Plan& p, bool host_private) {
         }
     };
     int last_shared = -1;
+    /* every device_t derives its own bins (src/config.cpp:666-667): a fleet may hold as many distinct groups of eight bins as it has dongles.  The lookup is a
+     * map (it was a linear search: 65 536 distinct plans = 2e9 vector compares), the host builds the first host_tables_max() = 4 096 tables and leaves the rest to the
+     * device (misc_kernels.hip, build_tables_kernel, at prepare() time: same arithmetic, the device's sincospi) -- a 3 GB host image of 65 536 tables is not needed
+     * to run them.  host_private (the host-only self test) builds everything here. */
+    std::map<std::vector<int>, int> shared_index;
     for (int d = 0; d < p.n_dev; d++) {
         for (int g = 0; g * 8 < p.dev[d].n_ch; g++) { /* one work item per group of 8 channels */
             std::vector<int> key;
@@ -409,12 +426,15 @@ void build_dft_tables(Plan& p, bool host_private) {
             }
             int found = -1, home = -1;
             if (last_shared >= 0 && shared_keys[last_shared] == key) home = last_shared; /* fleets of identical dongles: the common case */
-            for (size_t i = 0; home < 0 && i < shared_keys.size(); i++)
-                if (shared_keys[i] == key) home = (int)i;
+            if (home < 0) {
+                auto it = shared_index.find(key);
+                if (it != shared_index.end()) home = it->second;
+            }
             if (home < 0) {
                 home = (int)shared_keys.size();
                 shared_keys.push_back(key);
-                if (shared_keys.size() <= 4096) build(key); /* beyond that the caller falls back to the wavefront-FFT channelizer: no point in building on */
+                shared_index.emplace(key, home);
+                if (host_private || shared_keys.size() <= (size_t)host_tables_max()) build(key); /* the rest: on the device */
             }
             last_shared = home;
             if (private_table) {
@@ -430,13 +450,14 @@ void build_dft_tables(Plan& p, bool host_private) {
         }
     }
     p.n_shared_bsets = (int)shared_keys.size();
+    p.n_host_bsets = host_private ? p.n_shared_bsets : std::min(p.n_shared_bsets, host_tables_max());
     p.n_bsets = p.n_shared_bsets + (int)private_keys.size();
     for (int& b : p.item_bset)
         if (b < 0) b = p.n_shared_bsets + (-b - 1);
     p.bset_bins.assign((size_t)p.n_bsets * 8, -1);
     for (size_t b = 0; b < shared_keys.size(); b++)
         for (size_t c = 0; c < shared_keys[b].size(); c++) p.bset_bins[b * 8 + c] = shared_keys[b][c];
-    if (host_private && p.n_shared_bsets <= 4096)
+    if (host_private)
         for (size_t b = 0; b < private_keys.size(); b++) {
             build(private_keys[b]);
             for (size_t c = 0; c < private_keys[b].size(); c++) p.bset_bins[(p.n_shared_bsets + b) * 8 + c] = private_keys[b][c];
@@ -445,7 +466,8 @@ void build_dft_tables(Plan& p, bool host_private) {
     p.b_edge_hi_zero = NP == 1; /* window pieces have their small coefficients at one end only */
     const int edge = KS / 8;
     /* tables that AFC may re-tune to any bin: the top digit of an edge coefficient is zero whatever the bin iff the window itself is that small there */
-    for (int i = 0; !private_keys.empty() && p.b_edge_hi_zero && i < NS; i++) {
+    /* (the same for shared tables the device builds: they are not here to be looked at) */
+    for (int i = 0; (!private_keys.empty() || p.n_host_bsets < p.n_shared_bsets) && p.b_edge_hi_zero && i < NS; i++) {
         const int s_ = (2 * i) / 64;
         if (s_ >= edge && s_ < KS - edge) continue;
         if ((double)p.window[i] * S > 32639.0) p.b_edge_hi_zero = false;

@@ -39,6 +39,7 @@ struct Plan {
     double b_unscale = 0.0;
     bool b_edge_hi_zero = false;       /* digit 2 is zero in the outer k-steps (fft_size / 256 at either end) of every table */
     int n_bsets = 0, n_shared_bsets = 0; /* coefficient tables in all / those shared between work items (the rest belong to groups with an AFC channel) */
+    int n_host_bsets = 0;                /* shared tables [0, n_host_bsets) are in bfrag / bcorr; [n_host_bsets, n_shared_bsets) are built on the device at prepare() time (4 096, AIRBAND_HIP_HOST_TABLES_MAX) */
     std::vector<int> bset_bins;          /* [n_bsets][8] the bin every column pair of a table is built for (-1: unused) */
     int64_t hop_bytes_max = 0;
     bool uniform_hop = true;           /* every dongle has the same sfmt / hop (needed by the batched launch) */

@@ -105,9 +105,16 @@ def noise_mul_q8(sigma: float = 0.02) -> int:
     return int(round(sigma * 127.5 * 256.0 / ih_sigma * 256.0))
 
 
+def plan_shift_bins(dev: int, n_plans: int, n_channels: int = 8) -> List[int]:
+    """Fleets whose dongles do not share a channel plan (bench.py --distinct-plans, airband_hip_set_signal_plan_shift): dongle ``dev`` belongs to plan
+    p = dev mod n_plans and its channel c sits ((p >> 2c) & 3) shift units above the common plan's frequency -- 4**8 = 65 536 distinct plans of eight channels."""
+    p = dev % n_plans if n_plans > 1 else 0
+    return [(p >> (2 * (c & 15))) & 3 for c in range(n_channels)]
+
+
 def generate_u8(dev: int, start_sample: int, n_samples: int, carriers: Sequence[Carrier], *, seed: int = 0x5EED, noise_q8: int | None = None,
-                chunk: int = 1 << 20) -> np.ndarray:
-    """u8 interleaved I/Q bytes [2*n_samples] for dongle ``dev``, stream samples [start, start+n)."""
+                chunk: int = 1 << 20, n_plans: int = 1, shift_step: int = 0) -> np.ndarray:
+    """u8 interleaved I/Q bytes [2*n_samples] for dongle ``dev``, stream samples [start, start+n).  n_plans / shift_step (u32 turns per sample): see plan_shift_bins."""
     if noise_q8 is None:
         noise_q8 = noise_mul_q8()
     tab = sin_table().astype(np.int64)
@@ -120,7 +127,8 @@ def generate_u8(dev: int, start_sample: int, n_samples: int, carriers: Sequence[
         for ci, c in enumerate(carriers):
             with np.errstate(over="ignore"):
                 ph0 = mix64(np.array([(seed ^ 0xC0FFEE) + ((dev << 8) | ci)], dtype=np.uint64))[0] & MASK32
-                ph = (np.uint64(c.step) * n + ph0) & MASK32
+                step = (c.step + shift_step * plan_shift_bins(dev, n_plans, len(carriers))[ci]) & 0xFFFFFFFF
+                ph = (np.uint64(step) * n + ph0) & MASK32
                 pa = (np.uint64(c.step_mod) * n) & MASK32
             s_mod = tab[(pa >> np.uint64(32 - SIN_BITS)).astype(np.int64)]
             if c.kind == 0:
@@ -159,11 +167,12 @@ SAMPLE_RATE = 2_560_000
 PLAN_OFFSETS_HZ = [-1_000_000, -750_000, -500_000, -250_000, 250_000, 500_000, 750_000, 1_000_000]
 
 
-def baseline_plan(mixed: bool):
+def baseline_plan(mixed: bool, key_on_s: float = 0.75):
     """(channel config dicts, carriers) for one dongle of the BASELINE configs.
 
     mixed=False: 8 AM channels (configs #1/#2).  mixed=True: odd channels NFM; c%4==1 carries a 100 Hz CTCSS
     sub-tone with ``ctcss=100`` and ``notch=100``; c%4==3 has ``bandwidth=12500`` (configs #3-#5).
+    key_on_s: seconds of every 1.5 s a transmitter is keyed (0.75; bench.py --key-on-s measures quieter bands).
     """
     chans, carriers = [], []
     for c, off in enumerate(PLAN_OFFSETS_HZ):
@@ -174,11 +183,11 @@ def baseline_plan(mixed: bool):
             if c % 4 == 1:
                 cfg["ctcss_freq"] = 100.0
                 cfg["notch_freq"] = 100.0
-                carriers.append(make_carrier(off, SAMPLE_RATE, kind=1, ctcss_hz=100.0, key_slot=c))
+                carriers.append(make_carrier(off, SAMPLE_RATE, kind=1, ctcss_hz=100.0, key_slot=c, key_on_s=key_on_s))
             else:
                 cfg["bandwidth_hz"] = 12500
-                carriers.append(make_carrier(off, SAMPLE_RATE, kind=1, key_slot=c))
+                carriers.append(make_carrier(off, SAMPLE_RATE, kind=1, key_slot=c, key_on_s=key_on_s))
         else:
-            carriers.append(make_carrier(off, SAMPLE_RATE, kind=0, key_slot=c))
+            carriers.append(make_carrier(off, SAMPLE_RATE, kind=0, key_slot=c, key_on_s=key_on_s))
         chans.append(cfg)
     return chans, carriers

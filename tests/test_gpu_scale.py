@@ -61,6 +61,13 @@ CASES = [
     pytest.param(4096, True, 16000, 32, False, True, "force_fft", id="4096_mixed_fft_wave64"),
     pytest.param(4099, True, 16000, 32, False, False, "f32", id="4099_mixed_SFMT_F32"),
     pytest.param(1030, True, 16000, 16, False, False, "f32_fft", id="1030_mixed_SFMT_F32_fft_wave64"),
+    # round 6: a fleet in which no two dongles share a channel plan (every device_t derives its own bins, src/config.cpp:666-667) -- 5 000 coefficient tables, the ones
+    # past the host builder's 4 096 built on the device -- stays on the matrix-core channelizer (it fell to the wavefront FFT past 4 096 plans)
+    pytest.param(5000, True, 16000, 40, False, False, "plans", id="5000_mixed_5000_distinct_plans"),
+    # round 6: stage 2 re-sorted at every batch boundary (AIRBAND_HIP_FLAG_REGROUP): same results, bit for bit
+    pytest.param(4096, True, 16000, 40, False, True, "regroup", id="4096_mixed_regrouped"),
+    pytest.param(1000, False, 8000, 24, False, False, "regroup", id="1000_am_regrouped_partial_block"),
+    pytest.param(65536, True, 16000, 48, False, False, "regroup", id="configs2_65536_mixed_regrouped"),
 ]
 
 
@@ -71,26 +78,37 @@ def test_sampled_dongles_of_large_handles(pkg, built, n_dev, mixed, wave_rate, k
     n_batches = 7
     chans, carriers = pkg.siggen.baseline_plan(mixed=mixed)
 
+    n_plans = n_dev if path == "plans" else 1
+    bin_hz = pkg.siggen.SAMPLE_RATE // 512
+
     def device(d):
         ch = [dict(c) for c in chans]
         if tweak:
             _tweak(d, ch)
+        if n_plans > 1:  # channel c of dongle d sits ((d >> 2c) & 3) bins above the BASELINE plan's, and so does its carrier (set_signal_plan_shift below)
+            for c, sh in zip(ch, pkg.siggen.plan_shift_bins(d, n_plans, len(ch))):
+                c["frequency"] += sh * bin_hz
         return dict(channels=ch, sfmt=pkg.capi.SFMT_F32) if path.startswith("f32") else dict(channels=ch)
 
     devices = [device(d) for d in range(n_dev)]
     flags = pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_PIPELINE if pipelined else 0) | (pkg.capi.FLAG_FORCE_FFT if path in ("force_fft", "f32_fft") else 0)
+    flags |= pkg.capi.FLAG_REGROUP if path == "regroup" else 0
     dongles = pyverify.sample_dongles(n_dev, k)
     hip = pkg.AirbandHip(devices, wave_rate=wave_rate, flags=flags)
     iq = spot = None
     try:
-        assert hip.channelizer_name() == {"": "dft_mfma_i8", "force_fft": "fft_wave64", "f32": "dft_mfma_f32", "f32_fft": "fft_wave64"}[path]
+        assert hip.channelizer_name() == {"": "dft_mfma_i8", "force_fft": "fft_wave64", "f32": "dft_mfma_f32", "f32_fft": "fft_wave64", "plans": "dft_mfma_i8", "regroup": "dft_mfma_i8"}[path]
+        assert hip.stage2_regrouped() == (path == "regroup") or "AIRBAND_HIP_REGROUP" in __import__("os").environ
         g = hip.geometry
         lead = g.first_batch_bytes - g.batch_bytes
         span = lead + (RING + 1) * g.batch_bytes + g.lookahead_bytes
         stride = (span + 255) // 256 * 256
         iq = _resident_iq(torch, n_dev * stride)[:n_dev * stride].view(n_dev, stride)
+        shift_step = pkg.siggen._turns(float(bin_hz), pkg.siggen.SAMPLE_RATE) if n_plans > 1 else 0
         if not path.startswith("f32"):
             hip.set_signal_plan(carriers)
+            if n_plans > 1:
+                hip.set_signal_plan_shift(n_plans, float(bin_hz), pkg.siggen.SAMPLE_RATE)
             hip.generate_iq(iq.data_ptr(), stride, 0, span, seed=0x5EED)
             hip.synchronize()
         else:  # the generator emits u8: a u8 handle generates slab by slab, (b - 127.5) / 127.5 makes CF32 of it (what bench.py --sample-format f32 does)
@@ -112,7 +130,7 @@ def test_sampled_dongles_of_large_handles(pkg, built, n_dev, mixed, wave_rate, k
         last = dongles[-1]
         assert last == n_dev - 1
         if not path.startswith("f32"):
-            assert np.array_equal(host[last][:65536], pkg.siggen.generate_u8(last, 0, 32768, carriers))
+            assert np.array_equal(host[last][:65536], pkg.siggen.generate_u8(last, 0, 32768, carriers, n_plans=n_plans, shift_step=shift_step))
 
         spot = pyverify.SpotCheck(device, dongles, wave_rate=wave_rate)
 
@@ -162,6 +180,8 @@ REPLICA_CASES = [
     # ~10^9 transforms through the wavefronts' LDS exchange in ONE process, every dongle bit-identical to dongle 0: the single-process twin of the rare event the
     # chunking fuzz saw with twelve processes on the GPU (profiles/r04_experiments.md I)
     pytest.param(65536, True, 16000, False, False, "force_fft", id="configs2_65536_mixed_fft_wave64"),
+    # round 6: regrouped stage 2 -- whichever wavefront a channel lands in from batch to batch, its results are dongle 0's
+    pytest.param(5000, True, 16000, True, False, "regroup", id="5000_mixed_tweaked_regrouped"),
 ]
 
 
@@ -176,6 +196,7 @@ def test_every_dongle_of_a_replicated_handle(pkg, built, n_dev, mixed, wave_rate
     devices, carriers = helpers.plan_devices(1, mixed, _tweak_all if tweak else None)
     one = devices[0]
     flags = pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_PIPELINE if pipelined else 0) | (pkg.capi.FLAG_FORCE_FFT if path == "force_fft" else 0)
+    flags |= pkg.capi.FLAG_REGROUP if path == "regroup" else 0
     hip = pkg.AirbandHip([one] * n_dev, wave_rate=wave_rate, flags=flags)
     iq = spot = None
     try:

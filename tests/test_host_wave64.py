@@ -38,7 +38,19 @@ def wave64(tmp_path_factory):
     lib.hostdemod_collect.restype = None
     lib.hostdemod_stats.argtypes = [vp, vp]
     lib.hostdemod_stats.restype = None
+    lib.hostdemod_moved_slots.argtypes = [vp]
     return lib
+
+
+@pytest.fixture(params=[False, True], ids=["slot_order", "regrouped"])
+def regroup(request, monkeypatch):
+    """Round 6: stage 2 with its slots re-sorted after every batch by the library's own regroup kernels (AIRBAND_HIP_FLAG_REGROUP on the GPU): which 64 channels
+    share a wavefront changes from batch to batch, the results must not."""
+    if request.param:
+        monkeypatch.setenv("AB_HOST_REGROUP", "1")
+    else:
+        monkeypatch.delenv("AB_HOST_REGROUP", raising=False)
+    return request.param
 
 
 def _tweak(d, ch):
@@ -58,7 +70,7 @@ def _tweak(d, ch):
 
 @pytest.mark.parametrize("style,n_dev,mixed,wave_rate,n_batches", [("keyed", 3, True, 16000, 6), ("long", 3, True, 16000, 16), ("bursty", 3, True, 16000, 4), ("keyed", 8, False, 8000, 3),
                                                                     ("keyed", 32, True, 16000, 2)])
-def test_all_kinds_with_wavefront_semantics(wave64, style, n_dev, mixed, wave_rate, n_batches):
+def test_all_kinds_with_wavefront_semantics(wave64, regroup, style, n_dev, mixed, wave_rate, n_batches):
     """3 dongles: partial blocks (lane-private stores).  8 AM dongles: one full 64-channel block (cooperative stores).  32 mixed dongles: full blocks of
     the AM, NFM + lowpass and NFM + CTCSS kinds -- cooperative stores in the fused kinds, the front's hand-off rows, the back kernel."""
     devices, carriers = helpers.plan_devices(n_dev, mixed, _tweak if mixed else None)
@@ -89,6 +101,8 @@ def test_all_kinds_with_wavefront_semantics(wave64, style, n_dev, mixed, wave_ra
             ww = np.concatenate([w["waveout"] for w in want])
             assert np.array_equal(wave.view(np.uint32), ww.view(np.uint32)), "batch %d: waveout (channels %s)" % (b, np.nonzero((wave.view(np.uint32) != ww.view(np.uint32)).any(axis=1))[0])
             tone_seen += int(((wt >> 5) & 1).sum())
+        if regroup and n_dev >= 3 and n_batches >= 3:
+            assert wave64.hostdemod_moved_slots(hd.h) > 0  # the slot order did move
         if mixed and style != "bursty":
             assert tone_seen > 0  # the CTCSS gate did open somewhere (the short bursts of the other style never fill a detector window)
         st = hd.stats()
@@ -186,7 +200,7 @@ def random_scenario(seed, max_dev=9):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("AIRBAND_FUZZ_SEEDS_WAVE64", "4"))))
-def test_random_plans_with_wavefront_semantics(wave64, seed):
+def test_random_plans_with_wavefront_semantics(wave64, regroup, seed):
     """Random plans over EVERY kind -- CTCSS on FM and AM channels, lowpass + CTCSS, raw-I/Q outputs, notch, manual squelch -- on made-up stage-1 output
     with awkward values, several dongles (so that a wavefront's lanes sit in different squelch states and blocks are partly filled): the kernels with
     their wavefront semantics against the oracle, bit for bit, squelch trace (tone bit included), axcindicate, audio."""
