@@ -407,7 +407,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libairband_hip has no CPU fallback")
-    if torch.cuda.device_count() < world:
+    # Rehearsal of the N > 1 body on a ONE-GPU box (tests/test_gpu_fabric.py): AIRBAND_BENCH_LOCAL_DEVICE puts every rank on that device and
+    # AIRBAND_BENCH_DIST_BACKEND=gloo carries the barrier / the max-over-ranks / rank 0's communicator id over gloo -- RCCL proper refuses two ranks on one GPU,
+    # so such a run also needs AIRBAND_HIP_RCCL_LIB (the library's exchange then goes through the named stand-in).  Neither variable is set on a real node.
+    one_gpu = os.environ.get("AIRBAND_BENCH_LOCAL_DEVICE")
+    backend = os.environ.get("AIRBAND_BENCH_DIST_BACKEND", "nccl")
+    if one_gpu is not None:
+        local_rank = int(one_gpu)
+    elif torch.cuda.device_count() < world:
         raise SystemExit("bench.py: --gpus %d but only %d GPUs visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
@@ -415,7 +422,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
             os.environ["MASTER_PORT"] = str(free_port())  # only reachable at world size 1 (--force-dist)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
@@ -536,7 +546,7 @@ def main():
     sync()
     total_steps = args.warmup + args.steps
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -591,6 +601,7 @@ def main():
                            sample_format=args.sample_format, iq_resident="HBM", ring_batches=args.ring, mixers=n_mixers, afc=args.afc, distinct_plans=n_plans, key_on_s=args.key_on_s, stage2_regrouped=hip.stage2_regrouped(),
                            schedule="pipelined: stage 1 of batch k beside stage 2 of batch k-1" if args.pipelined else "one batch at a time",
                            parallelism="dongle-sharded x%d, %s" % (world, "mixer sums all-reduced over RCCL by airband_hip_allreduce_mixers" if exchange else "no collective"),
+                           rehearsal=("every rank on GPU %s, torch.distributed over %s, librccl = %s" % (one_gpu, backend, os.environ.get("AIRBAND_HIP_RCCL_LIB", "librccl.so"))) if one_gpu is not None else None,
                            channelizer=name,
                            arithmetic="stage 1: u8 x 24-bit window*twiddle as 3 int8 digits -> exact int32 MFMA sums -> 3 f32 FMAs -> f32 bins; stage 2: f32, reference operation order"
                            if name == "dft_mfma_i8" else "stage 1: f32 samples x f32 window*twiddle on v_mfma_f32_16x16x4_f32 (f32 products and sums); stage 2: f32, reference operation order"

@@ -209,3 +209,34 @@ def test_three_ranks_one_thread_and_a_rank_without_a_batch(pkg, built, tmp_path)
     assert seen
     lines = [l for l in open(log).read().splitlines() if l.startswith("allreduce ")]
     assert len(lines) == 3 * 3 * N_BATCHES and all("nranks=3" in l for l in lines)
+
+
+@need_double
+@pytest.mark.timeout(600)
+def test_bench_with_two_ranks_on_one_gpu(tmp_path):
+    """The REAL `bench.py --gpus 2 --mixers 64` body, end to end, before the first multi-GPU node sees it (round-5 review, item 7): its own launcher
+    (torch.distributed.run, two ranks), the process group, `device_index_offset` = rank x dongles, the per-step exchange through airband_hip_allreduce_mixers,
+    the barrier + MAX-reduced elapsed time, ONE JSON line from rank 0.  Both ranks sit on GPU 0 (AIRBAND_BENCH_LOCAL_DEVICE), torch.distributed runs over gloo and the
+    library's exchange through the stand-in (RCCL proper refuses two ranks on one GPU) -- everything else is what the driver will run with --gpus 8."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    env.update(AIRBAND_HIP_RCCL_LIB=FAKE_RCCL, FAKE_RCCL_LOG=str(tmp_path / "fake_rccl.log"), AIRBAND_BENCH_LOCAL_DEVICE="0", AIRBAND_BENCH_DIST_BACKEND="gloo",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("AIRBAND_BENCH_SPAWNED", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--mixers", "64", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+           "--verify", "2"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=540, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert "x2" in out["config"]["parallelism"] and "RCCL" in out["config"]["parallelism"] and out["config"]["mixers"] == 64
+    # whole-job aggregate: both ranks' dongles (64 each) over the max-over-ranks time
+    per_step = 2 * 64 * 320000
+    assert out["value"] is not None and abs(out["value"] - per_step / (out["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * out["value"]
+    assert out["verified_dongles"] == 2, out.get("verify")
+    log = open(str(tmp_path / "fake_rccl.log")).read()
+    assert "nranks=2" in log  # the exchange did run between two ranks
