@@ -113,8 +113,7 @@ struct airband_hip_handle {
     int ct_first_block = 0, ct_n_blocks = 0, ct_pk_pitch = 0;
     /* AIRBAND_HIP_FLAG_REGROUP: the batch's slot order (demod.hip, "regrouping") */
     bool regroup = false;
-    DevBuf<int> d_perm, d_rg_count, d_rg_offset;
-    DevBuf<uint8_t> d_sq_key;
+    DevBuf<uint8_t> d_sq_key; /* split kinds: the front kernel's note for the back kernel (had audio in this batch) */
     DevBuf<uint8_t> d_trace;
     DevBuf<float> d_out_wave, d_out_iq;
     DevBuf<uint8_t> d_out_axc;
@@ -220,7 +219,7 @@ void destroy(airband_hip_handle* h) {
     h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release(); h->d_ct_af.release(); h->d_ct_mask.release();
     h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
     h->d_tmp_wavein.release(); h->d_tmp_iqin.release(); h->d_tmp_trace.release(); h->d_spectrum.release();
-    h->d_perm.release(); h->d_rg_count.release(); h->d_rg_offset.release(); h->d_sq_key.release();
+    h->d_sq_key.release();
     h->d_ftab.release(); h->d_item_dev.release(); h->d_item_group.release(); h->d_item_bset.release(); h->d_item_private.release(); h->d_item_home.release(); h->d_bfrag.release(); h->d_bcorr.release(); h->d_dft_partial.release(); h->d_bset_bin.release();
     if (h->h2d) (void)hipStreamSynchronize(h->h2d);
     h->d_stage2[0].release(); h->d_stage2[1].release();
@@ -383,23 +382,9 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.wave_batch = h->B;
     da.row0 = h->row0;
     da.ring_rows = h->R;
-    da.perm = h->regroup ? h->d_perm.p : nullptr;
+    da.regroup = h->regroup ? 1 : 0;
     da.sq_key = h->regroup ? h->d_sq_key.p : nullptr;
     launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
-    if (h->regroup) { /* the NEXT batch's slot order, from the squelch states this batch ended in (the kinds' streams have joined `s` again) */
-        RegroupArgs ra;
-        ra.cc = h->d_cc.p;
-        ra.sq_key = h->d_sq_key.p;
-        ra.perm = h->d_perm.p;
-        ra.block_count = h->d_rg_count.p;
-        ra.block_offset = h->d_rg_offset.p;
-        ra.n_blocks = h->n_slots / AB_SLOT_BLOCK;
-        for (int k = 0; k < AB_KIND_COUNT; k++) {
-            ra.kind_first_block[k] = h->kind_first_block[k];
-            ra.kind_n_blocks[k] = h->kind_n_blocks[k];
-        }
-        launch_regroup(ra, s);
-    }
     if (h->any_afc && h->afc_spectrum_valid) { /* afc.finalize(), src/rtl_airband.cpp:626-630: may turn '*' into '<' / '>' */
         if (h->use_dft) (void)hipStreamWaitEvent(s, h->ev_spec[1], 0); /* the last hop's spectrum, computed beside stage 1 */
         const int epoch = (int)(h->batches_done % 0x7fffffff) + 1; /* never 0: that is the start-up build's */
@@ -659,18 +644,12 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
                  AIRBAND_HIP_ENOMEM);
         PREP_TRY(h->d_ct_mask.alloc((size_t)h->ct_n_blocks * (h->B / 50) * AB_SLOT_BLOCK), AIRBAND_HIP_ENOMEM);
     }
-    {   /* regrouped stage 2: the first batch runs in slot order (every squelch starts CLOSED) */
+    {   /* regrouped stage 2 (demod.hip, "regrouping") */
         const char* e = getenv("AIRBAND_HIP_REGROUP");
         h->regroup = e && *e ? (*e != '0') : (h->flags & AIRBAND_HIP_FLAG_REGROUP) != 0;
         if (h->regroup) {
-            std::vector<int> ident((size_t)h->n_slots);
-            for (int i = 0; i < h->n_slots; i++) ident[(size_t)i] = i;
-            PREP_TRY(upload(h->d_perm, ident), AIRBAND_HIP_ENOMEM);
             PREP_TRY(h->d_sq_key.alloc((size_t)h->n_slots), AIRBAND_HIP_ENOMEM);
             PREP_TRY(hipMemset(h->d_sq_key.p, 0, (size_t)h->n_slots), AIRBAND_HIP_ENOMEM);
-            const size_t nb = (size_t)h->n_slots / AB_SLOT_BLOCK;
-            PREP_TRY(h->d_rg_count.alloc(2 * nb), AIRBAND_HIP_ENOMEM);
-            PREP_TRY(h->d_rg_offset.alloc(2 * nb + 2 * AB_KIND_COUNT), AIRBAND_HIP_ENOMEM);
         }
     }
     if (h->flags & AIRBAND_HIP_FLAG_TRACE_SQUELCH) {

@@ -258,10 +258,12 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
     typedef __attribute__((address_space(3))) void* lptr_t;
     /* Cache policy of the transfers (the instruction's aux field; 2 = nt, non-temporal).  A staging step's FIRST piece holds the window overlap the previous step
      * fetched (its last piece: the same 1 KiB at hops of 320 bytes) and its LAST piece is what the next step fetches again -- those two are re-read from L2 and keep
-     * the default policy; the pieces in between are read exactly once by exactly one CU, which is what MI355X_MICROARCH.md's "nt-weights" / "ldsdma-fill" rows
-     * measure nt on (6.4 -> 6.5 - 6.8 TB/s chip-wide, issued -> landed -18 %).  Round 6 A/B: profiles/r06_experiments.md A. */
+     * the default policy; the pieces in between are read exactly once by exactly one CU and go out nt (MI355X_MICROARCH.md "nt-weights" / "ldsdma-fill": read-once
+     * LDS-DMA streams 6.4 -> 6.5 - 6.8 TB/s chip-wide).  Round 6, interleaved on three boxes (profiles/r06_experiments.md A, profiles/r06_nt/): hops of 640 bytes
+     * (nine of eleven pieces read once) 7.82 -> 7.33 ms per launch on every box; hops of 320 bytes (four of six) -5 %, -3 % and +1 %; EVERY piece nt: +13 % (the
+     * overlap is then fetched from memory twice); nt on the first piece as well, nt + sc0, nt + sc1: the same as nt; sc1 / sc0 sc1 alone: nothing. */
 #ifndef AB_DMA_NT_AUX
-#define AB_DMA_NT_AUX 0 /* interior (read-once) pieces of the hop-specialised variants */
+#define AB_DMA_NT_AUX 2 /* interior (read-once) pieces of the hop-specialised variants */
 #endif
 #ifndef AB_DMA_EDGE_AUX
 #define AB_DMA_EDGE_AUX 0 /* first and last piece of a step (the L2-hit overlap), and every piece of the run-time-hop variants */

@@ -253,7 +253,7 @@ struct KindBits {
                                                                     : 0u;
 };
 
-template <int KIND, bool WAVE_HAS_CTCSS>
+template <int KIND, bool WAVE_HAS_CTCSS, int W>
 __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, ChanState* sp, int slot, const float2* lut, float* ostage, const int* ext_of, int* skip_of, const int* slot_of,
                                            bool full_block) {
     const int lane = threadIdx.x & 63;
@@ -326,6 +326,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     wrow.wave_stride = a.wave_stride;
     wrow.coop = full_block;
     wrow.skip_of = skip_of;
+    lmask audio_seen = 0; /* split kinds of regrouped handles: lanes whose squelch let audio through somewhere in this batch (a scalar register pair: no vector work) */
     RowZero rz = {sp->row_zero, false, false};
     float2* iqout = a.iq_out + ab_ring_base(slot, B);
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
@@ -573,6 +574,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             }
         }
 #endif
+        if (WAVE_HAS_CTCSS && W > 1) audio_seen |= Q ? s.cO : sq_should_audio(s);
         const bool audio = ab_lane(Q ? s.cO : sq_should_audio(s));
         if (audio) {
             if (!nfm) { /* AM: src/rtl_airband.cpp:553-563 */
@@ -641,6 +643,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     const bool wave_has_notch = ab_any(ab_ballot((cc.flags & AB_F_NOTCH) != 0));
     const bool wave_has_iq_out = ab_any(ab_ballot((cc.flags & AB_F_IQ_OUT) != 0));
     auto stable_tail4 = [&](const int jq, const float* mcs, const float* mds, const float* qr, const float* qi) {
+        if (WAVE_HAS_CTCSS && W > 1) audio_seen |= sq_should_audio(s);
         const bool open = ab_lane(sq_should_audio(s)); /* Squelch::should_process_audio() == is_open() (no tone gate in these kinds), the same lanes for the four samples */
         /* Squelch::should_filter_sample() for the four samples: a CLOSED lane with signal would have ended the stable spell, so it is every lane that is not CLOSED or aborting */
         const bool filt = ab_lane(~s.cC & ~s.cA & s.active);
@@ -809,6 +812,10 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
      * first use of a group, which is right after the NEXT group's loads were issued.  The pair after the last one re-reads the
      * batch's last group instead (never used). */
     for (int j0 = 0; j0 < B; j0 += 2 * GS) {
+        /* regrouped handles: the workgroup's wavefronts walk the batch in step (every wavefront runs the same number of iterations; one whose lanes have all left is
+         * not waited for), so that a ring line two of them read is in L2 for the second -- a wavefront of closed channels runs ~3x faster than one of open ones.
+         * A waiting wavefront costs no issue slot, which is what stage 2 is short of. */
+        if (W > 1) __syncthreads();
         fetch(qb, j0 + GS, tail_in(GS)); /* flies under this group's samples */
         group(qa, j0);
         touch(qb);
@@ -833,8 +840,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     if (KIND == AB_KIND_NFM_LOWPASS) { sp->sh_nf = sh.nf; sp->sh_cap = sh.cap; sp->sh_capped = sh.capped; sp->sh_dly = s.dly; }
     if (KIND == AB_KIND_GENERIC) sp->sh_dly = sq_delayed(s, L); /* buffer_[buffer_tail_] for the stats mirror (signal_outside_filter); this kind keeps the delay line in memory */
     sq_store(s, L, sp, B);
-    /* regrouped handles: is this channel's squelch at rest in CLOSED?  (the next batch's slot order puts the others first: regroup kernels below) */
-    if (a.sq_key) a.sq_key[slot] = ab_lane(s.cC & s.nC) ? 0 : 1;
+    if (WAVE_HAS_CTCSS && W > 1) a.sq_key[slot] = ab_lane(audio_seen) ? 1 : 0; /* the back kernel deals its slots out by it */
     sp->lxr[1] = lxr1; sp->lxr[2] = lxr2; sp->lxi[1] = lxi1; sp->lxi[2] = lxi2;
     sp->lyr[1] = lyr1; sp->lyr[2] = lyr2; sp->lyi[1] = lyi1; sp->lyi[2] = lyi2;
 }
@@ -848,37 +854,100 @@ constexpr int TONE_GROUP = 50; /* samples per tone-kernel step; divides WAVE_BAT
  * CTCSS-capable kinds are split in three: this "front" (squelch + discriminator -> audio, flags), the tone kernel
  * (Goertzel banks, one wavefront per channel) and the back kernel (gate, notch, output). */
 constexpr int AB_DEMOD_WAVES = 3, AB_AM_WAVES = 4, AB_FRONT_WAVES = 3; /* (the front at four waves: 128 VGPRs with 18 of them spilled once it carries the quiet-group path -- 6.30 ms of stage 2 against 6.20 at three) */
-template <int KIND, bool WAVE_HAS_CTCSS>
-__device__ __forceinline__ void demod_block(const DemodArgs& a, int block, float* lds_demod) {
-    /* the lane's channel: slot = wavefront position, or what the batch's slot order says (DemodArgs::perm); padding slots carry flags == 0 */
-    const int pos = block * 64 + threadIdx.x;
-    const int slot = a.perm ? a.perm[pos] : pos;
-    const ChanConst cc = a.cc[slot];
+
+/* ---- regrouping (AIRBAND_HIP_FLAG_REGROUP): closed channels share wavefronts -----------------------------------------------------------------------
+ * Slots are assigned by demod KIND when a handle is prepared, and a wavefront works on 64 consecutive slots: at any time about half of its lanes (on the
+ * BASELINE signal; nine in ten on a real band) are channels whose squelch is closed, and they ride through the open lanes' instructions under an exec mask --
+ * ~180 of the NFM + lowpass kind's ~240 vector instructions per sample, ~35 of the AM kind's ~60.  Stage 2 is bound by vector issue (DESIGN.md 4.2), so those are
+ * paid in full; a wavefront whose lanes are ALL closed skips them.  Everything a lane touches is addressed by its slot, so which 64 slots a wavefront works on is
+ * free.  Round 6 first re-sorted every kind's slots GLOBALLY at batch boundaries: 30 % fewer vector instructions as predicted -- and a slower stage, because the
+ * slots that share a 128-byte line of the stage-1 rings (four AM / two NFM neighbours) then sat in different wavefronts that read the line milliseconds apart, once
+ * each from memory (+40 ... +90 % ring fetches, profiles/r06_regroup_global/).  Hence this form: a WORKGROUP of AB_REGROUP_WAVES wavefronts owns that many x 64
+ * consecutive slots, deals them out among its wavefronts (stable partition: channels not at rest in CLOSED, then the closed ones, then slots without a channel),
+ * and the wavefronts walk the batch in step (demod_wave: a barrier every eight samples): whatever line two of them share, the second reader finds it in L2.  The
+ * closed wavefronts wait at the barriers -- without using an issue slot.  Results are the same bit for bit: same operations on the same values, lane for lane. */
+constexpr int AB_REGROUP_WAVES = 4;
+constexpr int WAVE_LDS_FLOATS = RUN * OSTRIDE + 3 * 64; /* a wavefront's own LDS: the output-line staging area, ext_of / skip_of / slot_of */
+
+/* key: 0 = channel with work, 1 = channel at rest, 2 = slot without a channel, 3 = wavefront beyond the kind's last block (no slot at all).  Returns the slot this
+ * lane works on (-1: none).  slot_at [W * 64], wcnt [W][2]: LDS of the workgroup. */
+template <int W>
+__device__ __forceinline__ int wg_regroup(int key, int wave, int lane, int home, int nb, int* slot_at, int* wcnt) {
+    const lmask m0 = __ballot(key == 0), m1 = __ballot(key == 1), m2 = __ballot(key == 2);
+    if (lane == 0) {
+        wcnt[2 * wave] = __builtin_popcountll(m0);
+        wcnt[2 * wave + 1] = __builtin_popcountll(m1);
+    }
+    __syncthreads();
+    int tot0 = 0, tot1 = 0, off0 = 0, off1 = 0;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const int c0 = wcnt[2 * w], c1 = wcnt[2 * w + 1];
+        tot0 += c0;
+        tot1 += c1;
+        off0 += w < wave ? c0 : 0;
+        off1 += w < wave ? c1 : 0;
+    }
+    const lmask below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int at = key == 0   ? off0 + __builtin_popcountll(m0 & below)
+                   : key == 1 ? tot0 + off1 + __builtin_popcountll(m1 & below)
+                   : key == 2 ? tot0 + tot1 + (wave * 64 - off0 - off1) + __builtin_popcountll(m2 & below) /* (the earlier wavefronts' slots without a channel) */
+                              : -1;
+    if (at >= 0) slot_at[at] = home;
+    __syncthreads();
+    const int p = wave * 64 + lane;
+    return p < nb * 64 ? slot_at[p] : -1;
+}
+
+template <int KIND, bool WAVE_HAS_CTCSS, int W>
+__device__ __forceinline__ void demod_block(const DemodArgs& a, int first_block, int n_blocks, float* lds_demod) {
+    const int lane = threadIdx.x & 63;
+    const int wave = W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0; /* (the same number on every lane: scalar) */
     /* the (sin, cos) table of sincosf_lut (src/util.cpp:105-127), 257 float2 -- a sample's
      * derotation then costs one LDS read instead of four dependent trips to L2 on the serial path */
     float2* lut = reinterpret_cast<float2*>(lds_demod);
     if (KIND != AB_KIND_AM) {
-        for (int i = threadIdx.x; i < 257; i += 64) lut[i] = make_float2(a.sin_lut[i], a.cos_lut[i]);
-        __syncthreads(); /* one wavefront per block: orders the table writes before any lane's reads */
+        for (int i = threadIdx.x; i < 257; i += 64 * W) lut[i] = make_float2(a.sin_lut[i], a.cos_lut[i]);
+        if (W == 1) __syncthreads(); /* one wavefront per block: orders the table writes before any lane's reads (regrouped: the barriers of wg_regroup do) */
     }
-    float* ostage = reinterpret_cast<float*>(lut + (KIND == AB_KIND_AM ? 0 : 258));
+    float* areas = reinterpret_cast<float*>(lut + (KIND == AB_KIND_AM ? 0 : 258));
+    float* ostage = areas + wave * WAVE_LDS_FLOATS;
     int* ext_of = reinterpret_cast<int*>(ostage + RUN * OSTRIDE);
     int* skip_of = ext_of + 64;
     int* slot_of = skip_of + 64;
-    ext_of[threadIdx.x] = a.slot_to_ext[slot];
-    slot_of[threadIdx.x] = slot;
+    int slot; /* padding slots carry flags == 0 */
+    if (W == 1) {
+        slot = (first_block + blockIdx.x) * 64 + lane;
+    } else {
+        int* slot_at = reinterpret_cast<int*>(areas + W * WAVE_LDS_FLOATS);
+        int* wcnt = slot_at + W * 64;
+        const int block0 = first_block + blockIdx.x * W;
+        const int left = first_block + n_blocks - block0, nb = left < W ? left : W; /* the kind's last workgroup may own fewer blocks */
+        const int home = (block0 + wave) * 64 + lane;
+        int key = 3;
+        if (wave < nb) {
+            const ChanState* hp = a.cs + home;
+            key = !(a.cc[home].flags & AB_F_VALID) ? 2 : (hp->cur != AB_ST_CLOSED || hp->next != AB_ST_CLOSED) ? 0 : 1;
+        }
+        slot = wg_regroup<W>(key, wave, lane, home, nb, slot_at, wcnt);
+        if (slot < 0) return; /* whole wavefronts only (wave-uniform), behind the workgroup's set-up barriers */
+    }
+    const ChanConst cc = a.cc[slot];
+    ext_of[lane] = a.slot_to_ext[slot];
+    slot_of[lane] = slot;
     const bool full_block = __ballot((cc.flags & AB_F_VALID) != 0) == ~0ull; /* padding lanes leave early and cannot take part in a cooperative store */
-    __syncthreads();
-    demod_wave<KIND, WAVE_HAS_CTCSS>(a, cc, a.cs + slot, slot, lut, ostage, ext_of, skip_of, slot_of, full_block);
+    if (W == 1) __syncthreads();
+    else AB_LOCKSTEP_FENCED(); /* the tables are the wavefront's own */
+    demod_wave<KIND, WAVE_HAS_CTCSS, W>(a, cc, a.cs + slot, slot, lut, ostage, ext_of, skip_of, slot_of, full_block);
 }
 
-template <int KIND, bool WAVE_HAS_CTCSS>
 /* wavefronts per SIMD the register allocation is held to.  A lane-per-channel wavefront advances at about one instruction per
  * eight cycles whatever shares its SIMD (VALU -> SGPR -> SALU -> VALU hops of the lane-mask state machine), so throughput
  * rises with residency until the vector pipe saturates: the AM kind, light on registers, is built for four (2.12 -> 1.63 ms alone). */
-__global__ __launch_bounds__(64, KIND == AB_KIND_AM ? AB_AM_WAVES : KIND == AB_KIND_NFM_CTCSS ? AB_FRONT_WAVES : AB_DEMOD_WAVES) void demod_kernel(DemodArgs a, int first_block) {
+template <int KIND, bool WAVE_HAS_CTCSS, int W>
+__global__ __launch_bounds__(64 * W, KIND == AB_KIND_AM ? AB_AM_WAVES : KIND == AB_KIND_NFM_CTCSS ? AB_FRONT_WAVES : AB_DEMOD_WAVES) void demod_kernel(DemodArgs a, int first_block, int n_blocks) {
     AB_DYNAMIC_LDS(float, lds_demod);
-    demod_block<KIND, WAVE_HAS_CTCSS>(a, first_block + blockIdx.x, lds_demod);
+    demod_block<KIND, WAVE_HAS_CTCSS, W>(a, first_block, n_blocks, lds_demod);
 }
 
 /* CTCSS tone detection (reference: src/ctcss.cpp, driven by Squelch::process_audio_sample src/squelch.cpp:278-295).
@@ -920,9 +989,16 @@ __global__ __launch_bounds__(256) AB_TONE_RESIDENCY void tone_kernel(DemodArgs a
     /* tone tables: [ct_slot][detector][tone] coefficients, [ct_slot][detector][q1|q2][tone] state */
     const float* ctab = a.ct_coeff + (long)cc.ct_slot * 2 * AB_MAX_TONES;
     float* qtab = a.ct_q + (long)cc.ct_slot * 4 * AB_MAX_TONES;
-    const bool t0 = lane < n0, t1 = lane < n1;
-    const float c0 = t0 ? ctab[lane] : 0.0f, c1 = t1 ? ctab[AB_MAX_TONES + lane] : 0.0f;
-    float q1f = t0 ? qtab[lane] : 0.0f, q2f = t0 ? qtab[AB_MAX_TONES + lane] : 0.0f;
+    /* MERGED (round 6): the fast detector's window is an eighth of the slow one's, its tones fall on an eighth as many distinct Goertzel bins (11 against 49 for the
+     * standard tone set at 16 kHz), and 11 + 49 <= 64: where both banks fit the wavefront side by side -- slow tone i on lane i, fast tone i on lane n1 + i -- the
+     * steady state runs ONE three-operation recurrence per sample for both detectors instead of two.  Both detectors run for the first 0.4 s of a transmission: a
+     * third of the kernel's vector instructions on the BASELINE signal.  Otherwise (wave-uniform) lane i holds tone i of both banks as before. */
+    const bool merged = n0 + n1 <= 64;
+    const int fi = merged ? lane - n1 : lane; /* the fast tone this lane holds, if any */
+    const bool t0 = fi >= 0 && fi < n0, t1 = lane < n1;
+    const int fbase = merged ? n1 : 0;       /* lane of fast tone 0 */
+    const float c0 = t0 ? ctab[fi] : 0.0f, c1 = t1 ? ctab[AB_MAX_TONES + lane] : 0.0f;
+    float q1f = t0 ? qtab[fi] : 0.0f, q2f = t0 ? qtab[AB_MAX_TONES + fi] : 0.0f;
     float q1s = t1 ? qtab[2 * AB_MAX_TONES + lane] : 0.0f, q2s = t1 ? qtab[3 * AB_MAX_TONES + lane] : 0.0f;
 
     const long blk = (wave >> 6) + (first_block - a.ct_first_block); /* verdict masks: one table over both split kinds */
@@ -1016,6 +1092,31 @@ __global__ __launch_bounds__(256) AB_TONE_RESIDENCY void tone_kernel(DemodArgs a
                     q2s = q1s;
                     q1s = q0;
                 }
+            } else if (merged) { /* both detectors, side by side in the lanes: one recurrence (a lane without a tone computes on zeros and is never stored) */
+                const float cm = t1 ? c1 : c0;
+                float q1m = t1 ? q1s : q1f, q2m = t1 ? q2s : q2f;
+#pragma unroll 2
+                for (int u4 = 0; u4 < TONE_GROUP / 4; u4++) {
+                    const float4 nxt = xs4[u4 + 1];
+                    const float x4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float q0 = cm * q1m - q2m + x4[r];
+                        q2m = q1m;
+                        q1m = q0;
+                    }
+                    v = nxt;
+                }
+                const float x2[2] = {v.x, v.y};
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const float q0 = cm * q1m - q2m + x2[r];
+                    q2m = q1m;
+                    q1m = q0;
+                }
+                q1s = t1 ? q1m : q1s; q2s = t1 ? q2m : q2s;
+                q1f = t1 ? q1f : q1m; q2f = t1 ? q2f : q2m;
+                count0 += TONE_GROUP;
             } else { /* the fast detector runs until the slow one has a full window (src/squelch.cpp:288-293) */
 #pragma unroll 2
                 for (int u4 = 0; u4 < TONE_GROUP / 4; u4++) {
@@ -1071,12 +1172,13 @@ __global__ __launch_bounds__(256) AB_TONE_RESIDENCY void tone_kernel(DemodArgs a
                             scratch[lane] = q1 * q1 + q2 * q2 - q1 * q2 * co;
                             AB_LOCKSTEP(); /* every tone's power is in LDS (the readfirstlane below keeps the next window's writes behind these reads) */
                             float total = 0.0f, best = 0.0f;
+                            const int base = k ? 0 : fbase; /* lane of this bank's tone 0 */
                             for (int i = 0; i < n; i++) { /* index-order float sum, as ToneDetectorSet::sorted_powers does */
-                                const float m = scratch[i];
+                                const float m = scratch[base + i];
                                 total += m;
                                 if (i == 0 || m > best) best = m;
                             }
-                            const float target = scratch[0];
+                            const float target = scratch[base];
                             const float avg = total / (float)n;
                             const bool present = __builtin_amdgcn_readfirstlane((int)(target == best && target > avg)) != 0;
                             if (k) { enough1 = 1; has1 = present; if (present) found1++; else nf1++; }
@@ -1112,7 +1214,7 @@ __global__ __launch_bounds__(256) AB_TONE_RESIDENCY void tone_kernel(DemodArgs a
 #pragma unroll
         for (int k = 0; k < DEPTH; k++) maskp[(long)(NG - DEPTH + k) * AB_SLOT_BLOCK] = verdict[k];
     }
-    if (t0) { qtab[lane] = q1f; qtab[AB_MAX_TONES + lane] = q2f; }
+    if (t0) { qtab[fi] = q1f; qtab[AB_MAX_TONES + fi] = q2f; }
     if (t1) { qtab[2 * AB_MAX_TONES + lane] = q1s; qtab[3 * AB_MAX_TONES + lane] = q2s; }
     if (lane == 0) {
         sp->ct_enough[0] = enough0; sp->ct_enough[1] = enough1; sp->ct_count[0] = count0; sp->ct_count[1] = count1;
@@ -1123,18 +1225,35 @@ __global__ __launch_bounds__(256) AB_TONE_RESIDENCY void tone_kernel(DemodArgs a
 
 /* Back half of the split kinds: output gating (squelch open AND tone present), notch, ampfactor, clamp, AM fade-out
  * (reference: src/rtl_airband.cpp:532-547,589-620), one lane per channel, finished output runs of 32 samples staged through LDS and stored as whole lines. */
-template <bool PACKED>
-__global__ __launch_bounds__(64) void back_kernel(DemodArgs a, int first_block) {
-    __shared__ float staged[RUN][OSTRIDE];
-    __shared__ int ext_of[64];
-    __shared__ int skip_of[64];
-    const int lane = threadIdx.x;
-    const int pos = (first_block + blockIdx.x) * 64 + lane;
-    const int slot = a.perm ? a.perm[pos] : pos; /* regrouped handles: the batch's slot order (DemodArgs::perm) */
+template <bool PACKED, int W>
+__global__ __launch_bounds__(64 * W) void back_kernel(DemodArgs a, int first_block, int n_blocks) {
+    __shared__ float staged_all[W][RUN][OSTRIDE];
+    __shared__ int ext_of_all[W][64];
+    __shared__ int skip_of_all[W][64];
+    __shared__ int slot_at[W * 64];
+    __shared__ int wcnt[W * 2];
+    const int lane = threadIdx.x & 63;
+    const int wave = W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    float (*staged)[OSTRIDE] = staged_all[wave];
+    int* ext_of = ext_of_all[wave];
+    int* skip_of = skip_of_all[wave];
+    int slot;
+    if (W == 1) {
+        slot = (first_block + blockIdx.x) * 64 + lane;
+    } else { /* regrouped handles (demod_block): the channels that had audio in this batch -- the front kernel's note -- to the first wavefronts */
+        const int block0 = first_block + blockIdx.x * W;
+        const int left = first_block + n_blocks - block0, nb = left < W ? left : W;
+        const int home = (block0 + wave) * 64 + lane;
+        int key = 3;
+        if (wave < nb) key = !(a.cc[home].flags & AB_F_VALID) ? 2 : a.sq_key[home] ? 0 : 1;
+        slot = wg_regroup<W>(key, wave, lane, home, nb, slot_at, wcnt);
+        if (slot < 0) return;
+    }
     const ChanConst cc = a.cc[slot];
     ext_of[lane] = a.slot_to_ext[slot];
     const bool full_block = __ballot((cc.flags & AB_F_VALID) != 0) == ~0ull;
-    __syncthreads();
+    if (W == 1) __syncthreads();
+    else AB_LOCKSTEP_FENCED();
     if (!(cc.flags & AB_F_VALID)) return;
     ChanState* sp = a.cs + slot;
     const int B = a.wave_batch, NG = B / TONE_GROUP;
@@ -1182,6 +1301,7 @@ __global__ __launch_bounds__(64) void back_kernel(DemodArgs a, int first_block) 
     fetch(0);
     int jg = 0; /* position of the current sample in its tone-kernel step */
     for (int j0 = 0; j0 < B; j0 += PIECE) {
+        if (W > 1) __syncthreads(); /* regrouped handles: the workgroup's wavefronts walk the batch in step (demod_wave) */
 #pragma unroll
         for (int q = 0; q < NQ; q++) AB_NEEDED_NOW(AB_V(nxt[q].x), AB_V(nxt[q].y), AB_V(nxt[q].z), AB_V(nxt[q].w));
         AB_NEEDED_NOW(AB_V(nm_lo), AB_V(nm_hi));
@@ -1240,20 +1360,27 @@ static int tone_threads() {
 }
 
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev) {
-    auto lds_of = [](int k) { /* sincos table, output-line staging, ext_of */
-        return (size_t)(k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)RUN * OSTRIDE * sizeof(float) + 3 * 64 * sizeof(int); /* ext_of, skip_of, slot_of */
+    constexpr int RW = AB_REGROUP_WAVES;
+    const bool rg = a.regroup != 0;
+    auto lds_of = [&](int k) { /* sincos table; per wavefront: output-line staging, ext_of, skip_of, slot_of; regrouped: the workgroup's slot table and counts */
+        return (size_t)(k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)(rg ? RW : 1) * WAVE_LDS_FLOATS * sizeof(float) + (rg ? (size_t)(RW * 64 + 2 * RW) * sizeof(int) : 0);
     };
     auto launch_kind = [&](int k, hipStream_t s) {
         const size_t lds = lds_of(k);
         const int n = kind_n_blocks[k], f = kind_first_block[k];
         if (n <= 0) return;
+        const dim3 grid(rg ? (n + RW - 1) / RW : n), block(rg ? 64 * RW : 64);
+#define AB_LAUNCH_KIND(KIND, CT)                                                                     \
+    if (rg) hipLaunchKernelGGL((demod_kernel<KIND, CT, RW>), grid, block, lds, s, a, f, n);          \
+    else hipLaunchKernelGGL((demod_kernel<KIND, CT, 1>), grid, block, lds, s, a, f, n)
         switch (k) {
-            case AB_KIND_AM: hipLaunchKernelGGL((demod_kernel<AB_KIND_AM, false>), dim3(n), dim3(64), lds, s, a, f); break;
-            case AB_KIND_NFM: hipLaunchKernelGGL((demod_kernel<AB_KIND_NFM, false>), dim3(n), dim3(64), lds, s, a, f); break;
-            case AB_KIND_NFM_LOWPASS: hipLaunchKernelGGL((demod_kernel<AB_KIND_NFM_LOWPASS, false>), dim3(n), dim3(64), lds, s, a, f); break;
-            case AB_KIND_NFM_CTCSS: hipLaunchKernelGGL((demod_kernel<AB_KIND_NFM_CTCSS, true>), dim3(n), dim3(64), lds, s, a, f); break;
-            default: hipLaunchKernelGGL((demod_kernel<AB_KIND_GENERIC, true>), dim3(n), dim3(64), lds, s, a, f); break;
+            case AB_KIND_AM: AB_LAUNCH_KIND(AB_KIND_AM, false); break;
+            case AB_KIND_NFM: AB_LAUNCH_KIND(AB_KIND_NFM, false); break;
+            case AB_KIND_NFM_LOWPASS: AB_LAUNCH_KIND(AB_KIND_NFM_LOWPASS, false); break;
+            case AB_KIND_NFM_CTCSS: AB_LAUNCH_KIND(AB_KIND_NFM_CTCSS, true); break;
+            default: AB_LAUNCH_KIND(AB_KIND_GENERIC, true); break;
         }
+#undef AB_LAUNCH_KIND
     };
     const bool fork = side != nullptr && ev != nullptr;
     const int fused[3] = {AB_KIND_NFM_LOWPASS, AB_KIND_NFM, AB_KIND_AM};
@@ -1268,8 +1395,14 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
     const int tt = tone_threads();
     if (a.ct_pk_n_blocks > 0) hipLaunchKernelGGL(tone_kernel<true>, dim3((a.ct_pk_n_blocks * 64 * 64 + tt - 1) / tt), dim3(tt), 0, stream, a, a.ct_pk_first_block, a.ct_pk_n_blocks);
     if (a.ct_gen_n_blocks > 0) hipLaunchKernelGGL(tone_kernel<false>, dim3((a.ct_gen_n_blocks * 64 * 64 + tt - 1) / tt), dim3(tt), 0, stream, a, a.ct_gen_first_block, a.ct_gen_n_blocks);
-    if (a.ct_pk_n_blocks > 0) hipLaunchKernelGGL(back_kernel<true>, dim3(a.ct_pk_n_blocks), dim3(64), 0, stream, a, a.ct_pk_first_block);
-    if (a.ct_gen_n_blocks > 0) hipLaunchKernelGGL(back_kernel<false>, dim3(a.ct_gen_n_blocks), dim3(64), 0, stream, a, a.ct_gen_first_block);
+    if (a.ct_pk_n_blocks > 0) {
+        if (rg) hipLaunchKernelGGL((back_kernel<true, RW>), dim3((a.ct_pk_n_blocks + RW - 1) / RW), dim3(64 * RW), 0, stream, a, a.ct_pk_first_block, a.ct_pk_n_blocks);
+        else hipLaunchKernelGGL((back_kernel<true, 1>), dim3(a.ct_pk_n_blocks), dim3(64), 0, stream, a, a.ct_pk_first_block, a.ct_pk_n_blocks);
+    }
+    if (a.ct_gen_n_blocks > 0) {
+        if (rg) hipLaunchKernelGGL((back_kernel<false, RW>), dim3((a.ct_gen_n_blocks + RW - 1) / RW), dim3(64 * RW), 0, stream, a, a.ct_gen_first_block, a.ct_gen_n_blocks);
+        else hipLaunchKernelGGL((back_kernel<false, 1>), dim3(a.ct_gen_n_blocks), dim3(64), 0, stream, a, a.ct_gen_first_block, a.ct_gen_n_blocks);
+    }
     /* the fused kinds as forked launches (one kernel per kind keeps each kind's own register budget: the AM kind runs four waves per
      * SIMD, the heavier ones three; a single launch with host-interleaved blocks was measured equal at best, 7.8 vs 7.7 ms);
      * without side streams (AIRBAND_HIP_FLAG_SERIAL_DEMOD, profiling) one after the other */
@@ -1288,101 +1421,6 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
             (void)hipStreamWaitEvent(stream, ev[1 + i], 0);
         }
     }
-}
-
-/* ---- regrouping (AIRBAND_HIP_FLAG_REGROUP): closed channels share wavefronts -----------------------------------------------------
- * Slots are assigned by demod KIND when a handle is prepared, and a wavefront works on 64 consecutive slots: at any time about half of its lanes (on the
- * BASELINE signal; nine in ten on a real band) are channels whose squelch is closed, and they ride through the open lanes' instructions under an exec mask --
- * ~180 of the NFM + lowpass kind's ~240 vector instructions per sample, ~35 of the AM kind's ~60.  Stage 2 is bound by vector issue (DESIGN.md 4.2), so those are
- * paid in full.  A wavefront whose lanes are ALL closed skips them (the exec-masked regions are branched over when no lane takes them).
- * Everything a lane touches is addressed by its slot, so WHICH 64 slots a wavefront works on is free: at the end of a batch every lane leaves one byte -- is my
- * squelch at rest in CLOSED? (DemodArgs::sq_key) -- and three small kernels turn the bytes into the next batch's slot order, a STABLE partition inside each kind's
- * block range: active channels first, closed ones behind them, slots without a channel last.  Stable, so that slots sharing a 128-byte line of the stage-1 rings
- * (four AM / two NFM neighbours) stay neighbours inside their wavefront whenever they are in the same state.  The price is the rings' lines: where neighbours are
- * in DIFFERENT states their line is fetched by two wavefronts instead of one (profiles/r06_experiments.md B sizes it).  Results do not depend on the order -- same
- * operations on the same values, lane for lane. */
-namespace {
-__device__ __forceinline__ int regroup_key(const RegroupArgs& a, int slot) {
-    if (!(a.cc[slot].flags & AB_F_VALID)) return 2;
-    return a.sq_key[slot] ? 0 : 1;
-}
-__device__ __forceinline__ int regroup_kind_of(const RegroupArgs& a, int block) {
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < AB_KIND_COUNT; i++)
-        if (a.kind_n_blocks[i] > 0 && block >= a.kind_first_block[i] && block < a.kind_first_block[i] + a.kind_n_blocks[i]) k = i;
-    return k;
-}
-}  // namespace
-
-__global__ __launch_bounds__(64) void regroup_count_kernel(RegroupArgs a) {
-    const int block = blockIdx.x, lane = threadIdx.x;
-    const int key = regroup_key(a, block * 64 + lane);
-    const unsigned long long m0 = __ballot(key == 0), m1 = __ballot(key == 1);
-    if (lane == 0) {
-        a.block_count[2 * block] = __builtin_popcountll(m0);
-        a.block_count[2 * block + 1] = __builtin_popcountll(m1);
-    }
-}
-
-/* one workgroup per kind: exclusive sums of the per-block counts over the kind's blocks, and the kind's totals */
-__global__ __launch_bounds__(256) void regroup_scan_kernel(RegroupArgs a) {
-    __shared__ int part[256][2];
-    const int k = blockIdx.x, tid = threadIdx.x;
-    const int first = a.kind_first_block[k], n = a.kind_n_blocks[k];
-    if (n <= 0) return; /* block-uniform */
-    const int per = (n + 255) / 256;
-    const int b0 = tid * per < n ? tid * per : n, b1 = b0 + per < n ? b0 + per : n;
-    int s0 = 0, s1 = 0;
-    for (int b = b0; b < b1; b++) {
-        s0 += a.block_count[2 * (first + b)];
-        s1 += a.block_count[2 * (first + b) + 1];
-    }
-    part[tid][0] = s0;
-    part[tid][1] = s1;
-    __syncthreads();
-    if (tid == 0) { /* 256 partial sums: one lane walks them (a fraction of a microsecond; the launch is what costs) */
-        int r0 = 0, r1 = 0;
-        for (int i = 0; i < 256; i++) {
-            const int c0 = part[i][0], c1 = part[i][1];
-            part[i][0] = r0;
-            part[i][1] = r1;
-            r0 += c0;
-            r1 += c1;
-        }
-        a.block_offset[2 * a.n_blocks + 2 * k] = r0;
-        a.block_offset[2 * a.n_blocks + 2 * k + 1] = r1;
-    }
-    __syncthreads();
-    int o0 = part[tid][0], o1 = part[tid][1];
-    for (int b = b0; b < b1; b++) {
-        a.block_offset[2 * (first + b)] = o0;
-        a.block_offset[2 * (first + b) + 1] = o1;
-        o0 += a.block_count[2 * (first + b)];
-        o1 += a.block_count[2 * (first + b) + 1];
-    }
-}
-
-__global__ __launch_bounds__(64) void regroup_scatter_kernel(RegroupArgs a) {
-    const int block = blockIdx.x, lane = threadIdx.x;
-    const int slot = block * 64 + lane;
-    const int key = regroup_key(a, slot);
-    const unsigned long long m0 = __ballot(key == 0), m1 = __ballot(key == 1), m2 = __ballot(key == 2);
-    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    const int k = regroup_kind_of(a, block);
-    const int first = a.kind_first_block[k];
-    const int tot0 = a.block_offset[2 * a.n_blocks + 2 * k], tot1 = a.block_offset[2 * a.n_blocks + 2 * k + 1];
-    const int off0 = a.block_offset[2 * block], off1 = a.block_offset[2 * block + 1];
-    const int off2 = (block - first) * 64 - off0 - off1; /* slots without a channel in the kind's earlier blocks */
-    const int at = key == 0 ? off0 + __builtin_popcountll(m0 & below) : key == 1 ? tot0 + off1 + __builtin_popcountll(m1 & below) : tot0 + tot1 + off2 + __builtin_popcountll(m2 & below);
-    a.perm[first * 64 + at] = slot;
-}
-
-void launch_regroup(const RegroupArgs& a, hipStream_t stream) {
-    if (a.n_blocks <= 0) return;
-    hipLaunchKernelGGL(regroup_count_kernel, dim3(a.n_blocks), dim3(64), 0, stream, a);
-    hipLaunchKernelGGL(regroup_scan_kernel, dim3(AB_KIND_COUNT), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(regroup_scatter_kernel, dim3(a.n_blocks), dim3(64), 0, stream, a);
 }
 
 /* ---- raw I/Q outputs: time-major device rows -> the channel-major layout the output thread consumes (reference:

@@ -109,25 +109,14 @@ struct DemodArgs {
     const float* cos_lut;   /* 257 */
     int ct_stride;
     int n_slots, wave_batch, row0, ring_rows;
-    /* REGROUPED handles (AIRBAND_HIP_FLAG_REGROUP, demod.hip "regrouping"): which slot the lane at wavefront position p = block * 64 + lane works on.  Everything a
-     * lane touches is addressed by its SLOT (rings, state, result rows, hand-off rows), so any permutation inside a kind's block range computes the same results;
-     * the one the library uses puts the channels whose squelch is not CLOSED at a batch's start first, so that wavefronts of closed channels never run the open
-     * channels' instructions.  null: position p works on slot p. */
-    const int* perm;
-    uint8_t* sq_key;        /* [n_slots] written by the kernels that run the squelch: 1 = the channel's squelch is not at rest in CLOSED at the end of the batch (null: not kept) */
+    /* REGROUPED handles (AIRBAND_HIP_FLAG_REGROUP, demod.hip "regrouping"): the lane-per-channel kernels run as workgroups of AB_REGROUP_WAVES wavefronts that
+     * share AB_REGROUP_WAVES x 64 consecutive slots and deal them out among themselves by squelch state -- the channels that are not at rest in CLOSED to the first
+     * wavefronts, the closed ones to the last, so that whole wavefronts of closed channels skip the open channels' instructions -- and walk the batch in step
+     * (a workgroup barrier every eight samples), so that the ring lines neighbouring slots share are fetched from memory once.  Everything a lane touches is
+     * addressed by its SLOT: which lane works on which slot does not change a result.  0: lane l of block b works on slot 64 b + l. */
+    int regroup;
+    uint8_t* sq_key;        /* [n_slots] regrouped handles, split kinds: the front kernel leaves 1 where the channel had audio in this batch; the back kernel deals its slots out by it */
 };
-
-/* slot order of the NEXT batch from sq_key (stable partition inside each kind's block range: active channels, closed ones, slots without a channel) */
-struct RegroupArgs {
-    const ChanConst* cc;
-    const uint8_t* sq_key;
-    int* perm;              /* [n_slots] */
-    int* block_count;       /* [n_blocks][2] scratch: active / closed slots per home block */
-    int* block_offset;      /* [n_blocks][2] scratch: exclusive sums inside the kind + [AB_KIND_COUNT][2] kind totals behind them */
-    int n_blocks;           /* all kinds */
-    int kind_first_block[AB_KIND_COUNT], kind_n_blocks[AB_KIND_COUNT];
-};
-void launch_regroup(const RegroupArgs& a, hipStream_t stream);
 
 struct EmitArgs { /* raw I/Q outputs only: audio goes straight to its channel row */
     const float2* iq_out;

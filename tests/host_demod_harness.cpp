@@ -59,9 +59,8 @@ struct HostDemod {
     float2* ct_af = nullptr;
     unsigned long long* ct_mask = nullptr;
     int ct_first_block = 0, ct_n_blocks = 0, ct_pk_pitch = 0, ct_stride = 0;
-    /* regrouped stage 2 (AB_HOST_REGROUP=1 in the environment when the handle is created; wave64 mode): the library's own regroup kernels re-sort the slots after every batch */
+    /* regrouped stage 2 (AB_HOST_REGROUP=1 in the environment when the handle is created; wave64 mode): workgroups of AB_REGROUP_WAVES wavefronts deal their slots out by squelch state */
     bool regroup = false;
-    std::vector<int> perm, rg_count, rg_offset;
     std::vector<uint8_t> sq_key;
     ~HostDemod() {
         free(mag); free(iq); free(iq_out); free(sqbuf); free(out_wave); free(out_axc); free(trace); free(lds);
@@ -77,10 +76,12 @@ void run_kind(HostDemod* h, const DemodArgs& a) {
         for (int i = 0; i < 257; i++) lut[i] = make_float2(a.sin_lut[i], a.cos_lut[i]); /* a lane fills every 64th entry; one lane at a time needs them all */
         for (unsigned lane = 0; lane < 64; lane++) {
             threadIdx.x = lane;
-            demod_block<KIND, false>(a, h->kind_first[KIND] + b, h->lds);
+            blockIdx.x = (unsigned)b;
+            demod_block<KIND, false, 1>(a, h->kind_first[KIND], h->kind_blocks[KIND], h->lds);
         }
     }
     threadIdx.x = 0;
+    blockIdx.x = 0;
 }
 #endif
 
@@ -88,7 +89,7 @@ void run_kind(HostDemod* h, const DemodArgs& a) {
 
 #ifdef AB_WAVE64_EMU
 namespace airband {
-alignas(16) float lds_demod[258 * 2 + RUN * OSTRIDE + 3 * 64]; /* demod_kernel's dynamic LDS (one block runs at a time) */
+alignas(16) float lds_demod[258 * 2 + AB_REGROUP_WAVES * WAVE_LDS_FLOATS + AB_REGROUP_WAVES * 64 + 2 * AB_REGROUP_WAVES]; /* demod_kernel's dynamic LDS at its largest (regrouped workgroups) */ /* demod_kernel's dynamic LDS (one block runs at a time) */
 }
 #endif
 
@@ -173,13 +174,7 @@ int hostdemod_create(const airband_hip_config* cfg, int trace, void** out) {
     {
         const char* e = getenv("AB_HOST_REGROUP");
         h->regroup = e && *e && *e != '0';
-        if (h->regroup) {
-            h->perm.resize((size_t)h->n_slots);
-            for (int i = 0; i < h->n_slots; i++) h->perm[(size_t)i] = i;
-            h->sq_key.assign((size_t)h->n_slots, 0);
-            h->rg_count.assign((size_t)2 * (h->n_slots / 64), 0);
-            h->rg_offset.assign((size_t)2 * (h->n_slots / 64) + 2 * AB_KIND_COUNT, 0);
-        }
+        if (h->regroup) h->sq_key.assign((size_t)h->n_slots, 0);
     }
 #endif
     *out = h;
@@ -241,31 +236,10 @@ int hostdemod_process_bins(void* hv, const float* wavein, const float* iq_in) {
     a.ct_n_blocks = h->ct_n_blocks;
     a.ct_stride = h->ct_stride;
     if (h->regroup) {
-        a.perm = h->perm.data();
+        a.regroup = 1;
         a.sq_key = h->sq_key.data();
     }
     launch_demod(a, h->kind_first, h->kind_blocks, nullptr, nullptr, nullptr); /* the library's own launch sequence; every launch runs to completion */
-    if (h->regroup) { /* as run_back_half() does (csrc/airband_hip.cpp): the next batch's slot order from this batch's final squelch states */
-        RegroupArgs ra;
-        ra.cc = h->cc.data();
-        ra.sq_key = h->sq_key.data();
-        ra.perm = h->perm.data();
-        ra.block_count = h->rg_count.data();
-        ra.block_offset = h->rg_offset.data();
-        ra.n_blocks = h->n_slots / 64;
-        for (int k = 0; k < AB_KIND_COUNT; k++) {
-            ra.kind_first_block[k] = h->kind_first[k];
-            ra.kind_n_blocks[k] = h->kind_blocks[k];
-        }
-        launch_regroup(ra, nullptr);
-        /* a slot order is a permutation of every kind's block range, whatever the states were */
-        std::vector<char> seen((size_t)h->n_slots, 0);
-        for (int i = 0; i < h->n_slots; i++) {
-            const int sl = h->perm[(size_t)i];
-            if (sl < 0 || sl >= h->n_slots || seen[(size_t)sl]) return -200;
-            seen[(size_t)sl] = 1;
-        }
-    }
 #else
     run_kind<AB_KIND_NFM_LOWPASS>(h, a);
     run_kind<AB_KIND_NFM>(h, a);
@@ -274,14 +248,6 @@ int hostdemod_process_bins(void* hv, const float* wavein, const float* iq_in) {
     h->row0 = (h->row0 + B) % R;
     h->batches++;
     return 0;
-}
-
-// regrouped handles: how many wavefront positions hold a slot other than their own after the last batch (0 = the order never moved: the test would be vacuous)
-int hostdemod_moved_slots(void* hv) {
-    HostDemod* h = static_cast<HostDemod*>(hv);
-    int n = 0;
-    for (size_t i = 0; i < h->perm.size(); i++) n += h->perm[i] != (int)i;
-    return n;
 }
 
 // results of the last batch: waveout [total_channels][wave_batch], axc [total_channels], trace [total_channels][wave_batch] (if created with trace)

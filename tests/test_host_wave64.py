@@ -38,14 +38,13 @@ def wave64(tmp_path_factory):
     lib.hostdemod_collect.restype = None
     lib.hostdemod_stats.argtypes = [vp, vp]
     lib.hostdemod_stats.restype = None
-    lib.hostdemod_moved_slots.argtypes = [vp]
     return lib
 
 
 @pytest.fixture(params=[False, True], ids=["slot_order", "regrouped"])
 def regroup(request, monkeypatch):
-    """Round 6: stage 2 with its slots re-sorted after every batch by the library's own regroup kernels (AIRBAND_HIP_FLAG_REGROUP on the GPU): which 64 channels
-    share a wavefront changes from batch to batch, the results must not."""
+    """Round 6: regrouped stage 2 (AIRBAND_HIP_FLAG_REGROUP on the GPU): workgroups of four wavefronts deal their 256 slots out among themselves by squelch state at
+    every batch start and walk the batch in step -- which channels share a wavefront changes from batch to batch, the results must not."""
     if request.param:
         monkeypatch.setenv("AB_HOST_REGROUP", "1")
     else:
@@ -101,8 +100,6 @@ def test_all_kinds_with_wavefront_semantics(wave64, regroup, style, n_dev, mixed
             ww = np.concatenate([w["waveout"] for w in want])
             assert np.array_equal(wave.view(np.uint32), ww.view(np.uint32)), "batch %d: waveout (channels %s)" % (b, np.nonzero((wave.view(np.uint32) != ww.view(np.uint32)).any(axis=1))[0])
             tone_seen += int(((wt >> 5) & 1).sum())
-        if regroup and n_dev >= 3 and n_batches >= 3:
-            assert wave64.hostdemod_moved_slots(hd.h) > 0  # the slot order did move
         if mixed and style != "bursty":
             assert tone_seen > 0  # the CTCSS gate did open somewhere (the short bursts of the other style never fill a detector window)
         st = hd.stats()

@@ -78,9 +78,9 @@ def _hot_loop(body, needs):
 
 
 @pytest.mark.parametrize("kernel,per_iteration", [
-    ("demod_kernelILi0ELb0", 2),   # AM: two groups of four samples per iteration
-    ("demod_kernelILi2ELb0", 2),   # NFM + lowpass
-    ("demod_kernelILi3ELb1", 2),   # CTCSS front
+    ("demod_kernelILi0ELb0ELi1E", 2),   # AM: two groups of four samples per iteration
+    ("demod_kernelILi2ELb0ELi1E", 2),   # NFM + lowpass
+    ("demod_kernelILi3ELb1ELi1E", 2),   # CTCSS front
 ])
 def test_group_prefetch_is_waited_for_once_per_group(demod_asm, kernel, per_iteration):
     loop = _hot_loop(_function(demod_asm, kernel), r"global_load_dwordx4")
@@ -149,7 +149,7 @@ def test_tone_kernel_keeps_its_scalars_in_registers(demod_asm):
         assert not any(re.search(r"v_(read|write)lane", l) for l in b), "lane traffic inside a recurrence loop"
 
 
-@pytest.mark.parametrize("kernel", ["demod_kernelILi0ELb0E", "demod_kernelILi3ELb1E"], ids=["am", "ctcss_front"])
+@pytest.mark.parametrize("kernel", ["demod_kernelILi0ELb0ELi1E", "demod_kernelILi3ELb1ELi1E"], ids=["am", "ctcss_front"])
 def test_stable_group_is_one_block_of_four_samples(demod_asm, kernel):
     """Round 3: four samples of a stable wavefront run as one basic block (squelch_fsm.h sq_raw_stable4, demod.hip stable_tail4).  What makes it pay is
     its shape: the four squelch steps sit in ONE basic block, no branch between them (the per-sample path has several per sample).  A squelch step
@@ -203,8 +203,8 @@ def test_specialised_demod_kinds_do_not_spill(demod_asm):
     """The four specialised lane-per-channel kinds (AM, NFM, NFM + lowpass, CTCSS front) keep their per-channel state in registers: a change that makes one
     of them spill vector registers (round 3: the stable-group block on the plain NFM kind, 143 of them) is a regression no parity test shows."""
     text = "\n".join(demod_asm)
-    for k, ct in ((0, 0), (1, 0), (2, 0), (3, 1)):
-        name = "_ZN7airband12demod_kernelILi%dELb%dEEEvNS_9DemodArgsEi" % (k, ct)
+    for k, ct, w in [(k, ct, w) for k, ct in ((0, 0), (1, 0), (2, 0), (3, 1)) for w in (1, 4)]:  # w: wavefronts per workgroup -- 1, and the regrouped handles' 4 (AIRBAND_HIP_FLAG_REGROUP)
+        name = "_ZN7airband12demod_kernelILi%dELb%dELi%dEEEvNS_9DemodArgsEii" % (k, ct, w)
         at = text.index(".name:           " + name)
         meta = text[at:at + 1500]
         assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1)) == 0, name
@@ -216,13 +216,13 @@ def test_nfm_kinds_take_the_short_square_root(demod_asm):
     small argument by 2^32, `v_mul_f32 .., 0x4f800000`) behind a seldom-taken branch -- so exactly half of a kernel's `v_sqrt_f32` sit next to such a
     scaling.  A plain sqrtf() slipping back in (every one scaled) costs 6 vector instructions per square root and shows in no parity test."""
     for k, ct in ((1, 0), (2, 0), (3, 1)):
-        body = _function(demod_asm, "demod_kernelILi%dELb%dEEE" % (k, ct))
+        body = _function(demod_asm, "demod_kernelILi%dELb%dELi1EEE" % (k, ct))
         n_sqrt = sum(1 for l in body if re.match(r"^\s*v_sqrt_f32", l))
         n_scaled = sum(1 for l in body if re.match(r"^\s*v_mul_f32\w*\s+v\d+, 0x4f800000,", l))
         assert n_sqrt >= 8 and n_scaled * 2 == n_sqrt, (k, n_sqrt, n_scaled)
     # and the two divisions by the lowpass gain are corrected products: FMAs exist in this -ffp-contract=off file only where exact_math.h
     # (or the compiler's own division / square root) asks for one
-    body = _function(demod_asm, "demod_kernelILi2ELb0EEE")
+    body = _function(demod_asm, "demod_kernelILi2ELb0ELi1EEE")
     assert sum(1 for l in body if re.match(r"^\s*v_fma_f32", l)) >= 32
 
 
