@@ -361,7 +361,7 @@ def main():
                     "table and AFC's per-batch spectrum + re-tune kernels run (VERDICT r02 item 4)")
     ap.add_argument("--key-on-s", type=float, default=0.75, help="seconds of every 1.5 s a synthetic transmitter is keyed (SURVEY 8d / BASELINE: 0.75 = half the channels busy; a real "
                     "airband channel is quiet most of the time: 0.15 = a 10 %% duty cycle).  Anything but 0.75 is NOT the BASELINE signal and the line says so")
-    ap.add_argument("--regroup", type=int, default=-1, help="1 / 0: AIRBAND_HIP_FLAG_REGROUP on / off (stage 2 re-sorts its channels by squelch state at batch boundaries); -1: the library's default")
+    ap.add_argument("--regroup", type=int, default=-1, help="1 / 0: AIRBAND_HIP_FLAG_REGROUP / AIRBAND_HIP_FLAG_NO_REGROUP (stage 2 re-sorts its channels by squelch state at batch boundaries, or never does); -1: the library's own choice by residency")
     ap.add_argument("--distinct-plans", type=int, default=1, help="fleets whose dongles do NOT share a channel plan (every device_t derives its own bins, src/config.cpp:666-667): "
                     "dongle d belongs to plan p = d mod N and its channel c (frequency AND generated carrier) sits ((p >> 2c) & 3) bins above the BASELINE plan's -- up to "
                     "4^8 = 65 536 distinct groups of eight bins, one coefficient table each.  Default 1 = SURVEY 8d's fleet of identical dongles")
@@ -464,7 +464,7 @@ def main():
     # AIRBAND_BENCH_FLAGS adds AIRBAND_HIP_FLAG_* bits for experiments (e.g. 8 = demod kinds one after the other, for per-kernel profiles)
     flags = int(os.environ.get("AIRBAND_BENCH_FLAGS", "0"), 0) | (pkg.capi.FLAG_PIPELINE if args.pipelined else 0)
     if args.regroup >= 0:
-        flags = (flags & ~pkg.capi.FLAG_REGROUP) | (pkg.capi.FLAG_REGROUP if args.regroup else 0)
+        flags = (flags & ~(pkg.capi.FLAG_REGROUP | pkg.capi.FLAG_NO_REGROUP)) | (pkg.capi.FLAG_REGROUP if args.regroup else pkg.capi.FLAG_NO_REGROUP)
     hip = pkg.AirbandHip(devices, wave_rate=wave_rate, hip_device=local_rank, flags=flags, fft_log=args.fft_log)
     g = hip.geometry
     mg = importlib.import_module("rtlsdr-airband_amd.multigpu")  # the host logic tests/test_distributed_gloo.py and tests/test_gpu_multi.py exercise

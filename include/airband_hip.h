@@ -76,7 +76,12 @@ extern "C" {
                                                64 channels a wavefront works on.  Pays on a band whose channels \
                                                are mostly quiet; costs ring-line fetches where neighbouring     \
                                                channels differ in state.  AIRBAND_HIP_REGROUP=0|1 in the         \
-                                               environment overrides the flag either way (A/B measurements).    */
+                                               environment overrides the flags either way (A/B measurements).   \
+                                               With neither this flag nor NO_REGROUP the library decides by      \
+                                               residency: on while all of the handle's lane-per-channel          \
+                                               wavefronts are resident at once on a full chip (about 24 000 to   \
+                                               50 000 dongles of eight channels on an MI355X), off otherwise.   */
+#define AIRBAND_HIP_FLAG_NO_REGROUP 0x40u   /* never regroup (slot order), whatever the handle's size          */
 
 /* Per-channel configuration: the values a multichannel-mode `channels` entry carries after
  * parse_channels() (reference: src/config.cpp:306-726).  The library derives bin index, derotation
@@ -375,7 +380,7 @@ int airband_hip_timing_totals(airband_hip_handle* h, double* ms4_sum, int64_t* n
  * different file name and say here what they changed, so that a measurement can always be traced to the code that produced it). */
 const char* airband_hip_build_info(void);
 
-/* 1 if stage 2 of this handle re-sorts its channels at batch boundaries (AIRBAND_HIP_FLAG_REGROUP or AIRBAND_HIP_REGROUP=1 in the environment), else 0. */
+/* 1 if stage 2 of this handle re-sorts its channels at batch boundaries (AIRBAND_HIP_FLAG_REGROUP, AIRBAND_HIP_REGROUP=1 in the environment, or the library's own choice by residency), else 0. */
 int airband_hip_regrouped(const airband_hip_handle* h);
 
 /* Name of the channelizer variant the handle selected ("fft_wave64" / "dft_mfma_i8"). */

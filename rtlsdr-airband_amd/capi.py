@@ -9,7 +9,7 @@ SFMT_U8, SFMT_S8, SFMT_S16, SFMT_F32 = 1, 2, 3, 4
 MOD_AM, MOD_NFM = 0, 1
 FM_FAST_ATAN2, FM_QUADRI_DEMOD = 0, 1
 AGC_EXTRA = 100
-FLAG_TRACE_SQUELCH, FLAG_RESERVED_2, FLAG_FORCE_FFT, FLAG_SERIAL_DEMOD, FLAG_PIPELINE, FLAG_REGROUP = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+FLAG_TRACE_SQUELCH, FLAG_RESERVED_2, FLAG_FORCE_FFT, FLAG_SERIAL_DEMOD, FLAG_PIPELINE, FLAG_REGROUP, FLAG_NO_REGROUP = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40
 
 BYTES_PER_SAMPLE = {SFMT_U8: 1, SFMT_S8: 1, SFMT_S16: 2, SFMT_F32: 4}
 

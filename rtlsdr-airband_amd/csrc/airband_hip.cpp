@@ -305,6 +305,7 @@ void launch_retune_tables(airband_hip_handle* h, hipStream_t s, int epoch) {
     ra.bset_bin = h->d_bset_bin.p;
     ra.bfrag = h->d_bfrag.p;
     ra.corr = h->d_bcorr.p;
+    ra.ftab = h->use_f32 ? h->d_ftab.p : nullptr;
     ra.window = h->d_window.p;
     ra.n_items = (int)h->plan.item_dev.size();
     ra.fft_size = h->plan.fft_size;
@@ -386,10 +387,11 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.sq_key = h->regroup ? h->d_sq_key.p : nullptr;
     launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
     if (h->any_afc && h->afc_spectrum_valid) { /* afc.finalize(), src/rtl_airband.cpp:626-630: may turn '*' into '<' / '>' */
-        if (h->use_dft) (void)hipStreamWaitEvent(s, h->ev_spec[1], 0); /* the last hop's spectrum, computed beside stage 1 */
+        const bool tables = h->use_dft || h->use_f32; /* the matrix-core channelizers: a channel's bin is baked into its coefficient columns */
+        if (tables) (void)hipStreamWaitEvent(s, h->ev_spec[1], 0); /* the last hop's spectrum, computed beside stage 1 */
         const int epoch = (int)(h->batches_done % 0x7fffffff) + 1; /* never 0: that is the start-up build's */
-        launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, h->use_dft ? h->d_bset_bin.p + (size_t)h->plan.n_bsets * 8 : nullptr, epoch, s);
-        if (h->use_dft) launch_retune_tables(h, s, epoch); /* the next batch's stage 1 reads the moved channels' new columns */
+        launch_afc(h->d_cc.p, h->d_cs.p, h->d_spectrum.p, h->N, h->n_slots, tables ? h->d_bset_bin.p + (size_t)h->plan.n_bsets * 8 : nullptr, epoch, s);
+        if (tables) launch_retune_tables(h, s, epoch); /* the next batch's stage 1 reads the moved channels' new columns */
         launch_axc(h->d_cc.p, h->d_cs.p, h->d_slot_to_ext.p, h->d_out_axc.p, h->n_slots, s);
     }
     (void)hipEventRecord(ev[3], s);
@@ -645,8 +647,20 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
         PREP_TRY(h->d_ct_mask.alloc((size_t)h->ct_n_blocks * (h->B / 50) * AB_SLOT_BLOCK), AIRBAND_HIP_ENOMEM);
     }
     {   /* regrouped stage 2 (demod.hip, "regrouping") */
+        /* Default (neither flag, no environment override): by residency.  A regrouped workgroup's wavefronts of closed channels spend most of the batch waiting at the
+         * lockstep barriers -- without using an issue slot, but holding their registers.  While ALL of a handle's lane-per-channel wavefronts are resident at once (about
+         * four to six per SIMD) that costs nothing and the 22 % of vector instructions regrouping removes are time (32 768 dongles x 8 mixed channels: stage 2 3.42 ->
+         * 3.02 ms; 49 152: 4.53 -> 4.33); past that the waiting wavefronts keep the next round's out (65 536: 5.8 -> 6.05), and a chip that is not full is bound by ONE
+         * wavefront's dependent chain, which regrouping does not shorten (<= 16 384: 2.48 -> 2.54) -- profiles/r06_experiments.md D. */
+        int n_lane_blocks = 0;
+        for (int k = 0; k < AB_KIND_COUNT; k++) n_lane_blocks += h->kind_n_blocks[k];
+        int cus = 0, cur_dev = 0;
+        (void)hipGetDevice(&cur_dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cur_dev) != hipSuccess || cus <= 0) cus = 256;
+        const double waves_per_simd = (double)n_lane_blocks / (4.0 * cus);
+        const bool by_residency = waves_per_simd >= 2.75 && waves_per_simd <= 6.25;
         const char* e = getenv("AIRBAND_HIP_REGROUP");
-        h->regroup = e && *e ? (*e != '0') : (h->flags & AIRBAND_HIP_FLAG_REGROUP) != 0;
+        h->regroup = e && *e ? (*e != '0') : (h->flags & AIRBAND_HIP_FLAG_REGROUP) ? true : (h->flags & AIRBAND_HIP_FLAG_NO_REGROUP) ? false : by_residency;
         if (h->regroup) {
             PREP_TRY(h->d_sq_key.alloc((size_t)h->n_slots), AIRBAND_HIP_ENOMEM);
             PREP_TRY(hipMemset(h->d_sq_key.p, 0, (size_t)h->n_slots), AIRBAND_HIP_ENOMEM);
@@ -728,22 +742,39 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
                 PREP_TRY(h->d_dft_partial.alloc((size_t)p.item_dev.size() * dft_partial_tiles(h->B + AB_AGC_EXTRA) * 64 * 4), AIRBAND_HIP_ENOMEM);
         }
     }
-    /* CF32 (SoapySDR): the float32 matrix pipe, unless a channel has AFC (its tables would have to move at run time: those handles stay on the wavefront FFT) */
-    h->use_f32 = !h->use_dft && !(h->flags & AIRBAND_HIP_FLAG_FORCE_FFT) && !any_afc && f32_supported(p.fft_size, p.dev[0].hop_samples, p.dev[0].sfmt);
+    /* CF32 (SoapySDR): the float32 matrix pipe.  Round 6: also with AFC channels -- a group with one owns a private float table whose column pairs the re-tune kernel
+     * moves (misc_kernels.hip, build_column_pair_f32), exactly as the int8 path does; such handles stayed on the wavefront FFT before. */
+    h->use_f32 = !h->use_dft && !(h->flags & AIRBAND_HIP_FLAG_FORCE_FFT) && f32_supported(p.fft_size, p.dev[0].hop_samples, p.dev[0].sfmt);
     if (h->use_f32) {
         build_dft_tables(h->plan, false); /* the work items and the shared bin sets (its int8 tables are not used) */
-        /* bytes, not a count: a float table is f32_nw x (2 N / 4 / f32_nw) x 64 lanes x 4 bytes = 128 N bytes -- 64 KiB at fft 512, 256 KiB at 2048.  The tables are built
-         * on the host (params.cpp, build_f32_tables) and read once per work item per launch: past a budget the handle runs on the wavefront FFT rather than on a
-         * gigabyte-sized host build */
-        const size_t ftab_bytes = (size_t)p.n_shared_bsets * 128u * (size_t)p.fft_size;
-        if (ftab_bytes > AB_F32_TABLE_BUDGET) {
+        /* bytes, not a count: a float table is f32_nw x (2 N / 4 / f32_nw) x 64 lanes x 4 bytes = 128 N bytes -- 64 KiB at fft 512, 256 KiB at 2048.  The shared tables are
+         * built on the host (params.cpp, build_f32_tables) and read once per work item per launch: past a budget the handle runs on the wavefront FFT rather than on a
+         * gigabyte-sized host build; the private ones (device-built) count against the budget the int8 path's private tables have */
+        const size_t ftab_each = 128u * (size_t)p.fft_size;
+        const size_t ftab_bytes = (size_t)p.n_shared_bsets * ftab_each;
+        if (ftab_bytes > AB_F32_TABLE_BUDGET || (size_t)p.n_bsets * ftab_each > AB_PRIVATE_TABLE_BUDGET) {
             h->use_f32 = false;
         } else {
             build_f32_tables(h->plan);
             PREP_TRY(upload(h->d_item_dev, p.item_dev), AIRBAND_HIP_ENOMEM);
             PREP_TRY(upload(h->d_item_group, p.item_group), AIRBAND_HIP_ENOMEM);
             PREP_TRY(upload(h->d_item_bset, p.item_home), AIRBAND_HIP_ENOMEM);
+            if (p.n_bsets > p.n_shared_bsets) { /* groups with an AFC channel: their private tables follow the shared ones, built by the re-tune kernel right here */
+                PREP_TRY(upload(h->d_item_private, p.item_bset), AIRBAND_HIP_ENOMEM);
+                PREP_TRY(upload(h->d_item_home, p.item_home), AIRBAND_HIP_ENOMEM);
+                std::vector<int> with_epoch(p.bset_bins);
+                with_epoch.push_back(0);
+                PREP_TRY(upload(h->d_bset_bin, with_epoch), AIRBAND_HIP_ENOMEM);
+                PREP_TRY(h->d_ftab.alloc((size_t)p.n_bsets * ftab_each / sizeof(float)), AIRBAND_HIP_ENOMEM);
+                PREP_TRY(hipMemset(h->d_ftab.p, 0, (size_t)p.n_bsets * ftab_each), AIRBAND_HIP_ENOMEM);
+                PREP_TRY(hipMemcpy(h->d_ftab.p, p.ftab.data(), p.ftab.size() * sizeof(float), hipMemcpyHostToDevice), AIRBAND_HIP_ENOMEM);
+                launch_retune_tables(h, h->stream, 0);
+                PREP_TRY(hipGetLastError(), AIRBAND_HIP_ENODEV);
+                PREP_TRY(hipStreamSynchronize(h->stream), AIRBAND_HIP_ENODEV);
+            } else
             PREP_TRY(upload(h->d_ftab, p.ftab), AIRBAND_HIP_ENOMEM);
+            /* fft_size 4096 / 8192: partial sums between the launches of the window's segments (channelizer_f32.hip) */
+            if (f32_n_seg(p.fft_size) > 1) PREP_TRY(h->d_dft_partial.alloc((size_t)p.item_dev.size() * f32_partial_tiles(h->B + AB_AGC_EXTRA) * 64 * 4), AIRBAND_HIP_ENOMEM);
         }
         h->plan.bfrag.clear(); h->plan.bfrag.shrink_to_fit();
         h->plan.ftab.clear(); h->plan.ftab.shrink_to_fit();
@@ -933,6 +964,9 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         a.hop_bytes = (int)h->hop_bytes;
         a.pad = f32_pad_bytes(p.dev[0].hop_samples);
         a.lds_per_buf = f32_lds_per_buf(p.fft_size, p.dev[0].hop_samples);
+        a.seg = 0;
+        a.n_seg = 1;
+        a.partial = reinterpret_cast<float4*>(h->d_dft_partial.p);
         a.row0 = h->row0_front;
         a.ring_rows = h->R;
         a.first_row = first ? 0 : AB_AGC_EXTRA;
@@ -946,7 +980,15 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         h->last_iq = d_iq;
         h->last_iq_stride = stride_bytes;
         h->last_n_hops = a.n_hops;
-        h->afc_spectrum_valid = false;
+        h->afc_spectrum_valid = h->any_afc;
+        if (h->any_afc) { /* the spectrum of the batch's last hop, on a side stream beside stage 1 (as on the int8 path below) */
+            for (auto& e : h->ev_spec)
+                if (!e) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming), AIRBAND_HIP_ENODEV);
+            (void)hipEventRecord(h->ev_spec[0], s);
+            (void)hipStreamWaitEvent(h->side[0], h->ev_spec[0], 0);
+            launch_last_hop_spectrum(h, h->side[0]);
+            (void)hipEventRecord(h->ev_spec[1], h->side[0]);
+        }
         (void)hipEventRecord(ev[0], s);
         launch_channelizer_f32(a, s);
         launch_err = hipGetLastError(); /* right behind the launch: the event record below would mask it (or be blamed for it) */

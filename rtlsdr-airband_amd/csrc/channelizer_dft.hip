@@ -27,6 +27,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <cstdlib>
 
 #include "common.h"
 #include "kernels.h"
@@ -358,7 +359,14 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
         pre[2] = lds_read16<AL>(arow + 128);
         pre[3] = lds_read16<AL>(arow + 192);
     };
-    auto tile_body = [&](const uint8_t* arow, const v4i* pre, TileAcc& A) {
+    /* k-step behind which the multi-piece loop finishes the previous tile: late enough that the A-fragment registers fetched ahead are free again (the B fragments of a
+     * window piece fill 192 registers: in the middle of the sequence the finish costs spills), early enough that MFMAs are still in the pipe while it runs.  Measured
+     * (profiles/r06_fft_pieces/, per launch at 65 536 dongles, before -> 13 | 7 | 11 | 15): fft 1024 15.44 -> 15.2 | 16.2 | 16.1 | 15.3 ms, fft 2048 27.1 -> 26.8 | 29.3 |
+     * 28.6 | 26.8; fft 4096 56.8 -> 53.4, fft 8192 124.0 -> 118.5 (13 only). */
+#ifndef AB_MID_AT
+#define AB_MID_AT (KSTEPS - 3)
+#endif
+    auto tile_body = [&](const uint8_t* arow, const v4i* pre, TileAcc& A, auto&& mid) {
         A.a0 = (v4i){0, 0, 0, 0}; A.a1 = (v4i){0, 0, 0, 0}; A.a2 = (v4i){0, 0, 0, 0};
         /* A fragments are fetched four k-steps ahead of the MFMAs that consume them, so the LDS latency (and the 2-way bank conflict of
          * the strided rows) hides behind a dozen MFMAs instead of stalling in front of them; a scheduling fence every two k-steps keeps
@@ -377,14 +385,19 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
             A.a1 = ab_mfma(x, b1[s], A.a1);
             if (!(EDGE_HI_ZERO && (s < EDGE || s >= KSTEPS - EDGE))) A.a2 = ab_mfma(x, b2[s], A.a2);
             if (s & 1) __builtin_amdgcn_sched_barrier(0);
+            if (s == AB_MID_AT) { /* most of the tile's MFMAs are in the pipe: what the caller wants done under them (window pieces: the PREVIOUS tile's sums and stores) */
+                mid();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
-    auto tile_mfma = [&](const uint8_t* buf, int sb, TileAcc& A) {
+    auto no_mid = [] {};
+    auto tile_mfma = [&](const uint8_t* buf, int sb, TileAcc& A, auto&& mid) {
         if (!S16) {
             const uint8_t* arow = a_row(buf, sb);
             v4i pre[4];
             a_head(arow, pre);
-            tile_body(arow, pre, A);
+            tile_body(arow, pre, A, mid);
         } else {
             /* CS16: plane k-step s of the lane = 16 plane bytes = 8 samples x (I, Q) = 32 raw bytes [Ilo Ihi Qlo Qhi] x 8 */
             /* (round 5, measured and dropped: pulling the planes apart ONCE per landed step, in place in LDS -- 32 raw bytes -> [16 low bytes - 128 | 16 high bytes], 96
@@ -419,6 +432,8 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            mid(); /* (CS16: twice the accumulators -- behind the last MFMA, while the pipe drains) */
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     /* digit sums -> the lane's four values (hops grp * 4 .. + 3 of column col): recombine, restore the -127.5 offset of the reference's
@@ -533,7 +548,7 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
         for (int st = st_begin; st < st_end; st++) {
             uint8_t* buf = lds + buf_off;
             TileAcc now;
-            tile_body(a_row(buf, 0), pre, now);
+            tile_body(a_row(buf, 0), pre, now, no_mid);
             const bool more3 = st + 3 < st_end;
             if (more3) stage_fast(st + 3, buf); /* every LDS read of this buffer has returned (the MFMAs consumed them): it takes the step three ahead */
             const int mark_c = stores;
@@ -553,6 +568,32 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
         return;
     }
 
+    constexpr bool PIPE_PIECES = NP > 1 && !S16 && AL >= 4;
+    /* window pieces: wave 0's own sums of the tile whose other pieces it has yet to add (finished under the next tile's MFMAs) */
+    float pend[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int pend_t = 0;
+    bool have_pend = false;
+    auto finish_tile = [&](int t, float* val) {
+        const float4* ex = exch + (t & 1) * (NP - 1) * 64;
+#pragma unroll
+        for (int q = 0; q < NP - 1; q++) {
+            const float4 o = ex[q * 64 + lane];
+            val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
+        }
+        if (a.partial) { /* fft_size 8192: the first pass parks its sums (whole-wave 1 KiB rows), the second adds them to its own */
+            /* (row base through scalar registers: left to itself the compiler keeps a per-lane 64-bit base alive across the whole loop) */
+            const unsigned long long rb = (unsigned long long)(a.partial + ((long)item * tiles_total + t) * 64);
+            const unsigned rb_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rb), rb_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rb >> 32));
+            float4* row = reinterpret_cast<float4*>(((unsigned long long)rb_hi << 32) | rb_lo) + lane;
+            if (a.piece0 == 0) {
+                *row = make_float4(val[0], val[1], val[2], val[3]);
+                return;
+            }
+            const float4 o = *row;
+            val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
+        }
+        tile_store(t, val);
+    };
     for (int st = st_begin; st < st_end; st++) {
         uint8_t* buf = lds + cur * lds_per_buf;
         /* NP > 1: wave 0 runs the transfers and the waits; the barrier hands step st to the other waves and tells wave 0 that they
@@ -579,37 +620,50 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
             if (t >= tiles_total) break;
             float val[4];
             TileAcc now;
-            tile_mfma(buf, sb, now);
+            if (NP == 1) {
+                tile_mfma(buf, sb, now, no_mid);
+#pragma unroll
+                for (int r = 0; r < 4; r++) val[r] = tile_value(now, r);
+                tile_store(t, val);
+                continue;
+            }
+            /* Window pieces (round 6: software-pipelined across the workgroup barrier).  Every wave runs its piece's MFMAs for tile t; the other pieces' partial sums
+             * reach wave 0 through LDS (two areas alternate).  Wave 0 used to add them up and store right behind a second barrier per tile, with the other waves
+             * already waiting at the next one and the matrix pipe idle (0.40 busy at every window length, profiles/r04_experiments.md G: the review's reading was that this
+             * second barrier is what idles it -- it is 1.5 % of fft 1024's launch and 6 % of fft 4096's; the matrix time and the stream time of these sizes ADD UP instead of
+             * overlapping, 6.9 + 8.4 ms at fft 1024, because four workgroups per CU keep too few bytes in flight: profiles/r06_experiments.md F).  Now tile t - 1 is finished
+             * UNDER tile t's MFMAs -- `mid`, called with half of them issued -- and ONE barrier per tile does both jobs: it hands the staged step over and orders the
+             * waves' writes of tile t - 1's sums before wave 0's reads (the area tile t's sums go to was last read under tile t - 1, before this barrier). */
+            if (!PIPE_PIECES) { /* CS16 (twice the accumulators) and hops of an odd number of samples (five-dword fragment reads): no registers to spare for a tile in waiting */
+                tile_mfma(buf, sb, now, no_mid);
+#pragma unroll
+                for (int r = 0; r < 4; r++) val[r] = tile_value(now, r);
+                if (piece > 0) exch[((t & 1) * (NP - 1) + (piece - 1)) * 64 + lane] = make_float4(val[0], val[1], val[2], val[3]);
+                __syncthreads();
+                if (piece == 0) finish_tile(t, val);
+                continue;
+            }
+            if (sb > 0) __syncthreads(); /* (sb == 0: the step's barrier above) */
+            auto finish_pending = [&] {
+                if (piece == 0 && have_pend) finish_tile(pend_t, pend);
+            };
+            tile_mfma(buf, sb, now, finish_pending);
 #pragma unroll
             for (int r = 0; r < 4; r++) val[r] = tile_value(now, r);
-            if (NP > 1) {
-                /* the other pieces' partial sums (same lane layout) reach wave 0 through LDS; two areas alternate so that a wave ahead by a
-                 * tile never overwrites what wave 0 is still adding up */
-                float4* ex = exch + (t & 1) * (NP - 1) * 64;
-                if (piece > 0) ex[(piece - 1) * 64 + lane] = make_float4(val[0], val[1], val[2], val[3]);
-                __syncthreads();
-                if (piece > 0) continue;
+            if (piece > 0) {
+                exch[((t & 1) * (NP - 1) + (piece - 1)) * 64 + lane] = make_float4(val[0], val[1], val[2], val[3]);
+            } else {
 #pragma unroll
-                for (int q = 0; q < NP - 1; q++) {
-                    const float4 o = ex[q * 64 + lane];
-                    val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
-                }
+                for (int r = 0; r < 4; r++) pend[r] = val[r];
+                pend_t = t;
+                have_pend = true;
             }
-            if (NP > 1 && a.partial) { /* fft_size 8192: the first pass parks its sums (whole-wave 1 KiB rows), the second adds them to its own */
-                /* (row base through scalar registers: left to itself the compiler keeps a per-lane 64-bit base alive across the whole loop) */
-                const unsigned long long rb = (unsigned long long)(a.partial + ((long)item * tiles_total + t) * 64);
-                const unsigned rb_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rb), rb_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rb >> 32));
-                float4* row = reinterpret_cast<float4*>(((unsigned long long)rb_hi << 32) | rb_lo) + lane;
-                if (a.piece0 == 0) {
-                    *row = make_float4(val[0], val[1], val[2], val[3]);
-                    continue;
-                }
-                const float4 o = *row;
-                val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
-            }
-            tile_store(t, val);
         }
         cur = cur + 1 == nbuf ? 0 : cur + 1;
+    }
+    if (PIPE_PIECES) { /* the last tile's sums */
+        __syncthreads();
+        if (piece == 0 && have_pend) finish_tile(pend_t, pend);
     }
 }
 
@@ -634,7 +688,13 @@ int dft_partial_tiles(int n_hops_max) { return (15 + n_hops_max + TILE_HOPS - 1)
 template <int FFT_N, int HOPB, bool S16, int AL, int NP = 1>
 static void launch_al(const DftArgs& a, hipStream_t stream) {
     const long groups = (long)a.n_items * a.splits;
-    const size_t lds = (size_t)a.nbuf * a.lds_per_buf + (NP > 1 ? 2 * (NP - 1) * 64 * sizeof(float4) : 0);
+    /* AIRBAND_HIP_DFT_EXTRA_LDS=<bytes> (measurements only, profiles/r06_experiments.md G): LDS the launch asks for and never touches, so that fewer wavefronts fit a CU --
+     * what the channelizer loses when something else (a fused consumer, a resident stage-2 wavefront) takes a share of the CU */
+    static const size_t extra_lds = [] {
+        const char* e = getenv("AIRBAND_HIP_DFT_EXTRA_LDS");
+        return e ? (size_t)atol(e) : (size_t)0;
+    }();
+    const size_t lds = (size_t)a.nbuf * a.lds_per_buf + (NP > 1 ? 2 * (NP - 1) * 64 * sizeof(float4) : 0) + extra_lds;
     /* more than the default 64 KiB of dynamic LDS (eight-piece windows): opt in to the CU's 160 KiB, once per kernel variant */
     /* (once per kernel variant AND device: the attribute belongs to the function as loaded on the current device, and a process may drive several GPUs) */
     static std::atomic<bool> big_lds_dev[64][2]; /* (zero-initialised; one launching thread per GPU in the shim: setting it twice is harmless) */

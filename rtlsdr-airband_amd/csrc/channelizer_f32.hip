@@ -38,14 +38,18 @@ typedef unsigned v4u __attribute__((ext_vector_type(4))); /* (not HIP's uint4: a
 
 constexpr int TILE_HOPS = 16;
 
-__host__ __device__ constexpr int f32_pad(int hop_bytes) { return ((hop_bytes / 16) & 1) ? 0 : 16; }
+/* (hops of an odd number of samples -- 8 mod 16 bytes -- need no padding: their rows do not start in the same bank to begin with) */
+__host__ __device__ constexpr int f32_pad(int hop_bytes) { return (hop_bytes & 8) ? 0 : ((hop_bytes / 16) & 1) ? 0 : 16; }
 __host__ __device__ constexpr long f32_padded(long o, int hop_bytes, int pad) { return o + (long)pad * (o / hop_bytes); }
 
 /* FFT_N: 256 ... 2048 (window of 2 FFT_N floats = 8 FFT_N bytes); NW: waves per workgroup = pieces of the contraction index (f32_nw: 4 up to fft 512, 8 for 1024 / 2048,
  * round 5); KW = MFMAs per wave and tile = 2 FFT_N / 4 / NW = resident B registers: 32 (fft 256), 64 (512, 1024), 128 (2048) */
 /* MAX_LD: 16-byte pieces of a tile per thread (6: tiles up to 24 KiB at NW = 4 -- 2.56 MS/s at WAVE_RATE 16000 -- three workgroups per CU; 12: up to 48 KiB; twice that at NW = 8) */
 /* residency the register allocation is held to: NW = 4: three waves per SIMD (168 VGPRs) for the small tiles, one for the large; NW = 8: a workgroup is two waves per SIMD */
-template <int FFT_N, int MAX_LD, int NW>
+/* AL8 (round 6): hops of an ODD number of samples (2.0 MS/s at WAVE_RATE 16000: 125 samples = 1 000 bytes).  A hop is then 8 mod 16 bytes long: the stream is still staged
+ * in aligned 16-byte pieces -- the image starts `delta` = 0 or 8 bytes in front of the tile's first hop, the same for every tile of a launch since a tile is 16 hops --
+ * and the A fragments are assembled from two 8-byte LDS reads (this kernel waits for the matrix pipe, 128 cycles per fragment, not for LDS). */
+template <int FFT_N, int MAX_LD, int NW, bool AL8>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void channelizer_f32_kernel(F32Args a) {
     constexpr int WIN_BYTES = 8 * FFT_N;
     constexpr int KW = 2 * FFT_N / 4 / NW;   /* 64 (fft 512) or 32 (fft 256) */
@@ -78,10 +82,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void 
     const int t_end = min(tiles_total, t_begin + tiles_per_split);
     if (t_begin >= t_end) return;
 
-    const uint8_t* src = a.iq + (long)d * a.iq_stride;   /* first byte of the batch's first hop (16-byte aligned: airband_hip_process_device checks) */
-    const long span_end = (long)(a.n_hops - 1) * hop_bytes + WIN_BYTES; /* bytes of the batch span that may be read */
+    /* fft_size 4096 / 8192 (round 6): the window in SEGMENTS of 2 048 samples, one launch each -- segment a.seg contracts window samples [2048 seg, 2048 seg + 2048)
+     * against its own table, the first parks its (unscaled) sums in a.partial, the ones in between add theirs, the last adds, scales and writes the rings.  The stream is
+     * read once per segment: these sizes are bound by the float32 matrix pipe (16x / 32x the instructions of fft 512 per byte), not by the bytes. */
+    const uint8_t* src = a.iq + (long)d * a.iq_stride + (long)a.seg * WIN_BYTES;   /* first byte this launch reads of the batch's first hop (16-byte aligned: airband_hip_process_device checks) */
+    /* bytes of the batch span (from src) that may be read; odd hops: rounded up to a whole 16-byte piece (the caller's span is: geometry.lookahead_bytes includes the round-up) */
+    const long span_end = AL8 ? (((long)(a.n_hops - 1) * hop_bytes + WIN_BYTES + 15) & ~15L) : (long)(a.n_hops - 1) * hop_bytes + WIN_BYTES;
+    const int delta = AL8 ? (int)((-(long)shift * hop_bytes) & 15) : 0; /* 0 or 8 */
     const int tile_bytes = (TILE_HOPS - 1) * hop_bytes + WIN_BYTES;     /* stream bytes a tile looks at */
-    const int n16 = tile_bytes / 16;                                    /* (hop_bytes and WIN_BYTES are multiples of 16) */
+    const int n16 = (tile_bytes + delta + 15) / 16;                     /* (hop_bytes and WIN_BYTES are multiples of 16 -- of 8 with odd hops) */
     const int n_ld = (n16 + 64 * NW - 1) / (64 * NW);
     const int buf_bytes = a.lds_per_buf;
     uint8_t* lds = lds_all;
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void 
     const int fin = wg & (NW - 1);
 
     /* ---- B fragments: KW registers, resident ---- */
-    const float* btab = a.btab + ((long)a.item_bset[item] * NW + piece) * KW * 64 + lane;
+    const float* btab = a.btab + (((long)a.item_bset[item] * a.n_seg + a.seg) * NW + piece) * KW * 64 + lane;
     float b[KW];
 #pragma unroll
     for (int s = 0; s < KW; s++) b[s] = btab[s * 64];
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void 
 #pragma unroll
     for (int j = 0; j < READS; j++) {
         const int o = row_l * hop_bytes + piece * PIECE_BYTES + j * 64 + grp * 16;
-        aoff[j] = o + pad * (o / hop_bytes);
+        aoff[j] = AL8 ? o + delta : o + pad * (o / hop_bytes);
     }
 
     /* ---- staging: registers one tile ahead ---- */
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void 
     /* (an interior-tile fast path -- one 64-bit add per tile, pieces at constant offsets -- was tried: the second copy of the loads costs registers,
      * three spilled dwords more and the third workgroup per CU of the large-tile variant; 26.2 ms against 22.4.  One path.) */
     auto load_tile = [&](int t) {
-        const long base = ((long)t * TILE_HOPS - shift) * hop_bytes;
+        const long base = ((long)t * TILE_HOPS - shift) * hop_bytes - delta; /* a multiple of 16 */
 #pragma unroll
         for (int i = 0; i < MAX_LD; i++) {
             if (i >= n_ld) continue; /* (workgroup-uniform; `continue`, not `break`: with a loop exit the compiler keeps stage[] in scratch memory) */
@@ -155,6 +164,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void 
             if (p < n16) *reinterpret_cast<v4u*>(buf + poff[i]) = stage[i];
         }
     };
+    auto frag = [&](const uint8_t* p) { /* four consecutive stream values of the lane's hop */
+        if (!AL8) return *reinterpret_cast<const v4f*>(p);
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f lo = *reinterpret_cast<const v2f*>(p), hi = *reinterpret_cast<const v2f*>(p + 8);
+        return (v4f){lo.x, lo.y, hi.x, hi.y};
+    };
     auto pair_swap = [&](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); };
 
     load_tile(t_begin);
@@ -171,10 +186,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void 
         constexpr int AHEAD = 3;
         v4f av[AHEAD + 1];
 #pragma unroll
-        for (int j = 0; j < AHEAD && j < READS; j++) av[j] = *reinterpret_cast<const v4f*>(buf + aoff[j]);
+        for (int j = 0; j < AHEAD && j < READS; j++) av[j] = frag(buf + aoff[j]);
 #pragma unroll
         for (int j = 0; j < READS; j++) {
-            if (j + AHEAD < READS) av[(j + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const v4f*>(buf + aoff[j + AHEAD]);
+            if (j + AHEAD < READS) av[(j + AHEAD) % (AHEAD + 1)] = frag(buf + aoff[j + AHEAD]);
             const v4f x = av[j % (AHEAD + 1)];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, b[4 * j + 0], acc, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, b[4 * j + 1], acc1, 0, 0, 0);
@@ -194,6 +209,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void 
         for (int q = 0; q < NW - 1; q++) {
             const float4 o = ex[q * 64 + lane];
             val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
+        }
+        if (a.n_seg > 1) { /* (launch-uniform) window segments: whole-wave 1 KiB rows of partial sums, one per (work item, tile) */
+            float4* row = a.partial + ((long)item * tiles_total + t) * 64 + lane;
+            if (a.seg > 0) {
+                const float4 o = *row;
+                val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
+            }
+            if (a.seg + 1 < a.n_seg) {
+                *row = make_float4(val[0], val[1], val[2], val[3]);
+                continue;
+            }
         }
         float im4[4];
 #pragma unroll
@@ -239,14 +265,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void 
 
 }  // namespace
 
-/* CF32 at fft_size 256 / 512, hops of an even number of samples (rows of the staged image start on 16 bytes), a tile's bytes within the LDS budget of
+/* CF32 at fft_size 256 ... 8192, any hop (an odd number of samples: the AL8 variants), a tile's bytes within the LDS budget of
  * two workgroups per CU; dongles with an AFC channel stay on the wavefront FFT (their tables move at run time: the re-tune kernel builds int8 tables) */
 bool f32_supported(int fft_size, int hop_samples, int sfmt) {
     if (sfmt != AIRBAND_SFMT_F32) return false;
-    if (fft_size != 256 && fft_size != 512 && fft_size != 1024 && fft_size != 2048) return false; /* (4096 and beyond: 256+ B registers per wave of eight, or workgroups beyond 1 024 threads) */
-    if (hop_samples < 8 || (hop_samples & 1)) return false;
+    if (fft_size != 256 && fft_size != 512 && fft_size != 1024 && fft_size != 2048 && fft_size != 4096 && fft_size != 8192) return false; /* (4096, 8192: window segments of 2 048 samples, one launch each) */
+    if (hop_samples < 8) return false; /* (odd hops: the AL8 variants) */
     const int NW = f32_nw(fft_size);
-    if ((TILE_HOPS - 1) * 8 * hop_samples + 8 * fft_size > 12 * 64 * NW * 16) return false; /* a tile's bytes: twelve 16-byte pieces per thread */
+    if ((TILE_HOPS - 1) * 8 * hop_samples + 8 * f32_seg_size(fft_size) + ((hop_samples & 1) ? 16 : 0) > 12 * 64 * NW * 16) return false; /* a tile's bytes: twelve 16-byte pieces per thread */
     /* two workgroups per CU up to ~78 KiB each (2.56 MS/s at WAVE_RATE 16000: 54 KiB), one beyond (WAVE_RATE 8000: 92 KiB) */
     return f32_lds_per_buf(fft_size, hop_samples) * 2 + 2 * (NW - 1) * 64 * (int)sizeof(float4) <= 154 * 1024;
 }
@@ -255,29 +281,49 @@ int f32_pad_bytes(int hop_samples) { return f32_pad(8 * hop_samples); }
 
 int f32_lds_per_buf(int fft_size, int hop_samples) {
     const int hop_bytes = 8 * hop_samples, pad = f32_pad(hop_bytes);
-    const long tile_bytes = (long)(TILE_HOPS - 1) * hop_bytes + 8 * fft_size;
-    return (int)((f32_padded(tile_bytes, hop_bytes, pad) + 16 + 255) / 256 * 256);
+    const long tile_bytes = (long)(TILE_HOPS - 1) * hop_bytes + 8 * f32_seg_size(fft_size); /* (a launch stages one window segment) */
+    return (int)((f32_padded(tile_bytes, hop_bytes, pad) + 16 + ((hop_bytes & 8) ? 16 : 0) + 255) / 256 * 256); /* (odd hops: the image starts up to 8 bytes in front of the tile) */
 }
 
-template <int FFT_N, int MAX_LD, int NW>
-static void launch_f32(const F32Args& a, hipStream_t stream) {
+template <int FFT_N, int MAX_LD, int NW, bool AL8>
+static void launch_f32_al(const F32Args& a, hipStream_t stream) {
     const long groups = (long)a.n_items * a.splits;
     const size_t lds = (size_t)2 * a.lds_per_buf + 2 * (NW - 1) * 64 * sizeof(float4);
     /* more than the default 64 KiB of dynamic LDS: opt in to the CU's 160 KiB, once per kernel variant AND device (the attribute belongs to the function as loaded
      * on the current device; a process may drive several GPUs) */
-    static std::atomic<bool> big_lds[64]; /* (zero-initialised; the shim launches from one thread per GPU: set twice is harmless, torn is not possible) */
+    static std::atomic<bool> big_lds[64]; /* (per instantiation; zero-initialised; the shim launches from one thread per GPU: set twice is harmless, torn is not possible) */
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (lds > 64 * 1024 && (dev >= 64 || !big_lds[dev].load(std::memory_order_acquire))) {
         /* (the CU's whole 160 KiB, not this launch's size: a later handle of the same process may have longer hops) */
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_f32_kernel<FFT_N, MAX_LD, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess && dev < 64) big_lds[dev].store(true, std::memory_order_release);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&channelizer_f32_kernel<FFT_N, MAX_LD, NW, AL8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess && dev < 64) big_lds[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((channelizer_f32_kernel<FFT_N, MAX_LD, NW>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, a);
+    hipLaunchKernelGGL((channelizer_f32_kernel<FFT_N, MAX_LD, NW, AL8>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, a);
 }
 
-void launch_channelizer_f32(const F32Args& a, hipStream_t stream) {
-    const int tile_bytes = (TILE_HOPS - 1) * a.hop_bytes + 8 * a.fft_size;
+template <int FFT_N, int MAX_LD, int NW>
+static void launch_f32(const F32Args& a, hipStream_t stream) {
+    if (a.hop_bytes & 8) launch_f32_al<FFT_N, MAX_LD, NW, true>(a, stream);
+    else launch_f32_al<FFT_N, MAX_LD, NW, false>(a, stream);
+}
+
+int f32_partial_tiles(int n_hops_max) { return (15 + n_hops_max + TILE_HOPS - 1) / TILE_HOPS + 1; }
+
+void launch_channelizer_f32(const F32Args& a0, hipStream_t stream) {
+    F32Args a = a0;
+    a.n_seg = f32_n_seg(a0.fft_size);
+    a.seg = 0;
+    const int tile_bytes = (TILE_HOPS - 1) * a.hop_bytes + 8 * f32_seg_size(a.fft_size) + ((a.hop_bytes & 8) ? 16 : 0); /* (odd hops: the image may start 8 bytes in front of the tile) */
     const bool small = tile_bytes <= 6 * 64 * f32_nw(a.fft_size) * 16; /* six pieces per thread: the register budget of three workgroups per CU (NW = 4) */
+    if (a.n_seg > 1) { /* fft_size 4096 / 8192: the fft 2048 kernel once per window segment */
+        for (int seg = 0; seg < a.n_seg; seg++) {
+            a.seg = seg;
+            if (small) launch_f32<2048, 6, 8>(a, stream);
+            else launch_f32<2048, 12, 8>(a, stream);
+        }
+        return;
+    }
+    a.partial = nullptr;
     if (a.fft_size == 2048) return small ? launch_f32<2048, 6, 8>(a, stream) : launch_f32<2048, 12, 8>(a, stream);
     if (a.fft_size == 1024) return small ? launch_f32<1024, 6, 8>(a, stream) : launch_f32<1024, 12, 8>(a, stream);
     if (a.fft_size == 512) return small ? launch_f32<512, 6, 4>(a, stream) : launch_f32<512, 12, 4>(a, stream);

@@ -78,6 +78,8 @@ struct F32Args {
     int n_items, splits, fft_size;
     int hop_bytes, pad, lds_per_buf; /* bytes per hop (8 x hop_samples), padding per hop in the staged image, bytes per staging buffer */
     int row0, ring_rows, first_row, n_hops;
+    int seg, n_seg;         /* fft_size 4096 / 8192: window segment of this launch / segments per window (set by launch_channelizer_f32) */
+    float4* partial;        /* those sizes only: [n_items][f32_partial_tiles() tiles][64] partial sums between the segments' launches */
 };
 
 struct DemodArgs {
@@ -176,6 +178,10 @@ void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* ki
 /* waves per workgroup = pieces the contraction index (2 fft_size values) is cut into: four up to fft_size 512 (64 / 32 resident B registers per wave), eight for 1024 and 2048
  * (64 / 128): a workgroup of eight waves is two per SIMD, which is what 128 B registers beside everything else allow anyway */
 inline int f32_nw(int fft_size) { return fft_size <= 512 ? 4 : 8; }
+/* fft_size 4096 / 8192: the window in segments of 2 048 samples, each contracted by the fft 2048 kernel with the segment's own table (one launch per segment) */
+inline int f32_seg_size(int fft_size) { return fft_size < 2048 ? fft_size : 2048; }
+inline int f32_n_seg(int fft_size) { return fft_size / f32_seg_size(fft_size); }
+int f32_partial_tiles(int n_hops_max); /* 16-hop tiles a work item may touch in one launch (sizes F32Args::partial) */
 bool f32_supported(int fft_size, int hop_samples, int sfmt);
 int f32_pad_bytes(int hop_samples);
 int f32_lds_per_buf(int fft_size, int hop_samples);
@@ -203,6 +209,7 @@ struct RetuneArgs {
     int* bset_bin;          /* [n_bsets][8] */
     int8_t* bfrag;
     double* corr;
+    float* ftab;            /* CF32 handles (channelizer_f32.hip): the float tables instead of bfrag / corr (both null then); else null */
     const float* window;    /* fft_size */
     int n_items, fft_size, n_shared;
     const int* moved_epoch; /* the batch number afc_kernel stamped when it last moved a channel; the kernel works only if it equals `epoch` (start-up build: both 0) */

@@ -294,6 +294,37 @@ __device__ __forceinline__ void build_column_pair(int8_t* bfrag, double* corr, c
     }
 }
 
+/* The same for a CF32 handle's float table (channelizer_f32.hip; layout and arithmetic of params.cpp, build_f32_tables: window x twiddle in double, rounded once):
+ * entry [bset][segment][piece][s][lane] is coefficient (k, column lane & 15), k = segment * 2 SEG + piece * VPP + 16 (s / 4) + 4 (lane >> 4) + s % 4 */
+__device__ __forceinline__ void build_column_pair_f32(float* ftab, const float* window, int bset, int c, int bin, int N, int lane) {
+    const int SEG = N < 2048 ? N : 2048, NSEG = N / SEG, NW = N <= 512 ? 4 : 8, VPP = 2 * SEG / NW, KW = VPP / 4;
+    float* tab = ftab + (size_t)bset * NSEG * NW * KW * 64;
+    /* the column pair's lanes of every [segment][piece][s] row: lanes g * 16 + 2 c + {0, 1}, g = 0 .. 3 -- eight floats per row; a lane of this wave takes one of them */
+    const int rows = NSEG * NW * KW;
+    for (int e = lane; e < rows * 8; e += 64) {
+        const int row = e >> 3, g = (e >> 1) & 3, half = e & 1;
+        const int s_ = row % KW, piece = (row / KW) % NW, seg = row / (KW * NW);
+        const int k = seg * 2 * SEG + piece * VPP + 16 * (s_ / 4) + 4 * g + (s_ % 4);
+        const int n = k >> 1;
+        double sn, cs_;
+        sincospi(2.0 * (double)(((long long)bin * n) % N) / (double)N, &sn, &cs_);
+        const double wc = (double)window[n] * cs_, ws = (double)window[n] * sn;
+        const double v = half ? ((k & 1) ? wc : -ws) : ((k & 1) ? ws : wc);
+        tab[(size_t)row * 64 + g * 16 + 2 * c + half] = (float)v;
+    }
+}
+__device__ __forceinline__ void copy_column_pair_f32(float* ftab, int bset, int home, int c, int N, int lane) {
+    const int SEG = N < 2048 ? N : 2048, NSEG = N / SEG, NW = N <= 512 ? 4 : 8, KW = 2 * SEG / NW / 4;
+    const size_t each = (size_t)NSEG * NW * KW * 64;
+    float* tab = ftab + (size_t)bset * each;
+    const float* src = ftab + (size_t)home * each;
+    const int rows = NSEG * NW * KW;
+    for (int e = lane; e < rows * 8; e += 64) {
+        const size_t at = (size_t)(e >> 3) * 64 + ((e >> 1) & 3) * 16 + 2 * c + (e & 1);
+        tab[at] = src[at];
+    }
+}
+
 /* Shared coefficient tables beyond the ones the host builds (round 6: a fleet whose dongles do NOT share a channel plan -- every device_t derives its own bins,
  * src/config.cpp:666-667 -- has one table per distinct group of eight bins; the host builds the first few thousand, the rest are built here at prepare() time, one
  * wavefront per table): tables [first, first + n), every column from bset_bin. */
@@ -355,6 +386,12 @@ __global__ __launch_bounds__(256) void retune_kernel(RetuneArgs a) {
         /* a channel on its base bin takes its column pair from the group's HOME table, byte for byte: the host built that one (cos / sin / llround of the
          * platform's libm, params.cpp), this kernel builds with the device's sincospi, and a coefficient may differ by one unit between the two -- a
          * channel that has not moved must not see a different table because a neighbour's AFC has (its bins would change by ~1e-7) */
+        if (a.ftab) { /* (launch-uniform) CF32: the float table's column pair, copied from the home table or built */
+            if (bin == __shfl(my_base, c)) copy_column_pair_f32(a.ftab, bset, a.item_home[item], c, N, lane);
+            else build_column_pair_f32(a.ftab, a.window, bset, c, bin, N, lane);
+            if (lane == 0) a.bset_bin[bset * 8 + c] = bin;
+            continue;
+        }
         if (bin == __shfl(my_base, c)) {
             const int home = a.item_home[item];
             for (int piece = 0; piece < NP; piece++) {

@@ -325,22 +325,25 @@ int build_plan(const airband_hip_config* cfg, Plan& p) {
  * (same transform as src/rtl_airband.cpp:451-460 + :483-489 evaluated for one bin).  Values are scaled to 24-bit
  * integers and split into balanced base-256 digits d0 + 256 d1 + 65536 d2, each in [-128, 127]. */
 void build_f32_tables(Plan& p) {
-    const int N = p.fft_size, NW = N <= 512 ? 4 : 8, VPP = 2 * N / NW, KW = VPP / 4; /* values and MFMAs (K = 4) per piece; NW = kernels.h f32_nw() */
-    p.ftab.assign((size_t)p.n_shared_bsets * NW * KW * 64, 0.0f);
+    /* fft_size 4096 / 8192: the window in segments of 2 048 samples, each laid out like an fft 2048 table (kernels.h f32_seg_size / f32_n_seg) */
+    const int N = p.fft_size, SEG = N < 2048 ? N : 2048, NSEG = N / SEG;
+    const int NW = N <= 512 ? 4 : 8, VPP = 2 * SEG / NW, KW = VPP / 4; /* values and MFMAs (K = 4) per piece; NW = kernels.h f32_nw() */
+    p.ftab.assign((size_t)p.n_shared_bsets * NSEG * NW * KW * 64, 0.0f);
     for (int b = 0; b < p.n_shared_bsets; b++)
+      for (int seg = 0; seg < NSEG; seg++)
         for (int piece = 0; piece < NW; piece++)
             for (int s = 0; s < KW; s++)
                 for (int lane = 0; lane < 64; lane++) {
                     const int col = lane & 15, c = col >> 1, g = lane >> 4;
                     const int bin = p.bset_bins[(size_t)b * 8 + c];
                     if (bin < 0) continue; /* a group with fewer than 8 channels: unused columns stay zero */
-                    const int k = piece * VPP + 16 * (s / 4) + 4 * g + (s % 4);
+                    const int k = seg * 2 * SEG + piece * VPP + 16 * (s / 4) + 4 * g + (s % 4);
                     const int n = k >> 1;
                     const double th = 2.0 * M_PI * (double)(((long long)bin * n) % N) / (double)N; /* the phase is reduced exactly in integers first */
                     const double wc = (double)p.window[n] * std::cos(th), ws = (double)p.window[n] * std::sin(th);
                     /* (I + jQ) w e^{-j th} = (I w cos + Q w sin) + j (Q w cos - I w sin): value k = 2n is I, 2n + 1 is Q; column 2c is re, 2c + 1 im */
                     const double v = (col & 1) ? ((k & 1) ? wc : -ws) : ((k & 1) ? ws : wc);
-                    p.ftab[(((size_t)b * NW + piece) * KW + s) * 64 + lane] = (float)v;
+                    p.ftab[((((size_t)b * NSEG + seg) * NW + piece) * KW + s) * 64 + lane] = (float)v;
                 }
 }
 
@@ -489,7 +492,7 @@ void build_dft_tables(Plan& p, bool host_private) {
  * l supplying stream value 16 (s / 4) + 4 (l >> 4) + s % 4 of its piece against table entry [piece][s][l], partial sums of a piece in float, the four pieces
  * added in float -- against the double-precision sum, on pseudo-random windows; largest error relative to the RMS of the exact values */
 double f32_table_selftest(const Plan& p, int windows) {
-    const int N = p.fft_size, NW = N <= 512 ? 4 : 8, VPP = 2 * N / NW, KW = VPP / 4;
+    const int N = p.fft_size, SEG = N < 2048 ? N : 2048, NSEG = N / SEG, NW = N <= 512 ? 4 : 8, VPP = 2 * SEG / NW, KW = VPP / 4;
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     auto next = [&]() {
         rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
@@ -508,16 +511,20 @@ double f32_table_selftest(const Plan& p, int windows) {
                 for (int comp = 0; comp < 2; comp++) {
                     const int col = 2 * c + comp;
                     float total = 0.0f;
-                    for (int piece = 0; piece < NW; piece++) {
-                        float acc2[2] = {0.0f, 0.0f}; /* the kernel alternates two accumulators */
-                        for (int s_ = 0; s_ < KW; s_++) {
-                            float part = acc2[s_ & 1]; /* one MFMA: four products added to the accumulator */
-                            for (int gg = 0; gg < 4; gg++)
-                                part += raw[piece * VPP + 16 * (s_ / 4) + 4 * gg + (s_ % 4)] * p.ftab[(((size_t)set * NW + piece) * KW + s_) * 64 + gg * 16 + col];
-                            acc2[s_ & 1] = part;
+                    for (int seg = 0; seg < NSEG; seg++) { /* one launch per window segment; the sums of the earlier segments are added to the finishing wave's */
+                        float seg_total = 0.0f;
+                        for (int piece = 0; piece < NW; piece++) {
+                            float acc2[2] = {0.0f, 0.0f}; /* the kernel alternates two accumulators */
+                            for (int s_ = 0; s_ < KW; s_++) {
+                                float part = acc2[s_ & 1]; /* one MFMA: four products added to the accumulator */
+                                for (int gg = 0; gg < 4; gg++)
+                                    part += raw[seg * 2 * SEG + piece * VPP + 16 * (s_ / 4) + 4 * gg + (s_ % 4)] * p.ftab[((((size_t)set * NSEG + seg) * NW + piece) * KW + s_) * 64 + gg * 16 + col];
+                                acc2[s_ & 1] = part;
+                            }
+                            const float acc = acc2[0] + acc2[1];
+                            seg_total = piece == 0 ? acc : seg_total + acc;
                         }
-                        const float acc = acc2[0] + acc2[1];
-                        total = piece == 0 ? acc : total + acc;
+                        total = seg == 0 ? seg_total : seg_total + total;
                     }
                     const double got = (double)(total * p.dev[d].scale);
                     double want = 0.0;

@@ -724,7 +724,11 @@ def test_ragged_shapes_and_empty_inputs(pkg, built, fmt):
     # CF32 (SoapySDR) on the float32 matrix pipe since round 4: fft 512 / 256, 2.56 / 2.4 MS/s, both WAVE_RATEs (hops of 160 / 320 / 150 / 300 samples: padded and unpadded rows)
     ("SFMT_F32", 9, 2_560_000, 8000), ("SFMT_F32", 8, 2_560_000, 16000), ("SFMT_F32", 9, 2_400_000, 16000), ("SFMT_F32", 9, 2_400_000, 8000), ("SFMT_F32", 10, 2_560_000, 16000),
     # ... and at fft 1024 / 2048 since round 5 (workgroups of eight waves; 2048: 128 resident B registers per wave; WAVE_RATE 8000: the large-tile variants)
-    ("SFMT_F32", 11, 2_560_000, 16000), ("SFMT_F32", 10, 2_400_000, 8000), ("SFMT_F32", 11, 2_560_000, 8000), ("SFMT_F32", 11, 2_400_000, 16000)])
+    ("SFMT_F32", 11, 2_560_000, 16000), ("SFMT_F32", 10, 2_400_000, 8000), ("SFMT_F32", 11, 2_560_000, 8000), ("SFMT_F32", 11, 2_400_000, 16000),
+    # ... and at fft 4096 / 8192 since round 6 (two / four window segments of 2 048 samples, one launch of the fft 2048 kernel each, partial sums parked between them)
+    ("SFMT_F32", 12, 2_560_000, 16000), ("SFMT_F32", 13, 2_560_000, 16000), ("SFMT_F32", 12, 2_400_000, 8000), ("SFMT_F32", 13, 2_560_000, 8000),
+    # ... and with hops of an odd number of samples (125 / 251 / 75: rows of the staged image at 8-byte alignment, fragments from two 8-byte LDS reads)
+    ("SFMT_F32", 9, 2_000_000, 16000), ("SFMT_F32", 10, 2_008_000, 8000), ("SFMT_F32", 8, 1_200_000, 16000), ("SFMT_F32", 12, 2_000_000, 16000)])
 def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sample_rate, wave_rate):
     """Sample formats s8/s16/f32, fft sizes 256..8192, sample rates whose hop is not a multiple of 16 bytes: the matrix-core path
     takes u8, s8 and CS16 at every fft size and every hop (window pieces of 512 samples on cooperating waves from 1024 up, two passes at 8192; hops of an
@@ -741,7 +745,7 @@ def test_other_formats_fft_sizes_and_rates(pkg, built, sfmt_name, fft_log, sampl
     with pkg.AirbandHip(devices, wave_rate=wave_rate, fft_log=fft_log, flags=capi.FLAG_TRACE_SQUELCH) as hip:
         hop_bytes = 2 * hop * capi.BYTES_PER_SAMPLE[sfmt]
         expect_dft = (sfmt in (capi.SFMT_U8, capi.SFMT_S8) and 64 <= hop_bytes <= 1024) or (sfmt == capi.SFMT_S16 and hop_bytes % 4 == 0 and 128 <= hop_bytes <= 1280)
-        expect_f32 = sfmt == capi.SFMT_F32 and fft_log in (8, 9, 10, 11) and hop % 2 == 0   # CF32 on the float32 matrix pipe (channelizer_f32.hip; fft 1024 / 2048 since round 5)
+        expect_f32 = sfmt == capi.SFMT_F32   # CF32 on the float32 matrix pipe (channelizer_f32.hip; fft 1024 / 2048 since round 5; 4096 / 8192 as window segments and hops of an odd number of samples since round 6)
         assert hip.channelizer_name() == ("dft_mfma_i8" if expect_dft else "dft_mfma_f32" if expect_f32 else "fft_wave64")
         pos = [0] * n_dev
         for b in range(n_batches):
@@ -1025,25 +1029,28 @@ def test_device_enable_takes_a_failed_dongle_out(pkg, built):
             hip.device_enable(n_dev, False)
 
 
-@pytest.mark.parametrize("force_fft", [False, True], ids=["dft_mfma", "fft_wave64"])
-def test_afc(pkg, built, force_fft):
-    """AFC-enabled channels (src/rtl_airband.cpp:180-251).  On the matrix-core channelizer a group with an AFC channel owns its coefficient
-    table, one wavefront FFT per dongle gives AFC the spectrum of the batch's last hop, and the re-tune kernel rewrites the moved
+@pytest.mark.parametrize("force_fft,sfmt_name", [(False, "SFMT_U8"), (True, "SFMT_U8"), (False, "SFMT_F32")], ids=["dft_mfma", "fft_wave64", "dft_mfma_f32"])
+def test_afc(pkg, built, force_fft, sfmt_name):
+    """AFC-enabled channels (src/rtl_airband.cpp:180-251).  On the matrix-core channelizers (int8; CF32 on the float32 pipe since round 6) a group with an AFC
+    channel owns its coefficient table, one wavefront FFT per dongle gives AFC the spectrum of the batch's last hop, and the re-tune kernel rewrites the moved
     channel's columns; the wavefront-FFT channelizer reads the bin from the channel state."""
     n_dev, n_batches = 3, 14
     devices, carriers = helpers.afc_case(n_dev)
+    sfmt = getattr(pkg.capi, sfmt_name)
     nbytes = helpers.stream_bytes(n_batches, 8000)
-    iq = [pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers) for d in range(n_dev)]
+    iq = [helpers.convert_format(pkg.siggen.generate_u8(d, 0, nbytes // 2, carriers), sfmt, pkg.capi) for d in range(n_dev)]
+    for d in devices:
+        d["sfmt"] = sfmt
     orc = pyoracle.Oracle(devices, wave_rate=8000)
     ref = [orc.run_device(d, iq[d], n_batches) for d in range(n_dev)]
     moved = 0
     flags = pkg.capi.FLAG_TRACE_SQUELCH | (pkg.capi.FLAG_FORCE_FFT if force_fft else 0)
     with pkg.AirbandHip(devices, wave_rate=8000, flags=flags) as hip:
-        assert hip.channelizer_name() == ("fft_wave64" if force_fft else "dft_mfma_i8")
+        assert hip.channelizer_name() == ("fft_wave64" if force_fft else "dft_mfma_i8" if sfmt == pkg.capi.SFMT_U8 else "dft_mfma_f32")
         pos = [0] * n_dev
         for b in range(n_batches):
             for d in range(n_dev):
-                pos[d] += hip.submit(d, iq[d][pos[d]:])
+                pos[d] += hip.submit(d, iq[d].view(np.uint8)[pos[d]:])
             assert hip.process()
             out = hip.collect(stats=True)
             want_a = np.concatenate([r["axc"][b] for r in ref])

@@ -68,6 +68,8 @@ CASES = [
     pytest.param(4096, True, 16000, 40, False, True, "regroup", id="4096_mixed_regrouped"),
     pytest.param(1000, False, 8000, 24, False, False, "regroup", id="1000_am_regrouped_partial_block"),
     pytest.param(65536, True, 16000, 48, False, False, "regroup", id="configs2_65536_mixed_regrouped"),
+    # ... and by the library's own choice where all of a handle's lane-per-channel wavefronts are resident at once (BASELINE configs[3]'s per-GPU shard)
+    pytest.param(32768, True, 16000, 32, False, False, "auto_regroup", id="configs3_shard_32768_mixed_regrouped_by_residency"),
 ]
 
 
@@ -97,8 +99,8 @@ def test_sampled_dongles_of_large_handles(pkg, built, n_dev, mixed, wave_rate, k
     hip = pkg.AirbandHip(devices, wave_rate=wave_rate, flags=flags)
     iq = spot = None
     try:
-        assert hip.channelizer_name() == {"": "dft_mfma_i8", "force_fft": "fft_wave64", "f32": "dft_mfma_f32", "f32_fft": "fft_wave64", "plans": "dft_mfma_i8", "regroup": "dft_mfma_i8"}[path]
-        assert hip.stage2_regrouped() == (path == "regroup") or "AIRBAND_HIP_REGROUP" in __import__("os").environ
+        assert hip.channelizer_name() == {"": "dft_mfma_i8", "force_fft": "fft_wave64", "f32": "dft_mfma_f32", "f32_fft": "fft_wave64", "plans": "dft_mfma_i8", "regroup": "dft_mfma_i8", "auto_regroup": "dft_mfma_i8"}[path]
+        assert hip.stage2_regrouped() == (path in ("regroup", "auto_regroup")) or "AIRBAND_HIP_REGROUP" in __import__("os").environ
         g = hip.geometry
         lead = g.first_batch_bytes - g.batch_bytes
         span = lead + (RING + 1) * g.batch_bytes + g.lookahead_bytes
