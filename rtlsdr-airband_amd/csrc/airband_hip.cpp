@@ -1026,6 +1026,15 @@ static int launch_front(airband_hip_handle* h, const void* d_iq, size_t stride_b
         a.ring_rows = h->R;
         a.first_row = first ? 0 : AB_AGC_EXTRA;
         a.n_hops = first ? h->B + AB_AGC_EXTRA : h->B;
+        /* Pipelined handles (stage 1 of this batch runs beside stage 2 of the batch before): eight channelizer wavefronts of ~250 registers ARE a CU's register file, and
+         * stage-2 wavefronts then only get onto a CU when one of them retires.  Held to FIVE per CU (it loses ~5 % alone: 7 and 6 per CU cost nothing, 4 cost 12 %,
+         * profiles/r06_occupancy/) the channelizer leaves three SIMDs a wavefront's worth of registers each: configs[2] 14.05 ms sequential, 13.77 pipelined as before,
+         * 13.05 like this (13.5 / 14.0 at 4 / 6 per CU; profiles/r06_pipelined/).  The LDS it asks for and never touches is what holds it there. */
+        a.extra_lds = 0;
+        if (h->pipeline && np_total == 1) {
+            const int used = a.nbuf * a.lds_per_buf, want = 28 * 1024; /* 160 KiB / 28 KiB = 5 */
+            if (used < want) a.extra_lds = want - used;
+        }
         /* enough waves to fill 256 CUs x 8 waves even with few dongles: split each dongle's tiles */
         const int steps = ((a.n_hops + 15) / 16 + 1 + a.sub - 1) / a.sub;
         int splits = (8192 + a.n_items - 1) / a.n_items;

@@ -323,7 +323,17 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
         mark1 = b == 1 ? v : mark1;
         mark2 = b == 2 ? v : mark2;
     };
-    if (piece == 0) {
+    /* ---- round 6: the hop-specialised variants stage through ONE ring without the window overlap (below, "staging ring") ---- */
+#ifndef AB_RING
+#define AB_RING 0 /* 1: experiment builds (-DAB_RING=1).  Measured, parity-green and NOT adopted (profiles/r06_ring/, profiles/r06_experiments.md J): 8 % fewer L1 -> L2 read
+                   * requests, 18 % fewer L2 hits, the same bytes fetched -- and the same launch time, 8.31 / 8.42 / 8.95 against 8.34 / 8.42 / 8.43 ms (hops of 640 bytes:
+                   * 7.37 / 7.36 / 7.40 against 7.35 / 7.35 / 7.41): the kernel waits for HBM, not for its requests.  The product stays on round 5's three buffers. */
+#endif
+#ifndef AB_RING_640
+#define AB_RING_640 1 /* hops of 640 bytes (WAVE_RATE 8000): three slots of 10 KiB = 31 KiB per wave, five waves per CU (round 5: two buffers of 11 KiB, seven) */
+#endif
+    constexpr bool RING = AB_RING != 0 && HOPB != 0 && (HOPB != 640 || AB_RING_640 != 0) && NP == 1 && !S16 && AL >= 16 && (TILE_HOPS * (HOPB ? HOPB : 64)) % 1024 == 0;
+    if (!RING && piece == 0) {
         stage(st_begin, lds);
         if (nbuf == 3 && st_begin + 1 < st_end) stage(st_begin + 1, lds + lds_per_buf);
     }
@@ -514,6 +524,96 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
      * t - 1) -> the buffer tile t read is free: the transfer of step t + 3 goes out (three steps in flight, was two) -> wait for step
      * t + 1's bytes, issue tile t + 1's first A fragments -> recombine and store tile t while those LDS reads fly.  The wave no longer
      * stalls on LDS latency at the top of every tile, nor on the matrix pipe's drain with nothing else to issue. */
+    /* ---- staging ring (round 6; review item 3 ii): the stream of a wave lives ONCE in LDS.  Three slots of one 16-hop step each (5 KiB at hops of 320 bytes) form a
+     * ring; a step's transfer brings only its NEW bytes, and a tile reads its window tail in place -- the first 704 bytes of the NEXT slot (the ring's first KiB is kept a
+     * second time behind its end, so a row never wraps).  Against the three buffers of round 5: five transfers per step instead of six (the sixth re-read the previous
+     * step's last KiB out of L2: a sixth of this kernel's requests), none of them read twice, so EVERY piece may go out non-temporal (section A of
+     * profiles/r06_experiments.md: nt on every piece cost 13 % while two pieces in six were re-read), 16 KiB of LDS per wave instead of 18.  What it costs: tile st needs
+     * the head (first KiB) of step st + 1, so that transfer is waited for one tile earlier than its step used to be.  (Result: see AB_RING above -- no gain.)
+     * Order inside a step's transfer: piece 0, its replica (slot 0 only), pieces 1 ...: "the head of step v has landed" = at most tail(v) + everything younger outstanding. */
+    if constexpr (RING) {
+        constexpr int RS = TILE_HOPS * (HOPB ? HOPB : 64); /* bytes per step = per slot */
+        constexpr int RNP = RS / 1024;                     /* transfers per step */
+        constexpr int RING_BYTES = 3 * RS;                 /* + 1 KiB replica of the ring's first KiB behind it */
+        static_assert(RNP >= 2 && RNP <= 12, "pieces at immediate offsets below 12 KiB");
+#ifndef AB_RING_AUX
+#define AB_RING_AUX 2 /* nt: every piece of the ring is read once */
+#endif
+#ifndef AB_RING_HEAD_AUX
+#define AB_RING_HEAD_AUX 0 /* piece 0 of a slot-0 step is requested twice in a row (the ring and its replica) */
+#endif
+        const uint8_t* const rp_lane = src - (long)shift * HOPB + lane * 16; /* (16-byte aligned hops: mis = delta = 0) */
+        const int r_in_lo = shift > 0 ? 1 : 0;
+        const long room_n = span_end - (long)RNP * 1024, room_1 = span_end - 1024;
+        const int r_in_hi_n = __builtin_amdgcn_readfirstlane(room_n < 0 ? -1 : (int)((room_n / HOPB + shift) / TILE_HOPS));
+        const int r_in_hi_1 = __builtin_amdgcn_readfirstlane(room_1 < 0 ? -1 : (int)((room_1 / HOPB + shift) / TILE_HOPS));
+        /* step v (st_begin ... st_end: the one past the last tile's brings its head only) into ring slot `slot` */
+        auto ring_stage = [&](int v, int slot) {
+            const bool whole = v < st_end;
+            uint8_t* dst = lds + slot * RS;
+            if (v >= r_in_lo && v <= (whole ? r_in_hi_n : r_in_hi_1)) { /* wave-uniform: no lane's address needs clamping */
+                const uint8_t* p = rp_lane + (unsigned long long)(unsigned)v * (unsigned)RS;
+                if (slot == 0) {
+                    AB_DMA((gptr_t)p, (lptr_t)(uintptr_t)dst, 0, AB_RING_HEAD_AUX);
+                    AB_DMA((gptr_t)p, (lptr_t)(uintptr_t)(lds + RING_BYTES), 0, AB_RING_HEAD_AUX);
+                } else {
+                    AB_DMA((gptr_t)p, (lptr_t)(uintptr_t)dst, 0, AB_RING_AUX);
+                }
+                if (whole) {
+#define AB_RPIECE(K, BASE, OFF) \
+    if (RNP > (K)) AB_DMA((gptr_t)(p + (BASE)), (lptr_t)(uintptr_t)(dst + (BASE)), (OFF), AB_RING_AUX)
+                    AB_RPIECE(1, 0, 1024); AB_RPIECE(2, 0, 2048); AB_RPIECE(3, 0, 3072);
+                    AB_RPIECE(4, 4096, 0); AB_RPIECE(5, 4096, 1024); AB_RPIECE(6, 4096, 2048); AB_RPIECE(7, 4096, 3072);
+                    AB_RPIECE(8, 8192, 0); AB_RPIECE(9, 8192, 1024); AB_RPIECE(10, 8192, 2048); AB_RPIECE(11, 8192, 3072);
+#undef AB_RPIECE
+                }
+                return;
+            }
+            const long base = ((long)v * TILE_HOPS - shift) * HOPB;
+            const int np = whole ? RNP : 1;
+            for (int i = 0; i < np; i++) {
+                long so = base + i * 1024 + lane * 16;
+                if (so + 16 > span_end) so = span_end - 16;
+                if (so < 0) so = 0;
+                AB_DMA((gptr_t)(src + so), (lptr_t)(uintptr_t)(dst + i * 1024), 0, 0);
+                if (i == 0 && slot == 0) AB_DMA((gptr_t)(src + so), (lptr_t)(uintptr_t)(lds + RING_BYTES), 0, 0);
+            }
+        };
+        const int nst = st_end - st_begin;
+        ring_stage(st_begin, 0);
+        ring_stage(st_begin + 1, 1);
+        if (nst >= 2) ring_stage(st_begin + 2, 2);
+        /* step st_begin whole + the head of the next: younger are that step's tail and the third transfer */
+        wait_vmcnt((nst >= 2 ? RNP - 1 : 0) + (nst >= 3 ? RNP : nst == 2 ? 1 : 0));
+        v4i pre[4];
+        a_head(a_row(lds, 0), pre);
+        int mark2 = 0; /* `stores` when the transfer of step st + 2 was issued */
+        int slot = 0;
+        for (int st = st_begin; st < st_end; st++) {
+            TileAcc now;
+            tile_body(a_row(lds + slot * RS, 0), pre, now, no_mid);
+            const bool has3 = st + 3 <= st_end;
+            if (has3) ring_stage(st + 3, slot); /* every LDS read of this slot has returned (the MFMAs consumed them; the tile before read its first 704 bytes): it takes the step three ahead */
+            const int mark3 = stores;
+            const int slot1 = slot == 2 ? 0 : slot + 1;
+            if (st + 1 < st_end) {
+                /* tile st + 1 needs step st + 1 whole and the head of step st + 2 (transfers land in issue order): younger than that head are its step's tail, the
+                 * transfer just issued and the stores since step st + 2 went out */
+                const int tail2 = st + 2 < st_end ? RNP - 1 : 0;
+                const int cnt3 = has3 ? (st + 3 < st_end ? RNP : 1) + (slot == 0 ? 1 : 0) : 0;
+                wait_vmcnt(tail2 + cnt3 + (stores - mark2));
+                a_head(a_row(lds + slot1 * RS, 0), pre);
+            }
+            mark2 = mark3;
+            float val[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) val[r] = tile_value(now, r);
+            tile_store(st, val);
+            slot = slot1;
+        }
+        return;
+    }
+
     if (NP == 1 && !S16 && nbuf == 3 && sub == 1) {
         /* steps whose transfer lies wholly inside the batch span (no lane's address needs clamping), as a range worked out once: the per-step
          * test is two scalar compares and the source address one multiply-add */
@@ -694,7 +794,8 @@ static void launch_al(const DftArgs& a, hipStream_t stream) {
         const char* e = getenv("AIRBAND_HIP_DFT_EXTRA_LDS");
         return e ? (size_t)atol(e) : (size_t)0;
     }();
-    const size_t lds = (size_t)a.nbuf * a.lds_per_buf + (NP > 1 ? 2 * (NP - 1) * 64 * sizeof(float4) : 0) + extra_lds;
+    constexpr bool ring = AB_RING != 0 && HOPB != 0 && (HOPB != 640 || AB_RING_640 != 0) && NP == 1 && !S16 && AL >= 16 && (TILE_HOPS * (HOPB ? HOPB : 64)) % 1024 == 0; /* (the kernel's RING) */
+    const size_t lds = (ring ? (size_t)3 * TILE_HOPS * HOPB + 1024 : (size_t)a.nbuf * a.lds_per_buf + (NP > 1 ? 2 * (NP - 1) * 64 * sizeof(float4) : 0)) + extra_lds + (size_t)(a.extra_lds > 0 ? a.extra_lds : 0);
     /* more than the default 64 KiB of dynamic LDS (eight-piece windows): opt in to the CU's 160 KiB, once per kernel variant */
     /* (once per kernel variant AND device: the attribute belongs to the function as loaded on the current device, and a process may drive several GPUs) */
     static std::atomic<bool> big_lds_dev[64][2]; /* (zero-initialised; one launching thread per GPU in the shim: setting it twice is harmless) */

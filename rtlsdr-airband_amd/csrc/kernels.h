@@ -60,6 +60,8 @@ struct DftArgs {
     int edge_hi_zero;                /* most significant digit is zero in k-steps 0,1,14,15 for every coefficient table */
     int hop_bytes, lds_per_buf, sub, nbuf; /* sub = 16-hop MFMA tiles per staging step; nbuf staging buffers */
     int row0, ring_rows, first_row, n_hops;
+    int extra_lds;          /* bytes of LDS the launch asks for beyond what it uses: AIRBAND_HIP_FLAG_PIPELINE handles hold the channelizer to five wavefronts per CU, so that
+                             * every CU has register room for the stage-2 wavefronts of the batch before (airband_hip.cpp; profiles/r06_experiments.md I) */
 };
 
 /* CF32 dongles on the float32 matrix pipe (channelizer_f32.hip) */
