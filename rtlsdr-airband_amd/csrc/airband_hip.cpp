@@ -384,7 +384,7 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.row0 = h->row0;
     da.ring_rows = h->R;
     da.regroup = h->regroup ? 1 : 0;
-    da.sq_key = h->regroup ? h->d_sq_key.p : nullptr;
+    da.sq_key = h->d_sq_key.p;
     launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
     if (h->any_afc && h->afc_spectrum_valid) { /* afc.finalize(), src/rtl_airband.cpp:626-630: may turn '*' into '<' / '>' */
         const bool tables = h->use_dft || h->use_f32; /* the matrix-core channelizers: a channel's bin is baked into its coefficient columns */
@@ -661,7 +661,7 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
         const bool by_residency = waves_per_simd >= 2.75 && waves_per_simd <= 6.25;
         const char* e = getenv("AIRBAND_HIP_REGROUP");
         h->regroup = e && *e ? (*e != '0') : (h->flags & AIRBAND_HIP_FLAG_REGROUP) ? true : (h->flags & AIRBAND_HIP_FLAG_NO_REGROUP) ? false : by_residency;
-        if (h->regroup) {
+        if (h->regroup || h->ct_n_blocks > 0) { /* the front kernel's note per channel: had audio / went CLOSED in this batch (tone kernel; regrouped back kernel) */
             PREP_TRY(h->d_sq_key.alloc((size_t)h->n_slots), AIRBAND_HIP_ENOMEM);
             PREP_TRY(hipMemset(h->d_sq_key.p, 0, (size_t)h->n_slots), AIRBAND_HIP_ENOMEM);
         }

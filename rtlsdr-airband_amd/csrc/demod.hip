@@ -326,7 +326,8 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     wrow.wave_stride = a.wave_stride;
     wrow.coop = full_block;
     wrow.skip_of = skip_of;
-    lmask audio_seen = 0; /* split kinds of regrouped handles: lanes whose squelch let audio through somewhere in this batch (a scalar register pair: no vector work) */
+    lmask audio_seen = 0; /* split kinds: lanes whose squelch let audio through, or went CLOSED, somewhere in this batch (a scalar register pair: no vector work) -- a channel
+                           * without either has nothing for the tone kernel to do, and regrouped handles deal the back kernel's slots out by it */
     RowZero rz = {sp->row_zero, false, false};
     float2* iqout = a.iq_out + ab_ring_base(slot, B);
     uint8_t* trace = a.trace ? a.trace + ab_ring_base(slot, B) : nullptr;
@@ -574,7 +575,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             }
         }
 #endif
-        if (WAVE_HAS_CTCSS && W > 1) audio_seen |= Q ? s.cO : sq_should_audio(s);
+        if (WAVE_HAS_CTCSS) audio_seen |= (Q ? s.cO : sq_should_audio(s)) | went_closed;
         const bool audio = ab_lane(Q ? s.cO : sq_should_audio(s));
         if (audio) {
             if (!nfm) { /* AM: src/rtl_airband.cpp:553-563 */
@@ -643,7 +644,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     const bool wave_has_notch = ab_any(ab_ballot((cc.flags & AB_F_NOTCH) != 0));
     const bool wave_has_iq_out = ab_any(ab_ballot((cc.flags & AB_F_IQ_OUT) != 0));
     auto stable_tail4 = [&](const int jq, const float* mcs, const float* mds, const float* qr, const float* qi) {
-        if (WAVE_HAS_CTCSS && W > 1) audio_seen |= sq_should_audio(s);
+        if (WAVE_HAS_CTCSS) audio_seen |= sq_should_audio(s);
         const bool open = ab_lane(sq_should_audio(s)); /* Squelch::should_process_audio() == is_open() (no tone gate in these kinds), the same lanes for the four samples */
         /* Squelch::should_filter_sample() for the four samples: a CLOSED lane with signal would have ended the stable spell, so it is every lane that is not CLOSED or aborting */
         const bool filt = ab_lane(~s.cC & ~s.cA & s.active);
@@ -815,7 +816,9 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
         /* regrouped handles: the workgroup's wavefronts walk the batch in step (every wavefront runs the same number of iterations; one whose lanes have all left is
          * not waited for), so that a ring line two of them read is in L2 for the second -- a wavefront of closed channels runs ~3x faster than one of open ones.
          * A waiting wavefront costs no issue slot, which is what stage 2 is short of. */
+#if !defined(AB_REGROUP_FREE) /* experiment builds: the regrouped workgroup's wavefronts NOT in step (closed ones run ahead, finish and free their registers; shared ring lines are fetched once per reader) */
         if (W > 1) __syncthreads();
+#endif
         fetch(qb, j0 + GS, tail_in(GS)); /* flies under this group's samples */
         group(qa, j0);
         touch(qb);
@@ -840,7 +843,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
     if (KIND == AB_KIND_NFM_LOWPASS) { sp->sh_nf = sh.nf; sp->sh_cap = sh.cap; sp->sh_capped = sh.capped; sp->sh_dly = s.dly; }
     if (KIND == AB_KIND_GENERIC) sp->sh_dly = sq_delayed(s, L); /* buffer_[buffer_tail_] for the stats mirror (signal_outside_filter); this kind keeps the delay line in memory */
     sq_store(s, L, sp, B);
-    if (WAVE_HAS_CTCSS && W > 1) a.sq_key[slot] = ab_lane(audio_seen) ? 1 : 0; /* the back kernel deals its slots out by it */
+    if (WAVE_HAS_CTCSS) a.sq_key[slot] = ab_lane(audio_seen) ? 1 : 0; /* the tone kernel skips the channels without (round 6); regrouped handles: the back kernel deals its slots out by it */
     sp->lxr[1] = lxr1; sp->lxr[2] = lxr2; sp->lxi[1] = lxi1; sp->lxi[2] = lxi2;
     sp->lyr[1] = lyr1; sp->lyr[2] = lyr2; sp->lyi[1] = lyi1; sp->lyi[2] = lyi2;
 }
@@ -1002,6 +1005,15 @@ __global__ __launch_bounds__(256) AB_TONE_RESIDENCY void tone_kernel(DemodArgs a
     float q1s = t1 ? qtab[2 * AB_MAX_TONES + lane] : 0.0f, q2s = t1 ? qtab[3 * AB_MAX_TONES + lane] : 0.0f;
 
     const long blk = (wave >> 6) + (first_block - a.ct_first_block); /* verdict masks: one table over both split kinds */
+    /* Round 6: a channel whose squelch neither let a sample through nor went CLOSED in this batch (the front kernel's note) has forty idle steps in front of it: the
+     * detectors' state cannot change, every step's verdict is the standing one.  More than half of the channels of the BASELINE signal at any time: their wavefronts used
+     * to fetch and decode the whole hand-off row to find that out (0.6 GB and ~1e8 vector instructions per batch at configs[2]). */
+    if (!a.sq_key[slot]) {
+        const unsigned long long standing = ((sp->ct_enough[1] ? sp->ct_has_tone[1] : sp->ct_has_tone[0]) != 0) ? ~0ull : 0ull;
+        unsigned long long* mp = a.ct_mask + (blk * (a.wave_batch / TONE_GROUP)) * AB_SLOT_BLOCK + (wave & 63);
+        if (lane < a.wave_batch / TONE_GROUP) mp[(long)lane * AB_SLOT_BLOCK] = standing;
+        return;
+    }
     /* this channel's batch, contiguous: 50 lanes fetch 400 (one-word hand-off: 200) consecutive bytes; rows are counted from the kind's first block */
     const long hrow = wave + (long)(first_block - (PACKED ? a.ct_pk_first_block : a.ct_gen_first_block)) * 64;
     const float2* af = PACKED ? nullptr : a.ct_af + hrow * B;
@@ -1301,7 +1313,9 @@ __global__ __launch_bounds__(64 * W) void back_kernel(DemodArgs a, int first_blo
     fetch(0);
     int jg = 0; /* position of the current sample in its tone-kernel step */
     for (int j0 = 0; j0 < B; j0 += PIECE) {
+#if !defined(AB_REGROUP_FREE)
         if (W > 1) __syncthreads(); /* regrouped handles: the workgroup's wavefronts walk the batch in step (demod_wave) */
+#endif
 #pragma unroll
         for (int q = 0; q < NQ; q++) AB_NEEDED_NOW(AB_V(nxt[q].x), AB_V(nxt[q].y), AB_V(nxt[q].z), AB_V(nxt[q].w));
         AB_NEEDED_NOW(AB_V(nm_lo), AB_V(nm_hi));

@@ -119,7 +119,7 @@ struct DemodArgs {
      * (a workgroup barrier every eight samples), so that the ring lines neighbouring slots share are fetched from memory once.  Everything a lane touches is
      * addressed by its SLOT: which lane works on which slot does not change a result.  0: lane l of block b works on slot 64 b + l. */
     int regroup;
-    uint8_t* sq_key;        /* [n_slots] regrouped handles, split kinds: the front kernel leaves 1 where the channel had audio in this batch; the back kernel deals its slots out by it */
+    uint8_t* sq_key;        /* [n_slots] split kinds: the front kernel leaves 1 where the channel had audio or went CLOSED in this batch; the tone kernel skips the others, regrouped handles' back kernel deals its slots out by it */
 };
 
 struct EmitArgs { /* raw I/Q outputs only: audio goes straight to its channel row */

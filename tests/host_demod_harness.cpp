@@ -174,9 +174,9 @@ int hostdemod_create(const airband_hip_config* cfg, int trace, void** out) {
     {
         const char* e = getenv("AB_HOST_REGROUP");
         h->regroup = e && *e && *e != '0';
-        if (h->regroup) h->sq_key.assign((size_t)h->n_slots, 0);
     }
 #endif
+    h->sq_key.assign((size_t)h->n_slots, 0); /* the front kernel's note per channel (tone kernel: channels without audio in the batch are skipped) */
     *out = h;
     return 0;
 }
@@ -221,6 +221,7 @@ int hostdemod_process_bins(void* hv, const float* wavein, const float* iq_in) {
     a.wave_batch = B;
     a.row0 = h->row0;
     a.ring_rows = R;
+    a.sq_key = h->sq_key.data();
 #ifdef AB_WAVE64_EMU
     a.ct_coeff = h->ct_coeff;
     a.ct_q = h->ct_q;
@@ -235,10 +236,8 @@ int hostdemod_process_bins(void* hv, const float* wavein, const float* iq_in) {
     a.ct_first_block = h->ct_first_block;
     a.ct_n_blocks = h->ct_n_blocks;
     a.ct_stride = h->ct_stride;
-    if (h->regroup) {
-        a.regroup = 1;
-        a.sq_key = h->sq_key.data();
-    }
+    a.sq_key = h->sq_key.data();
+    if (h->regroup) a.regroup = 1;
     launch_demod(a, h->kind_first, h->kind_blocks, nullptr, nullptr, nullptr); /* the library's own launch sequence; every launch runs to completion */
 #else
     run_kind<AB_KIND_NFM_LOWPASS>(h, a);
