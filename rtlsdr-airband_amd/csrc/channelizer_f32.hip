@@ -49,8 +49,13 @@ __host__ __device__ constexpr long f32_padded(long o, int hop_bytes, int pad) { 
 /* AL8 (round 6): hops of an ODD number of samples (2.0 MS/s at WAVE_RATE 16000: 125 samples = 1 000 bytes).  A hop is then 8 mod 16 bytes long: the stream is still staged
  * in aligned 16-byte pieces -- the image starts `delta` = 0 or 8 bytes in front of the tile's first hop, the same for every tile of a launch since a tile is 16 hops --
  * and the A fragments are assembled from two 8-byte LDS reads (this kernel waits for the matrix pipe, 128 cycles per fragment, not for LDS). */
-template <int FFT_N, int MAX_LD, int NW, bool AL8>
+/* LAY = 2 (round 6): hops that are whole multiples of 256 bytes (32 samples: 2.56 MS/s at either WAVE_RATE) carry their padding every 256 stream bytes instead of every
+ * hop -- byte o of the tile lands at o + 16 floor(o / 256).  A hop is an odd-or-even number m of such units, rows still fall in sixteen different bank groups ((64 + 4) m
+ * dwords apart), and floor() now separates: a lane's READS fragment offsets are base + 64 j + 16 (j >> 2) and a thread's parking offsets base + i * const -- immediates
+ * of the LDS instructions instead of 32 + 12 registers computed once and kept.  The fft 2048 variants (and fft 4096 / 8192, which run them) spilled 48 - 126 registers. */
+template <int FFT_N, int MAX_LD, int NW, int LAY>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void channelizer_f32_kernel(F32Args a) {
+    constexpr bool AL8 = LAY == 1, P256 = LAY == 2;
     constexpr int WIN_BYTES = 8 * FFT_N;
     constexpr int KW = 2 * FFT_N / 4 / NW;   /* 64 (fft 512) or 32 (fft 256) */
     constexpr int READS = KW / 4;            /* 16-byte fragment reads per wave and tile */
@@ -124,11 +129,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void 
 
     /* the lane's sixteen fragment reads of a tile, as offsets into the padded image: byte o = row hop_bytes + piece PIECE_BYTES + 64 j + 16 grp of the
      * tile's stream lands at o + pad floor(o / hop_bytes) */
+    static_assert(!P256 || PIECE_BYTES % 256 == 0, "a piece starts on a padding unit");
+    const int abase0 = row_l * hop_bytes + piece * PIECE_BYTES + grp * 16;
+    const int abase = abase0 + 16 * (abase0 >> 8); /* LAY = 2 */
     int aoff[READS];
 #pragma unroll
     for (int j = 0; j < READS; j++) {
-        const int o = row_l * hop_bytes + piece * PIECE_BYTES + j * 64 + grp * 16;
-        aoff[j] = AL8 ? o + delta : o + pad * (o / hop_bytes);
+        const int o = abase0 + j * 64;
+        aoff[j] = P256 ? abase + 64 * j + 16 * (j >> 2) : AL8 ? o + delta : o + pad * (o / hop_bytes);
     }
 
     /* ---- staging: registers one tile ahead ---- */
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void 
 #pragma unroll
     for (int i = 0; i < MAX_LD; i++) {
         const int o = (i * 64 * NW + (int)threadIdx.x) * 16;
-        poff[i] = o + pad * (o / hop_bytes);
+        poff[i] = P256 ? 16 * ((int)threadIdx.x + ((int)threadIdx.x >> 4)) + i * (1024 + 64) * NW : o + pad * (o / hop_bytes);
     }
     /* (an interior-tile fast path -- one 64-bit add per tile, pieces at constant offsets -- was tried: the second copy of the loads costs registers,
      * three spilled dwords more and the third workgroup per CU of the large-tile variant; 26.2 ms against 22.4.  One path.) */
@@ -282,10 +290,11 @@ int f32_pad_bytes(int hop_samples) { return f32_pad(8 * hop_samples); }
 int f32_lds_per_buf(int fft_size, int hop_samples) {
     const int hop_bytes = 8 * hop_samples, pad = f32_pad(hop_bytes);
     const long tile_bytes = (long)(TILE_HOPS - 1) * hop_bytes + 8 * f32_seg_size(fft_size); /* (a launch stages one window segment) */
+    if (f32_layout(fft_size, hop_bytes) == 2) return (int)((tile_bytes + 16 * ((tile_bytes + 255) / 256) + 16 + 255) / 256 * 256); /* 16 bytes of padding per 256 of stream */
     return (int)((f32_padded(tile_bytes, hop_bytes, pad) + 16 + ((hop_bytes & 8) ? 16 : 0) + 255) / 256 * 256); /* (odd hops: the image starts up to 8 bytes in front of the tile) */
 }
 
-template <int FFT_N, int MAX_LD, int NW, bool AL8>
+template <int FFT_N, int MAX_LD, int NW, int AL8>
 static void launch_f32_al(const F32Args& a, hipStream_t stream) {
     const long groups = (long)a.n_items * a.splits;
     const size_t lds = (size_t)2 * a.lds_per_buf + 2 * (NW - 1) * 64 * sizeof(float4);
@@ -303,8 +312,10 @@ static void launch_f32_al(const F32Args& a, hipStream_t stream) {
 
 template <int FFT_N, int MAX_LD, int NW>
 static void launch_f32(const F32Args& a, hipStream_t stream) {
-    if (a.hop_bytes & 8) launch_f32_al<FFT_N, MAX_LD, NW, true>(a, stream);
-    else launch_f32_al<FFT_N, MAX_LD, NW, false>(a, stream);
+    const int lay = f32_layout(a.fft_size, a.hop_bytes);
+    if (lay == 1) launch_f32_al<FFT_N, MAX_LD, NW, 1>(a, stream);
+    else if (lay == 2) launch_f32_al<FFT_N, MAX_LD, NW, 2>(a, stream);
+    else launch_f32_al<FFT_N, MAX_LD, NW, 0>(a, stream);
 }
 
 int f32_partial_tiles(int n_hops_max) { return (15 + n_hops_max + TILE_HOPS - 1) / TILE_HOPS + 1; }
