@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Prints DESIGN.md section 5's table from profiles/<round>_bench_*.json (so that the document quotes the tracked files and nothing else).  usage: design_table.py r05"""
+"""Prints DESIGN.md section 5's table from profiles/<round>_bench_*.json (so that the document quotes the tracked files and nothing else).  usage: design_table.py r06"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 
 def L(n):
@@ -38,7 +38,8 @@ def main():
             row("configs[1] 1 024 × 8 AM", "cfg2", extra_rt=" (one wavefront's dependent chain, §4.2)"),
             row("configs[1], `--pipelined`", "cfg2_pipelined"),
             row("65 536 × 8 AM (hop 640)", "am65536"),
-            row("configs[2], `--pipelined`", "cfg3_pipelined", "(kernels share the chip)"),
+            row("configs[2], `--pipelined` (the channelizer held to five wavefronts per CU, §4.3)", "cfg3_pipelined", "(kernels share the chip)"),
+            row("configs[2], 65 536 DISTINCT channel plans (one coefficient table per dongle, §4.1)", "cfg3_plans65536"),
             row("configs[2] + AFC on one channel per dongle (`--afc 2`)", "cfg3_afc"),
             row("configs[2] with CS16 dongles", "cfg3_cs16"),
             row("configs[2] at 2.4 MS/s (hops of 300 bytes)", "cfg3_2400k"),
@@ -52,9 +53,14 @@ def main():
     r = L("f32_32768")["roofline"]
     rows.append(row("32 768 CF32 dongles × 8 mixed, float32 matrix pipe (§4.5)", "f32_32768", "float32 matrix pipe %.2f; HBM %.2f read-only" % (r["frac"], r.get("frac_read_only", 0))))
     rows.append(row("the same forced onto the wavefront FFT", "f32_32768_force_fft"))
+    for n, lab in (("f32_32768_fft4096", "the same at fft_size 4096 (two window segments, §4.5)"), ("f32_32768_afc", "the same with AFC on one channel per dongle (float tables re-tuned on the device)"),
+                   ("f32_32768_2000k", "the same at 2.0 MS/s (hops of 125 samples: `LAY = 1`)")):
+        r = L(n)["roofline"]
+        rows.append(row(lab, n, "float32 matrix pipe %.2f; HBM %.2f read-only" % (r["frac"], r.get("frac_read_only", 0))))
     r = L("f32_am16384")["roofline"]
     rows.append(row("16 384 CF32 dongles × 8 AM (hop 320 samples)", "f32_am16384", "float32 matrix pipe %.2f; HBM %.2f read-only" % (r["frac"], r.get("frac_read_only", 0))))
-    rows.append(row("configs[3] shard: 32 768 dongles per GPU", "cfg4_shard"))
+    rows.append(row("configs[3] shard: 32 768 dongles per GPU (stage 2 regrouped by residency, §4.2)", "cfg4_shard"))
+    rows.append(row("the same in slot order (`AIRBAND_HIP_FLAG_NO_REGROUP`)", "cfg4_shard_slot_order"))
     rows.append(row("configs[2] + 64 mixers (configs[4] exchange through `airband_hip_allreduce_mixers`, RCCL at world size 1)", "cfg3_mixers64"))
     j = L("cfg3_hostpath")
     rows.append(row("configs[2], the run that also times the host path (%.0f Msamples/s = %s GB/s over PCIe, never `value`)" % (j["host_path"]["value"], j["host_path"].get("gbytes_per_s")), "cfg3_hostpath"))

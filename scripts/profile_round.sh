@@ -1,8 +1,8 @@
 # Regenerates the round's measurements on a GPU box:  rm -rf gpurun_out/final; gpurun --timeout 2400 -- 'bash scripts/profile_round.sh'
-# (gpurun MERGES into the local gpurun_out/, so remove the old copy first), then `python scripts/collect_profiles.py r05` copies the summaries into profiles/.
+# (gpurun MERGES into the local gpurun_out/, so remove the old copy first), then `python scripts/collect_profiles.py r06` copies the summaries into profiles/.
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=${R:-r05}
+R=${R:-r06}
 O=gpurun_out/final; rm -rf $O; mkdir -p $O
 # LIMIT=<seconds>: commands that would start after that many seconds of this script are skipped (most important first; a skipped measurement keeps the file of the
 # previous run of the round in profiles/ -- scripts/collect_profiles.py only copies what exists)
@@ -22,9 +22,14 @@ ok && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_
 ok && AIRBAND_BENCH_FLAGS=4 timeout 300 python bench.py --no-cpu-baseline --no-traffic --no-verify-all --verify 4 --steps 6 --warmup 2 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg3_force_fft.json
 ok && timeout 300 python bench.py --no-cpu-baseline --no-traffic --no-verify-all --verify 4 --steps 12 --warmup 2 --sample-format f32 --ring 1 --dongles 32768 2>/dev/null | tail -n 1 > $O/${R}_bench_f32_32768.json
 ok && AIRBAND_BENCH_FLAGS=4 timeout 300 python bench.py --no-cpu-baseline --no-traffic --no-verify-all --verify 4 --steps 4 --warmup 2 --sample-format f32 --ring 1 --dongles 32768 2>/dev/null | tail -n 1 > $O/${R}_bench_f32_32768_force_fft.json
+ok && timeout 300 python bench.py --no-cpu-baseline --no-traffic --no-verify-all --verify 4 --steps 6 --warmup 2 --sample-format f32 --ring 1 --dongles 32768 --fft-log 12 2>/dev/null | tail -n 1 > $O/${R}_bench_f32_32768_fft4096.json
+ok && timeout 300 python bench.py --no-cpu-baseline --no-traffic --no-verify-all --verify 4 --steps 12 --warmup 2 --sample-format f32 --ring 1 --dongles 32768 --afc 2 2>/dev/null | tail -n 1 > $O/${R}_bench_f32_32768_afc.json
+ok && timeout 300 python bench.py --no-cpu-baseline --no-traffic --no-verify-all --verify 4 --steps 12 --warmup 2 --sample-format f32 --ring 1 --dongles 32768 --sample-rate 2000000 2>/dev/null | tail -n 1 > $O/${R}_bench_f32_32768_2000k.json
 ok && timeout 300 python bench.py $N --fft-log 12 --steps 12 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg3_fft4096.json
 ok && timeout 300 python bench.py $N --fft-log 13 --steps 8 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg3_fft8192.json
 ok && timeout 300 python bench.py $N --workload cfg4 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg4_shard.json
+ok && timeout 300 python bench.py $N --workload cfg4 --regroup 0 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg4_shard_slot_order.json
+ok && timeout 300 python bench.py $N --distinct-plans 65536 --verify 16 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg3_plans65536.json
 ok && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg4 -- python bench.py $K --workload cfg4 > $O/kt_cfg4.log 2>&1
 ok && timeout 300 python bench.py $N --afc 2 2>/dev/null | tail -n 1 > $O/${R}_bench_cfg3_afc.json
 ok && AIRBAND_BENCH_FLAGS=8 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_cfg3_afc -- python bench.py $K --afc 2 > $O/kt_afc.log 2>&1

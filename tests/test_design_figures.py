@@ -1,4 +1,4 @@
-"""DESIGN.md section 5's table is PRINTED from the tracked bench lines (scripts/design_table.py reads profiles/r05_bench_*.json): a figure quoted there that no longer matches its
+"""DESIGN.md section 5's table is PRINTED from the tracked bench lines (scripts/design_table.py reads profiles/r06_bench_*.json): a figure quoted there that no longer matches its
 file -- a profile run filed without the table being regenerated, a hand-edited number -- fails here."""
 import os
 import subprocess
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_design_section_5_is_the_table_the_tracked_bench_lines_print():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "design_table.py"), "r05"], check=True, stdout=subprocess.PIPE, text=True, cwd=ROOT).stdout
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "design_table.py"), "r06"], check=True, stdout=subprocess.PIPE, text=True, cwd=ROOT).stdout
     rows = [l for l in out.split("\n") if l.startswith("| ")]
     assert len(rows) >= 20
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
@@ -19,7 +19,7 @@ def test_design_section_5_is_the_table_the_tracked_bench_lines_print():
 def test_at_a_glance_quotes_the_tracked_headline_line():
     import json
 
-    j = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_cfg3.json")))
+    j = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_cfg3.json")))
     head = open(os.path.join(ROOT, "DESIGN.md")).read().split("## 1. The path and its boundary")[0]
     ms, value = j["ms_per_step"], j["value"]
     assert "%.2f ms" % ms in head
