@@ -60,8 +60,17 @@ constexpr __host__ __device__ int c_lds_for(int hop_bytes, int sub, int win_byte
 /* three small buffers (two steps in flight) when eight waves of them fit a CU's 160 KiB, else two larger ones */
 /* (np = wavefronts sharing the buffers: fft_size > 512 runs one wave per window piece of 512 samples, 8 / np workgroups per CU -- fewer
  * streams per CU, so a shared step is made two tiles long when three such buffers fit: more bytes in flight, half the barriers) */
-constexpr __host__ __device__ int c_nbuf(int hop_bytes, int win_bytes = 1024, int np = 1) { return 3 * c_lds_for(hop_bytes, 1, win_bytes) * (8 / np) <= 152 * 1024 ? 3 : 2; }
+/* (experiment builds, profiles/r06_experiments.md F: -DAB_NP_INFLIGHT=1 -- window pieces with two two-tile buffers, ONE step of 10 KiB in flight per workgroup -- and =2 -- three
+ * one-tile buffers, two steps of 5 KiB -- against the product's three two-tile buffers, two steps of 10 KiB: how much of these sizes' launch time is bytes in flight) */
+#ifndef AB_NP_INFLIGHT
+#define AB_NP_INFLIGHT 0
+#endif
+constexpr __host__ __device__ int c_nbuf(int hop_bytes, int win_bytes = 1024, int np = 1) {
+    if (AB_NP_INFLIGHT == 1 && np > 1) return 2;
+    return 3 * c_lds_for(hop_bytes, 1, win_bytes) * (8 / np) <= 152 * 1024 ? 3 : 2;
+}
 constexpr __host__ __device__ bool c_long3(int hop_bytes, int win_bytes, int np) {
+    if (AB_NP_INFLIGHT != 0) return false;
     return np > 1 && c_sub_tiles(hop_bytes) >= 2 && 3 * c_lds_for(hop_bytes, 2, win_bytes) * (8 / np) <= 152 * 1024;
 }
 constexpr __host__ __device__ int c_sub(int hop_bytes, int win_bytes = 1024, int np = 1) {

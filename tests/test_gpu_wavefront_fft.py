@@ -13,7 +13,7 @@ CASES = [
     ("SFMT_U8", 9, 2_000_000, 16000, True),   # (round 4: the matrix-core path takes 250-byte hops too; forced here to keep the FFT path's odd-hop case)
     ("SFMT_F32", 10, 2_400_000, 8000, True),    # (round 5: CF32 at fft 1024 / 2048 runs on the float32 matrix pipe; forced here to keep the FFT path's decimated f32 cases)
     ("SFMT_F32", 11, 2_560_000, 16000, True),
-    ("SFMT_F32", 12, 2_560_000, 16000, False),  # fft 4096 and beyond: still this kernel's
+    ("SFMT_F32", 12, 2_560_000, 16000, True),   # (round 6: CF32 at fft 4096 / 8192 runs on the float32 matrix pipe as window segments; forced here to keep the FFT path's 8-transform f32 case)
     ("SFMT_U8", 12, 2_560_000, 8000, True),
 ]
 
