@@ -61,7 +61,8 @@ constexpr __host__ __device__ int c_lds_for(int hop_bytes, int sub, int win_byte
 /* (np = wavefronts sharing the buffers: fft_size > 512 runs one wave per window piece of 512 samples, 8 / np workgroups per CU -- fewer
  * streams per CU, so a shared step is made two tiles long when three such buffers fit: more bytes in flight, half the barriers) */
 /* (experiment builds, profiles/r06_experiments.md F: -DAB_NP_INFLIGHT=1 -- window pieces with two two-tile buffers, ONE step of 10 KiB in flight per workgroup -- and =2 -- three
- * one-tile buffers, two steps of 5 KiB -- against the product's three two-tile buffers, two steps of 10 KiB: how much of these sizes' launch time is bytes in flight) */
+ * one-tile buffers, two steps of 5 KiB -- against the product's three two-tile buffers, two steps of 10 KiB: how much of these sizes' launch time is bytes in flight.  Little: fft 1024
+ * 15.38 -> 15.6 / 16.3 ms, fft 2048 27.2 -> 27.6 / 29.1) */
 #ifndef AB_NP_INFLIGHT
 #define AB_NP_INFLIGHT 0
 #endif
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(64 * NP, NP <= 4 ? 2 : 1) void channelizer_dft_kern
              * reach wave 0 through LDS (two areas alternate).  Wave 0 used to add them up and store right behind a second barrier per tile, with the other waves
              * already waiting at the next one and the matrix pipe idle (0.40 busy at every window length, profiles/r04_experiments.md G: the review's reading was that this
              * second barrier is what idles it -- it is 1.5 % of fft 1024's launch and 6 % of fft 4096's; the matrix time and the stream time of these sizes ADD UP instead of
-             * overlapping, 6.9 + 8.4 ms at fft 1024, because four workgroups per CU keep too few bytes in flight: profiles/r06_experiments.md F).  Now tile t - 1 is finished
+             * overlapping, 6.9 + 8.4 ms at fft 1024, and what binds them is a workgroup's own tile latency at the residency the B fragments allow -- half the bytes in flight cost 1.5 - 6 %, three workgroups per CU instead of four 11 %, two 50 %: profiles/r06_experiments.md F).  Now tile t - 1 is finished
              * UNDER tile t's MFMAs -- `mid`, called with half of them issued -- and ONE barrier per tile does both jobs: it hands the staged step over and orders the
              * waves' writes of tile t - 1's sums before wave 0's reads (the area tile t's sums go to was last read under tile t - 1, before this barrier). */
             if (!PIPE_PIECES) { /* CS16 (twice the accumulators) and hops of an odd number of samples (five-dword fragment reads): no registers to spare for a tile in waiting */
