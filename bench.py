@@ -381,6 +381,8 @@ def main():
     ap.add_argument("--pipelined", action="store_true", help="AIRBAND_HIP_FLAG_PIPELINE: stage 1 of batch k beside stage 2 of batch k-1 (results one batch late); the "
                     "channelizer's launch time, which the roofline figure is built on, is then no longer that of the kernel alone, so the default is one batch at a time")
     ap.add_argument("--sequential", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--throughput-mode", dest="throughput_mode", action="store_true", default=True, help="at N = 1, after the timed region: also time the library's pipelined mode on the same ring (reported as `throughput_mode`, never as `value`; default on)")
+    ap.add_argument("--no-throughput-mode", dest="throughput_mode", action="store_false")
     ap.add_argument("--force-dist", action="store_true", help="initialise a process group even at world size 1 (plumbing check of the RCCL leg)")
     ap.add_argument("--dry-run", action="store_true", help="launcher check without GPUs: form the N-rank group over gloo, print the JSON skeleton")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # profiled child of measure_traffic(): steps only, no extras, no JSON
@@ -693,6 +695,32 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     hip.close()
+    if rank == 0 and world == 1 and args.throughput_mode and not args.pipelined and args.afc == 0 and n_mixers == 0 and name != "fft_wave64":
+        # The library's THROUGHPUT mode on the same resident ring, after the timed region and never `value`: AIRBAND_HIP_FLAG_PIPELINE runs stage 1 of batch k beside stage 2 of
+        # batch k - 1 (results one call late; such handles hold the channelizer to five wavefronts per CU so that stage 2 finds register room on every CU).  A fresh
+        # handle; the per-kernel roofline figures above stay those of the sequential schedule, where a launch has the chip to itself.
+        try:
+            ph = pkg.AirbandHip(devices, wave_rate=wave_rate, hip_device=local_rank, flags=flags | pkg.capi.FLAG_PIPELINE, fft_log=args.fft_log)
+            ks = min(args.steps, 40)
+            for i in range(args.warmup):
+                ph.process_device(iq.data_ptr() + offset(i), stride, 0)
+            ph.synchronize()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.warmup, args.warmup + ks):
+                ph.process_device(iq.data_ptr() + offset(i), stride, 0)
+            ph.synchronize()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            ph.flush()
+            ph.synchronize()
+            ph.close()
+            out["throughput_mode"] = dict(value=round(float(D) * samples_per_batch * ks / el / 1e6, 2), unit="Msamples/s", ms_per_step=round(el / ks * 1e3, 3), steps=ks,
+                                          end_to_end_frac=round(alg_bytes_per_sample * D * samples_per_batch / (el / ks) / 1e9 / HBM_PEAK_GBS, 4),
+                                          schedule="AIRBAND_HIP_FLAG_PIPELINE: stage 1 of batch k beside stage 2 of batch k-1, results one call late, the channelizer held to five wavefronts per CU",
+                                          note="opt-in mode, measured after the timed region on a fresh handle over the same resident ring; reported beside `value`, never as it")
+        except Exception as e:  # noqa: BLE001
+            out["throughput_mode"] = dict(error=repr(e)[:300])
     if rank == 0 and world == 1 and args.verify_all and not s16 and n_plans > 1:
         out["verify_all"] = dict(skipped="the replica check feeds every dongle dongle 0's bytes and plan: blind to plan diversity by construction; see `verify` (sampled dongles "
                                          "against the oracle, each with its own plan)")

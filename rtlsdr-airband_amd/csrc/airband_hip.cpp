@@ -113,6 +113,7 @@ struct airband_hip_handle {
     int ct_first_block = 0, ct_n_blocks = 0, ct_pk_pitch = 0;
     /* AIRBAND_HIP_FLAG_REGROUP: the batch's slot order (demod.hip, "regrouping") */
     bool regroup = false;
+    int regroup_mode = 1;          /* 1: channels sorted inside lockstep workgroups; 2: line groups sorted, wavefronts free-running (demod.hip) */
     DevBuf<uint8_t> d_sq_key; /* split kinds: the front kernel's note for the back kernel (had audio in this batch) */
     DevBuf<uint8_t> d_trace;
     DevBuf<float> d_out_wave, d_out_iq;
@@ -383,7 +384,7 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.wave_batch = h->B;
     da.row0 = h->row0;
     da.ring_rows = h->R;
-    da.regroup = h->regroup ? 1 : 0;
+    da.regroup = h->regroup ? h->regroup_mode : 0;
     da.sq_key = h->d_sq_key.p;
     launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
     if (h->any_afc && h->afc_spectrum_valid) { /* afc.finalize(), src/rtl_airband.cpp:626-630: may turn '*' into '<' / '>' */
@@ -661,6 +662,7 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
         const bool by_residency = waves_per_simd >= 2.75 && waves_per_simd <= 6.25;
         const char* e = getenv("AIRBAND_HIP_REGROUP");
         h->regroup = e && *e ? (*e != '0') : (h->flags & AIRBAND_HIP_FLAG_REGROUP) ? true : (h->flags & AIRBAND_HIP_FLAG_NO_REGROUP) ? false : by_residency;
+        h->regroup_mode = (e && *e == '2') ? 2 : 1;
         if (h->regroup || h->ct_n_blocks > 0) { /* the front kernel's note per channel: had audio / went CLOSED in this batch (tone kernel; regrouped back kernel) */
             PREP_TRY(h->d_sq_key.alloc((size_t)h->n_slots), AIRBAND_HIP_ENOMEM);
             PREP_TRY(hipMemset(h->d_sq_key.p, 0, (size_t)h->n_slots), AIRBAND_HIP_ENOMEM);

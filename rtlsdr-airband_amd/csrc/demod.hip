@@ -817,7 +817,7 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
          * not waited for), so that a ring line two of them read is in L2 for the second -- a wavefront of closed channels runs ~3x faster than one of open ones.
          * A waiting wavefront costs no issue slot, which is what stage 2 is short of. */
 #if !defined(AB_REGROUP_FREE) /* experiment builds: the regrouped workgroup's wavefronts NOT in step (closed ones run ahead, finish and free their registers; shared ring lines are fetched once per reader) */
-        if (W > 1) __syncthreads();
+        if (W > 1 && a.regroup != 2) __syncthreads(); /* (line-group regrouping: nothing is shared, nobody waits) */
 #endif
         fetch(qb, j0 + GS, tail_in(GS)); /* flies under this group's samples */
         group(qa, j0);
@@ -930,7 +930,19 @@ __device__ __forceinline__ void demod_block(const DemodArgs& a, int first_block,
         int key = 3;
         if (wave < nb) {
             const ChanState* hp = a.cs + home;
-            key = !(a.cc[home].flags & AB_F_VALID) ? 2 : (hp->cur != AB_ST_CLOSED || hp->next != AB_ST_CLOSED) ? 0 : 1;
+            const bool valid = (a.cc[home].flags & AB_F_VALID) != 0;
+            bool busy = valid && (hp->cur != AB_ST_CLOSED || hp->next != AB_ST_CLOSED);
+            if (a.regroup == 2) {
+                /* LINE GROUPS move together (round 6, second form): the slots that share a 128-byte line of the stage-1 rings -- four of the |bin| ring (32 bytes per slot and
+                 * 8-row tile), two of the raw-I/Q ring (64) -- are busy if any of them is.  Then no line is read by two wavefronts, the workgroup's wavefronts need not walk
+                 * in step, and a wavefront of closed groups finishes in a third of the time and gives its registers back.  The price: a closed channel next to an open one
+                 * stays in the open wavefronts (on the BASELINE signal 28 % of the NFM pairs and 8 % of the AM quads are closed outright; on a quiet band most are). */
+                constexpr int G = (KIND == AB_KIND_AM || KIND == AB_KIND_GENERIC) ? 4 : 2;
+                const lmask any_busy = __ballot(busy);
+                const lmask gmask = ((1ull << G) - 1ull) << (lane & ~(G - 1));
+                busy = (any_busy & gmask) != 0ull;
+            }
+            key = !valid ? 2 : busy ? 0 : 1;
         }
         slot = wg_regroup<W>(key, wave, lane, home, nb, slot_at, wcnt);
         if (slot < 0) return; /* whole wavefronts only (wave-uniform), behind the workgroup's set-up barriers */
@@ -1314,7 +1326,7 @@ __global__ __launch_bounds__(64 * W) void back_kernel(DemodArgs a, int first_blo
     int jg = 0; /* position of the current sample in its tone-kernel step */
     for (int j0 = 0; j0 < B; j0 += PIECE) {
 #if !defined(AB_REGROUP_FREE)
-        if (W > 1) __syncthreads(); /* regrouped handles: the workgroup's wavefronts walk the batch in step (demod_wave) */
+        if (W > 1 && a.regroup != 2) __syncthreads(); /* regrouped handles: the workgroup's wavefronts walk the batch in step (demod_wave) */
 #endif
 #pragma unroll
         for (int q = 0; q < NQ; q++) AB_NEEDED_NOW(AB_V(nxt[q].x), AB_V(nxt[q].y), AB_V(nxt[q].z), AB_V(nxt[q].w));

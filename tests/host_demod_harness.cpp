@@ -61,6 +61,7 @@ struct HostDemod {
     int ct_first_block = 0, ct_n_blocks = 0, ct_pk_pitch = 0, ct_stride = 0;
     /* regrouped stage 2 (AB_HOST_REGROUP=1 in the environment when the handle is created; wave64 mode): workgroups of AB_REGROUP_WAVES wavefronts deal their slots out by squelch state */
     bool regroup = false;
+    int regroup_mode = 1;
     std::vector<uint8_t> sq_key;
     ~HostDemod() {
         free(mag); free(iq); free(iq_out); free(sqbuf); free(out_wave); free(out_axc); free(trace); free(lds);
@@ -174,6 +175,7 @@ int hostdemod_create(const airband_hip_config* cfg, int trace, void** out) {
     {
         const char* e = getenv("AB_HOST_REGROUP");
         h->regroup = e && *e && *e != '0';
+        h->regroup_mode = (e && *e == '2') ? 2 : 1; /* 2: line groups sorted, the workgroup's wavefronts free-running */
     }
 #endif
     h->sq_key.assign((size_t)h->n_slots, 0); /* the front kernel's note per channel (tone kernel: channels without audio in the batch are skipped) */
@@ -237,7 +239,7 @@ int hostdemod_process_bins(void* hv, const float* wavein, const float* iq_in) {
     a.ct_n_blocks = h->ct_n_blocks;
     a.ct_stride = h->ct_stride;
     a.sq_key = h->sq_key.data();
-    if (h->regroup) a.regroup = 1;
+    if (h->regroup) a.regroup = h->regroup_mode;
     launch_demod(a, h->kind_first, h->kind_blocks, nullptr, nullptr, nullptr); /* the library's own launch sequence; every launch runs to completion */
 #else
     run_kind<AB_KIND_NFM_LOWPASS>(h, a);
