@@ -114,6 +114,7 @@ struct airband_hip_handle {
     /* AIRBAND_HIP_FLAG_REGROUP: the batch's slot order (demod.hip, "regrouping") */
     bool regroup = false;
     int regroup_mode = 1;          /* 1: channels sorted inside lockstep workgroups; 2: line groups sorted, wavefronts free-running (demod.hip) */
+    DevBuf<int> d_perm;       /* regroup mode 3: the batch's slot permutation (demod.hip, regroup_perm_kernel) */
     DevBuf<uint8_t> d_sq_key; /* split kinds: the front kernel's note for the back kernel (had audio in this batch) */
     DevBuf<uint8_t> d_trace;
     DevBuf<float> d_out_wave, d_out_iq;
@@ -220,7 +221,7 @@ void destroy(airband_hip_handle* h) {
     h->d_iq.release(); h->d_iq_out.release(); h->d_trace.release(); h->d_ct_af.release(); h->d_ct_mask.release();
     h->d_out_wave.release(); h->d_out_iq.release(); h->d_out_axc.release(); h->d_stats.release();
     h->d_tmp_wavein.release(); h->d_tmp_iqin.release(); h->d_tmp_trace.release(); h->d_spectrum.release();
-    h->d_sq_key.release();
+    h->d_sq_key.release(); h->d_perm.release();
     h->d_ftab.release(); h->d_item_dev.release(); h->d_item_group.release(); h->d_item_bset.release(); h->d_item_private.release(); h->d_item_home.release(); h->d_bfrag.release(); h->d_bcorr.release(); h->d_dft_partial.release(); h->d_bset_bin.release();
     if (h->h2d) (void)hipStreamSynchronize(h->h2d);
     h->d_stage2[0].release(); h->d_stage2[1].release();
@@ -386,6 +387,7 @@ int run_back_half(airband_hip_handle* h, hipStream_t s) {
     da.ring_rows = h->R;
     da.regroup = h->regroup ? h->regroup_mode : 0;
     da.sq_key = h->d_sq_key.p;
+    da.perm = (h->regroup && h->regroup_mode == 3) ? h->d_perm.p : nullptr;
     launch_demod(da, h->kind_first_block, h->kind_n_blocks, s, (h->flags & AIRBAND_HIP_FLAG_SERIAL_DEMOD) ? nullptr : h->side, h->fork_ev);
     if (h->any_afc && h->afc_spectrum_valid) { /* afc.finalize(), src/rtl_airband.cpp:626-630: may turn '*' into '<' / '>' */
         const bool tables = h->use_dft || h->use_f32; /* the matrix-core channelizers: a channel's bin is baked into its coefficient columns */
@@ -662,7 +664,8 @@ int airband_hip_prepare(const airband_hip_config* cfg, airband_hip_handle** out)
         const bool by_residency = waves_per_simd >= 2.75 && waves_per_simd <= 6.25;
         const char* e = getenv("AIRBAND_HIP_REGROUP");
         h->regroup = e && *e ? (*e != '0') : (h->flags & AIRBAND_HIP_FLAG_REGROUP) ? true : (h->flags & AIRBAND_HIP_FLAG_NO_REGROUP) ? false : by_residency;
-        h->regroup_mode = (e && *e == '2') ? 2 : 1;
+        h->regroup_mode = (e && *e == '2') ? 2 : (e && *e == '3') ? 3 : 1;
+        if (h->regroup && h->regroup_mode == 3) PREP_TRY(h->d_perm.alloc((size_t)h->n_slots), AIRBAND_HIP_ENOMEM);
         if (h->regroup || h->ct_n_blocks > 0) { /* the front kernel's note per channel: had audio / went CLOSED in this batch (tone kernel; regrouped back kernel) */
             PREP_TRY(h->d_sq_key.alloc((size_t)h->n_slots), AIRBAND_HIP_ENOMEM);
             PREP_TRY(hipMemset(h->d_sq_key.p, 0, (size_t)h->n_slots), AIRBAND_HIP_ENOMEM);

@@ -921,6 +921,7 @@ __device__ __forceinline__ void demod_block(const DemodArgs& a, int first_block,
     int slot; /* padding slots carry flags == 0 */
     if (W == 1) {
         slot = (first_block + blockIdx.x) * 64 + lane;
+        if (a.perm) slot = a.perm[slot]; /* regroup == 3: the batch's permutation (regroup_perm_kernel) */
     } else {
         int* slot_at = reinterpret_cast<int*>(areas + W * WAVE_LDS_FLOATS);
         int* wcnt = slot_at + W * 64;
@@ -963,6 +964,32 @@ template <int KIND, bool WAVE_HAS_CTCSS, int W>
 __global__ __launch_bounds__(64 * W, KIND == AB_KIND_AM ? AB_AM_WAVES : KIND == AB_KIND_NFM_CTCSS ? AB_FRONT_WAVES : AB_DEMOD_WAVES) void demod_kernel(DemodArgs a, int first_block, int n_blocks) {
     AB_DYNAMIC_LDS(float, lds_demod);
     demod_block<KIND, WAVE_HAS_CTCSS, W>(a, first_block, n_blocks, lds_demod);
+}
+
+/* regroup == 3: the batch's permutation of one kind's slots.  One workgroup of sixteen wavefronts per segment of sixteen blocks (1 024 slots): wg_regroup's stable partition with
+ * the line group as the unit -- a group is busy if any of its G slots has a channel that is not at rest in CLOSED (G = 4 where the |bin| ring is read, 2 for the raw-I/Q ring) --
+ * written to perm[] where the one-wavefront kernels of the stage pick their slots up.  ~10 us per batch at 65 536 dongles. */
+constexpr int AB_PERM_WAVES = 16;
+template <int G>
+__global__ __launch_bounds__(64 * AB_PERM_WAVES) void regroup_perm_kernel(DemodArgs a, int first_block, int n_blocks) {
+    __shared__ int slot_at[AB_PERM_WAVES * 64];
+    __shared__ int wcnt[AB_PERM_WAVES * 2];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int block0 = first_block + blockIdx.x * AB_PERM_WAVES;
+    const int left = first_block + n_blocks - block0, nb = left < AB_PERM_WAVES ? left : AB_PERM_WAVES;
+    const int home = (block0 + wave) * 64 + lane;
+    int key = 3;
+    if (wave < nb) {
+        const ChanState* hp = a.cs + home;
+        const bool valid = (a.cc[home].flags & AB_F_VALID) != 0;
+        const bool busy1 = valid && (hp->cur != AB_ST_CLOSED || hp->next != AB_ST_CLOSED);
+        const lmask any_busy = __ballot(busy1);
+        const lmask gmask = ((1ull << G) - 1ull) << (lane & ~(G - 1));
+        key = !valid ? 2 : (any_busy & gmask) != 0ull ? 0 : 1;
+    }
+    const int slot = wg_regroup<AB_PERM_WAVES>(key, wave, lane, home, nb, slot_at, wcnt);
+    if (slot >= 0) a.perm[home] = slot;
 }
 
 /* CTCSS tone detection (reference: src/ctcss.cpp, driven by Squelch::process_audio_sample src/squelch.cpp:278-295).
@@ -1387,7 +1414,16 @@ static int tone_threads() {
 
 void launch_demod(const DemodArgs& a, const int* kind_first_block, const int* kind_n_blocks, hipStream_t stream, hipStream_t* side, hipEvent_t* ev) {
     constexpr int RW = AB_REGROUP_WAVES;
-    const bool rg = a.regroup != 0;
+    const bool rg = a.regroup == 1 || a.regroup == 2; /* the workgroup forms; 3: one-wavefront workgroups behind a permutation */
+    if (a.regroup == 3 && a.perm) {
+        for (int k = 0; k < AB_KIND_COUNT; k++) {
+            const int n = kind_n_blocks[k], f = kind_first_block[k];
+            if (n <= 0) continue;
+            const dim3 grid((n + AB_PERM_WAVES - 1) / AB_PERM_WAVES), block(64 * AB_PERM_WAVES);
+            if (k == AB_KIND_AM || k == AB_KIND_GENERIC) hipLaunchKernelGGL((regroup_perm_kernel<4>), grid, block, 0, stream, a, f, n);
+            else hipLaunchKernelGGL((regroup_perm_kernel<2>), grid, block, 0, stream, a, f, n);
+        }
+    }
     auto lds_of = [&](int k) { /* sincos table; per wavefront: output-line staging, ext_of, skip_of, slot_of; regrouped: the workgroup's slot table and counts */
         return (size_t)(k == AB_KIND_AM ? 0 : 258 * sizeof(float2)) + (size_t)(rg ? RW : 1) * WAVE_LDS_FLOATS * sizeof(float) + (rg ? (size_t)(RW * 64 + 2 * RW) * sizeof(int) : 0);
     };

@@ -119,6 +119,10 @@ struct DemodArgs {
      * (a workgroup barrier every eight samples), so that the ring lines neighbouring slots share are fetched from memory once.  Everything a lane touches is
      * addressed by its SLOT: which lane works on which slot does not change a result.  0: lane l of block b works on slot 64 b + l. */
     int regroup;
+    /* regroup == 3 (round 6, third form): a per-batch permutation of every kind's slots, built by regroup_perm_kernel in front of the stage -- inside segments of sixteen
+     * blocks the LINE GROUPS (slots that share a 128-byte ring line) with a channel that is not at rest come first, the groups at rest behind them -- read by ordinary
+     * one-wavefront workgroups: lane l of block b works on slot perm[64 b + l].  Nothing is shared between wavefronts, nobody waits, no workgroup needs four slots at once. */
+    int* perm;
     uint8_t* sq_key;        /* [n_slots] split kinds: the front kernel leaves 1 where the channel had audio or went CLOSED in this batch; the tone kernel skips the others, regrouped handles' back kernel deals its slots out by it */
 };
 

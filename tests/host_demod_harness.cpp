@@ -63,6 +63,7 @@ struct HostDemod {
     bool regroup = false;
     int regroup_mode = 1;
     std::vector<uint8_t> sq_key;
+    std::vector<int> perm;
     ~HostDemod() {
         free(mag); free(iq); free(iq_out); free(sqbuf); free(out_wave); free(out_axc); free(trace); free(lds);
         free(ct_coeff); free(ct_q); free(ct_af); free(ct_mask);
@@ -175,7 +176,8 @@ int hostdemod_create(const airband_hip_config* cfg, int trace, void** out) {
     {
         const char* e = getenv("AB_HOST_REGROUP");
         h->regroup = e && *e && *e != '0';
-        h->regroup_mode = (e && *e == '2') ? 2 : 1; /* 2: line groups sorted, the workgroup's wavefronts free-running */
+        h->regroup_mode = (e && *e == '2') ? 2 : (e && *e == '3') ? 3 : 1; /* 2: line groups sorted, the workgroup's wavefronts free-running; 3: a permutation in front of one-wavefront workgroups */
+        if (h->regroup_mode == 3) h->perm.assign((size_t)h->n_slots, 0);
     }
 #endif
     h->sq_key.assign((size_t)h->n_slots, 0); /* the front kernel's note per channel (tone kernel: channels without audio in the batch are skipped) */
@@ -240,6 +242,7 @@ int hostdemod_process_bins(void* hv, const float* wavein, const float* iq_in) {
     a.ct_stride = h->ct_stride;
     a.sq_key = h->sq_key.data();
     if (h->regroup) a.regroup = h->regroup_mode;
+    if (h->regroup && h->regroup_mode == 3) a.perm = h->perm.data();
     launch_demod(a, h->kind_first, h->kind_blocks, nullptr, nullptr, nullptr); /* the library's own launch sequence; every launch runs to completion */
 #else
     run_kind<AB_KIND_NFM_LOWPASS>(h, a);

@@ -51,7 +51,7 @@ static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) {
 
 namespace ab_emu {
 
-constexpr int MAX_THREADS = 256, WAVE = 64;
+constexpr int MAX_THREADS = 1024, WAVE = 64; /* (1 024: regroup_perm_kernel, sixteen wavefronts per workgroup) */
 constexpr size_t STACK_BYTES = 512 * 1024;
 
 struct Group { /* a wavefront or a block: the lanes that rendezvous */

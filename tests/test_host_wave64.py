@@ -41,7 +41,7 @@ def wave64(tmp_path_factory):
     return lib
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["slot_order", "regrouped", "regrouped_line_groups"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["slot_order", "regrouped", "regrouped_line_groups", "permuted_line_groups"])
 def regroup(request, monkeypatch):
     """Round 6: regrouped stage 2 (AIRBAND_HIP_FLAG_REGROUP on the GPU): workgroups of four wavefronts deal their 256 slots out among themselves by squelch state at
     every batch start and walk the batch in step -- which channels share a wavefront changes from batch to batch, the results must not.  2: the second form, the
