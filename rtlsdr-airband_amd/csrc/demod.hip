@@ -856,7 +856,10 @@ constexpr int TONE_GROUP = 50; /* samples per tone-kernel step; divides WAVE_BAT
  * the AM kernel does not pay for the lowpass registers.  Slot blocks of one kind are contiguous.
  * CTCSS-capable kinds are split in three: this "front" (squelch + discriminator -> audio, flags), the tone kernel
  * (Goertzel banks, one wavefront per channel) and the back kernel (gate, notch, output). */
-constexpr int AB_DEMOD_WAVES = 3, AB_AM_WAVES = 4, AB_FRONT_WAVES = 3; /* (the front at four waves: 128 VGPRs with 18 of them spilled once it carries the quiet-group path -- 6.30 ms of stage 2 against 6.20 at three) */
+#ifndef AB_AM_WAVES_N
+#define AB_AM_WAVES_N 4 /* experiment builds: 5 = the AM kind held to 96 registers (14 of them spilled) so that a fifth wavefront fits a SIMD -- profiles/r06_experiments.md N */
+#endif
+constexpr int AB_DEMOD_WAVES = 3, AB_AM_WAVES = AB_AM_WAVES_N, AB_FRONT_WAVES = 3; /* (the front at four waves: 128 VGPRs with 18 of them spilled once it carries the quiet-group path -- 6.30 ms of stage 2 against 6.20 at three) */
 
 /* ---- regrouping (AIRBAND_HIP_FLAG_REGROUP): closed channels share wavefronts -----------------------------------------------------------------------
  * Slots are assigned by demod KIND when a handle is prepared, and a wavefront works on 64 consecutive slots: at any time about half of its lanes (on the
