@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r06"
+R = next((a for a in sys.argv[1:] if not a.startswith("-")), "r06")
 L = lambda n: json.load(open(os.path.join(ROOT, "profiles", "%s_bench_%s.json" % (R, n))))
 sp = lambda v, nd=-2: "{:,}".format(int(round(v, nd))).replace(",", " ")
 
@@ -74,6 +74,12 @@ fft 1024 / 2048 / 4096 / 8192 21.5 / 32.9 / 62.9 / 129.7 → {f10['ms_per_step']
     s = between(s, "glance", glance)
     s = between(s, "table5", rows)
     s = between(s, "clocks", clocks)
+    if "--check" in sys.argv:  # tests/test_design_figures.py: the document must BE what the tracked lines print
+        if s != open(p).read():
+            print("DESIGN.md is out of sync with profiles/%s_*: run scripts/design_glance.py %s" % (R, R))
+            sys.exit(1)
+        print("DESIGN.md in sync with profiles/%s_*" % R)
+        return
     open(p, "w").write(s)
     print("DESIGN.md: at a glance, section 5 table and clocks paragraph rewritten from profiles/%s_*" % R)
 

@@ -26,3 +26,10 @@ def test_at_a_glance_quotes_the_tracked_headline_line():
     assert "{:,}".format(int(round(value, -2))).replace(",", " ") in head  # Msamples/s, rounded to hundreds, thin-space grouped
     assert "**%.3f**" % j["roofline"]["frac"] in head and "**%.3f**" % j["roofline"]["frac_read_only"] in head
     assert "**%.2f ms**" % j["stage_ms"]["demod"] in head
+
+
+def test_the_figure_blocks_are_what_the_generator_prints():
+    """The at-a-glance table, section 5's table and the clocks paragraph sit between markers and are written by scripts/design_glance.py from the tracked files: hand-edited
+    or stale figures fail here."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "design_glance.py"), "r06", "--check"], stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout
