@@ -76,7 +76,11 @@ extern "C" {
                                                64 channels a wavefront works on.  Pays on a band whose channels \
                                                are mostly quiet; costs ring-line fetches where neighbouring     \
                                                channels differ in state.  AIRBAND_HIP_REGROUP=0|1 in the         \
-                                               environment overrides the flags either way (A/B measurements).   \
+                                               environment overrides the flags either way (A/B measurements;    \
+                                               2 and 3 select the two other forms that were measured: line      \
+                                               groups sorted with free-running wavefronts, and a per-batch      \
+                                               permutation in front of one-wavefront workgroups --              \
+                                               profiles/r06_experiments.md L, M).                               \
                                                With neither this flag nor NO_REGROUP the library decides by      \
                                                residency: on while all of the handle's lane-per-channel          \
                                                wavefronts are resident at once on a full chip (about 24 000 to   \
