@@ -48,6 +48,14 @@ namespace {
 #define AB_V(x) 0
 #endif
 #endif
+/* a point the compiler's scheduler does not move instructions across (nothing in the ISA) */
+#if !defined(AB_SCHED_FENCE)
+#if defined(__has_builtin) && __has_builtin(__builtin_amdgcn_sched_barrier)
+#define AB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define AB_SCHED_FENCE() ((void)0)
+#endif
+#endif
 /* The 64 lanes of a wavefront execute in lockstep, and LDS operations of one wavefront complete in order: where lanes exchange data through LDS
  * WITHOUT a barrier (the cooperative row stores, the tone kernel's power sum) the code relies on that.  AB_LOCKSTEP() marks those places; it is
  * nothing on the GPU.  tests/hostshim_wave64 runs the lanes as fibers and makes them meet there. */
@@ -732,6 +740,127 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
             }
         }
     };
+    /* ---- four samples of a STABLE wavefront of the NFM + lowpass kind as one block (round 6; the review's item 1 c) ----------------------------------------------
+     * The same bargain as sq_raw_stable4() / stable_tail4() with the post-filter path inside it.  While no lane is entering a state, no timer runs out and no CLOSED lane is
+     * due to forget its recent opens (sq_stable4), four process_raw_sample() / filter / process_filtered_sample() rounds change no lane mask -- unless a lane asks for a
+     * transition: OPEN without signal (the pre-filter average OR the post-filter gate), CLOSED with it, a low-signal abort, the post-filter average falling under the delay
+     * line's entry (src/squelch.cpp:248-276).  So the rounds run on COPIES -- the squelch's averages and counters, the derotation phase, the biquad's delay lines -- with the
+     * requests only collected; if none came the copies are the state after four reference rounds, bit for bit, and are committed, and the audio chain of the OPEN / CLOSING lanes
+     * runs for the four filtered samples behind it.  Otherwise nothing is committed and the four samples go through sample() as before.  What it saves is the per-sample scalar
+     * work (request algebra, the any() branches around every region, emit_sample's flag tests): an open wavefront's own instruction stream is what the stage's time follows
+     * (profiles/r06_experiments.md M), and this kind's is the longest.
+     * MEASURED AND NOT ADOPTED (profiles/r06_experiments.md O): bit-exact (emulated wavefront, 113 GPU cases), 13 % fewer branches and 8 % fewer scalar instructions -- and the
+     * kind needs 168 registers instead of 123 (three wavefronts per SIMD instead of four) with 30 of them and 149 scalar ones spilled: alone 2.09 -> 2.81 ms, the stage 5.63 -> 6.65.
+     * The copies a roll-back needs do not fit beside the per-sample path they fall back to.  Experiment builds: -DAB_LP_STABLE4. */
+    constexpr bool SPEC4_LP = KIND == AB_KIND_NFM_LOWPASS
+#if !defined(AB_LP_STABLE4)
+                              && false
+#endif
+        ;
+    auto lp_stable4 = [&](const int jq, const float* mcs, const float* mds, const float* qr, const float* qi) -> bool {
+        SqRegs t = s;
+        unsigned phi = dm_phi;
+        float xr1 = lxr1, xr2 = lxr2, xi1 = lxi1, xi2 = lxi2, yr1 = lyr1, yr2 = lyr2, yi1 = lyi1, yi2 = lyi2;
+        float fre[4], fim[4];
+        const lmask timed = t.cOg | t.cCg | t.cA;
+        const lmask counting = t.cOg | t.cCg | t.cO; /* the lanes whose low-signal run length is kept (:233-245) */
+        const lmask care = t.cO | t.cC, want = t.cO;  /* OPEN lanes ask for CLOSING without the signal, CLOSED lanes for OPENING with it */
+        lmask bad = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            /* update_current_state() where nothing is entered and nothing expires (sq_advance): the closed-sample count, the timers, the delay line's cursors */
+            const lmask below = ab_ballot(t.closed_count < 1000u);
+            t.closed_count += ab_lane(t.cC & below) ? 1u : 0u;
+            t.delay += ab_lane(timed) ? 1 : 0;
+            t.tail = t.tail + 1 == AB_SQ_BUF ? 0 : t.tail + 1;
+            t.head = t.head + 1 == AB_SQ_BUF ? 0 : t.head + 1;
+            t.dly = mds[r];
+            t.sample_count++;
+            if (r == 0 && AB_UNLIKELY((t.sample_count & 15u) == 0u)) sq_noise_floor(t, L); /* (aligned4: only the first of the four can be a 16th sample) */
+            sq_avg(t.cap, t.pre_full, t.pre_capped, mcs[r]);
+            const lmask pre = ab_ballot(t.pre_capped >= t.lvl);
+            lmask sig = pre; /* has_signal(), src/squelch.cpp:462-475 */
+            if (ab_any(t.using_post)) sig &= ~t.using_post | ab_ballot(t.post_capped >= t.dly);
+            const lmask low = counting & ab_ballot(!(mcs[r] >= t.lvl));
+            const int run_len = t.low_count + 1;
+            const int idle_len = ab_lane(counting) ? 0 : t.low_count;
+            t.low_count = ab_lane(low) ? run_len : idle_len;
+            bad |= ((sig ^ want) & care) | (low & ab_ballot(t.low_count >= 88)); /* low_signal_abort_ */
+            /* should_filter_sample() (:136-138), then the lanes it names: derotation, Bessel lowpass, the filtered magnitude (src/rtl_airband.cpp:510-530) */
+            const lmask filt = (pre | ~t.cC) & ~t.cA & t.active;
+            float re = qr[r], im = qi[r], fmag = 0.0f;
+            if (ab_lane(filt)) {
+                const unsigned idx = phi >> 16; /* sincosf_lut (src/util.cpp:113-127) */
+                const float fract = (float)(phi & 0xffffu) / 65536.0f;
+                const float2 e0 = lut[idx], e1 = lut[idx + 1];
+                const float s0 = e0.x, s1 = e1.x, c0 = e0.y, c1 = e1.y;
+                const float swf = s0 + (s1 - s0) * fract;
+                const float cwf = c0 + (c1 - c0) * fract;
+                const float nswf = -swf;
+                const float tr = re * cwf - im * nswf; /* multiply(real, imag, cwf, -swf) */
+                const float ti = im * cwf + re * nswf;
+                phi = (phi + cc.dm_dphi) & 0xffffffu;
+                /* LowpassFilter::apply (src/filters.cpp:146-163) */
+                const float xr0 = xr1, xi0 = xi1;
+                xr1 = xr2; xi1 = xi2;
+                ab_div_const2(tr, ti, cc.lp_gain, cc.lp_rgain, div_lo, xr2, xi2);
+                const float yr0 = yr1, yi0 = yi1;
+                yr1 = yr2; yi1 = yi2;
+                yr2 = (xr0 + xr2) + (2.0f * xr1) + (cc.lp_yc0 * yr0) + (cc.lp_yc1 * yr1);
+                yi2 = (xi0 + xi2) + (2.0f * xi1) + (cc.lp_yc0 * yi0) + (cc.lp_yc1 * yi1);
+                re = yr2;
+                im = yi2;
+                fmag = ab_sqrt_rn(re * re + im * im);
+            }
+            fre[r] = re;
+            fim[r] = im;
+            /* process_filtered_sample() (:248-276) for those lanes; a lane whose post-filter average falls under the delay line's entry asks for CLOSED: the spell ends */
+            if (ab_any(filt)) {
+                const float delayed = t.dly;
+                const lmask run = filt & ~(t.cOg & ab_ballot(t.delay < AB_SQ_BUF));
+                const lmask seed = run & t.cOg & ab_ballot(t.delay == AB_SQ_BUF);
+                float full = ab_lane(seed) ? delayed : t.post_full, capped = ab_lane(seed) ? delayed : t.post_capped;
+                t.using_post |= run;
+                sq_avg(t.cap, full, capped, fmag);
+                t.post_full = ab_lane(run) ? full : t.post_full;
+                t.post_capped = ab_lane(run) ? capped : t.post_capped;
+                bad |= run & ab_ballot(capped < delayed);
+            }
+            AB_SCHED_FENCE(); /* one sample after the other: interleaved, the four rounds' temporaries are all live at once (278 spilled registers) */
+        }
+        bad |= t.cC & ~ab_ballot(t.closed_count < 1000u) & t.recent_nz; /* sq_saturated(): the count is monotonic, so the end of the group tells */
+        if (AB_UNLIKELY(ab_any(bad & t.active))) return false;
+        s = t;
+        dm_phi = phi;
+        lxr1 = xr1; lxr2 = xr2; lxi1 = xi1; lxi2 = xi2; lyr1 = yr1; lyr2 = yr2; lyi1 = yi1; lyi2 = yi2;
+        /* the audio chain of the lanes whose squelch lets samples through -- the same lanes for the four samples (src/rtl_airband.cpp:565-620) */
+        const bool audio = ab_lane(sq_should_audio(s));
+        const int state = !a.trace ? 0 : sq_cur(s);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float out = 0.0f;
+            const float re = fre[r], im = fim[r];
+            if (audio) {
+                if (!(cc.flags & AB_F_QUADRI)) {
+                    const float nbj = -pj;
+                    const float cr = re * pr - im * nbj;
+                    const float cj = im * pr + re * nbj;
+                    out = (float)((double)fast_atan2_dev(cj, cr) * 0.31830988618379067154);
+                } else {
+                    out = (float)((double)((pr * im - re * pj) / (re * re + im * im + 1.0f)) * 0.31830988618379067154);
+                }
+                pr = re;
+                pj = im;
+                agc = agc * 0.995f + out * 0.005f;
+                out -= agc;
+                out = out * one_minus_alpha + prev_out * cc.alpha;
+                prev_out = out;
+            }
+            emit_sample(a, cc, o, wrow, rz, iqout, trace, jq + r, audio, false, true, state, out, re, im, true);
+            AB_SCHED_FENCE();
+        }
+        return true;
+    };
     auto group = [&](const Group& q, int j0) {
 #pragma unroll
         for (int g = 0; g < GQ; g++) {
@@ -791,6 +920,9 @@ __device__ __forceinline__ void demod_wave(const DemodArgs& a, ChanConst cc, Cha
                     stable_tail4(jq, mcs, mds, qr, qi);
                     continue;
                 }
+            }
+            if (SPEC4_LP && AB_LIKELY(aligned4 && sq_stable4(s))) { /* wave-uniform */
+                if (AB_LIKELY(lp_stable4(jq, mcs, mds, qr, qi))) continue;
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) sample(jq + r, mcs[r], mds[r], qr[r], qi[r], r == 0 AB_MD_ARG(r));
