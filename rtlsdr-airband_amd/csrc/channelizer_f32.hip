@@ -55,7 +55,7 @@ __host__ __device__ constexpr long f32_padded(long o, int hop_bytes, int pad) { 
  * of the LDS instructions instead of 32 + 12 registers computed once and kept.  The fft 2048 variants (and fft 4096 / 8192, which run them) spilled 48 - 126 registers. */
 template <int FFT_N, int MAX_LD, int NW, int LAY>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void channelizer_f32_kernel(F32Args a) {
-    constexpr bool AL8 = LAY == 1, P256 = LAY == 2;
+    constexpr bool AL8 = LAY == 1, P256 = LAY == 2, NOPAD = LAY == 3; /* 3: hops of an odd number of 16-byte units need no padding (f32_pad() returns 0 for them): plain offsets */
     constexpr int WIN_BYTES = 8 * FFT_N;
     constexpr int KW = 2 * FFT_N / 4 / NW;   /* 64 (fft 512) or 32 (fft 256) */
     constexpr int READS = KW / 4;            /* 16-byte fragment reads per wave and tile */
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void 
 #pragma unroll
     for (int j = 0; j < READS; j++) {
         const int o = abase0 + j * 64;
-        aoff[j] = P256 ? abase + 64 * j + 16 * (j >> 2) : AL8 ? o + delta : o + pad * (o / hop_bytes);
+        aoff[j] = P256 ? abase + 64 * j + 16 * (j >> 2) : AL8 ? o + delta : NOPAD ? o : o + pad * (o / hop_bytes);
     }
 
     /* ---- staging: registers one tile ahead ---- */
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? (MAX_LD <= 6 ? 3 : 1) : 2) void 
 #pragma unroll
     for (int i = 0; i < MAX_LD; i++) {
         const int o = (i * 64 * NW + (int)threadIdx.x) * 16;
-        poff[i] = P256 ? 16 * ((int)threadIdx.x + ((int)threadIdx.x >> 4)) + i * (1024 + 64) * NW : o + pad * (o / hop_bytes);
+        poff[i] = P256 ? 16 * ((int)threadIdx.x + ((int)threadIdx.x >> 4)) + i * (1024 + 64) * NW : NOPAD ? o : o + pad * (o / hop_bytes);
     }
     /* (an interior-tile fast path -- one 64-bit add per tile, pieces at constant offsets -- was tried: the second copy of the loads costs registers,
      * three spilled dwords more and the third workgroup per CU of the large-tile variant; 26.2 ms against 22.4.  One path.) */
@@ -315,6 +315,7 @@ static void launch_f32(const F32Args& a, hipStream_t stream) {
     const int lay = f32_layout(a.fft_size, a.hop_bytes);
     if (lay == 1) launch_f32_al<FFT_N, MAX_LD, NW, 1>(a, stream);
     else if (lay == 2) launch_f32_al<FFT_N, MAX_LD, NW, 2>(a, stream);
+    else if (lay == 3) launch_f32_al<FFT_N, MAX_LD, NW, 3>(a, stream);
     else launch_f32_al<FFT_N, MAX_LD, NW, 0>(a, stream);
 }
 

@@ -188,11 +188,12 @@ inline int f32_nw(int fft_size) { return fft_size <= 512 ? 4 : 8; }
 inline int f32_seg_size(int fft_size) { return fft_size < 2048 ? fft_size : 2048; }
 inline int f32_n_seg(int fft_size) { return fft_size / f32_seg_size(fft_size); }
 int f32_partial_tiles(int n_hops_max); /* 16-hop tiles a work item may touch in one launch (sizes F32Args::partial) */
-/* layout of the staged image (channelizer_f32.hip): 1 = hops of an odd number of samples (no padding, fragments from two 8-byte reads), 2 = 16 bytes of padding per 256 stream
+/* layout of the staged image (channelizer_f32.hip): 1 = hops of an odd number of samples (no padding, fragments from two 8-byte reads), 3 = hops of an odd number of 16-byte units (no padding), 2 = 16 bytes of padding per 256 stream
  * bytes (hops that are multiples of 256 bytes; offsets become immediates), 0 = 16 bytes per hop where the hop is an even number of 16-byte units.  fft 512 with the small tiles
  * of WAVE_RATE 16000 stays on 0: layout 2's 6 % more LDS would cost it its third workgroup per CU (measured: 22.1 -> 24.1 ms; every other variant gains, fft 2048 27 %) */
 inline int f32_layout(int fft_size, int hop_bytes) {
     if (hop_bytes & 8) return 1;
+    if ((hop_bytes / 16) & 1) return 3; /* an odd number of 16-byte units per hop (2.4 MS/s: 1 200 / 2 400 bytes): the rows fall in different bank groups as they are -- no padding, offsets are immediates */
     if (hop_bytes % 256) return 0;
     const bool small_tile = 15 * hop_bytes + 8 * f32_seg_size(fft_size) <= 6 * 64 * f32_nw(fft_size) * 16;
     return (fft_size == 512 && small_tile) ? 0 : 2;
