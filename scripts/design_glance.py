@@ -44,7 +44,7 @@ def main():
     tr_ro = r["frac_read_only"] * r["avg_launch_ms"] / side["channelizer"][0]
     glance = f'''| what | driver, round 5 | builder's box, round 6 | file |
 |---|---|---|---|
-| configs[2] (65 536 dongles × 8 mixed AM / NFM + CTCSS channels, fft 512, u8, 1× MI355X), one step | 14.62 ms = 1 435 000 Msamples/s | **{j['ms_per_step']:.2f} ms = {sp(j['value'])} Msamples/s** (13.83 - 14.28 over the round's boxes) | `profiles/{R}_bench_cfg3.json` |
+| configs[2] (65 536 dongles × 8 mixed AM / NFM + CTCSS channels, fft 512, u8, 1× MI355X), one step | 14.62 ms = 1 435 000 Msamples/s | **{j['ms_per_step']:.2f} ms = {sp(j['value'])} Msamples/s** (13.83 - 14.30 over the round's boxes) | `profiles/{R}_bench_cfg3.json` |
 | channelizer launch, HIP events in the timed run | 8.92 ms = 0.647 of the 8 TB/s roofline on algorithmic bytes, 0.588 on input bytes alone | {r['avg_launch_ms']:.2f} ms = **{r['frac']:.3f}**, **{r['frac_read_only']:.3f}** on input bytes alone (8.19 - 8.68 ms = 0.70 - 0.66 / 0.64 - 0.60 over the round's boxes) | same file, `roofline` |
 | channelizer launch, rocprofv3's clock | 9.09 ms (its 12-launch child) = 0.635 / 0.577 | the run's own {rp['launches']}-launch child: {rp['avg_launch_ms']:.2f} ms (min {rp['min_launch_ms']:.2f}) = {rp['frac']:.3f} / {rp['frac_read_only']:.3f}; a separate traced run: {side['channelizer'][0]:.2f} ms ({side['channelizer'][2]} launches, min {side['channelizer'][1]:.2f}) = {tr_frac:.3f} / {tr_ro:.3f} | `roofline.rocprof`; `profiles/{R}_cfg3_kernel_stats.csv` |
 | stage 2 (HIP events) | 5.67 ms | **{j['stage_ms']['demod']:.2f} ms** (5.55 - 5.69 over the round's boxes; the tone kernel skipping idle channels: 5.66 -> 5.55 interleaved, `profiles/r06_tone_skip/`) | `profiles/{R}_bench_cfg3.json`, `stage_ms` |
