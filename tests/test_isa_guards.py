@@ -274,3 +274,33 @@ def test_exchange_fft_kernel_is_shuffle_free_and_keeps_four_waves(fft_asm):
     # the exchange itself: per 512-point hop five rounds of eight 8-byte LDS operations (paired by the compiler into ds_read2 / ds_write2)
     body = _function(fft_asm, "channelizer_fft8_kernelILi3ELi0E")
     assert sum(1 for l in body if re.match(r"^\s*ds_write2?_b64", l)) >= 12
+
+
+@pytest.fixture(scope="module")
+def f32_asm(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
+    out = str(tmp_path_factory.mktemp("isa") / "f32.s")
+    src = os.path.join(ROOT, "rtlsdr-airband_amd", "csrc", "channelizer_f32.hip")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-std=c++17"] + _product_flags("channelizer_f32.hip") + ["-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", out, src]
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL, timeout=900)
+    return open(out).read()
+
+
+def test_cf32_layouts_with_immediate_offsets_do_not_spill(f32_asm):
+    """Round 6 (profiles/r06_experiments.md H, addendum): the CF32 kernel's fft 2048 variants -- which also run fft 4096 / 8192 -- spilled 48 - 126 registers while every lane kept
+    its 32 fragment offsets and 12 parking offsets of the padded image in registers.  The layouts whose offsets are immediates (1: hops of an odd number of samples, 2: padding every
+    256 stream bytes, 3: no padding needed) must stay free of spills at every size; layout 0 (per-hop padding) is what is left for the other hops and is allowed its old spills."""
+    seen = 0
+    for blk in f32_asm.split("  - .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        m = re.search(r"channelizer_f32_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+        if not m:
+            continue
+        lay = int(m.group(4))
+        if lay == 0:
+            continue
+        seen += 1
+        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, name
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name
+    assert seen == 24  # 4 fft sizes x 2 tile sizes x 3 layouts
